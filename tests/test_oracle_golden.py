@@ -1,0 +1,89 @@
+"""Oracle (oracle/*) vs golden vectors produced by the imported reference (tests/golden/make_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import encoders_ref, render_ref
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_g1_sample_pdf(golden_dir):
+    g = _load(golden_dir, "g1_sample_pdf.npz")
+    bins, w = torch.from_numpy(g["bins"]), torch.from_numpy(g["weights"])
+    det = render_ref.sample_pdf(bins, w, 64, det=True)
+    np.testing.assert_array_equal(det.numpy(), g["det"])
+    rnd = render_ref.sample_pdf(bins, w, 64, det=False, u=torch.from_numpy(g["u"]))
+    np.testing.assert_array_equal(rnd.numpy(), g["rnd"])
+
+
+class _Stub(torch.nn.Module):
+    def __init__(self, g):
+        super().__init__()
+        for n in ("a0", "a", "bump", "M", "Wc"):
+            setattr(self, n, torch.nn.Parameter(torch.from_numpy(g[f"param_{n}"]).clone()))
+
+    def density(self, x):
+        r = x.norm(dim=-1)
+        sigma = torch.exp(self.a0 + (x * self.a).sum(-1)) + self.bump[2] * torch.exp(
+            -((r - self.bump[0]) / self.bump[1]) ** 2)
+        return sigma, torch.tanh(x @ self.M.t() * 3.0)
+
+    def color(self, x, d, mask, geo):
+        rgbs = torch.zeros(mask.shape[0], 2, dtype=x.dtype)
+        if not mask.any():
+            return rgbs
+        rgbs[mask] = torch.sigmoid(torch.cat([d[mask], geo[mask]], -1) @ self.Wc.t())
+        return rgbs
+
+
+@pytest.mark.parametrize("tag", ["eval", "train"])
+def test_g2_renderer_run(golden_dir, tag):
+    g = _load(golden_dir, "g2_renderer_run.npz")
+    m = _Stub(g)
+    aabb = torch.tensor([-1.0, -1, -1, 1, 1, 1])
+    scale = 0.010784853507573345
+    train = tag == "train"
+    res = render_ref.run_lidar(torch.from_numpy(g["rays_o"]), torch.from_numpy(g["rays_d"]), m.density, m.color, aabb,
+                               scale, 768, 64, perturb=train, training=train,
+                               noise=torch.from_numpy(g["train_noise"]) if train else None,
+                               u=torch.from_numpy(g["train_u"]) if train else None)
+    np.testing.assert_allclose(res["depth_lidar"].detach().numpy(), g[f"{tag}_depth"][0], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(res["image_lidar"].detach().numpy(), g[f"{tag}_image"][0], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(res["weights_sum_lidar"].detach().numpy(), g[f"{tag}_ws"], rtol=1e-6, atol=1e-7)
+    loss = ((res["depth_lidar"] * torch.from_numpy(g["cd"])).sum()
+            + (res["image_lidar"] * torch.from_numpy(g["ci"][0])).sum()
+            + (res["weights_sum_lidar"] * torch.from_numpy(g["cw"])).sum())
+    loss.backward()
+    for n in ("a0", "a", "bump", "M", "Wc"):
+        np.testing.assert_allclose(getattr(m, n).grad.numpy(), g[f"{tag}_grad_{n}"], rtol=2e-4, atol=1e-5,
+                                   err_msg=f"grad {n}")
+
+
+def test_g4_freq_layout(golden_dir):
+    g = _load(golden_dir, "g4_freq_encoder.npz")
+    y = encoders_ref.freq_forward_exactcos(g["d"], 12)
+    np.testing.assert_allclose(y, g["y"], rtol=0, atol=2e-6)
+    # kernel form (cos as sin(x + pi/2) in float32): same layout, looser at high frequencies
+    yk = encoders_ref.freq_forward(g["d"], 12)
+    np.testing.assert_allclose(yk, g["y"], rtol=0, atol=3e-4)
+    gd = encoders_ref.freq_backward(g["g"], g["y"], 3, 12)
+    np.testing.assert_allclose(gd, g["gd"], rtol=2e-4, atol=2e-2)
+    # torch twin used by the CPU baseline
+    yt = render_ref.freq_encode_torch(torch.from_numpy(g["d"]), 12).numpy()
+    np.testing.assert_allclose(yt, g["y"], rtol=0, atol=1e-6)
+
+
+def test_g5_trunc_exp(golden_dir):
+    g = _load(golden_dir, "g5_trunc_exp.npz")
+    np.testing.assert_allclose(encoders_ref.trunc_exp_forward(g["x"]), g["y"], rtol=2e-7)
+    np.testing.assert_allclose(encoders_ref.trunc_exp_backward(g["g"], g["x"]), g["gx"], rtol=2e-7)
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    y = render_ref.trunc_exp(x)
+    y.backward(torch.from_numpy(g["g"]))
+    np.testing.assert_array_equal(y.detach().numpy(), g["y"])
+    np.testing.assert_array_equal(x.grad.numpy(), g["gx"])
