@@ -1,0 +1,64 @@
+// common.h — shared host/device helpers of liblidarnerf_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/lidarnerf_hip.h"
+
+typedef _Float16 half_t;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+
+#define LNH_WAVE 64
+
+// thread-local last-error string (lnh_last_error)
+void lnh_set_error(const char *fmt, ...);
+
+#define LNH_REQUIRE(cond, code, ...)     \
+    do {                                 \
+        if (!(cond)) {                   \
+            lnh_set_error(__VA_ARGS__);  \
+            return (code);               \
+        }                                \
+    } while (0)
+
+static inline int lnh_check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        lnh_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return LNH_ERR_LAUNCH;
+    }
+    return LNH_OK;
+}
+
+static inline uint32_t div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+// ---- wave-level primitives (64 lanes) ------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// inclusive scan (sum) across the 64 lanes of a wave
+__device__ __forceinline__ float wave_scan_add(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+// inclusive scan (product)
+__device__ __forceinline__ float wave_scan_mul(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float t = __shfl_up(v, o, 64);
+        if (lane >= o) v *= t;
+    }
+    return v;
+}

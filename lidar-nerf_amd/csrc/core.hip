@@ -1,0 +1,17 @@
+// core.hip — version / error plumbing of liblidarnerf_hip.so.
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void lnh_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+int lnh_version(void) { return 100; }
+const char *lnh_last_error(void) { return g_err; }
+const char *lnh_arch(void) { return "gfx950"; }
+}

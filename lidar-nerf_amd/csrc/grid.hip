@@ -1,0 +1,673 @@
+// grid.hip — multi-resolution hash / tiled grid encoder for gfx950 (MI355X).
+//
+// Semantics follow the reference kernels (lidarnerf/gridencoder/src/gridencoder.cu:53-390, 695-807); the
+// implementation is organised for CDNA4:
+//   * the level geometry (scale, resolution, dense/hash decision, modulo strategy) is resolved ONCE on the host and
+//     handed to the kernel in kernarg SGPRs, so the per-corner index math is a handful of VALU ops with no
+//     per-thread loop-carried stride test and no integer division on the hot levels;
+//   * one 2D launch, blockIdx.y = level (dispatch order is x-fastest, so the chip works level-major and every XCD's
+//     4 MiB L2 holds the ~2 MiB fp16 table of the level in flight);
+//   * 64 consecutive lanes = 64 consecutive sample points (consecutive samples along a LiDAR ray): coarse-level
+//     corner gathers of a wave hit a few cache lines; the [L,B,C] output store is a fully coalesced 256 B / wave;
+//   * backward: packed `global_atomic_pk_add_f16` (fp16 tables) / `global_atomic_add_f32`, preceded by a
+//     wave-level run-merge: lanes whose sample falls in the same cell as their lower neighbour (the common case on
+//     coarse levels, where one cell spans many consecutive samples of a ray) are summed with a segmented shuffle
+//     scan and only the run tail issues the atomic.
+#include "common.h"
+
+#include <cmath>
+
+namespace {
+
+struct LevelParams {
+    float scale;
+    uint32_t resolution;
+    uint32_t hashmap_size;
+    uint32_t offset;  // rows before this level
+    uint32_t flags;   // bits 0-3: dims accumulated densely; bit4 hash; bit5 pow2 table; bit6 no wrap needed
+};
+struct GridMeta {
+    LevelParams lv[LNH_MAX_LEVELS];
+};
+enum { LV_HASH = 16, LV_POW2 = 32, LV_NOWRAP = 64 };
+
+// gridencoder.cu:55-57 (spatial-hash primes); folded to immediates after unrolling
+__host__ __device__ constexpr uint32_t prime_of(int d) {
+    return d == 0 ? 1u : d == 1 ? 2654435761u : d == 2 ? 805459861u : d == 3 ? 3674653429u
+         : d == 4 ? 2097192037u : d == 5 ? 1434869437u : 2165219737u;
+}
+
+// Host: gridencoder.cu:146-148 + the stride loop of get_grid_index (69-84) evaluated once per level.
+// exp2f(level*S) is evaluated in double and rounded once (same convention as the oracle).
+int build_meta(GridMeta &m, const int32_t *offsets, uint32_t D, uint32_t L, float S, uint32_t H, uint32_t gridtype,
+               bool align) {
+    for (uint32_t l = 0; l < L; l++) {
+        LevelParams &p = m.lv[l];
+        float e = (float)l * S;
+        float pw = (float)exp2((double)e);
+        p.scale = pw * (float)H - 1.0f;
+        p.resolution = (uint32_t)ceilf(p.scale) + 1u;
+        int64_t hm = (int64_t)offsets[l + 1] - (int64_t)offsets[l];
+        if (hm <= 0 || offsets[l] < 0) return -1;
+        p.hashmap_size = (uint32_t)hm;
+        p.offset = (uint32_t)offsets[l];
+        uint32_t R = align ? p.resolution : p.resolution + 1;
+        uint32_t stride = 1, nd = 0;
+        uint64_t exact = 1;
+        for (uint32_t d = 0; d < D && stride <= p.hashmap_size; d++) {
+            stride *= R;  // uint32 wrap-around exactly like the device code it replaces
+            exact *= R;
+            nd++;
+        }
+        uint32_t f = nd;
+        bool hash = (gridtype == 0 && stride > p.hashmap_size);
+        if (hash) f |= LV_HASH;
+        if ((p.hashmap_size & (p.hashmap_size - 1)) == 0) f |= LV_POW2;
+        if (!hash && nd == D && exact <= p.hashmap_size) f |= LV_NOWRAP;
+        p.flags = f;
+    }
+    return 0;
+}
+
+template <int D>
+struct Cell {
+    uint32_t term[D][2];  // per-dimension contribution to the row index for offset 0 / +1
+    float frac[D];
+    float deriv[D];
+};
+
+// Position inside the level lattice (gridencoder.cu:150-167).  Returns false for out-of-range points.
+template <int D>
+__device__ __forceinline__ bool locate(const float (&x)[D], const LevelParams &lv, bool align, uint32_t interp,
+                                       Cell<D> &c) {
+    bool ok = true;
+#pragma unroll
+    for (int d = 0; d < D; d++) ok = ok && !(x[d] < 0.0f || x[d] > 1.0f);
+    if (!ok) return false;
+    const uint32_t R = align ? lv.resolution : lv.resolution + 1;
+    const bool hash = lv.flags & LV_HASH;
+    const uint32_t nd = lv.flags & 15u;
+    uint32_t stride = 1;
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        float p = fmaf(x[d], lv.scale, align ? 0.0f : 0.5f);
+        float fl = floorf(p);
+        uint32_t g = (uint32_t)fl;
+        p -= (float)g;
+        if (interp == 1) {
+            c.deriv[d] = 6.0f * p * (1.0f - p);
+            p = p * p * (3.0f - 2.0f * p);
+        } else {
+            c.deriv[d] = 1.0f;
+        }
+        c.frac[d] = p;
+        if (hash) {
+            uint32_t t0 = g * prime_of(d);
+            c.term[d][0] = t0;
+            c.term[d][1] = t0 + prime_of(d);
+        } else if ((uint32_t)d < nd) {
+            uint32_t t0 = g * stride;
+            c.term[d][0] = t0;
+            c.term[d][1] = t0 + stride;
+            stride *= R;
+        } else {  // tiled grid whose stride already exceeded the table: dimension ignored (gridencoder.cu:81)
+            c.term[d][0] = 0;
+            c.term[d][1] = 0;
+        }
+    }
+    return true;
+}
+
+template <int D>
+__device__ __forceinline__ uint32_t corner_row(const Cell<D> &c, const LevelParams &lv, uint32_t corner) {
+    uint32_t idx = 0;
+    if (lv.flags & LV_HASH) {
+#pragma unroll
+        for (int d = 0; d < D; d++) idx ^= c.term[d][(corner >> d) & 1];
+    } else {
+#pragma unroll
+        for (int d = 0; d < D; d++) idx += c.term[d][(corner >> d) & 1];
+    }
+    if (lv.flags & LV_POW2) idx &= lv.hashmap_size - 1;
+    else if (!(lv.flags & LV_NOWRAP)) idx %= lv.hashmap_size;
+    return idx;
+}
+
+template <int D>
+__device__ __forceinline__ float corner_weight(const Cell<D> &c, uint32_t corner) {
+    float w = 1.0f;
+#pragma unroll
+    for (int d = 0; d < D; d++) w *= ((corner >> d) & 1) ? c.frac[d] : (1.0f - c.frac[d]);
+    return w;
+}
+
+template <typename T, int C>
+struct Vec {
+    T v[C];
+};
+template <typename T, int C>
+__device__ __forceinline__ Vec<T, C> load_vec(const T *p) {
+    Vec<T, C> r;
+    if constexpr (sizeof(T) * C == 4) {
+        uint32_t raw = *reinterpret_cast<const uint32_t *>(p);
+        __builtin_memcpy(&r, &raw, 4);
+    } else if constexpr (sizeof(T) * C == 8) {
+        uint2 raw = *reinterpret_cast<const uint2 *>(p);
+        __builtin_memcpy(&r, &raw, 8);
+    } else if constexpr (sizeof(T) * C == 16) {
+        uint4 raw = *reinterpret_cast<const uint4 *>(p);
+        __builtin_memcpy(&r, &raw, 16);
+    } else if constexpr (sizeof(T) * C == 32) {
+        uint4 a = reinterpret_cast<const uint4 *>(p)[0], b = reinterpret_cast<const uint4 *>(p)[1];
+        __builtin_memcpy(&r, &a, 16);
+        __builtin_memcpy(reinterpret_cast<char *>(&r) + 16, &b, 16);
+    } else {
+#pragma unroll
+        for (int i = 0; i < C; i++) r.v[i] = p[i];
+    }
+    return r;
+}
+template <typename T, int C>
+__device__ __forceinline__ void store_vec(T *p, const Vec<T, C> &r) {
+    if constexpr (sizeof(T) * C == 4) {
+        uint32_t raw;
+        __builtin_memcpy(&raw, &r, 4);
+        *reinterpret_cast<uint32_t *>(p) = raw;
+    } else if constexpr (sizeof(T) * C == 8) {
+        uint2 raw;
+        __builtin_memcpy(&raw, &r, 8);
+        *reinterpret_cast<uint2 *>(p) = raw;
+    } else if constexpr (sizeof(T) * C == 16) {
+        uint4 raw;
+        __builtin_memcpy(&raw, &r, 16);
+        *reinterpret_cast<uint4 *>(p) = raw;
+    } else {
+#pragma unroll
+        for (int i = 0; i < C; i++) p[i] = r.v[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <typename T, int D, int C, bool DYDX>
+__global__ void __launch_bounds__(256)
+k_grid_forward(const float *__restrict__ inputs, const T *__restrict__ table, T *__restrict__ outputs,
+               T *__restrict__ dy_dx, uint32_t B, uint32_t L, GridMeta meta, uint32_t align, uint32_t interp) {
+    const uint32_t level = blockIdx.y;
+    const LevelParams lv = meta.lv[level];
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float x[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) x[d] = inputs[(size_t)b * D + d];
+    const T *tab = table + (size_t)lv.offset * C;
+    T *out = outputs + ((size_t)level * B + b) * C;
+    Cell<D> cell;
+    Vec<T, C> res;
+#pragma unroll
+    for (int ch = 0; ch < C; ch++) res.v[ch] = (T)0.0f;
+    const bool ok = locate<D>(x, lv, align != 0, interp, cell);
+    if (ok) {
+        // issue all 2^D gathers before consuming any of them
+        Vec<T, C> g[1 << D];
+#pragma unroll
+        for (uint32_t c = 0; c < (1u << D); c++) g[c] = load_vec<T, C>(tab + (size_t)corner_row<D>(cell, lv, c) * C);
+#pragma unroll
+        for (uint32_t c = 0; c < (1u << D); c++) {
+            const float w = corner_weight<D>(cell, c);
+            // accumulate in the table type, one rounding per corner (gridencoder.cu:173,198)
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) res.v[ch] = (T)fmaf(w, (float)g[c].v[ch], (float)res.v[ch]);
+        }
+    }
+    store_vec<T, C>(out, res);
+    if constexpr (DYDX) {
+        // gridencoder.cu:214-262: d out / d x for every input dimension, layout [B, L, D, C]
+        T *dd = dy_dx + (((size_t)b * L + level) * D) * C;
+#pragma unroll
+        for (int gd = 0; gd < D; gd++) {
+            Vec<T, C> rg;
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) rg.v[ch] = (T)0.0f;
+            if (ok) {
+#pragma unroll
+                for (uint32_t k = 0; k < (1u << (D - 1)); k++) {
+                    float w = lv.scale;
+                    uint32_t corner = 0;
+#pragma unroll
+                    for (int nd = 0; nd < D - 1; nd++) {
+                        const int d = (nd >= gd) ? nd + 1 : nd;
+                        if ((k >> nd) & 1) {
+                            w *= cell.frac[d];
+                            corner |= 1u << d;
+                        } else {
+                            w *= 1.0f - cell.frac[d];
+                        }
+                    }
+                    Vec<T, C> gl = load_vec<T, C>(tab + (size_t)corner_row<D>(cell, lv, corner) * C);
+                    Vec<T, C> gr = load_vec<T, C>(tab + (size_t)corner_row<D>(cell, lv, corner | (1u << gd)) * C);
+#pragma unroll
+                    for (int ch = 0; ch < C; ch++) {
+                        T diff = (T)(gr.v[ch] - gl.v[ch]);
+                        rg.v[ch] = (T)((float)rg.v[ch] + w * (float)diff * cell.deriv[gd]);
+                    }
+                }
+            }
+            store_vec<T, C>(dd + gd * C, rg);
+        }
+    }
+}
+
+// Debug kernel for the bit-exact index contract.
+template <int D>
+__global__ void __launch_bounds__(256)
+k_grid_indices(const float *__restrict__ inputs, uint32_t *__restrict__ out, uint32_t B, uint32_t C, GridMeta meta,
+               uint32_t align) {
+    const uint32_t level = blockIdx.y;
+    const LevelParams lv = meta.lv[level];
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float x[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) x[d] = inputs[(size_t)b * D + d];
+    Cell<D> cell;
+    const bool ok = locate<D>(x, lv, align != 0, 0, cell);
+    uint32_t *o = out + ((size_t)level * B + b) * (1u << D);
+#pragma unroll
+    for (uint32_t c = 0; c < (1u << D); c++) o[c] = ok ? corner_row<D>(cell, lv, c) * C : 0xffffffffu;
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+__device__ __forceinline__ void atomic_add_pair(half_t *p, float a, float b) {
+    half2_t v = {(half_t)a, (half_t)b};
+    __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) half2_t *)p, v);
+}
+__device__ __forceinline__ void atomic_add_pair(float *p, float a, float b) {
+    unsafeAtomicAdd(p, a);
+    unsafeAtomicAdd(p + 1, b);
+}
+__device__ __forceinline__ void atomic_add_one(float *p, float a) { unsafeAtomicAdd(p, a); }
+
+// One thread = one (point, level, channel pair).  NC = channels per thread (1 or 2).
+// MERGE: wave-level run merge of equal cells before the atomics (see file header).
+template <typename T, int D, int C, int NC, bool MERGE>
+__global__ void __launch_bounds__(256)
+k_grid_backward(const T *__restrict__ grad, const float *__restrict__ inputs, T *__restrict__ grad_table, uint32_t B,
+                GridMeta meta, uint32_t align, uint32_t interp) {
+    constexpr int NP = C / NC;  // channel groups per point
+    const uint32_t level = blockIdx.y;
+    const LevelParams lv = meta.lv[level];
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b = t / NP;
+    const uint32_t ch = (t % NP) * NC;
+    const bool in_range = b < B;
+    float x[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) x[d] = in_range ? inputs[(size_t)b * D + d] : -1.0f;
+    Cell<D> cell;
+    const bool ok = in_range && locate<D>(x, lv, align != 0, interp, cell);
+    float g[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) g[c] = ok ? (float)grad[((size_t)level * B + b) * C + ch + c] : 0.0f;
+    T *gt = grad_table + (size_t)lv.offset * C + ch;
+
+    if constexpr (MERGE && NP == 1) {
+        // Lanes are consecutive samples.  If this lane's base cell equals the previous lane's, both touch the same
+        // 2^D table rows: pre-reduce w*g over such runs with a segmented inclusive scan; the LAST lane of each run
+        // issues the atomics.  Cell identity = all per-dimension base terms equal (exact, hash or dense).
+        const int lane = threadIdx.x & 63;
+        uint32_t key[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) key[d] = ok ? cell.term[d][0] : 0xffffffffu - lane;  // invalid lanes never match
+        bool same_prev = lane > 0;
+#pragma unroll
+        for (int d = 0; d < D; d++) same_prev = same_prev && (__shfl_up(key[d], 1, 64) == key[d]);
+        const unsigned long long heads = __ballot(!same_prev);  // bit set where a run starts
+        // distance to the start of my run
+        const unsigned long long below = heads & ((2ull << lane) - 1ull);
+        const int run_start = 63 - __builtin_clzll(below);
+        const bool any_merge = (~heads) != 0ull;
+        const unsigned long long heads_above = (lane == 63) ? 0ull : (heads >> (lane + 1));
+        const bool is_tail = (lane == 63) || (heads_above & 1ull);
+        if (any_merge) {  // wave-uniform
+#pragma unroll
+            for (uint32_t c = 0; c < (1u << D); c++) {
+                const float w = ok ? corner_weight<D>(cell, c) : 0.0f;
+                float v[NC];
+#pragma unroll
+                for (int k = 0; k < NC; k++) {
+                    v[k] = w * g[k];
+                    if constexpr (sizeof(T) == 2) v[k] = (float)(half_t)v[k];  // per-contribution rounding (cu:350)
+                }
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+#pragma unroll
+                    for (int k = 0; k < NC; k++) {
+                        float up = __shfl_up(v[k], o, 64);
+                        if (lane - o >= run_start) v[k] += up;
+                    }
+                }
+                if (ok && is_tail) {
+                    T *p = gt + (size_t)corner_row<D>(cell, lv, c) * C;
+                    if constexpr (NC == 2) atomic_add_pair(p, v[0], v[1]);
+                    else atomic_add_one(p, v[0]);
+                }
+            }
+            return;
+        }
+    }
+    if (!ok) return;
+#pragma unroll
+    for (uint32_t c = 0; c < (1u << D); c++) {
+        const float w = corner_weight<D>(cell, c);
+        T *p = gt + (size_t)corner_row<D>(cell, lv, c) * C;
+        if constexpr (NC == 2) atomic_add_pair(p, w * g[0], w * g[1]);
+        else atomic_add_one(p, w * g[0]);
+    }
+}
+
+// gridencoder.cu:364-390
+template <typename T, int D, int C>
+__global__ void k_grid_input_backward(const T *__restrict__ grad, const T *__restrict__ dy_dx,
+                                      T *__restrict__ grad_inputs, uint32_t B, uint32_t L) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * D) return;
+    const uint32_t b = t / D, d = t - b * D;
+    T r = (T)0.0f;
+    for (uint32_t l = 0; l < L; l++)
+#pragma unroll
+        for (int ch = 0; ch < C; ch++)
+            r = (T)((float)r + (float)grad[((size_t)l * B + b) * C + ch] *
+                                   (float)dy_dx[(((size_t)b * L + l) * D + d) * C + ch]);
+    grad_inputs[t] = r;
+}
+
+// ------------------------------------------------------------------------------------------------ TV gradient
+// gridencoder.cu:695-807
+template <typename T, int D, int C>
+__global__ void __launch_bounds__(256)
+k_grad_tv(const T *__restrict__ inputs, const T *__restrict__ table, T *__restrict__ grad, float weight, uint32_t B,
+          GridMeta meta, uint32_t align) {
+    const uint32_t level = blockIdx.y;
+    const LevelParams lv = meta.lv[level];
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float x[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) x[d] = (float)inputs[(size_t)b * D + d];
+    Cell<D> cell;
+    if (!locate<D>(x, lv, align != 0, 0, cell)) return;
+    const T *tab = table + (size_t)lv.offset * C;
+    T *gt = grad + (size_t)lv.offset * C;
+    // integer lattice position of the base corner and a row-index helper working on explicit coordinates
+    uint32_t pg[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) pg[d] = (uint32_t)floorf(fmaf(x[d], lv.scale, align ? 0.0f : 0.5f));
+    auto row_of = [&](const uint32_t(&p)[D]) {
+        const uint32_t R = align ? lv.resolution : lv.resolution + 1;
+        const uint32_t nd = lv.flags & 15u;
+        uint32_t idx = 0, stride = 1;
+        if (lv.flags & LV_HASH) {
+#pragma unroll
+            for (int d = 0; d < D; d++) idx ^= p[d] * prime_of(d);
+        } else {
+#pragma unroll
+            for (int d = 0; d < D; d++)
+                if ((uint32_t)d < nd) {
+                    idx += p[d] * stride;
+                    stride *= R;
+                }
+        }
+        return idx % lv.hashmap_size;
+    };
+    const uint32_t index = row_of(pg) * C;
+    float results[C], idelta[C];
+#pragma unroll
+    for (int ch = 0; ch < C; ch++) results[ch] = idelta[ch] = 0.0f;
+    const T w = (T)(weight / (2 * D));
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        const uint32_t cur = pg[d];
+        if (cur < lv.resolution) {
+            pg[d] = cur + 1;
+            const uint32_t ir = row_of(pg) * C;
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) {
+                T gv = (T)(tab[index + ch] - tab[ir + ch]);
+                results[ch] = (float)(T)(results[ch] + (float)gv);
+                idelta[ch] = (float)(T)(idelta[ch] + (float)(T)(gv * gv));
+            }
+        }
+        if (cur > 0) {
+            pg[d] = cur - 1;
+            const uint32_t il = row_of(pg) * C;
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) {
+                T gv = (T)(tab[index + ch] - tab[il + ch]);
+                results[ch] = (float)(T)(results[ch] + (float)gv);
+                idelta[ch] = (float)(T)(idelta[ch] + (float)(T)(gv * gv));
+            }
+        }
+        pg[d] = cur;
+    }
+#pragma unroll
+    for (int ch = 0; ch < C; ch++) {
+        const float v = (float)w * results[ch] * rsqrtf(idelta[ch] + 1e-9f);
+        if constexpr (sizeof(T) == 4) {
+            unsafeAtomicAdd((float *)gt + index + ch, v);
+        } else {
+            // scalar fp16 atomic through the aligned packed instruction: add (v,0) or (0,v)
+            half_t *p = (half_t *)gt + index + ch;
+            const bool hi = ((uintptr_t)p & 2) != 0;
+            half_t *pa = hi ? p - 1 : p;
+            atomic_add_pair(pa, hi ? 0.0f : v, hi ? v : 0.0f);
+        }
+    }
+}
+
+template <typename T, int D>
+int launch_forward_c(const float *inputs, const T *emb, T *out, T *dy_dx, uint32_t B, uint32_t C, uint32_t L,
+                     const GridMeta &m, uint32_t align, uint32_t interp, hipStream_t s) {
+    dim3 grid(div_up(B, 256), L), block(256);
+#define LNH_FWD(CC)                                                                                               \
+    if (dy_dx)                                                                                                    \
+        hipLaunchKernelGGL((k_grid_forward<T, D, CC, true>), grid, block, 0, s, inputs, emb, out, dy_dx, B, L, m, \
+                           align, interp);                                                                        \
+    else                                                                                                          \
+        hipLaunchKernelGGL((k_grid_forward<T, D, CC, false>), grid, block, 0, s, inputs, emb, out, dy_dx, B, L, m, \
+                           align, interp);
+    switch (C) {
+        case 1: LNH_FWD(1) break;
+        case 2: LNH_FWD(2) break;
+        case 4: LNH_FWD(4) break;
+        case 8: LNH_FWD(8) break;
+        default: lnh_set_error("GridEncoding: C must be 1, 2, 4, or 8 (got %u)", C); return LNH_ERR_UNSUPPORTED;
+    }
+#undef LNH_FWD
+    return lnh_check_launch("lnh_grid_encode_forward");
+}
+
+template <typename T, int D>
+int launch_backward_c(const T *grad, const float *inputs, T *ge, uint32_t B, uint32_t C, uint32_t L,
+                      const GridMeta &m, uint32_t align, uint32_t interp, hipStream_t s) {
+    dim3 block(256);
+    switch (C) {
+        case 1:
+            if constexpr (sizeof(T) == 2) {
+                lnh_set_error("grid backward: fp16 tables need an even C (the reference forces fp32 when C is odd, "
+                              "grid.py:54-57)");
+                return LNH_ERR_UNSUPPORTED;
+            } else {
+                hipLaunchKernelGGL((k_grid_backward<T, D, 1, 1, true>), dim3(div_up(B, 256), L), block, 0, s, grad,
+                                   inputs, ge, B, m, align, interp);
+            }
+            break;
+        case 2:
+            hipLaunchKernelGGL((k_grid_backward<T, D, 2, 2, true>), dim3(div_up(B, 256), L), block, 0, s, grad, inputs,
+                               ge, B, m, align, interp);
+            break;
+        case 4:
+            hipLaunchKernelGGL((k_grid_backward<T, D, 4, 2, false>), dim3(div_up((uint64_t)B * 2, 256), L), block, 0, s,
+                               grad, inputs, ge, B, m, align, interp);
+            break;
+        case 8:
+            hipLaunchKernelGGL((k_grid_backward<T, D, 8, 2, false>), dim3(div_up((uint64_t)B * 4, 256), L), block, 0, s,
+                               grad, inputs, ge, B, m, align, interp);
+            break;
+        default: lnh_set_error("GridEncoding: C must be 1, 2, 4, or 8 (got %u)", C); return LNH_ERR_UNSUPPORTED;
+    }
+    return lnh_check_launch("lnh_grid_encode_backward");
+}
+
+template <typename T, int D>
+int launch_input_backward_c(const T *grad, const T *dy_dx, T *gi, uint32_t B, uint32_t C, uint32_t L, hipStream_t s) {
+    dim3 grid(div_up((uint64_t)B * D, 256)), block(256);
+    switch (C) {
+        case 1: hipLaunchKernelGGL((k_grid_input_backward<T, D, 1>), grid, block, 0, s, grad, dy_dx, gi, B, L); break;
+        case 2: hipLaunchKernelGGL((k_grid_input_backward<T, D, 2>), grid, block, 0, s, grad, dy_dx, gi, B, L); break;
+        case 4: hipLaunchKernelGGL((k_grid_input_backward<T, D, 4>), grid, block, 0, s, grad, dy_dx, gi, B, L); break;
+        case 8: hipLaunchKernelGGL((k_grid_input_backward<T, D, 8>), grid, block, 0, s, grad, dy_dx, gi, B, L); break;
+        default: return LNH_ERR_UNSUPPORTED;
+    }
+    return lnh_check_launch("lnh_grid_encode_backward(inputs)");
+}
+
+template <typename T, int D>
+int launch_tv_c(const T *inputs, const T *emb, T *grad, float weight, uint32_t B, uint32_t C, uint32_t L,
+                const GridMeta &m, uint32_t align, hipStream_t s) {
+    dim3 grid(div_up(B, 256), L), block(256);
+    switch (C) {
+        case 1:
+            if constexpr (sizeof(T) == 2) {
+                lnh_set_error("grad_total_variation: fp16 needs an even C");
+                return LNH_ERR_UNSUPPORTED;
+            } else {
+                hipLaunchKernelGGL((k_grad_tv<T, D, 1>), grid, block, 0, s, inputs, emb, grad, weight, B, m, align);
+            }
+            break;
+        case 2: hipLaunchKernelGGL((k_grad_tv<T, D, 2>), grid, block, 0, s, inputs, emb, grad, weight, B, m, align); break;
+        case 4: hipLaunchKernelGGL((k_grad_tv<T, D, 4>), grid, block, 0, s, inputs, emb, grad, weight, B, m, align); break;
+        case 8: hipLaunchKernelGGL((k_grad_tv<T, D, 8>), grid, block, 0, s, inputs, emb, grad, weight, B, m, align); break;
+        default: lnh_set_error("GridEncoding: C must be 1, 2, 4, or 8 (got %u)", C); return LNH_ERR_UNSUPPORTED;
+    }
+    return lnh_check_launch("lnh_grad_total_variation");
+}
+
+int check_common(const void *inputs, const int32_t *offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                 int dtype) {
+    LNH_REQUIRE(inputs && offsets_host, LNH_ERR_INVALID_ARG, "grid: null inputs/offsets");
+    LNH_REQUIRE(L >= 1 && L <= LNH_MAX_LEVELS, LNH_ERR_UNSUPPORTED, "grid: L must be in 1..%d (got %u)", LNH_MAX_LEVELS, L);
+    LNH_REQUIRE(D >= 2 && D <= 5, LNH_ERR_UNSUPPORTED, "GridEncoding: D must be 2, 3, 4 or 5 (got %u)", D);
+    LNH_REQUIRE(C == 1 || C == 2 || C == 4 || C == 8, LNH_ERR_UNSUPPORTED, "GridEncoding: C must be 1, 2, 4, or 8 (got %u)", C);
+    LNH_REQUIRE(dtype == LNH_F32 || dtype == LNH_F16, LNH_ERR_UNSUPPORTED, "grid: dtype must be LNH_F32 or LNH_F16");
+    (void)B;
+    return LNH_OK;
+}
+
+}  // namespace
+
+#define LNH_DISPATCH_D(D, CALL)                                   \
+    switch (D) {                                                  \
+        case 2: { constexpr int DD = 2; rc = CALL; } break;       \
+        case 3: { constexpr int DD = 3; rc = CALL; } break;       \
+        case 4: { constexpr int DD = 4; rc = CALL; } break;       \
+        case 5: { constexpr int DD = 5; rc = CALL; } break;       \
+        default: rc = LNH_ERR_UNSUPPORTED;                        \
+    }
+
+extern "C" {
+
+int lnh_grid_encode_forward(const float *inputs, const void *embeddings, const int32_t *offsets_host, void *outputs,
+                            uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void *dy_dx,
+                            uint32_t gridtype, int align_corners, uint32_t interp, int dtype, lnh_stream_t stream) {
+    int rc = check_common(inputs, offsets_host, B, D, C, L, dtype);
+    if (rc) return rc;
+    LNH_REQUIRE(embeddings && outputs, LNH_ERR_INVALID_ARG, "grid forward: null embeddings/outputs");
+    if (B == 0) return LNH_OK;
+    GridMeta m;
+    LNH_REQUIRE(build_meta(m, offsets_host, D, L, S, H, gridtype, align_corners != 0) == 0, LNH_ERR_INVALID_ARG,
+                "grid: offsets must be increasing and non-negative");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == LNH_F32) {
+        LNH_DISPATCH_D(D, (launch_forward_c<float, DD>(inputs, (const float *)embeddings, (float *)outputs,
+                                                       (float *)dy_dx, B, C, L, m, align_corners != 0, interp, s)))
+    } else {
+        LNH_DISPATCH_D(D, (launch_forward_c<half_t, DD>(inputs, (const half_t *)embeddings, (half_t *)outputs,
+                                                        (half_t *)dy_dx, B, C, L, m, align_corners != 0, interp, s)))
+    }
+    return rc;
+}
+
+int lnh_grid_encode_backward(const void *grad, const float *inputs, const void *embeddings,
+                             const int32_t *offsets_host, void *grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
+                             uint32_t L, float S, uint32_t H, const void *dy_dx, void *grad_inputs, uint32_t gridtype,
+                             int align_corners, uint32_t interp, int dtype, lnh_stream_t stream) {
+    (void)embeddings;
+    int rc = check_common(inputs, offsets_host, B, D, C, L, dtype);
+    if (rc) return rc;
+    LNH_REQUIRE(grad && grad_embeddings, LNH_ERR_INVALID_ARG, "grid backward: null grad/grad_embeddings");
+    LNH_REQUIRE((dy_dx == nullptr) == (grad_inputs == nullptr), LNH_ERR_INVALID_ARG,
+                "grid backward: dy_dx and grad_inputs must be given together");
+    if (B == 0) return LNH_OK;
+    GridMeta m;
+    LNH_REQUIRE(build_meta(m, offsets_host, D, L, S, H, gridtype, align_corners != 0) == 0, LNH_ERR_INVALID_ARG,
+                "grid: offsets must be increasing and non-negative");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == LNH_F32) {
+        LNH_DISPATCH_D(D, (launch_backward_c<float, DD>((const float *)grad, inputs, (float *)grad_embeddings, B, C, L,
+                                                        m, align_corners != 0, interp, s)))
+        if (rc == LNH_OK && dy_dx)
+            LNH_DISPATCH_D(D, (launch_input_backward_c<float, DD>((const float *)grad, (const float *)dy_dx,
+                                                                  (float *)grad_inputs, B, C, L, s)))
+    } else {
+        LNH_DISPATCH_D(D, (launch_backward_c<half_t, DD>((const half_t *)grad, inputs, (half_t *)grad_embeddings, B, C,
+                                                         L, m, align_corners != 0, interp, s)))
+        if (rc == LNH_OK && dy_dx)
+            LNH_DISPATCH_D(D, (launch_input_backward_c<half_t, DD>((const half_t *)grad, (const half_t *)dy_dx,
+                                                                   (half_t *)grad_inputs, B, C, L, s)))
+    }
+    return rc;
+}
+
+int lnh_grad_total_variation(const void *inputs, const void *embeddings, void *grad, const int32_t *offsets_host,
+                             float weight, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                             uint32_t gridtype, int align_corners, int dtype, lnh_stream_t stream) {
+    int rc = check_common(inputs, offsets_host, B, D, C, L, dtype);
+    if (rc) return rc;
+    LNH_REQUIRE(embeddings && grad, LNH_ERR_INVALID_ARG, "grad_total_variation: null embeddings/grad");
+    if (B == 0) return LNH_OK;
+    GridMeta m;
+    LNH_REQUIRE(build_meta(m, offsets_host, D, L, S, H, gridtype, align_corners != 0) == 0, LNH_ERR_INVALID_ARG,
+                "grid: offsets must be increasing and non-negative");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == LNH_F32) {
+        LNH_DISPATCH_D(D, (launch_tv_c<float, DD>((const float *)inputs, (const float *)embeddings, (float *)grad,
+                                                  weight, B, C, L, m, align_corners != 0, s)))
+    } else {
+        LNH_DISPATCH_D(D, (launch_tv_c<half_t, DD>((const half_t *)inputs, (const half_t *)embeddings, (half_t *)grad,
+                                                   weight, B, C, L, m, align_corners != 0, s)))
+    }
+    return rc;
+}
+
+int lnh_grid_corner_indices(const float *inputs, const int32_t *offsets_host, uint32_t *out_idx, uint32_t B,
+                            uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype,
+                            int align_corners, lnh_stream_t stream) {
+    int rc = check_common(inputs, offsets_host, B, D, C, L, LNH_F32);
+    if (rc) return rc;
+    LNH_REQUIRE(out_idx, LNH_ERR_INVALID_ARG, "grid indices: null output");
+    if (B == 0) return LNH_OK;
+    GridMeta m;
+    LNH_REQUIRE(build_meta(m, offsets_host, D, L, S, H, gridtype, align_corners != 0) == 0, LNH_ERR_INVALID_ARG,
+                "grid: offsets must be increasing and non-negative");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(div_up(B, 256), L), block(256);
+    switch (D) {
+        case 2: hipLaunchKernelGGL((k_grid_indices<2>), grid, block, 0, s, inputs, out_idx, B, C, m, (uint32_t)(align_corners != 0)); break;
+        case 3: hipLaunchKernelGGL((k_grid_indices<3>), grid, block, 0, s, inputs, out_idx, B, C, m, (uint32_t)(align_corners != 0)); break;
+        case 4: hipLaunchKernelGGL((k_grid_indices<4>), grid, block, 0, s, inputs, out_idx, B, C, m, (uint32_t)(align_corners != 0)); break;
+        case 5: hipLaunchKernelGGL((k_grid_indices<5>), grid, block, 0, s, inputs, out_idx, B, C, m, (uint32_t)(align_corners != 0)); break;
+    }
+    return lnh_check_launch("lnh_grid_corner_indices");
+}
+
+}  // extern "C"

@@ -1,0 +1,303 @@
+// mlp_bwd.h — backward of the fused tiny MLP on gfx950 MFMA (included by the mlp_bwd_*.hip translation units).
+//
+// One 256-thread workgroup = 4 waves walks the batch in steps of PB = 4*NT*16 points.  Per step every wave
+//   1. recomputes the hidden activations of ITS NT point tiles in registers (mlp_common.h chaining),
+//   2. back-propagates dY -> dH_l -> dX in registers with transposed weight fragments,
+// and the four waves COOPERATE on the weight gradients dW_l[o][i] = sum_p dH_l[p][o] * A_{l-1}[p][i]:
+//   3. each wave drops its dH_l^T / A_{l-1}^T columns into two workgroup-shared LDS tiles ([channel][point] fp16),
+//   4. after a barrier the 16x16 output tiles of dW_l are dealt round-robin to the waves; each wave contracts ITS
+//      tiles over all PB points with MFMA (k = points) into persistent fp32 accumulators.
+// The accumulators live in registers for the whole kernel and are flushed with one fp32 atomic per element per
+// workgroup.  (The reference computes dW with split-K CUTLASS GEMMs on side streams from saved activations,
+// lidarnerf/ffmlp/src/ffmlp.cu:1107-1263; here nothing but X, dY and W is read from HBM.)
+#pragma once
+#include "mlp_common.h"
+
+struct MlpBwdArgs {
+    const half_t *dY;  // [B,16]
+    const half_t *X;   // [B,in_dim]
+    const half_t *W;   // flat fp16 weights
+    half_t *dX;        // NULL or [B,in_dim]
+    float *dW;         // flat fp32, atomically accumulated
+    uint32_t B, in_dim, hidden, act, out_act;
+};
+
+template <int IN_KS, int HT, int NHM, int NT>
+struct BwdCfg {
+    static constexpr int HS = HT / 2;              // k-steps over a hidden vector
+    static constexpr int IT = IN_KS * 2;           // 16-feature input tiles (upper bound, masked by in_dim)
+    static constexpr int PB = 4 * NT * 16;         // points per workgroup step
+    static constexpr int LDP = PB + 8;             // LDS row pitch (halves): 16-byte aligned rows, staggered banks
+    static constexpr int PKS = PB / 32;            // k-steps over the points of a step
+    static constexpr int ROWS_G = HT * 16;         // gradient tile rows (hidden, or 16 for dY)
+    static constexpr int ROWS_A = (IT > HT ? IT : HT) * 16;  // activation tile rows
+    static constexpr int NQ0 = (HT * IT + 3) / 4;  // dW0 tiles per wave
+    static constexpr int NQH = (HT * HT + 3) / 4;  // dWh tiles per wave
+    static constexpr int NQO = (HT + 3) / 4;       // dWo tiles per wave
+    static constexpr size_t lds_bytes() { return (size_t)(ROWS_G + ROWS_A) * LDP * sizeof(half_t); }
+};
+
+template <int IN_KS, int HT, int NHM, int NT>
+__global__ void __launch_bounds__(256)
+k_mlp_backward(MlpBwdArgs a) {
+    using Cfg = BwdCfg<IN_KS, HT, NHM, NT>;
+    constexpr int HS = Cfg::HS, IT = Cfg::IT, PB = Cfg::PB, LDP = Cfg::LDP, PKS = Cfg::PKS;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    half_t *tileG = reinterpret_cast<half_t *>(smem_raw);  // [ROWS_G][LDP]  gradient^T
+    half_t *tileA = tileG + Cfg::ROWS_G * LDP;             // [ROWS_A][LDP]  activation^T
+
+    const uint32_t wid = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+    const uint32_t hidden = HT * 16, in_dim = a.in_dim, act = a.act, in_tiles = in_dim / 16;
+    const bool want_dx = a.dX != nullptr;
+    const uint32_t col0 = wid * NT * 16;  // this wave's first column inside the step
+
+    const half_t *W0 = a.W;
+    const half_t *Wh = W0 + (size_t)hidden * in_dim;
+    const half_t *Wo = Wh + (size_t)NHM * hidden * hidden;
+    float *dW0 = a.dW;
+    float *dWh = dW0 + (size_t)hidden * in_dim;
+    float *dWo = dWh + (size_t)NHM * hidden * hidden;
+
+    // ---- weight fragments (registers, once per wave)
+    half8_t w0[HT][IN_KS];
+#pragma unroll
+    for (int t = 0; t < HT; t++)
+#pragma unroll
+        for (int s = 0; s < IN_KS; s++) w0[t][s] = load_a_natural(W0, in_dim, 16 * t + c, s, g, in_dim);
+    half8_t wh[NHM > 0 ? NHM : 1][HT][HS], whT[NHM > 0 ? NHM : 1][HT][HS];
+#pragma unroll
+    for (int m = 0; m < NHM; m++)
+#pragma unroll
+        for (int t = 0; t < HT; t++)
+#pragma unroll
+            for (int s = 0; s < HS; s++) {
+                wh[m][t][s] = load_a_nu(Wh + (size_t)m * hidden * hidden, hidden, 16 * t + c, s, g);
+                whT[m][t][s] = load_at_nu(Wh + (size_t)m * hidden * hidden, hidden, 16 * t + c, s, g);
+            }
+    half8_t woT[HT];  // dH_last^T = Wo^T dY^T: K = 16 outputs in one zero-padded k-step
+#pragma unroll
+    for (int t = 0; t < HT; t++) woT[t] = load_at_natural(Wo, hidden, 16 * t + c, 0, g, 16);
+    half8_t w0T[IT][HS];
+#pragma unroll
+    for (int t = 0; t < IT; t++)
+#pragma unroll
+        for (int s = 0; s < HS; s++)
+            w0T[t][s] = (want_dx && (uint32_t)t < in_tiles) ? load_at_nu(W0, in_dim, 16 * t + c, s, g) : zero_h8();
+
+    // ---- this wave's share of the weight-gradient tiles
+    f32x4 gW0[Cfg::NQ0], gWh[NHM > 0 ? NHM : 1][Cfg::NQH], gWo[Cfg::NQO];
+#pragma unroll
+    for (int q = 0; q < Cfg::NQ0; q++) gW0[q] = zero_f4();
+#pragma unroll
+    for (int m = 0; m < NHM; m++)
+#pragma unroll
+        for (int q = 0; q < Cfg::NQH; q++) gWh[m][q] = zero_f4();
+#pragma unroll
+    for (int q = 0; q < Cfg::NQO; q++) gWo[q] = zero_f4();
+
+    auto put_packed = [&](half_t *tile, const half8_t (&v)[NT][HS]) {  // rows nu(s,g,j), columns of this wave
+#pragma unroll
+        for (int n = 0; n < NT; n++)
+#pragma unroll
+            for (int s = 0; s < HS; s++)
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    tile[(16 * (2 * s + (j >> 2)) + 4 * g + (j & 3)) * LDP + col0 + 16 * n + c] = v[n][s][j];
+    };
+    // contraction over the PB points of the step: acc += G^T rows [16*tg, +16) x A^T rows [16*ta, +16)
+    auto wgrad_tile = [&](f32x4 acc, uint32_t tg, uint32_t ta) {
+#pragma unroll
+        for (int ks = 0; ks < PKS; ks++) {
+            const half8_t fa = *reinterpret_cast<const half8_t *>(tileG + (16 * tg + c) * LDP + 32 * ks + 8 * g);
+            const half8_t fb = *reinterpret_cast<const half8_t *>(tileA + (16 * ta + c) * LDP + 32 * ks + 8 * g);
+            acc = MFMA16(fa, fb, acc);
+        }
+        return acc;
+    };
+
+    for (uint64_t step = (uint64_t)blockIdx.x * PB; step < a.B; step += (uint64_t)gridDim.x * PB) {
+        const uint64_t base = step + col0;
+        // ---- loads + forward recompute
+        half8_t bx[NT][IN_KS], by[NT];
+#pragma unroll
+        for (int n = 0; n < NT; n++) {
+            const uint64_t p = base + n * 16 + c;
+#pragma unroll
+            for (int s = 0; s < IN_KS; s++) {
+                const uint32_t k0 = 32 * s + 8 * g;
+                bx[n][s] = (p < a.B && k0 < in_dim) ? *reinterpret_cast<const half8_t *>(a.X + p * in_dim + k0) : zero_h8();
+            }
+            by[n] = (p < a.B && g < 2) ? *reinterpret_cast<const half8_t *>(a.dY + p * 16 + 8 * g) : zero_h8();
+        }
+        half8_t bh[NHM + 1][NT][HS];
+#pragma unroll
+        for (int n = 0; n < NT; n++) {
+            f32x4 acc[HT];
+#pragma unroll
+            for (int t = 0; t < HT; t++) {
+                acc[t] = zero_f4();
+#pragma unroll
+                for (int s = 0; s < IN_KS; s++) acc[t] = MFMA16(w0[t][s], bx[n][s], acc[t]);
+            }
+#pragma unroll
+            for (int s = 0; s < HS; s++)
+                bh[0][n][s] = pack_pair(acc[2 * s], acc[2 * s + 1], [&](float v) { return act_forward(act, v); });
+        }
+#pragma unroll
+        for (int m = 0; m < NHM; m++)
+#pragma unroll
+            for (int n = 0; n < NT; n++) {
+                f32x4 acc[HT];
+#pragma unroll
+                for (int t = 0; t < HT; t++) {
+                    acc[t] = zero_f4();
+#pragma unroll
+                    for (int s = 0; s < HS; s++) acc[t] = MFMA16(wh[m][t][s], bh[m][n][s], acc[t]);
+                }
+#pragma unroll
+                for (int s = 0; s < HS; s++)
+                    bh[m + 1][n][s] = pack_pair(acc[2 * s], acc[2 * s + 1], [&](float v) { return act_forward(act, v); });
+            }
+
+        // ---- output matrix: dWo[o][i] += sum_p dY[p][o] h_last[p][i]
+        if (g < 2) {
+#pragma unroll
+            for (int n = 0; n < NT; n++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) tileG[(8 * g + j) * LDP + col0 + 16 * n + c] = by[n][j];
+        }
+        put_packed(tileA, bh[NHM]);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < Cfg::NQO; q++) {
+            const uint32_t i = 4 * q + wid;
+            if (i < HT) gWo[q] = wgrad_tile(gWo[q], 0, i);
+        }
+        __syncthreads();
+
+        // ---- dH_last^T = Wo^T dY^T through the last hidden activation
+        half8_t bd[NT][HS];
+#pragma unroll
+        for (int n = 0; n < NT; n++) {
+            f32x4 acc[HT];
+#pragma unroll
+            for (int t = 0; t < HT; t++) acc[t] = MFMA16(woT[t], by[n], zero_f4());
+#pragma unroll
+            for (int s = 0; s < HS; s++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    bd[n][s][j] = (half_t)act_backward_post(act, acc[2 * s][j], (float)bh[NHM][n][s][j]);
+                    bd[n][s][4 + j] = (half_t)act_backward_post(act, acc[2 * s + 1][j], (float)bh[NHM][n][s][4 + j]);
+                }
+        }
+        // ---- hidden matrices, last to first
+#pragma unroll
+        for (int m = NHM - 1; m >= 0; m--) {
+            put_packed(tileG, bd);
+            put_packed(tileA, bh[m]);
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < Cfg::NQH; q++) {
+                const uint32_t idx = 4 * q + wid;
+                if (idx < HT * HT) gWh[m][q] = wgrad_tile(gWh[m][q], idx / HT, idx % HT);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int n = 0; n < NT; n++) {
+                f32x4 acc[HT];
+#pragma unroll
+                for (int t = 0; t < HT; t++) {
+                    acc[t] = zero_f4();
+#pragma unroll
+                    for (int s = 0; s < HS; s++) acc[t] = MFMA16(whT[m][t][s], bd[n][s], acc[t]);
+                }
+#pragma unroll
+                for (int s = 0; s < HS; s++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        bd[n][s][j] = (half_t)act_backward_post(act, acc[2 * s][j], (float)bh[m][n][s][j]);
+                        bd[n][s][4 + j] = (half_t)act_backward_post(act, acc[2 * s + 1][j], (float)bh[m][n][s][4 + j]);
+                    }
+            }
+        }
+        // ---- first matrix: dW0[o][i] += sum_p dH_0[p][o] x[p][i]
+        put_packed(tileG, bd);
+#pragma unroll
+        for (int n = 0; n < NT; n++)
+#pragma unroll
+            for (int s = 0; s < IN_KS; s++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) tileA[(32 * s + 8 * g + j) * LDP + col0 + 16 * n + c] = bx[n][s][j];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < Cfg::NQ0; q++) {
+            const uint32_t idx = 4 * q + wid;
+            if (idx < HT * IT) gW0[q] = wgrad_tile(gW0[q], idx / IT, idx % IT);
+        }
+        __syncthreads();
+        // ---- dX^T = W0^T dH_0^T
+        if (want_dx) {
+#pragma unroll
+            for (int n = 0; n < NT; n++) {
+                const uint64_t p = base + n * 16 + c;
+#pragma unroll
+                for (int t = 0; t < IT; t++) {
+                    f32x4 acc = zero_f4();
+#pragma unroll
+                    for (int s = 0; s < HS; s++) acc = MFMA16(w0T[t][s], bd[n][s], acc);
+                    if (p < a.B && (uint32_t)t < in_tiles) {
+                        half4_t v = {(half_t)acc[0], (half_t)acc[1], (half_t)acc[2], (half_t)acc[3]};
+                        *reinterpret_cast<half4_t *>(a.dX + p * in_dim + 16 * t + 4 * g) = v;
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- flush (D layout: element (row 4g+r, col c) of each 16x16 tile)
+#pragma unroll
+    for (int q = 0; q < Cfg::NQ0; q++) {
+        const uint32_t idx = 4 * q + wid, t = idx / IT, i = idx % IT;
+        if (idx < HT * IT && i < in_tiles) {
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                unsafeAtomicAdd(dW0 + (size_t)(16 * t + 4 * g + r) * in_dim + 16 * i + c, gW0[q][r]);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < NHM; m++)
+#pragma unroll
+        for (int q = 0; q < Cfg::NQH; q++) {
+            const uint32_t idx = 4 * q + wid, t = idx / HT, i = idx % HT;
+            if (idx < HT * HT) {
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    unsafeAtomicAdd(dWh + (size_t)m * hidden * hidden + (size_t)(16 * t + 4 * g + r) * hidden + 16 * i + c,
+                                    gWh[m][q][r]);
+            }
+        }
+#pragma unroll
+    for (int q = 0; q < Cfg::NQO; q++) {
+        const uint32_t i = 4 * q + wid;
+        if (i < HT) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) unsafeAtomicAdd(dWo + (size_t)(4 * g + r) * hidden + 16 * i + c, gWo[q][r]);
+        }
+    }
+}
+
+template <int IN_KS, int HT, int NHM>
+int launch_mlp_backward(const MlpBwdArgs &a, hipStream_t s) {
+    constexpr int NT = 2;
+    using Cfg = BwdCfg<IN_KS, HT, NHM, NT>;
+    const size_t lds = Cfg::lds_bytes();
+    const uint32_t steps = div_up(a.B, Cfg::PB);
+    const uint32_t grid = steps < 768 ? steps : 768;
+    auto k = k_mlp_backward<IN_KS, HT, NHM, NT>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, a);
+    return lnh_check_launch("lnh_mlp_backward");
+}
+
+
+

@@ -1,0 +1,111 @@
+// mlp_common.h — register-resident tiny-MLP building blocks on gfx950 MFMA (v_mfma_f32_16x16x32_f16).
+//
+// Orientation: every layer is computed TRANSPOSED,  H^T[neuron, point] = W[neuron, k] * X^T[k, point]:
+//   A operand = weight matrix (row m = output neuron),  B operand = activations (column n = sample point).
+// With the 16x16 C/D layout (lane = 16*g + c holds D[4g + r][c], r = 0..3) a lane ends up with the values
+// {neuron 16t + 4g + r} of ITS OWN point c.  The B operand of the next layer needs, per lane, 8 k-values of the same
+// point c — and since a dot product does not care in which order k is enumerated as long as A and B agree, we DEFINE
+// the k-enumeration of hidden-layer products as
+//        k-step s, lane group g, element j  <->  neuron  nu(s, g, j) = 16 * (2s + (j >> 2)) + 4g + (j & 3)
+// which is exactly what the lane already holds in its accumulators.  The activation is applied in registers, the
+// result is narrowed to fp16 and fed straight back as the next B operand: no LDS, no cross-lane traffic, no global
+// round trip between layers.  The weight fragments are gathered once per wave with the same enumeration.
+//
+// Replaces the shared-memory/WMMA chain of lidarnerf/ffmlp/src/ffmlp.cu:54-180,460-576 (semantics only).
+#pragma once
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+
+constexpr float kActK = 10.0f;  // utils.h squareplus / softplus sharpness
+
+// lidarnerf/ffmlp/src/utils.h:479-531
+__device__ __forceinline__ float act_forward(uint32_t a, float x) {
+    switch (a) {
+        case LNH_ACT_RELU: return x > 0.0f ? x : 0.0f;
+        case LNH_ACT_EXPONENTIAL: return expf(x);
+        case LNH_ACT_SINE: return sinf(x);
+        case LNH_ACT_SIGMOID: return 1.0f / (1.0f + expf(-x));
+        case LNH_ACT_SQUAREPLUS: {
+            const float y = x * kActK;
+            return 0.5f * (y + sqrtf(y * y + 4.0f)) / kActK;
+        }
+        case LNH_ACT_SOFTPLUS: return logf(expf(x * kActK) + 1.0f) / kActK;
+        default: return x;
+    }
+}
+// lidarnerf/ffmlp/src/utils.h:609-664 (transfer from the stored POST-activation)
+__device__ __forceinline__ float act_backward_post(uint32_t a, float g, float post) {
+    switch (a) {
+        case LNH_ACT_RELU: return post > 0.0f ? g : 0.0f;
+        case LNH_ACT_EXPONENTIAL: return g * post;
+        case LNH_ACT_SIGMOID: return g * post * (1.0f - post);
+        case LNH_ACT_SQUAREPLUS: {
+            const float y = post * kActK;
+            return g * (y * y / (y * y + 1.0f));
+        }
+        case LNH_ACT_SOFTPLUS: return g * (1.0f - expf(-post * kActK));
+        default: return g;
+    }
+}
+
+__device__ __forceinline__ half8_t zero_h8() {
+    half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+    return z;
+}
+__device__ __forceinline__ f32x4 zero_f4() {
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    return z;
+}
+
+// A fragment of a row-major [rows, ld] matrix with the NATURAL k enumeration (first layer: k = 32s + 8g + j).
+__device__ __forceinline__ half8_t load_a_natural(const half_t *__restrict__ W, uint32_t ld, uint32_t row, uint32_t s,
+                                                  uint32_t g, uint32_t kmax) {
+    const uint32_t k0 = 32 * s + 8 * g;
+    if (k0 >= kmax) return zero_h8();
+    return *reinterpret_cast<const half8_t *>(W + (size_t)row * ld + k0);
+}
+// A fragment with the nu() enumeration (hidden layers): two 4-element groups.
+__device__ __forceinline__ half8_t load_a_nu(const half_t *__restrict__ W, uint32_t ld, uint32_t row, uint32_t s,
+                                             uint32_t g) {
+    const half4_t lo = *reinterpret_cast<const half4_t *>(W + (size_t)row * ld + 32 * s + 4 * g);
+    const half4_t hi = *reinterpret_cast<const half4_t *>(W + (size_t)row * ld + 32 * s + 16 + 4 * g);
+    half8_t r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return r;
+}
+// Transposed A fragment: A[m][k] = W[k-th row][m-th column] of a row-major [rows, ld] matrix, natural k.
+// Used by the backward pass (dX^T = W^T dY^T).  kmax = number of valid rows of W.
+__device__ __forceinline__ half8_t load_at_natural(const half_t *__restrict__ W, uint32_t ld, uint32_t col,
+                                                   uint32_t s, uint32_t g, uint32_t kmax) {
+    half8_t r;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t k = 32 * s + 8 * g + j;
+        r[j] = k < kmax ? W[(size_t)k * ld + col] : (half_t)0.0f;
+    }
+    return r;
+}
+__device__ __forceinline__ half8_t load_at_nu(const half_t *__restrict__ W, uint32_t ld, uint32_t col, uint32_t s,
+                                              uint32_t g) {
+    half8_t r;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t k = 16 * (2 * s + (j >> 2)) + 4 * g + (j & 3);
+        r[j] = W[(size_t)k * ld + col];
+    }
+    return r;
+}
+
+// Pack the accumulators of two consecutive M-tiles (2s, 2s+1) of one point tile into the next B operand.
+template <typename F>
+__device__ __forceinline__ half8_t pack_pair(const f32x4 &lo, const f32x4 &hi, F &&f) {
+    half8_t r;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        r[j] = (half_t)f(lo[j]);
+        r[4 + j] = (half_t)f(hi[j]);
+    }
+    return r;
+}

@@ -1,0 +1,412 @@
+// raymarch.hip — ray utilities and occupancy-grid machinery for gfx950.
+// Semantics: lidarnerf/raymarching/src/raymarching.cu (near/far 104-157, sphere 182-217, Morton 71-95/237-279,
+// packbits 286-306, march_rays_train 331-534, composite_rays_train 577-772).
+//
+// Built with -ffp-contract=off: every a*b+c that the reference's compiler fuses is written as an explicit fmaf
+// below, everything else is evaluated exactly as written, so the integer results (cell index, occupancy bit, step
+// counts, (id, offset, count) ray table) are bit-identical to the CPU oracle.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)); }
+__device__ __forceinline__ float signf(float x) { return copysignf(1.0f, x); }
+
+// raymarching.cu:71-95 — 10-bit-per-axis Morton code via magic-number bit spreading
+__device__ __forceinline__ uint32_t spread3(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+__device__ __forceinline__ uint32_t morton_encode(uint32_t x, uint32_t y, uint32_t z) {
+    return spread3(x) | (spread3(y) << 1) | (spread3(z) << 2);
+}
+__device__ __forceinline__ uint32_t compact3(uint32_t x) {
+    x &= 0x49249249u;
+    x = (x | (x >> 2)) & 0xc30c30c3u;
+    x = (x | (x >> 4)) & 0x0f00f00fu;
+    x = (x | (x >> 8)) & 0xff0000ffu;
+    x = (x | (x >> 16)) & 0x0000ffffu;
+    return x;
+}
+
+// raymarching.cu:51-69
+__device__ __forceinline__ int mip_from_pos(float x, float y, float z, float max_cascade) {
+    const float mx = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
+    int e;
+    frexpf(mx, &e);
+    return (int)fminf(max_cascade - 1, fmaxf(0.0f, (float)e));
+}
+__device__ __forceinline__ int mip_from_dt(float dt, float H, float max_cascade) {
+    const float mx = (float)((double)(dt * H) * 0.5);
+    int e;
+    frexpf(mx, &e);
+    return (int)fminf(max_cascade - 1, fmaxf(0.0f, (float)e));
+}
+// raymarching.cu:397-405: product in double, clamp in float, truncate
+__device__ __forceinline__ int cell_coord(float x, float mip_rbound, uint32_t H) {
+    const double v = 0.5 * (double)fmaf(x, mip_rbound, 1.0f) * (double)H;
+    return (int)clampf((float)v, 0.0f, (float)(H - 1));
+}
+
+struct Probe {
+    float x, y, z, dt, t_next;
+    uint32_t index;
+    bool occ;
+};
+
+struct MarchRay {
+    float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
+};
+
+// One decision of the marcher at parameter t (raymarching.cu:379-439).
+__device__ __forceinline__ Probe probe(const MarchRay &r, float t, const uint8_t *__restrict__ grid, float bound,
+                                       float dt_gamma, float dt_min, float dt_max, uint32_t C, uint32_t H, float rH,
+                                       float H3) {
+    Probe p;
+    p.x = clampf(fmaf(t, r.dx, r.ox), -bound, bound);
+    p.y = clampf(fmaf(t, r.dy, r.oy), -bound, bound);
+    p.z = clampf(fmaf(t, r.dz, r.oz), -bound, bound);
+    p.dt = clampf(t * dt_gamma, dt_min, dt_max);
+    const int level = max(mip_from_pos(p.x, p.y, p.z, (float)C), mip_from_dt(p.dt, (float)H, (float)C));
+    const float mip_bound = fminf(scalbnf(1.0f, level), bound);
+    const float mip_rbound = 1 / mip_bound;
+    const int nx = cell_coord(p.x, mip_rbound, H), ny = cell_coord(p.y, mip_rbound, H),
+              nz = cell_coord(p.z, mip_rbound, H);
+    p.index = (uint32_t)((float)level * H3 + (float)morton_encode((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
+    p.occ = (grid[p.index >> 3] & (1u << (p.index & 7u))) != 0;
+    p.t_next = t;
+    if (!p.occ) {
+        const float tx = (((nx + 0.5f + 0.5f * signf(r.dx)) * rH * 2 - 1) * mip_bound - p.x) * r.rdx;
+        const float ty = (((ny + 0.5f + 0.5f * signf(r.dy)) * rH * 2 - 1) * mip_bound - p.y) * r.rdy;
+        const float tz = (((nz + 0.5f + 0.5f * signf(r.dz)) * rH * 2 - 1) * mip_bound - p.z) * r.rdz;
+        const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+        do {
+            t += clampf(t * dt_gamma, dt_min, dt_max);
+        } while (t < tt);
+        p.t_next = t;
+    }
+    return p;
+}
+
+__global__ void __launch_bounds__(128)
+k_near_far(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ aabb,
+           uint32_t N, float min_near, float *__restrict__ nears, float *__restrict__ fars) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+    const float rdx = 1 / rays_d[n * 3], rdy = 1 / rays_d[n * 3 + 1], rdz = 1 / rays_d[n * 3 + 2];
+    const float FMAX = 3.402823466e+38f;
+    float near = (aabb[0] - ox) * rdx, far = (aabb[3] - ox) * rdx;
+    if (near > far) { float t = near; near = far; far = t; }
+    float ny = (aabb[1] - oy) * rdy, fy = (aabb[4] - oy) * rdy;
+    if (ny > fy) { float t = ny; ny = fy; fy = t; }
+    if (near > fy || ny > far) { nears[n] = fars[n] = FMAX; return; }
+    if (ny > near) near = ny;
+    if (fy < far) far = fy;
+    float nz = (aabb[2] - oz) * rdz, fz = (aabb[5] - oz) * rdz;
+    if (nz > fz) { float t = nz; nz = fz; fz = t; }
+    if (near > fz || nz > far) { nears[n] = fars[n] = FMAX; return; }
+    if (nz > near) near = nz;
+    if (fz < far) far = fz;
+    if (near < min_near) near = min_near;
+    nears[n] = near;
+    fars[n] = far;
+}
+
+__global__ void __launch_bounds__(128)
+k_sph_from_ray(const float *__restrict__ rays_o, const float *__restrict__ rays_d, float radius, uint32_t N,
+               float *__restrict__ coords) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+    const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
+    const float A = dx * dx + dy * dy + dz * dz;
+    const float Bh = ox * dx + oy * dy + oz * dz;
+    const float Cc = ox * ox + oy * oy + oz * oz - radius * radius;
+    const float t = (-Bh + sqrtf(Bh * Bh - A * Cc)) / A;
+    const float x = ox + t * dx, y = oy + t * dy, z = oz + t * dz;
+    const float theta = atan2f(sqrtf(x * x + z * z), y);
+    const float phi = atan2f(z, x);
+    coords[n * 2] = 2 * theta * 0.3183098861837907f - 1;
+    coords[n * 2 + 1] = phi * 0.3183098861837907f;
+}
+
+__global__ void __launch_bounds__(256)
+k_morton(const int32_t *__restrict__ coords, uint32_t N, int32_t *__restrict__ indices) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    indices[n] = (int32_t)morton_encode((uint32_t)coords[n * 3], (uint32_t)coords[n * 3 + 1], (uint32_t)coords[n * 3 + 2]);
+}
+__global__ void __launch_bounds__(256)
+k_morton_invert(const int32_t *__restrict__ indices, uint32_t N, int32_t *__restrict__ coords) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int32_t ind = indices[n];  // arithmetic shifts of the signed value, as in the reference
+    coords[n * 3] = (int32_t)compact3((uint32_t)(ind >> 0));
+    coords[n * 3 + 1] = (int32_t)compact3((uint32_t)(ind >> 1));
+    coords[n * 3 + 2] = (int32_t)compact3((uint32_t)(ind >> 2));
+}
+
+// One thread = one output byte = 8 floats read as two 16-byte loads (32 B contiguous per lane).
+__global__ void __launch_bounds__(256)
+k_packbits(const float *__restrict__ grid, uint32_t N, float thresh, uint8_t *__restrict__ bitfield) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float4 a = reinterpret_cast<const float4 *>(grid)[(size_t)n * 2];
+    const float4 b = reinterpret_cast<const float4 *>(grid)[(size_t)n * 2 + 1];
+    uint32_t bits = 0;
+    bits |= (a.x > thresh) ? 1u : 0u;
+    bits |= (a.y > thresh) ? 2u : 0u;
+    bits |= (a.z > thresh) ? 4u : 0u;
+    bits |= (a.w > thresh) ? 8u : 0u;
+    bits |= (b.x > thresh) ? 16u : 0u;
+    bits |= (b.y > thresh) ? 32u : 0u;
+    bits |= (b.z > thresh) ? 64u : 0u;
+    bits |= (b.w > thresh) ? 128u : 0u;
+    bitfield[n] = (uint8_t)bits;
+}
+
+__global__ void __launch_bounds__(256)
+k_occupancy_lookup(const float *__restrict__ xyz, const float *__restrict__ dt, const uint8_t *__restrict__ grid,
+                   float bound, uint32_t N, uint32_t C, uint32_t H, uint32_t *__restrict__ cell_index,
+                   uint8_t *__restrict__ occ) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float x = clampf(xyz[n * 3], -bound, bound), y = clampf(xyz[n * 3 + 1], -bound, bound),
+                z = clampf(xyz[n * 3 + 2], -bound, bound);
+    const int level = max(mip_from_pos(x, y, z, (float)C), mip_from_dt(dt[n], (float)H, (float)C));
+    const float mip_bound = fminf(scalbnf(1.0f, level), bound);
+    const float mip_rbound = 1 / mip_bound;
+    const int nx = cell_coord(x, mip_rbound, H), ny = cell_coord(y, mip_rbound, H), nz = cell_coord(z, mip_rbound, H);
+    const float H3 = (float)(H * H * H);
+    const uint32_t index = (uint32_t)((float)level * H3 + (float)morton_encode((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
+    cell_index[n] = index;
+    occ[n] = (grid[index >> 3] & (1u << (index & 7u))) != 0;
+}
+
+// raymarching.cu:331-534.  One lane per ray (the march is a data-dependent serial walk); 64-thread workgroups so a
+// 4096-ray batch still spreads over 64 CUs.  Both passes recompute the walk; only pass 2 writes.
+__global__ void __launch_bounds__(64)
+k_march_rays_train(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                   const uint8_t *__restrict__ grid, float bound, float dt_gamma, uint32_t max_steps, uint32_t N,
+                   uint32_t C, uint32_t H, uint32_t M, const float *__restrict__ nears,
+                   const float *__restrict__ fars, float *__restrict__ xyzs, float *__restrict__ dirs,
+                   float *__restrict__ deltas, int32_t *__restrict__ rays, int32_t *__restrict__ counter,
+                   const float *__restrict__ noises) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    MarchRay r;
+    r.ox = rays_o[n * 3]; r.oy = rays_o[n * 3 + 1]; r.oz = rays_o[n * 3 + 2];
+    r.dx = rays_d[n * 3]; r.dy = rays_d[n * 3 + 1]; r.dz = rays_d[n * 3 + 2];
+    r.rdx = 1 / r.dx; r.rdy = 1 / r.dy; r.rdz = 1 / r.dz;
+    const float rH = 1 / (float)H, H3 = (float)(H * H * H);
+    const float far = fars[n];
+    const float SQRT3 = 1.7320508075688772f;
+    const float dt_min = 2 * SQRT3 / max_steps;
+    const float dt_max = 2 * SQRT3 * (float)(1 << (C - 1)) / H;
+    float t0 = nears[n];
+    t0 += clampf(t0 * dt_gamma, dt_min, dt_max) * noises[n];
+
+    float t = t0;
+    uint32_t num_steps = 0;
+    while (t < far && num_steps < max_steps) {
+        const Probe p = probe(r, t, grid, bound, dt_gamma, dt_min, dt_max, C, H, rH, H3);
+        if (p.occ) {
+            num_steps++;
+            t += p.dt;
+        } else {
+            t = p.t_next;
+        }
+    }
+    const uint32_t point_index = (uint32_t)atomicAdd(counter, (int32_t)num_steps);
+    const uint32_t ray_index = (uint32_t)atomicAdd(counter + 1, 1);
+    rays[ray_index * 3] = (int32_t)n;
+    rays[ray_index * 3 + 1] = (int32_t)point_index;
+    rays[ray_index * 3 + 2] = (int32_t)num_steps;
+    if (num_steps == 0) return;
+    if (point_index + num_steps > M) return;
+
+    float *px = xyzs + (size_t)point_index * 3, *pd = dirs + (size_t)point_index * 3,
+          *pl = deltas + (size_t)point_index * 2;
+    t = t0;
+    uint32_t step = 0;
+    float last_t = t;
+    while (t < far && step < num_steps) {
+        const Probe p = probe(r, t, grid, bound, dt_gamma, dt_min, dt_max, C, H, rH, H3);
+        if (p.occ) {
+            px[0] = p.x; px[1] = p.y; px[2] = p.z;
+            pd[0] = r.dx; pd[1] = r.dy; pd[2] = r.dz;
+            t += p.dt;
+            pl[0] = p.dt;
+            pl[1] = t - last_t;
+            last_t = t;
+            px += 3; pd += 3; pl += 2;
+            step++;
+        } else {
+            t = p.t_next;
+        }
+    }
+}
+
+// raymarching.cu:577-655
+__global__ void __launch_bounds__(64)
+k_composite_train_fwd(const float *__restrict__ sigmas, const float *__restrict__ rgbs,
+                      const float *__restrict__ deltas, const int32_t *__restrict__ rays, uint32_t M, uint32_t N,
+                      float T_thresh, float *__restrict__ weights_sum, float *__restrict__ depth,
+                      float *__restrict__ image) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1],
+                   num_steps = (uint32_t)rays[n * 3 + 2];
+    if (num_steps == 0 || offset + num_steps > M) {
+        weights_sum[index] = 0; depth[index] = 0;
+        image[index * 3] = 0; image[index * 3 + 1] = 0; image[index * 3 + 2] = 0;
+        return;
+    }
+    const float *s = sigmas + offset, *c = rgbs + (size_t)offset * 3, *dl = deltas + (size_t)offset * 2;
+    float T = 1.0f, r = 0, g = 0, b = 0, ws = 0, t = 0, d = 0;
+    for (uint32_t step = 0; step < num_steps; step++) {
+        const float alpha = 1.0f - expf(-s[0] * dl[0]);
+        const float weight = alpha * T;
+        r += weight * c[0]; g += weight * c[1]; b += weight * c[2];
+        t += dl[1];
+        d += weight * t;
+        ws += weight;
+        T *= 1.0f - alpha;
+        if (T < T_thresh) break;
+        s++; c += 3; dl += 2;
+    }
+    weights_sum[index] = ws; depth[index] = d;
+    image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
+}
+
+// raymarching.cu:690-772
+__global__ void __launch_bounds__(64)
+k_composite_train_bwd(const float *__restrict__ grad_ws, const float *__restrict__ grad_image,
+                      const float *__restrict__ sigmas, const float *__restrict__ rgbs,
+                      const float *__restrict__ deltas, const int32_t *__restrict__ rays,
+                      const float *__restrict__ weights_sum, const float *__restrict__ image, uint32_t M, uint32_t N,
+                      float T_thresh, float *__restrict__ grad_sigmas, float *__restrict__ grad_rgbs) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1],
+                   num_steps = (uint32_t)rays[n * 3 + 2];
+    if (num_steps == 0 || offset + num_steps > M) return;
+    const float gi0 = grad_image[index * 3], gi1 = grad_image[index * 3 + 1], gi2 = grad_image[index * 3 + 2];
+    const float gws = grad_ws[index], ws_final = weights_sum[index];
+    const float rf = image[index * 3], gf = image[index * 3 + 1], bf = image[index * 3 + 2];
+    const float *s = sigmas + offset, *c = rgbs + (size_t)offset * 3, *dl = deltas + (size_t)offset * 2;
+    float *gs = grad_sigmas + offset, *gc = grad_rgbs + (size_t)offset * 3;
+    float T = 1.0f, r = 0, g = 0, b = 0, ws = 0;
+    for (uint32_t step = 0; step < num_steps; step++) {
+        const float alpha = 1.0f - expf(-s[0] * dl[0]);
+        const float weight = alpha * T;
+        r += weight * c[0]; g += weight * c[1]; b += weight * c[2];
+        ws += weight;
+        T *= 1.0f - alpha;
+        gc[0] = gi0 * weight; gc[1] = gi1 * weight; gc[2] = gi2 * weight;
+        gs[0] = dl[0] * (gi0 * (T * c[0] - (rf - r)) + gi1 * (T * c[1] - (gf - g)) + gi2 * (T * c[2] - (bf - b)) +
+                         gws * (1 - ws_final));
+        if (T < T_thresh) break;
+        s++; c += 3; dl += 2; gs++; gc += 3;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int lnh_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb, uint32_t N, float min_near,
+                           float *nears, float *fars, lnh_stream_t stream) {
+    LNH_REQUIRE(rays_o && rays_d && aabb && nears && fars, LNH_ERR_INVALID_ARG, "near_far_from_aabb: null pointer");
+    if (N == 0) return LNH_OK;
+    hipLaunchKernelGGL(k_near_far, dim3(div_up(N, 128)), dim3(128), 0, (hipStream_t)stream, rays_o, rays_d, aabb, N,
+                       min_near, nears, fars);
+    return lnh_check_launch("lnh_near_far_from_aabb");
+}
+
+int lnh_sph_from_ray(const float *rays_o, const float *rays_d, float radius, uint32_t N, float *coords,
+                     lnh_stream_t stream) {
+    LNH_REQUIRE(rays_o && rays_d && coords, LNH_ERR_INVALID_ARG, "sph_from_ray: null pointer");
+    if (N == 0) return LNH_OK;
+    hipLaunchKernelGGL(k_sph_from_ray, dim3(div_up(N, 128)), dim3(128), 0, (hipStream_t)stream, rays_o, rays_d, radius,
+                       N, coords);
+    return lnh_check_launch("lnh_sph_from_ray");
+}
+
+int lnh_morton3D(const int32_t *coords, uint32_t N, int32_t *indices, lnh_stream_t stream) {
+    LNH_REQUIRE(coords && indices, LNH_ERR_INVALID_ARG, "morton3D: null pointer");
+    if (N == 0) return LNH_OK;
+    hipLaunchKernelGGL(k_morton, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, coords, N, indices);
+    return lnh_check_launch("lnh_morton3D");
+}
+
+int lnh_morton3D_invert(const int32_t *indices, uint32_t N, int32_t *coords, lnh_stream_t stream) {
+    LNH_REQUIRE(coords && indices, LNH_ERR_INVALID_ARG, "morton3D_invert: null pointer");
+    if (N == 0) return LNH_OK;
+    hipLaunchKernelGGL(k_morton_invert, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, indices, N, coords);
+    return lnh_check_launch("lnh_morton3D_invert");
+}
+
+int lnh_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *bitfield, lnh_stream_t stream) {
+    LNH_REQUIRE(grid && bitfield, LNH_ERR_INVALID_ARG, "packbits: null pointer");
+    LNH_REQUIRE(((uintptr_t)grid & 15) == 0, LNH_ERR_INVALID_ARG, "packbits: grid must be 16-byte aligned");
+    if (N == 0) return LNH_OK;
+    hipLaunchKernelGGL(k_packbits, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, grid, N, density_thresh,
+                       bitfield);
+    return lnh_check_launch("lnh_packbits");
+}
+
+int lnh_occupancy_lookup(const float *xyz, const float *dt, const uint8_t *bitfield, float bound, uint32_t N,
+                         uint32_t C, uint32_t H, uint32_t *cell_index, uint8_t *occ, lnh_stream_t stream) {
+    LNH_REQUIRE(xyz && dt && bitfield && cell_index && occ, LNH_ERR_INVALID_ARG, "occupancy_lookup: null pointer");
+    LNH_REQUIRE(C >= 1 && C <= 8 && H >= 1 && H <= 1024, LNH_ERR_INVALID_ARG, "occupancy_lookup: bad cascade / grid size");
+    if (N == 0) return LNH_OK;
+    hipLaunchKernelGGL(k_occupancy_lookup, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, xyz, dt, bitfield,
+                       bound, N, C, H, cell_index, occ);
+    return lnh_check_launch("lnh_occupancy_lookup");
+}
+
+int lnh_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma,
+                         uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float *nears,
+                         const float *fars, float *xyzs, float *dirs, float *deltas, int32_t *rays, int32_t *counter,
+                         const float *noises, lnh_stream_t stream) {
+    LNH_REQUIRE(rays_o && rays_d && grid && nears && fars && xyzs && dirs && deltas && rays && counter && noises,
+                LNH_ERR_INVALID_ARG, "march_rays_train: null pointer");
+    LNH_REQUIRE(C >= 1 && C <= 8 && H >= 1 && H <= 1024 && max_steps >= 1, LNH_ERR_INVALID_ARG,
+                "march_rays_train: bad cascade / grid size / max_steps");
+    if (N == 0) return LNH_OK;
+    hipLaunchKernelGGL(k_march_rays_train, dim3(div_up(N, 64)), dim3(64), 0, (hipStream_t)stream, rays_o, rays_d, grid,
+                       bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays, counter, noises);
+    return lnh_check_launch("lnh_march_rays_train");
+}
+
+int lnh_composite_rays_train_forward(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays,
+                                     uint32_t M, uint32_t N, float T_thresh, float *weights_sum, float *depth,
+                                     float *image, lnh_stream_t stream) {
+    LNH_REQUIRE(sigmas && rgbs && deltas && rays && weights_sum && depth && image, LNH_ERR_INVALID_ARG,
+                "composite_rays_train_forward: null pointer");
+    if (N == 0) return LNH_OK;
+    hipLaunchKernelGGL(k_composite_train_fwd, dim3(div_up(N, 64)), dim3(64), 0, (hipStream_t)stream, sigmas, rgbs,
+                       deltas, rays, M, N, T_thresh, weights_sum, depth, image);
+    return lnh_check_launch("lnh_composite_rays_train_forward");
+}
+
+int lnh_composite_rays_train_backward(const float *grad_weights_sum, const float *grad_image, const float *sigmas,
+                                      const float *rgbs, const float *deltas, const int32_t *rays,
+                                      const float *weights_sum, const float *image, uint32_t M, uint32_t N,
+                                      float T_thresh, float *grad_sigmas, float *grad_rgbs, lnh_stream_t stream) {
+    LNH_REQUIRE(grad_weights_sum && grad_image && sigmas && rgbs && deltas && rays && weights_sum && image &&
+                    grad_sigmas && grad_rgbs,
+                LNH_ERR_INVALID_ARG, "composite_rays_train_backward: null pointer");
+    if (N == 0) return LNH_OK;
+    hipLaunchKernelGGL(k_composite_train_bwd, dim3(div_up(N, 64)), dim3(64), 0, (hipStream_t)stream, grad_weights_sum,
+                       grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, T_thresh, grad_sigmas,
+                       grad_rgbs);
+    return lnh_check_launch("lnh_composite_rays_train_backward");
+}
+
+}  // extern "C"

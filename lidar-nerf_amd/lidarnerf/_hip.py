@@ -1,0 +1,105 @@
+"""ctypes binding of liblidarnerf_hip.so (C ABI: include/lidarnerf_hip.h).
+
+PyTorch is used only for device memory and streams: every call passes raw device pointers + sizes + the current HIP
+stream.  There is NO CPU fallback: if the library is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "liblidarnerf_hip.so")
+
+P, U32, I32, F32 = C.c_void_p, C.c_uint32, C.c_int, C.c_float
+
+# name -> argument ctypes (stream is appended automatically)
+_SIGS = {
+    "lnh_grid_encode_forward": [P, P, P, P, U32, U32, U32, U32, F32, U32, P, U32, I32, U32, I32],
+    "lnh_grid_encode_backward": [P, P, P, P, P, U32, U32, U32, U32, F32, U32, P, P, U32, I32, U32, I32],
+    "lnh_grad_total_variation": [P, P, P, P, F32, U32, U32, U32, U32, F32, U32, U32, I32, I32],
+    "lnh_grid_corner_indices": [P, P, P, U32, U32, U32, U32, F32, U32, U32, I32],
+    "lnh_freq_encode_forward": [P, U32, U32, U32, U32, P],
+    "lnh_freq_encode_backward": [P, P, U32, U32, U32, U32, P],
+    "lnh_sh_encode_forward": [P, P, U32, U32, U32, P],
+    "lnh_sh_encode_backward": [P, P, U32, U32, U32, P, P],
+    "lnh_mlp_forward": [P, P, U32, U32, U32, U32, U32, U32, U32, P, P],
+    "lnh_mlp_backward": [P, P, P, U32, U32, U32, U32, U32, U32, U32, P, P],
+    "lnh_near_far_from_aabb": [P, P, P, U32, F32, P, P],
+    "lnh_sph_from_ray": [P, P, F32, U32, P],
+    "lnh_morton3D": [P, U32, P],
+    "lnh_morton3D_invert": [P, U32, P],
+    "lnh_packbits": [P, U32, F32, P],
+    "lnh_occupancy_lookup": [P, P, P, F32, U32, U32, U32, P, P],
+    "lnh_march_rays_train": [P, P, P, F32, F32, U32, U32, U32, U32, U32, P, P, P, P, P, P, P, P],
+    "lnh_composite_rays_train_forward": [P, P, P, P, U32, U32, F32, P, P, P],
+    "lnh_composite_rays_train_backward": [P, P, P, P, P, P, P, P, U32, U32, F32, P, P],
+    "lnh_lidar_weights": [P, P, P, U32, U32, F32, P],
+    "lnh_lidar_composite_forward": [P, P, P, P, U32, U32, U32, F32, P, P, P, P],
+    "lnh_lidar_composite_backward": [P, P, P, P, P, P, P, U32, U32, U32, F32, P, P],
+    "lnh_lidar_resample": [P, P, P, P, U32, U32, U32, F32, P, P, P],
+}
+EXPORTS = sorted(list(_SIGS) + ["lnh_version", "lnh_last_error", "lnh_arch"])
+
+LNH_F32, LNH_F16 = 0, 1
+
+_lib = None
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def lib():
+    """Load the shared library (fails loudly: the HIP extension IS the product path)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(
+                f"{_LIB_PATH} not found — build it with `python lidar-nerf_amd/build.py` "
+                "(hipcc --offload-arch=gfx950); there is no CPU fallback.")
+        L = C.CDLL(_LIB_PATH)
+        for name, sig in _SIGS.items():
+            fn = getattr(L, name)
+            fn.argtypes = sig + [P]
+            fn.restype = C.c_int
+        L.lnh_last_error.restype = C.c_char_p
+        L.lnh_arch.restype = C.c_char_p
+        L.lnh_version.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def ptr(t):
+    """Device (or host) pointer of a tensor, None -> NULL."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Invoke an entry point on the current stream; raise on any non-zero status."""
+    L = lib()
+    rc = getattr(L, name)(*args, stream())
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {L.lnh_last_error().decode()}")
+
+
+def dtype_code(dt):
+    if dt == torch.float32:
+        return LNH_F32
+    if dt == torch.float16:
+        return LNH_F16
+    raise RuntimeError(f"lidarnerf_hip: unsupported table dtype {dt} (float32 / float16 only)")
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("lidarnerf_hip: tensor must live on the GPU (no CPU path in this library)")
+        if t is not None and not t.is_contiguous():
+            raise RuntimeError("lidarnerf_hip: tensor must be contiguous")

@@ -1,0 +1,111 @@
+"""Fused MFMA MLP (lnh_mlp_forward/backward) vs the float64 oracle.
+
+Tolerance: inputs/weights/activations are fp16 in both; the kernel accumulates in fp32 and rounds each stored
+activation once to fp16 (the reference accumulates in fp16).  fp16 has 11 significant bits -> one rounding is
+<= 2^-11 relative; a 64-term dot product of O(1) values lands within ~3e-3 absolute of the exact value.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mlp_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_fwd(x, w, in_dim, hidden, nhm, act, out_act=6, fb=None):
+    from gpu_util import call, dev, host
+    B = x.shape[0]
+    y = torch.empty((B, 16), dtype=torch.float16, device="cuda")
+    call("lnh_mlp_forward", dev(x), dev(w), B, in_dim, 16, hidden, nhm, act, out_act, fb, y)
+    return host(y)
+
+
+@pytest.mark.parametrize("in_dim,nhm", [(32, 0), (32, 1), (96, 1), (16, 0), (48, 2), (128, 1), (64, 2)])
+@pytest.mark.parametrize("B", [64, 1000])
+def test_forward_relu(in_dim, nhm, B):
+    r = np.random.default_rng(in_dim + nhm)
+    x = r.standard_normal((B, in_dim)).astype(np.float16)
+    n = mlp_ref.ffmlp_num_params(in_dim, 16, 64, nhm + 1)
+    w = (r.uniform(-1, 1, n) * np.sqrt(3 / 64)).astype(np.float16)
+    mats = mlp_ref.ffmlp_split_weights(w, in_dim, 16, 64, nhm + 1)
+    want, _ = mlp_ref.mlp_forward(x, mats)
+    got = _run_fwd(x, w, in_dim, 64, nhm, mlp_ref.ACT_RELU)
+    np.testing.assert_allclose(got.astype(np.float64), want, rtol=2e-3, atol=4e-3)
+
+
+def test_forward_is_not_transposed():
+    """Asymmetric one-hot weights: output o must read hidden unit o (catches row/col or k-enumeration mix-ups)."""
+    in_dim, B = 32, 48
+    x = np.zeros((B, in_dim), np.float16)
+    for b in range(B):
+        x[b, b % in_dim] = 1 + b
+    W0 = np.zeros((64, in_dim), np.float16)
+    for h in range(64):
+        W0[h, (h * 5 + 3) % in_dim] = 1 + 0.01 * h
+    Wo = np.zeros((16, 64), np.float16)
+    for o in range(16):
+        Wo[o, (o * 7 + 2) % 64] = 1 + 0.1 * o
+    w = np.concatenate([W0.ravel(), Wo.ravel()])
+    want, _ = mlp_ref.mlp_forward(x, [W0, Wo])
+    got = _run_fwd(x, w, in_dim, 64, 0, mlp_ref.ACT_RELU)
+    np.testing.assert_allclose(got.astype(np.float64), want, rtol=2e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("act", [1, 2, 3, 4, 5, 6])
+def test_forward_activations(act):
+    r = np.random.default_rng(act)
+    x = (r.standard_normal((256, 32)) * 0.5).astype(np.float16)
+    w = (r.uniform(-1, 1, mlp_ref.ffmlp_num_params(32, 16, 64, 2)) * 0.15).astype(np.float16)
+    mats = mlp_ref.ffmlp_split_weights(w, 32, 16, 64, 2)
+    want, _ = mlp_ref.mlp_forward(x, mats, act=act)
+    got = _run_fwd(x, w, 32, 64, 1, act)
+    np.testing.assert_allclose(got.astype(np.float64), want, rtol=4e-3, atol=4e-3)
+
+
+def test_forward_buffer_matches_hidden_activations():
+    from gpu_util import host
+    r = np.random.default_rng(9)
+    B = 130
+    x = r.standard_normal((B, 32)).astype(np.float16)
+    w = (r.uniform(-1, 1, mlp_ref.ffmlp_num_params(32, 16, 64, 2)) * 0.2).astype(np.float16)
+    mats = mlp_ref.ffmlp_split_weights(w, 32, 16, 64, 2)
+    _, saved = mlp_ref.mlp_forward(x, mats)
+    fb = torch.zeros((2, B, 64), dtype=torch.float16, device="cuda")
+    _run_fwd(x, w, 32, 64, 1, 0, fb=fb)
+    got = host(fb).astype(np.float64)
+    np.testing.assert_allclose(got[0], saved[0], rtol=2e-3, atol=3e-3)
+    np.testing.assert_allclose(got[1], saved[1], rtol=2e-3, atol=3e-3)
+
+
+@pytest.mark.parametrize("in_dim,nhm", [(32, 0), (96, 1), (32, 1), (64, 2), (16, 0)])
+@pytest.mark.parametrize("B", [128, 1000])
+def test_backward(in_dim, nhm, B):
+    from gpu_util import call, dev, host
+    r = np.random.default_rng(in_dim * 3 + nhm)
+    x = r.standard_normal((B, in_dim)).astype(np.float16)
+    n = mlp_ref.ffmlp_num_params(in_dim, 16, 64, nhm + 1)
+    w = (r.uniform(-1, 1, n) * np.sqrt(3 / 64)).astype(np.float16)
+    gy = (r.standard_normal((B, 16)) * 0.1).astype(np.float16)
+    mats = mlp_ref.ffmlp_split_weights(w, in_dim, 16, 64, nhm + 1)
+    gx_want, dws = mlp_ref.mlp_backward(x, mats, gy)
+    dw_want = np.concatenate([d.ravel() for d in dws])
+    gx = torch.zeros((B, in_dim), dtype=torch.float16, device="cuda")
+    dw = torch.zeros(n, dtype=torch.float32, device="cuda")
+    call("lnh_mlp_backward", dev(gy), dev(x), dev(w), B, in_dim, 16, 64, nhm, 0, 6, gx, dw)
+    np.testing.assert_allclose(host(gx).astype(np.float64), gx_want, rtol=5e-3, atol=2e-3)
+    scale = np.abs(dw_want).max()
+    np.testing.assert_allclose(host(dw).astype(np.float64), dw_want, rtol=5e-3, atol=2e-3 * scale)
+    # weights-only variant (grad_inputs == NULL)
+    dw2 = torch.zeros(n, dtype=torch.float32, device="cuda")
+    call("lnh_mlp_backward", dev(gy), dev(x), dev(w), B, in_dim, 16, 64, nhm, 0, 6, None, dw2)
+    np.testing.assert_allclose(host(dw2), host(dw), rtol=1e-4, atol=1e-4 * scale)
+
+
+def test_unsupported_shapes_fail_loudly():
+    from lidarnerf import _hip
+    t = torch.zeros(16, device="cuda")
+    with pytest.raises(RuntimeError, match="input_dim should be 16"):
+        _hip.call("lnh_mlp_forward", t.data_ptr(), t.data_ptr(), 16, 20, 16, 64, 0, 0, 6, None, t.data_ptr())
+    with pytest.raises(RuntimeError, match="hidden_dim"):
+        _hip.call("lnh_mlp_forward", t.data_ptr(), t.data_ptr(), 16, 32, 16, 256, 0, 0, 6, None, t.data_ptr())

@@ -1,0 +1,131 @@
+"""Occupancy-grid indexing / marching / ragged compositing (lnh_* raymarching entry points) vs the C oracle.
+Integer results are compared bit-exactly; the atomic ray allocation is compared keyed by ray id."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def test_morton_bit_exact():
+    from gpu_util import call, dev, host
+    c = np.random.default_rng(0).integers(0, 1024, size=(100000, 3), dtype=np.int32)
+    out = torch.empty(100000, dtype=torch.int32, device="cuda")
+    call("lnh_morton3D", dev(c), 100000, out)
+    want = c_oracle.morton3D(c)
+    np.testing.assert_array_equal(host(out), want)
+    back = torch.empty((100000, 3), dtype=torch.int32, device="cuda")
+    call("lnh_morton3D_invert", out, 100000, back)
+    np.testing.assert_array_equal(host(back), c)
+    # negative / high-bit indices follow the arithmetic-shift semantics of the reference
+    idx = np.array([-1, -2, 0x7FFFFFFF, -2147483648, 5], dtype=np.int32)
+    b2 = torch.empty((5, 3), dtype=torch.int32, device="cuda")
+    call("lnh_morton3D_invert", dev(idx), 5, b2)
+    np.testing.assert_array_equal(host(b2), c_oracle.morton3D_invert(idx))
+
+
+def test_packbits_bit_exact_full_grid():
+    from gpu_util import call, dev, host
+    g = np.random.default_rng(1).random(128 ** 3, dtype=np.float32)
+    g[:16] = 0.5  # exactly at the threshold: strict '>'
+    out = torch.empty(128 ** 3 // 8, dtype=torch.uint8, device="cuda")
+    call("lnh_packbits", dev(g), 128 ** 3 // 8, 0.5, out)
+    np.testing.assert_array_equal(host(out), c_oracle.packbits(g, 0.5))
+
+
+def _scene(cascade):
+    Hh = 128
+    r = np.random.default_rng(3)
+    dens = np.zeros(cascade * Hh ** 3, np.float32)
+    idx = np.arange(Hh ** 3, dtype=np.int32)
+    xyz = (c_oracle.morton3D_invert(idx).astype(np.float32) + 0.5) / Hh * 2 - 1
+    for cas in range(cascade):
+        rr = np.linalg.norm(xyz * (2 ** cas), axis=1)
+        dens[cas * Hh ** 3:(cas + 1) * Hh ** 3][(rr < 0.6 * 2 ** cas) & (r.random(Hh ** 3) < 0.7)] = 1.0
+    return c_oracle.packbits(dens, 0.01), Hh
+
+
+@pytest.mark.parametrize("cascade,bound", [(1, 1.0), (2, 2.0)])
+def test_occupancy_lookup_bit_exact(cascade, bound):
+    from gpu_util import call, dev, host
+    bits, Hh = _scene(cascade)
+    r = np.random.default_rng(5)
+    N = 200000
+    xyz = ((r.random((N, 3), dtype=np.float32) * 2 - 1) * bound * 1.1).astype(np.float32)
+    dt = (r.random(N, dtype=np.float32) * 0.05).astype(np.float32)
+    ci = torch.empty(N, dtype=torch.int32, device="cuda")
+    occ = torch.empty(N, dtype=torch.uint8, device="cuda")
+    call("lnh_occupancy_lookup", dev(xyz), dev(dt), dev(bits), bound, N, cascade, Hh, ci, occ)
+    wci, wocc = c_oracle.occupancy_lookup(xyz, dt, bits, bound, cascade, Hh)
+    np.testing.assert_array_equal(host(ci).view(np.uint32), wci)
+    np.testing.assert_array_equal(host(occ), wocc)
+
+
+@pytest.mark.parametrize("cascade,bound,dt_gamma", [(1, 1.0, 0.0), (2, 2.0, 1 / 128)])
+def test_march_rays_train(cascade, bound, dt_gamma):
+    from gpu_util import call, dev, host
+    bits, Hh = _scene(cascade)
+    r = np.random.default_rng(7)
+    N = 1000
+    o = (r.standard_normal((N, 3)) * 0.05 + np.array([-0.8 * bound, 0.1, 0.0])).astype(np.float32)
+    d = r.standard_normal((N, 3)).astype(np.float32)
+    d[:, 0] = np.abs(d[:, 0]) + 0.7
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)
+    nears = torch.empty(N, device="cuda")
+    fars = torch.empty(N, device="cuda")
+    call("lnh_near_far_from_aabb", dev(o), dev(d), dev(aabb), N, 0.05, nears, fars)
+    wn, wf = c_oracle.near_far_from_aabb(o, d, aabb, 0.05)
+    np.testing.assert_array_equal(host(nears), wn)
+    np.testing.assert_array_equal(host(fars), wf)
+    noises = r.random(N, dtype=np.float32)
+    M = N * 256
+    xyzs = torch.zeros((M, 3), device="cuda")
+    dirs = torch.zeros((M, 3), device="cuda")
+    deltas = torch.zeros((M, 2), device="cuda")
+    rays = torch.zeros((N, 3), dtype=torch.int32, device="cuda")
+    counter = torch.zeros(2, dtype=torch.int32, device="cuda")
+    call("lnh_march_rays_train", dev(o), dev(d), dev(bits), bound, dt_gamma, 1024, N, cascade, Hh, M, nears, fars, xyzs,
+         dirs, deltas, rays, counter, dev(noises))
+    wx, wd, wdl, wr, wc = c_oracle.march_rays_train(o, d, bits, bound, dt_gamma, 1024, cascade, Hh, M, wn, wf, noises)
+    g_rays, g_cnt = host(rays), host(counter)
+    np.testing.assert_array_equal(g_cnt, wc)
+    assert wc[0] > 1000 and wc[0] <= M
+    # ray table keyed by id: counts identical; offsets are a permutation-consistent allocation
+    order = np.argsort(g_rays[:, 0])
+    g_sorted = g_rays[order]
+    np.testing.assert_array_equal(g_sorted[:, 0], np.arange(N))
+    np.testing.assert_array_equal(g_sorted[:, 2], wr[:, 2])
+    spans = sorted((int(a), int(a + b)) for _, a, b in g_rays if b > 0)
+    assert all(spans[i][1] <= spans[i + 1][0] for i in range(len(spans) - 1))  # disjoint
+    gx, gd, gdl = host(xyzs), host(dirs), host(deltas)
+    for n in range(0, N, 7):
+        a, k = g_sorted[n, 1], g_sorted[n, 2]
+        b = wr[n, 1]
+        np.testing.assert_array_equal(gx[a:a + k], wx[b:b + k])
+        np.testing.assert_array_equal(gd[a:a + k], wd[b:b + k])
+        np.testing.assert_array_equal(gdl[a:a + k], wdl[b:b + k])
+    # ragged compositing on top of the marched samples
+    P = int(wc[0])
+    sig = (r.random(M, dtype=np.float32) * 30).astype(np.float32)
+    rgb = r.random((M, 3), dtype=np.float32)
+    ws = torch.zeros(N, device="cuda")
+    dep = torch.zeros(N, device="cuda")
+    img = torch.zeros((N, 3), device="cuda")
+    call("lnh_composite_rays_train_forward", dev(sig), dev(rgb), deltas, rays, M, N, 1e-4, ws, dep, img)
+    w_ws, w_dep, w_img = c_oracle.composite_rays_train_forward(sig, rgb, gdl, g_rays, 1e-4)
+    np.testing.assert_allclose(host(ws), w_ws, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(host(dep), w_dep, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(host(img), w_img, rtol=1e-5, atol=1e-6)
+    gws = r.standard_normal(N).astype(np.float32)
+    gim = r.standard_normal((N, 3)).astype(np.float32)
+    gs = torch.zeros(M, device="cuda")
+    gc = torch.zeros((M, 3), device="cuda")
+    call("lnh_composite_rays_train_backward", dev(gws), dev(gim), dev(sig), dev(rgb), deltas, rays, ws, img, M, N, 1e-4,
+         gs, gc)
+    w_gs, w_gc = c_oracle.composite_rays_train_backward(gws, gim, sig, rgb, gdl, g_rays, host(ws), host(img), 1e-4)
+    np.testing.assert_allclose(host(gs), w_gs, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(host(gc), w_gc, rtol=1e-5, atol=1e-6)
+    assert P > 0
