@@ -216,7 +216,13 @@ k_grid_forward(const float *__restrict__ inputs, const T *__restrict__ table, T 
             const float w = corner_weight<D>(cell, c);
             // accumulate in the table type, one rounding per corner (gridencoder.cu:173,198)
 #pragma unroll
-            for (int ch = 0; ch < C; ch++) res.v[ch] = (T)fmaf(w, (float)g[c].v[ch], (float)res.v[ch]);
+            for (int ch = 0; ch < C; ch++) {
+                float acc = fmaf(w, (float)g[c].v[ch], (float)res.v[ch]);
+                // keep the fp32 rounding of the fma visible: without this hipcc fuses fma+narrowing into
+                // v_fma_mixlo_f16 (ONE rounding), while the reference rounds to fp32 and then to fp16
+                if constexpr (sizeof(T) == 2) asm volatile("" : "+v"(acc));
+                res.v[ch] = (T)acc;
+            }
         }
     }
     store_vec<T, C>(out, res);
@@ -318,9 +324,14 @@ k_grid_backward(const T *__restrict__ grad, const float *__restrict__ inputs, T 
         uint32_t key[D];
 #pragma unroll
         for (int d = 0; d < D; d++) key[d] = ok ? cell.term[d][0] : 0xffffffffu - lane;  // invalid lanes never match
-        bool same_prev = lane > 0;
+        // NB: every shuffle must execute with all 64 lanes active — no short-circuit around it
+        bool same_prev = true;
 #pragma unroll
-        for (int d = 0; d < D; d++) same_prev = same_prev && (__shfl_up(key[d], 1, 64) == key[d]);
+        for (int d = 0; d < D; d++) {
+            const uint32_t up = __shfl_up(key[d], 1, 64);
+            same_prev &= (up == key[d]);
+        }
+        same_prev &= lane > 0;
         const unsigned long long heads = __ballot(!same_prev);  // bit set where a run starts
         // distance to the start of my run
         const unsigned long long below = heads & ((2ull << lane) - 1ull);
