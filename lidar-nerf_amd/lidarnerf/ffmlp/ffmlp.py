@@ -1,0 +1,113 @@
+"""FFMLP — fully fused tiny MLP on MFMA (API of lidarnerf/ffmlp/ffmlp.py:187-283).
+
+`FFMLP(input_dim, output_dim, hidden_dim, num_layers, activation)` keeps the reference's flat `weights` Parameter
+([hidden*in | hidden*hidden*(num_layers-1) | out_pad16*hidden], each row-major [out,in]) and its seed-42
+U(+-sqrt(3/hidden)) initialisation.  `fused_mlp(x, mats, act)` is the functional form used by the networks: it takes
+the individual bias-free Linear weight matrices (so nn.Linear state-dict keys stay intact) and runs them as ONE kernel.
+"""
+import math
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from .. import _hip
+
+_ACT = {"relu": 0, "exponential": 1, "sine": 2, "sigmoid": 3, "squareplus": 4, "softplus": 5}
+
+
+def convert_activation(act):
+    return _ACT.get(act, 6)
+
+
+def _forward_raw(x16, w16, in_dim, hidden, nhm, act, out_act, save_hidden=False):
+    B = x16.shape[0]
+    y = torch.empty((B, 16), dtype=torch.half, device=x16.device)
+    fb = torch.empty((nhm + 1, B, hidden), dtype=torch.half, device=x16.device) if save_hidden else None
+    _hip.call("lnh_mlp_forward", x16.data_ptr(), w16.data_ptr(), B, in_dim, 16, hidden, nhm, act, out_act,
+              _hip.ptr(fb), y.data_ptr())
+    return y, fb
+
+
+def _backward_raw(gy16, x16, w16, in_dim, hidden, nhm, act, need_dx):
+    B = x16.shape[0]
+    gx = torch.empty((B, in_dim), dtype=torch.half, device=x16.device) if need_dx else None
+    gw = torch.zeros(w16.numel(), dtype=torch.float32, device=x16.device)
+    _hip.call("lnh_mlp_backward", gy16.data_ptr(), x16.data_ptr(), w16.data_ptr(), B, in_dim, 16, hidden, nhm, act, 6,
+              _hip.ptr(gx), gw.data_ptr())
+    return gx, gw
+
+
+class _FusedMLP(Function):
+    """x [B,in_pad] (any float dtype), flat weights (any float dtype) -> y [B,16] fp16."""
+
+    @staticmethod
+    def forward(ctx, x, w, in_dim, hidden, nhm, act, out_act, inference):
+        x16 = x.contiguous().to(torch.half)
+        w16 = w.contiguous().to(torch.half)
+        _hip.require_cuda(x16, w16)
+        y, _ = _forward_raw(x16, w16, in_dim, hidden, nhm, act, out_act)
+        if not inference:
+            ctx.save_for_backward(x16, w16)
+            ctx.meta = (in_dim, hidden, nhm, act, out_act, x.dtype, w.dtype, x.requires_grad)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x16, w16 = ctx.saved_tensors
+        in_dim, hidden, nhm, act, out_act, xdt, wdt, need_dx = ctx.meta
+        if out_act != 6:
+            raise RuntimeError("fused MLP: backward through an output activation is not supported (ffmlp.py:196)")
+        gx, gw = _backward_raw(gy.contiguous().to(torch.half), x16, w16, in_dim, hidden, nhm, act, need_dx)
+        return (gx.to(xdt) if gx is not None else None), gw.to(wdt), None, None, None, None, None, None
+
+
+def fused_mlp(x, mats, activation=0, inference=False):
+    """Bias-free Linear stack as one kernel.  mats: list of weight tensors [out_k, in_k] (>= 2); hidden width 64;
+    last out <= 16; first in <= 128.  Returns [B, out_last] fp16."""
+    hidden = mats[0].shape[0]
+    in_dim = mats[0].shape[1]
+    out_dim = mats[-1].shape[0]
+    in_pad = (in_dim + 15) // 16 * 16
+    w0 = mats[0] if in_pad == in_dim else torch.nn.functional.pad(mats[0], (0, in_pad - in_dim))
+    wl = mats[-1] if out_dim == 16 else torch.nn.functional.pad(mats[-1], (0, 0, 0, 16 - out_dim))
+    flat = torch.cat([w0.reshape(-1)] + [m.reshape(-1) for m in mats[1:-1]] + [wl.reshape(-1)])
+    if x.shape[1] != in_pad:
+        x = torch.nn.functional.pad(x, (0, in_pad - x.shape[1]))
+    y = _FusedMLP.apply(x, flat, in_pad, hidden, len(mats) - 2, activation, 6, inference)
+    return y[:, :out_dim] if out_dim != 16 else y
+
+
+class FFMLP(nn.Module):
+    def __init__(self, input_dim, output_dim, hidden_dim, num_layers, activation="relu"):
+        super().__init__()
+        self.input_dim, self.output_dim, self.hidden_dim, self.num_layers = input_dim, output_dim, hidden_dim, num_layers
+        self.activation = convert_activation(activation)
+        self.output_activation = convert_activation("none")
+        self.tensorcore_width = 16
+        assert hidden_dim in [16, 32, 64, 128, 256], \
+            f"FFMLP only support hidden_dim in [16, 32, 64, 128, 256], but got {hidden_dim}"
+        assert input_dim > 0 and input_dim % 16 == 0, f"FFMLP input_dim should be 16 * m (m  > 0), but got {input_dim}"
+        assert output_dim <= 16, f"FFMLP current only supports output dim <= 16, but got {output_dim}"
+        assert num_layers >= 2, f"FFMLP num_layers should be larger than 2 (3 matmuls), but got {num_layers}"
+        self.padded_output_dim = int(math.ceil(output_dim / 16)) * 16
+        self.num_parameters = hidden_dim * (input_dim + hidden_dim * (num_layers - 1) + self.padded_output_dim)
+        self.weights = nn.Parameter(torch.zeros(self.num_parameters))
+        self.reset_parameters()
+
+    def cleanup(self):  # the reference frees its split-K streams here; nothing to free
+        pass
+
+    def __repr__(self):
+        return (f"FFMLP: input_dim={self.input_dim} output_dim={self.output_dim} hidden_dim={self.hidden_dim} "
+                f"num_layers={self.num_layers} activation={self.activation}")
+
+    def reset_parameters(self):
+        torch.manual_seed(42)
+        std = math.sqrt(3 / self.hidden_dim)
+        self.weights.data.uniform_(-std, std)
+
+    def forward(self, inputs):
+        y = _FusedMLP.apply(inputs, self.weights, self.input_dim, self.hidden_dim, self.num_layers - 1,
+                            self.activation, self.output_activation, not self.training)
+        return y[:, :self.output_dim] if self.output_dim != self.padded_output_dim else y

@@ -1,0 +1,100 @@
+"""NeRFNetwork — hash-grid + tiny-MLP field (API / state-dict layout of lidarnerf/nerf/network.py:10-253).
+
+Module and parameter names match the reference (`encoder.embeddings`, `encoder.offsets`, `sigma_net.{i}.weight`,
+`color_net.{i}.weight`, `lidar_color_net.{i}.weight`, ...), so its checkpoints load with strict=True.
+Under fp16 autocast (the reference's documented `--fp16` / `-L` mode) every bias-free Linear stack runs as ONE MFMA
+kernel (ffmlp.fused_mlp); in fp32 mode the stacks run as plain library GEMMs like the reference.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..activation import trunc_exp
+from ..encoding import get_encoder
+from ..ffmlp import fused_mlp
+from .renderer import NeRFRenderer
+
+
+def _linear_stack(dims):
+    return nn.ModuleList([nn.Linear(dims[i], dims[i + 1], bias=False) for i in range(len(dims) - 1)])
+
+
+class NeRFNetwork(NeRFRenderer):
+    def __init__(self, encoding="hashgrid", encoding_dir="frequency", multires=15, encoding_bg="hashgrid",
+                 desired_resolution=2048, log2_hashmap_size=19, num_layers=2, hidden_dim=64, geo_feat_dim=15,
+                 num_layers_color=3, hidden_dim_color=64, num_layers_bg=2, hidden_dim_bg=64, out_color_dim=3,
+                 out_lidar_color_dim=2, bound=1, **kwargs):
+        super().__init__(bound, **kwargs)
+        self.num_layers, self.hidden_dim, self.geo_feat_dim = num_layers, hidden_dim, geo_feat_dim
+        self.out_color_dim, self.out_lidar_color_dim = out_color_dim, out_lidar_color_dim
+        self.num_layers_color, self.hidden_dim_color = num_layers_color, hidden_dim_color
+
+        self.encoder, self.in_dim = get_encoder(encoding, desired_resolution=desired_resolution,
+                                                log2_hashmap_size=log2_hashmap_size)
+        self.sigma_net = _linear_stack([self.in_dim] + [hidden_dim] * (num_layers - 1) + [1 + geo_feat_dim])
+
+        self.encoder_dir, self.in_dim_dir = get_encoder("sphere_harmonics")
+        self.color_net = _linear_stack([self.in_dim_dir + geo_feat_dim] + [hidden_dim_color] * (num_layers_color - 1)
+                                       + [out_color_dim])
+
+        self.encoder_lidar_dir, self.in_dim_dir = get_encoder("frequency", multires=12)
+        self.lidar_color_net = _linear_stack([self.in_dim_dir + geo_feat_dim]
+                                             + [hidden_dim_color] * (num_layers_color - 1) + [out_lidar_color_dim])
+
+        if self.bg_radius > 0:
+            self.num_layers_bg, self.hidden_dim_bg = num_layers_bg, hidden_dim_bg
+            self.encoder_bg, self.in_dim_bg = get_encoder(encoding_bg, input_dim=2, num_levels=4,
+                                                          log2_hashmap_size=19, desired_resolution=2048)
+            self.bg_net = _linear_stack([self.in_dim_bg + self.in_dim_dir] + [hidden_dim_bg] * (num_layers_bg - 1) + [3])
+        else:
+            self.bg_net = None
+
+    # -- one bias-free Linear/ReLU stack ----------------------------------------------------------------------
+    def _mlp(self, net, h):
+        mats = [lin.weight for lin in net]
+        fusable = (h.is_cuda and torch.is_autocast_enabled() and len(mats) >= 2 and mats[0].shape[0] == 64
+                   and all(m.shape == (64, 64) for m in mats[1:-1]) and mats[-1].shape[0] <= 16
+                   and mats[0].shape[1] <= 128 and len(mats) <= 4)
+        if fusable:
+            return fused_mlp(h, mats, activation=0, inference=not torch.is_grad_enabled())
+        for i, lin in enumerate(net):
+            h = lin(h)
+            if i != len(net) - 1:
+                h = F.relu(h, inplace=True)
+        return h
+
+    def forward(self, x, d):
+        dens = self.density(x)
+        h = torch.cat([self.encoder_dir(d), dens["geo_feat"]], dim=-1)
+        return dens["sigma"], torch.sigmoid(self._mlp(self.color_net, h))
+
+    def density(self, x):
+        h = self._mlp(self.sigma_net, self.encoder(x, bound=self.bound))
+        return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
+
+    def background(self, x, d):
+        h = torch.cat([self.encoder_dir(d), self.encoder_bg(x)], dim=-1)
+        return torch.sigmoid(self._mlp(self.bg_net, h))
+
+    def color(self, x, d, cal_lidar_color=False, mask=None, geo_feat=None, **kwargs):
+        rgbs = None
+        if mask is not None:
+            rgbs = torch.zeros(mask.shape[0], self.out_dim, dtype=x.dtype, device=x.device)
+            if not mask.any():
+                return rgbs
+            x, d, geo_feat = x[mask], d[mask], geo_feat[mask]
+        enc, net = (self.encoder_lidar_dir, self.lidar_color_net) if cal_lidar_color \
+            else (self.encoder_dir, self.color_net)
+        h = torch.cat([enc(d).to(geo_feat.dtype), geo_feat], dim=-1)
+        h = torch.sigmoid(self._mlp(net, h))
+        if mask is None:
+            return h
+        rgbs[mask] = h.to(rgbs.dtype)
+        return rgbs
+
+    def get_params(self, lr):
+        groups = [self.encoder, self.sigma_net, self.encoder_dir, self.color_net, self.encoder_lidar_dir,
+                  self.lidar_color_net]
+        if self.bg_radius > 0:
+            groups += [self.encoder_bg, self.bg_net]
+        return [{"params": g.parameters(), "lr": lr} for g in groups]

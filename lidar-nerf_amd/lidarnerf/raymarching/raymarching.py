@@ -1,0 +1,123 @@
+"""Ray utilities / occupancy grid / ragged compositing (API of lidarnerf/raymarching/raymarching.py).
+
+Each function allocates its outputs and calls the matching lnh_* entry point on the current stream."""
+import torch
+from torch.autograd import Function
+
+from .. import _hip
+
+
+def near_far_from_aabb(rays_o, rays_d, aabb, min_near=0.2):
+    rays_o = rays_o.contiguous().float().view(-1, 3)
+    rays_d = rays_d.contiguous().float().view(-1, 3)
+    aabb = aabb.contiguous().float()
+    _hip.require_cuda(rays_o, rays_d, aabb)
+    N = rays_o.shape[0]
+    nears = torch.empty(N, dtype=torch.float32, device=rays_o.device)
+    fars = torch.empty(N, dtype=torch.float32, device=rays_o.device)
+    _hip.call("lnh_near_far_from_aabb", rays_o.data_ptr(), rays_d.data_ptr(), aabb.data_ptr(), N, float(min_near),
+              nears.data_ptr(), fars.data_ptr())
+    return nears, fars
+
+
+def sph_from_ray(rays_o, rays_d, radius):
+    rays_o = rays_o.contiguous().float().view(-1, 3)
+    rays_d = rays_d.contiguous().float().view(-1, 3)
+    _hip.require_cuda(rays_o, rays_d)
+    N = rays_o.shape[0]
+    coords = torch.empty((N, 2), dtype=torch.float32, device=rays_o.device)
+    _hip.call("lnh_sph_from_ray", rays_o.data_ptr(), rays_d.data_ptr(), float(radius), N, coords.data_ptr())
+    return coords
+
+
+def morton3D(coords):
+    coords = coords.contiguous().int()
+    _hip.require_cuda(coords)
+    N = coords.shape[0]
+    out = torch.empty(N, dtype=torch.int32, device=coords.device)
+    _hip.call("lnh_morton3D", coords.data_ptr(), N, out.data_ptr())
+    return out
+
+
+def morton3D_invert(indices):
+    indices = indices.contiguous().int()
+    _hip.require_cuda(indices)
+    N = indices.shape[0]
+    out = torch.empty((N, 3), dtype=torch.int32, device=indices.device)
+    _hip.call("lnh_morton3D_invert", indices.data_ptr(), N, out.data_ptr())
+    return out
+
+
+def packbits(grid, thresh, bitfield=None):
+    grid = grid.contiguous().float()
+    _hip.require_cuda(grid)
+    C, H3 = grid.shape[0], grid.shape[-1] if grid.dim() == 2 else grid[0].numel()
+    N = C * H3 // 8
+    if bitfield is None:
+        bitfield = torch.empty(N, dtype=torch.uint8, device=grid.device)
+    _hip.call("lnh_packbits", grid.data_ptr(), N, float(thresh), bitfield.data_ptr())
+    return bitfield
+
+
+def march_rays_train(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter=None, mean_count=-1,
+                     perturb=False, align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024):
+    """Returns xyzs [M,3], dirs [M,3], deltas [M,2], rays [N,3] (id, offset, count).  Same argument list and the same
+    output-trimming rules as the reference wrapper (raymarching.py:171-282)."""
+    rays_o = rays_o.contiguous().float().view(-1, 3)
+    rays_d = rays_d.contiguous().float().view(-1, 3)
+    density_bitfield = density_bitfield.contiguous()
+    _hip.require_cuda(rays_o, rays_d, density_bitfield, nears, fars)
+    N = rays_o.shape[0]
+    M = N * max_steps
+    if not force_all_rays and mean_count > 0:
+        if align > 0:
+            mean_count += align - mean_count % align
+        M = mean_count
+    dev = rays_o.device
+    xyzs = torch.zeros((M, 3), dtype=torch.float32, device=dev)
+    dirs = torch.zeros((M, 3), dtype=torch.float32, device=dev)
+    deltas = torch.zeros((M, 2), dtype=torch.float32, device=dev)
+    rays = torch.empty((N, 3), dtype=torch.int32, device=dev)
+    if step_counter is None:
+        step_counter = torch.zeros(2, dtype=torch.int32, device=dev)
+    noises = torch.rand(N, dtype=torch.float32, device=dev) if perturb else torch.zeros(N, dtype=torch.float32, device=dev)
+    _hip.call("lnh_march_rays_train", rays_o.data_ptr(), rays_d.data_ptr(), density_bitfield.data_ptr(), float(bound),
+              float(dt_gamma), int(max_steps), N, int(C), int(H), M, nears.contiguous().data_ptr(),
+              fars.contiguous().data_ptr(), xyzs.data_ptr(), dirs.data_ptr(), deltas.data_ptr(), rays.data_ptr(),
+              step_counter.data_ptr(), noises.data_ptr())
+    if force_all_rays or mean_count <= 0:
+        m = int(step_counter[0].item())  # host sync, as in the reference (raymarching.py:268-275)
+        if align > 0:
+            m += align - m % align
+        xyzs, dirs, deltas = xyzs[:m], dirs[:m], deltas[:m]
+    return xyzs, dirs, deltas, rays
+
+
+class _CompositeRaysTrain(Function):
+    @staticmethod
+    def forward(ctx, sigmas, rgbs, deltas, rays, T_thresh=1e-4):
+        sigmas, rgbs = sigmas.contiguous().float(), rgbs.contiguous().float()
+        deltas, rays = deltas.contiguous().float(), rays.contiguous().int()
+        M, N = sigmas.shape[0], rays.shape[0]
+        ws = torch.empty(N, dtype=torch.float32, device=sigmas.device)
+        depth = torch.empty(N, dtype=torch.float32, device=sigmas.device)
+        image = torch.empty((N, 3), dtype=torch.float32, device=sigmas.device)
+        _hip.call("lnh_composite_rays_train_forward", sigmas.data_ptr(), rgbs.data_ptr(), deltas.data_ptr(),
+                  rays.data_ptr(), M, N, float(T_thresh), ws.data_ptr(), depth.data_ptr(), image.data_ptr())
+        ctx.save_for_backward(sigmas, rgbs, deltas, rays, ws, image)
+        ctx.dims = (M, N, T_thresh)
+        return ws, depth, image
+
+    @staticmethod
+    def backward(ctx, g_ws, g_depth, g_image):  # no depth gradient, as in the reference (raymarching.py:330)
+        sigmas, rgbs, deltas, rays, ws, image = ctx.saved_tensors
+        M, N, T_thresh = ctx.dims
+        gs = torch.zeros_like(sigmas)
+        gc = torch.zeros_like(rgbs)
+        _hip.call("lnh_composite_rays_train_backward", g_ws.contiguous().data_ptr(), g_image.contiguous().data_ptr(),
+                  sigmas.data_ptr(), rgbs.data_ptr(), deltas.data_ptr(), rays.data_ptr(), ws.data_ptr(),
+                  image.data_ptr(), M, N, float(T_thresh), gs.data_ptr(), gc.data_ptr())
+        return gs, gc, None, None, None
+
+
+composite_rays_train = _CompositeRaysTrain.apply
