@@ -71,6 +71,20 @@ LNH_API int lnh_grid_encode_backward(const void *grad, const float *inputs, cons
                                      uint32_t gridtype, int align_corners, uint32_t interp, int dtype,
                                      lnh_stream_t stream);
 /*
+ * Same result as lnh_grid_encode_backward for the hot configuration (D == 3, C == 2) without a single atomic add to
+ * HBM: contributions are binned per 8192-row table bucket in a caller-provided workspace and reduced in LDS
+ * (grid.hip, "bucketed backward").  `workspace` is scratch device memory of at least
+ * lnh_grid_backward_workspace_size(...) bytes (0 = configuration not supported by this path); its content is
+ * irrelevant before and after the call.  No dy_dx / grad_inputs (LiDAR sample positions carry no gradient).
+ */
+LNH_API uint64_t lnh_grid_backward_workspace_size(const int32_t *offsets_host, uint32_t B, uint32_t D, uint32_t C,
+                                                  uint32_t L, float S, uint32_t H, uint32_t gridtype,
+                                                  int align_corners, int dtype);
+LNH_API int lnh_grid_encode_backward_ws(const void *grad, const float *inputs, const int32_t *offsets_host,
+                                        void *grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                        uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, int dtype,
+                                        void *workspace, uint64_t workspace_bytes, lnh_stream_t stream);
+/*
  * Replaces grad_total_variation  gridencoder.h:43-55 (gridencoder.cu:695-910): adds the TV-regulariser gradient
  * of the cells visited by `inputs` into `grad` (same layout as embeddings).
  */

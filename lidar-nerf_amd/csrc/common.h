@@ -36,6 +36,14 @@ static inline int lnh_check_launch(const char *what) {
     return LNH_OK;
 }
 
+// Launch with a clean error slot: hipGetLastError() is sticky per thread, so an unrelated earlier failure (e.g. a
+// runtime probe made by another library) must not be reported as a failure of this launch.
+#define LNH_LAUNCH(...)                      \
+    do {                                     \
+        (void)hipGetLastError();             \
+        hipLaunchKernelGGL(__VA_ARGS__);     \
+    } while (0)
+
 static inline uint32_t div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
 // ---- wave-level primitives (64 lanes) ------------------------------------------------------------------------

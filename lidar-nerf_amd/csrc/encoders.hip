@@ -137,7 +137,7 @@ int lnh_freq_encode_forward(const float *inputs, uint32_t B, uint32_t D, uint32_
     LNH_REQUIRE(D >= 1 && C == D + 2 * D * deg, LNH_ERR_INVALID_ARG, "freq forward: C (%u) must equal D + 2*D*deg (%u)",
                 C, D + 2 * D * deg);
     if (B == 0) return LNH_OK;
-    hipLaunchKernelGGL(k_freq_forward, dim3(div_up((uint64_t)B * D, 256)), dim3(256), 0, (hipStream_t)stream, inputs,
+    LNH_LAUNCH(k_freq_forward, dim3(div_up((uint64_t)B * D, 256)), dim3(256), 0, (hipStream_t)stream, inputs,
                        B, D, deg, C, outputs);
     return lnh_check_launch("lnh_freq_encode_forward");
 }
@@ -147,7 +147,7 @@ int lnh_freq_encode_backward(const float *grad, const float *outputs, uint32_t B
     LNH_REQUIRE(grad && outputs && grad_inputs, LNH_ERR_INVALID_ARG, "freq backward: null pointer");
     LNH_REQUIRE(D >= 1 && C == D + 2 * D * deg, LNH_ERR_INVALID_ARG, "freq backward: C (%u) must equal D + 2*D*deg", C);
     if (B == 0) return LNH_OK;
-    hipLaunchKernelGGL(k_freq_backward, dim3(div_up((uint64_t)B * D, 256)), dim3(256), 0, (hipStream_t)stream, grad,
+    LNH_LAUNCH(k_freq_backward, dim3(div_up((uint64_t)B * D, 256)), dim3(256), 0, (hipStream_t)stream, grad,
                        outputs, B, D, deg, C, grad_inputs);
     return lnh_check_launch("lnh_freq_encode_backward");
 }
@@ -161,9 +161,9 @@ int lnh_sh_encode_forward(const float *inputs, float *outputs, uint32_t B, uint3
     if (B == 0) return LNH_OK;
     dim3 grid(div_up(B, 256)), block(256);
     if (dy_dx)
-        hipLaunchKernelGGL(k_sh_forward<true>, grid, block, 0, (hipStream_t)stream, inputs, outputs, B, degree, dy_dx);
+        LNH_LAUNCH(k_sh_forward<true>, grid, block, 0, (hipStream_t)stream, inputs, outputs, B, degree, dy_dx);
     else
-        hipLaunchKernelGGL(k_sh_forward<false>, grid, block, 0, (hipStream_t)stream, inputs, outputs, B, degree, dy_dx);
+        LNH_LAUNCH(k_sh_forward<false>, grid, block, 0, (hipStream_t)stream, inputs, outputs, B, degree, dy_dx);
     return lnh_check_launch("lnh_sh_encode_forward");
 }
 
@@ -173,7 +173,7 @@ int lnh_sh_encode_backward(const float *grad, const float *inputs, uint32_t B, u
     LNH_REQUIRE(grad && dy_dx && grad_inputs, LNH_ERR_INVALID_ARG, "sh backward: null pointer");
     LNH_REQUIRE(D == 3 && degree >= 1 && degree <= 4, LNH_ERR_UNSUPPORTED, "sh backward: D must be 3, degree 1..4");
     if (B == 0) return LNH_OK;
-    hipLaunchKernelGGL(k_sh_backward, dim3(div_up((uint64_t)B * D, 256)), dim3(256), 0, (hipStream_t)stream, grad, B, D,
+    LNH_LAUNCH(k_sh_backward, dim3(div_up((uint64_t)B * D, 256)), dim3(256), 0, (hipStream_t)stream, grad, B, D,
                        degree, dy_dx, grad_inputs);
     return lnh_check_launch("lnh_sh_encode_backward");
 }

@@ -19,6 +19,9 @@
 
 namespace {
 
+// experiment knobs (scratch/ micro-benchmarks only): level window + kernel flags
+static uint32_t g_dbg_l0 = 0, g_dbg_ln = 0, g_dbg_flags = 0;
+
 struct LevelParams {
     float scale;
     uint32_t resolution;
@@ -298,11 +301,20 @@ __device__ __forceinline__ void atomic_add_one(float *p, float a) { unsafeAtomic
 template <typename T, int D, int C, int NC, bool MERGE>
 __global__ void __launch_bounds__(256)
 k_grid_backward(const T *__restrict__ grad, const float *__restrict__ inputs, T *__restrict__ grad_table, uint32_t B,
-                GridMeta meta, uint32_t align, uint32_t interp) {
+                GridMeta meta, uint32_t align, uint32_t interp, uint32_t xflags) {
     constexpr int NP = C / NC;  // channel groups per point
-    const uint32_t level = blockIdx.y;
+    uint32_t level = blockIdx.y + (xflags >> 8);
+    uint32_t bx = blockIdx.x;
+    if (xflags & 4) {  // experiment: XCD-affine — block's XCD (bid % 8) picks one of 8 consecutive levels
+        level = (xflags >> 8) + (blockIdx.x & 7);
+        bx = blockIdx.x >> 3;
+    } else if (xflags & 1) {  // experiment: only blocks that land on XCD 0 (bid % 8 == 0) work
+        const uint32_t lin = blockIdx.y * gridDim.x + blockIdx.x;
+        if (lin & 7) return;
+        bx = blockIdx.x >> 3;
+    }
     const LevelParams lv = meta.lv[level];
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = bx * blockDim.x + threadIdx.x;
     const uint32_t b = t / NP;
     const uint32_t ch = (t % NP) * NC;
     const bool in_range = b < B;
@@ -316,7 +328,7 @@ k_grid_backward(const T *__restrict__ grad, const float *__restrict__ inputs, T 
     for (int c = 0; c < NC; c++) g[c] = ok ? (float)grad[((size_t)level * B + b) * C + ch + c] : 0.0f;
     T *gt = grad_table + (size_t)lv.offset * C + ch;
 
-    if constexpr (MERGE && NP == 1) {
+    if (MERGE && NP == 1 && !(xflags & 2)) {
         // Lanes are consecutive samples.  If this lane's base cell equals the previous lane's, both touch the same
         // 2^D table rows: pre-reduce w*g over such runs with a segmented inclusive scan; the LAST lane of each run
         // issues the atomics.  Cell identity = all per-dimension base terms equal (exact, hash or dense).
@@ -374,6 +386,293 @@ k_grid_backward(const T *__restrict__ grad, const float *__restrict__ inputs, T 
         if constexpr (NC == 2) atomic_add_pair(p, w * g[0], w * g[1]);
         else atomic_add_one(p, w * g[0]);
     }
+}
+
+
+// ------------------------------------------------------------------------------------------------ bucketed backward
+// Device-scope atomics top out at ~20 G/s on MI355X no matter how the work is spread over XCDs (measured,
+// scratch/bench_grid.py), and every LiDAR ray starts in the same few cells around the sensor, which serialises the
+// coarse levels on a handful of addresses.  The fast path therefore never adds into HBM atomically:
+//   pass 1 (k_grid_bwd_scatter): per (point, level) the run-merged corner contributions (row, w*g) are appended to
+//           the pool of the table BUCKET they belong to (bucket = 8192 consecutive rows of one level); slots are
+//           reserved with LDS counters + ONE global atomic per bucket per workgroup, so the pool writes of a
+//           workgroup are contiguous per bucket;
+//   pass 2 (k_grid_bwd_reduce): one workgroup per bucket accumulates its pool in a 64 KiB LDS image and adds the
+//           touched rows into the gradient table with plain stores — it owns those rows.  The LDS image is 64-bit
+//           FIXED POINT: measured on MI355X, ds_add_f32 sustains ~100 G adds/s chip-wide while ds_add_u64 keeps up
+//           with the 6 TB/s pool stream (scratch/ldsbench), and integer accumulation makes the sum exact and
+//           order-independent (fp16 contributions are multiples of 2^-24, so scale 2^24 loses nothing).
+// A bucket whose pool overflows (adversarial, non-uniform input) falls back to global atomics for the excess in
+// pass 1, which completes before pass 2 starts (kernel boundary), so the result is always the full sum.
+constexpr uint32_t kBucketRowsLog2 = 12;
+constexpr uint32_t kBucketRows = 1u << kBucketRowsLog2;
+constexpr uint32_t kMaxBucketsPerLevel = 128;
+
+struct BucketPlan {
+    uint32_t first_bucket[LNH_MAX_LEVELS + 1];  // prefix sum of buckets per level
+    uint32_t cap[LNH_MAX_LEVELS];               // pool slots per bucket of that level
+    uint64_t pool_off[LNH_MAX_LEVELS];          // first pool slot of that level
+};
+
+template <typename T>
+struct PoolEntry;
+template <>
+struct PoolEntry<half_t> {
+    uint32_t row;
+    half2_t v;
+};
+template <>
+struct PoolEntry<float> {
+    uint32_t row;
+    float v0, v1;
+};
+__device__ __forceinline__ void entry_set(PoolEntry<half_t> &e, uint32_t row, float a, float b) {
+    e.row = row;
+    e.v = half2_t{(half_t)a, (half_t)b};
+}
+__device__ __forceinline__ void entry_set(PoolEntry<float> &e, uint32_t row, float a, float b) {
+    e.row = row;
+    e.v0 = a;
+    e.v1 = b;
+}
+__device__ __forceinline__ void entry_get(const PoolEntry<half_t> &e, float &a, float &b) {
+    a = (float)e.v[0];
+    b = (float)e.v[1];
+}
+__device__ __forceinline__ void entry_get(const PoolEntry<float> &e, float &a, float &b) {
+    a = e.v0;
+    b = e.v1;
+}
+
+// PPT points per thread (same level, 1024 points apart so that lanes stay consecutive samples): every workgroup
+// reserves its pool slots with ONE global atomic per touched bucket for 1024*PPT points — the cursor atomics are
+// device atomics too (~20 G/s), so fewer, larger reservations matter.
+template <typename T, int D, int PPT>
+__global__ void __launch_bounds__(1024)
+k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs, T *__restrict__ grad_table,
+                   uint32_t B, GridMeta meta, BucketPlan plan, PoolEntry<T> *__restrict__ pool,
+                   uint32_t *__restrict__ cursor, uint32_t align, uint32_t interp, uint32_t dbg) {
+    constexpr int C = 2, NCORN = 1 << D;
+    __shared__ uint32_t lcnt[kMaxBucketsPerLevel];
+    __shared__ uint32_t lbase[kMaxBucketsPerLevel];
+    const uint32_t level = blockIdx.y;
+    const LevelParams lv = meta.lv[level];
+    const uint32_t fb = plan.first_bucket[level], nb = plan.first_bucket[level + 1] - fb, cap = plan.cap[level];
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x < kMaxBucketsPerLevel) lcnt[threadIdx.x] = 0;
+
+    float v0[PPT][NCORN], v1[PPT][NCORN];
+    uint32_t row[PPT][NCORN];
+    bool emit[PPT];
+#pragma unroll
+    for (int q = 0; q < PPT; q++) {
+        const uint32_t b = (blockIdx.x * PPT + q) * blockDim.x + threadIdx.x;
+        const bool in_range = b < B;
+        float x[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) x[d] = in_range ? inputs[(size_t)b * D + d] : -1.0f;
+        Cell<D> cell;
+        const bool ok = in_range && locate<D>(x, lv, align != 0, interp, cell);
+        float g0 = 0.0f, g1 = 0.0f;
+        if (ok) {
+            const Vec<T, 2> gv = load_vec<T, 2>(grad + ((size_t)level * B + b) * C);
+            g0 = (float)gv.v[0];
+            g1 = (float)gv.v[1];
+        }
+        // ---- wave run-merge (see k_grid_backward)
+        uint32_t key[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) key[d] = ok ? cell.term[d][0] : 0xffffffffu - lane;
+        bool same_prev = true;
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            const uint32_t up = __shfl_up(key[d], 1, 64);
+            same_prev &= (up == key[d]);
+        }
+        same_prev &= lane > 0;
+        const unsigned long long heads = __ballot(!same_prev);
+        const unsigned long long below = heads & ((2ull << lane) - 1ull);
+        const int run_start = 63 - __builtin_clzll(below);
+        const bool any_merge = (~heads) != 0ull;
+        const unsigned long long heads_above = (lane == 63) ? 0ull : (heads >> (lane + 1));
+        emit[q] = ok && ((lane == 63) || (heads_above & 1ull));
+#pragma unroll
+        for (uint32_t c = 0; c < (uint32_t)NCORN; c++) {
+            const float w = ok ? corner_weight<D>(cell, c) : 0.0f;
+            v0[q][c] = w * g0;
+            v1[q][c] = w * g1;
+            if constexpr (sizeof(T) == 2) {  // per-contribution rounding of the reference (gridencoder.cu:350)
+                v0[q][c] = (float)(half_t)v0[q][c];
+                v1[q][c] = (float)(half_t)v1[q][c];
+            }
+            row[q][c] = ok ? corner_row<D>(cell, lv, c) : 0u;
+        }
+        if (any_merge && !(dbg & 2)) {  // wave-uniform
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const bool take = lane - o >= run_start;
+#pragma unroll
+                for (uint32_t c = 0; c < (uint32_t)NCORN; c++) {
+                    const float u0 = __shfl_up(v0[q][c], o, 64), u1 = __shfl_up(v1[q][c], o, 64);
+                    if (take) {
+                        v0[q][c] += u0;
+                        v1[q][c] += u1;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- reserve pool slots: LDS rank per (bucket), one global atomic per touched bucket per workgroup
+    uint32_t rank[PPT][NCORN];
+#pragma unroll
+    for (int q = 0; q < PPT; q++)
+        if (emit[q]) {
+#pragma unroll
+            for (uint32_t c = 0; c < (uint32_t)NCORN; c++)
+                rank[q][c] = (dbg & 4) ? threadIdx.x : atomicAdd(&lcnt[row[q][c] >> kBucketRowsLog2], 1u);
+        }
+    __syncthreads();
+    if (threadIdx.x < nb) {
+        const uint32_t n = lcnt[threadIdx.x];
+        lbase[threadIdx.x] = n ? atomicAdd(&cursor[fb + threadIdx.x], n) : 0u;
+    }
+    __syncthreads();
+    PoolEntry<T> *lp = pool + plan.pool_off[level];
+    T *gt = grad_table + (size_t)lv.offset * C;
+#pragma unroll
+    for (int q = 0; q < PPT; q++)
+        if (emit[q]) {
+#pragma unroll
+            for (uint32_t c = 0; c < (uint32_t)NCORN; c++) {
+                const uint32_t bk = row[q][c] >> kBucketRowsLog2;
+                const uint32_t pos = lbase[bk] + rank[q][c];
+                if (pos < cap) {
+                    PoolEntry<T> e;
+                    entry_set(e, row[q][c] & (kBucketRows - 1), v0[q][c], v1[q][c]);
+                    if (!(dbg & 8) || v0[q][c] == 12345.0f) lp[(size_t)bk * cap + pos] = e;
+                } else {  // pool overflow: exact but slow
+                    atomic_add_pair(gt + (size_t)row[q][c] * C, v0[q][c], v1[q][c]);
+                }
+            }
+        }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(1024)
+k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, const PoolEntry<T> *__restrict__ pool,
+                  const uint32_t *__restrict__ cursor, uint32_t L) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    unsigned long long *acc = reinterpret_cast<unsigned long long *>(smem_raw);  // [kBucketRows][2] fixed point
+    // fp16 contributions are exact multiples of 2^-24; fp32 ones get 2^-40 resolution and +-8e6 of range
+    constexpr int K = sizeof(T) == 2 ? 24 : 40;
+    const uint32_t bid = blockIdx.x;
+    uint32_t level = 0;
+    for (uint32_t l = 0; l < L; l++)
+        if (bid >= plan.first_bucket[l]) level = l;
+    const LevelParams lv = meta.lv[level];
+    const uint32_t bk = bid - plan.first_bucket[level], cap = plan.cap[level];
+    const uint32_t n = min(cursor[bid], cap);
+    if (n == 0) return;  // workgroup-uniform
+    const uint32_t rows = min(kBucketRows, lv.hashmap_size - bk * kBucketRows);
+    for (uint32_t i = threadIdx.x; i < rows * 2; i += blockDim.x) acc[i] = 0ull;
+    __syncthreads();
+    const PoolEntry<T> *src = pool + plan.pool_off[level] + (size_t)bk * cap;
+    // One workgroup streams its whole pool: keep UNROLL independent loads in flight per lane.
+    constexpr uint32_t UNROLL = 4;
+    const uint32_t stride = blockDim.x * UNROLL;
+    for (uint32_t i0 = threadIdx.x; i0 < n; i0 += stride) {
+        PoolEntry<T> e[UNROLL];
+#pragma unroll
+        for (uint32_t u = 0; u < UNROLL; u++) {  // unconditional (clamped) loads: a predicated load would be
+            const uint32_t i = i0 + u * blockDim.x;  // branched around and waited for one by one
+            e[u] = src[i < n ? i : n - 1];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < UNROLL; u++) {
+            const uint32_t i = i0 + u * blockDim.x;
+            if (i < n) {
+                float a, b;
+                entry_get(e[u], a, b);
+                const long long qa = (long long)ldexp((double)a, K), qb = (long long)ldexp((double)b, K);
+                atomicAdd(&acc[e[u].row * 2], (unsigned long long)qa);  // ds_add_u64
+                atomicAdd(&acc[e[u].row * 2 + 1], (unsigned long long)qb);
+            }
+        }
+    }
+    __syncthreads();
+    T *gt = grad_table + ((size_t)lv.offset + (size_t)bk * kBucketRows) * 2;
+    for (uint32_t r = threadIdx.x; r < rows; r += blockDim.x) {
+        const long long qa = (long long)acc[2 * r], qb = (long long)acc[2 * r + 1];
+        if (qa != 0 || qb != 0) {
+            const float a = (float)ldexp((double)qa, -K), b = (float)ldexp((double)qb, -K);
+            Vec<T, 2> cur = load_vec<T, 2>(gt + 2 * r);
+            cur.v[0] = (T)((float)cur.v[0] + a);
+            cur.v[1] = (T)((float)cur.v[1] + b);
+            store_vec<T, 2>(gt + 2 * r, cur);
+        }
+    }
+}
+
+// Host: bucket layout + pool sizing.  Returns the number of bytes of workspace needed (cursor array + pool).
+template <typename T>
+uint64_t plan_buckets(BucketPlan &plan, const GridMeta &m, uint32_t L, uint32_t B, uint32_t D, uint32_t &total_buckets) {
+    const uint64_t per_level = (uint64_t)B << D;  // worst-case entries of one level
+    uint64_t slots = 0;
+    uint32_t nbt = 0;
+    for (uint32_t l = 0; l < L; l++) {
+        const uint32_t nb = (m.lv[l].hashmap_size + kBucketRows - 1) / kBucketRows;
+        plan.first_bucket[l] = nbt;
+        // even split of the worst case plus 12.5 % head-room for the statistical imbalance of hashed levels
+        uint64_t cap = (per_level + nb - 1) / nb;
+        cap += cap / 8 + 64;
+        if (cap > per_level) cap = per_level;
+        if (cap > 0xffffffffull) cap = 0xffffffffull;
+        plan.cap[l] = (uint32_t)cap;
+        plan.pool_off[l] = slots;
+        slots += cap * nb;
+        nbt += nb;
+    }
+    plan.first_bucket[L] = nbt;
+    total_buckets = nbt;
+    const uint64_t cursor_bytes = ((uint64_t)nbt * 4 + 255) / 256 * 256;
+    return cursor_bytes + slots * sizeof(PoolEntry<T>);
+}
+
+template <typename T>
+int launch_backward_bucketed(const T *grad, const float *inputs, T *ge, uint32_t B, uint32_t L, const GridMeta &m,
+                             uint32_t align, uint32_t interp, void *workspace, uint64_t workspace_bytes,
+                             hipStream_t s) {
+    BucketPlan plan;
+    uint32_t nbt = 0;
+    const uint64_t need = plan_buckets<T>(plan, m, L, B, 3, nbt);
+    if (workspace == nullptr || workspace_bytes < need) {
+        lnh_set_error("grid backward: workspace too small (%llu < %llu bytes)", (unsigned long long)workspace_bytes,
+                      (unsigned long long)need);
+        return LNH_ERR_INVALID_ARG;
+    }
+    for (uint32_t l = 0; l < L; l++)
+        if (plan.first_bucket[l + 1] - plan.first_bucket[l] > kMaxBucketsPerLevel) {
+            lnh_set_error("grid backward (bucketed): level %u has more than %u buckets", l, kMaxBucketsPerLevel);
+            return LNH_ERR_UNSUPPORTED;
+        }
+    const uint64_t cursor_bytes = ((uint64_t)nbt * 4 + 255) / 256 * 256;
+    uint32_t *cursor = reinterpret_cast<uint32_t *>(workspace);
+    PoolEntry<T> *pool = reinterpret_cast<PoolEntry<T> *>(reinterpret_cast<char *>(workspace) + cursor_bytes);
+    (void)hipGetLastError();
+    if (hipMemsetAsync(cursor, 0, cursor_bytes, s) != hipSuccess) {
+        lnh_set_error("grid backward: hipMemsetAsync failed");
+        return LNH_ERR_LAUNCH;
+    }
+    constexpr int PPT = 2;
+    LNH_LAUNCH((k_grid_bwd_scatter<T, 3, PPT>), dim3(div_up(B, 1024 * PPT), L), dim3(1024), 0, s, grad, inputs, ge, B, m,
+               plan, pool, cursor, align, interp, g_dbg_flags);
+    int rc = lnh_check_launch("lnh_grid_encode_backward_ws(scatter)");
+    if (rc) return rc;
+    auto k = k_grid_bwd_reduce<T>;
+    const size_t lds = (size_t)kBucketRows * 2 * sizeof(unsigned long long);
+    LNH_LAUNCH(k, dim3(nbt), dim3(1024), lds, s, ge, m, plan, pool, cursor, L);
+    return lnh_check_launch("lnh_grid_encode_backward_ws(reduce)");
 }
 
 // gridencoder.cu:364-390
@@ -481,10 +780,10 @@ int launch_forward_c(const float *inputs, const T *emb, T *out, T *dy_dx, uint32
     dim3 grid(div_up(B, 256), L), block(256);
 #define LNH_FWD(CC)                                                                                               \
     if (dy_dx)                                                                                                    \
-        hipLaunchKernelGGL((k_grid_forward<T, D, CC, true>), grid, block, 0, s, inputs, emb, out, dy_dx, B, L, m, \
+        LNH_LAUNCH((k_grid_forward<T, D, CC, true>), grid, block, 0, s, inputs, emb, out, dy_dx, B, L, m, \
                            align, interp);                                                                        \
     else                                                                                                          \
-        hipLaunchKernelGGL((k_grid_forward<T, D, CC, false>), grid, block, 0, s, inputs, emb, out, dy_dx, B, L, m, \
+        LNH_LAUNCH((k_grid_forward<T, D, CC, false>), grid, block, 0, s, inputs, emb, out, dy_dx, B, L, m, \
                            align, interp);
     switch (C) {
         case 1: LNH_FWD(1) break;
@@ -497,10 +796,14 @@ int launch_forward_c(const float *inputs, const T *emb, T *out, T *dy_dx, uint32
     return lnh_check_launch("lnh_grid_encode_forward");
 }
 
+
 template <typename T, int D>
 int launch_backward_c(const T *grad, const float *inputs, T *ge, uint32_t B, uint32_t C, uint32_t L,
                       const GridMeta &m, uint32_t align, uint32_t interp, hipStream_t s) {
     dim3 block(256);
+    const uint32_t xflags = (g_dbg_flags & 0xff) | (g_dbg_l0 << 8);
+    const uint32_t xm = (g_dbg_flags & 5) ? 8 : 1;
+    if (g_dbg_ln) L = g_dbg_ln;
     switch (C) {
         case 1:
             if constexpr (sizeof(T) == 2) {
@@ -508,21 +811,21 @@ int launch_backward_c(const T *grad, const float *inputs, T *ge, uint32_t B, uin
                               "grid.py:54-57)");
                 return LNH_ERR_UNSUPPORTED;
             } else {
-                hipLaunchKernelGGL((k_grid_backward<T, D, 1, 1, true>), dim3(div_up(B, 256), L), block, 0, s, grad,
-                                   inputs, ge, B, m, align, interp);
+                LNH_LAUNCH((k_grid_backward<T, D, 1, 1, true>), dim3(div_up(B, 256) * xm, L), block, 0, s, grad,
+                                   inputs, ge, B, m, align, interp, xflags);
             }
             break;
         case 2:
-            hipLaunchKernelGGL((k_grid_backward<T, D, 2, 2, true>), dim3(div_up(B, 256), L), block, 0, s, grad, inputs,
-                               ge, B, m, align, interp);
+            LNH_LAUNCH((k_grid_backward<T, D, 2, 2, true>), dim3(div_up(B, 256) * xm, L), block, 0, s, grad, inputs,
+                               ge, B, m, align, interp, xflags);
             break;
         case 4:
-            hipLaunchKernelGGL((k_grid_backward<T, D, 4, 2, false>), dim3(div_up((uint64_t)B * 2, 256), L), block, 0, s,
-                               grad, inputs, ge, B, m, align, interp);
+            LNH_LAUNCH((k_grid_backward<T, D, 4, 2, false>), dim3(div_up((uint64_t)B * 2, 256), L), block, 0, s,
+                               grad, inputs, ge, B, m, align, interp, xflags);
             break;
         case 8:
-            hipLaunchKernelGGL((k_grid_backward<T, D, 8, 2, false>), dim3(div_up((uint64_t)B * 4, 256), L), block, 0, s,
-                               grad, inputs, ge, B, m, align, interp);
+            LNH_LAUNCH((k_grid_backward<T, D, 8, 2, false>), dim3(div_up((uint64_t)B * 4, 256), L), block, 0, s,
+                               grad, inputs, ge, B, m, align, interp, xflags);
             break;
         default: lnh_set_error("GridEncoding: C must be 1, 2, 4, or 8 (got %u)", C); return LNH_ERR_UNSUPPORTED;
     }
@@ -533,10 +836,10 @@ template <typename T, int D>
 int launch_input_backward_c(const T *grad, const T *dy_dx, T *gi, uint32_t B, uint32_t C, uint32_t L, hipStream_t s) {
     dim3 grid(div_up((uint64_t)B * D, 256)), block(256);
     switch (C) {
-        case 1: hipLaunchKernelGGL((k_grid_input_backward<T, D, 1>), grid, block, 0, s, grad, dy_dx, gi, B, L); break;
-        case 2: hipLaunchKernelGGL((k_grid_input_backward<T, D, 2>), grid, block, 0, s, grad, dy_dx, gi, B, L); break;
-        case 4: hipLaunchKernelGGL((k_grid_input_backward<T, D, 4>), grid, block, 0, s, grad, dy_dx, gi, B, L); break;
-        case 8: hipLaunchKernelGGL((k_grid_input_backward<T, D, 8>), grid, block, 0, s, grad, dy_dx, gi, B, L); break;
+        case 1: LNH_LAUNCH((k_grid_input_backward<T, D, 1>), grid, block, 0, s, grad, dy_dx, gi, B, L); break;
+        case 2: LNH_LAUNCH((k_grid_input_backward<T, D, 2>), grid, block, 0, s, grad, dy_dx, gi, B, L); break;
+        case 4: LNH_LAUNCH((k_grid_input_backward<T, D, 4>), grid, block, 0, s, grad, dy_dx, gi, B, L); break;
+        case 8: LNH_LAUNCH((k_grid_input_backward<T, D, 8>), grid, block, 0, s, grad, dy_dx, gi, B, L); break;
         default: return LNH_ERR_UNSUPPORTED;
     }
     return lnh_check_launch("lnh_grid_encode_backward(inputs)");
@@ -552,12 +855,12 @@ int launch_tv_c(const T *inputs, const T *emb, T *grad, float weight, uint32_t B
                 lnh_set_error("grad_total_variation: fp16 needs an even C");
                 return LNH_ERR_UNSUPPORTED;
             } else {
-                hipLaunchKernelGGL((k_grad_tv<T, D, 1>), grid, block, 0, s, inputs, emb, grad, weight, B, m, align);
+                LNH_LAUNCH((k_grad_tv<T, D, 1>), grid, block, 0, s, inputs, emb, grad, weight, B, m, align);
             }
             break;
-        case 2: hipLaunchKernelGGL((k_grad_tv<T, D, 2>), grid, block, 0, s, inputs, emb, grad, weight, B, m, align); break;
-        case 4: hipLaunchKernelGGL((k_grad_tv<T, D, 4>), grid, block, 0, s, inputs, emb, grad, weight, B, m, align); break;
-        case 8: hipLaunchKernelGGL((k_grad_tv<T, D, 8>), grid, block, 0, s, inputs, emb, grad, weight, B, m, align); break;
+        case 2: LNH_LAUNCH((k_grad_tv<T, D, 2>), grid, block, 0, s, inputs, emb, grad, weight, B, m, align); break;
+        case 4: LNH_LAUNCH((k_grad_tv<T, D, 4>), grid, block, 0, s, inputs, emb, grad, weight, B, m, align); break;
+        case 8: LNH_LAUNCH((k_grad_tv<T, D, 8>), grid, block, 0, s, inputs, emb, grad, weight, B, m, align); break;
         default: lnh_set_error("GridEncoding: C must be 1, 2, 4, or 8 (got %u)", C); return LNH_ERR_UNSUPPORTED;
     }
     return lnh_check_launch("lnh_grad_total_variation");
@@ -586,6 +889,13 @@ int check_common(const void *inputs, const int32_t *offsets_host, uint32_t B, ui
     }
 
 extern "C" {
+
+// not part of the public ABI (not declared in lidarnerf_hip.h): experiment knobs for scratch/ micro-benchmarks
+__attribute__((visibility("default"))) void lnh_debug_grid_bwd(uint32_t l0, uint32_t ln, uint32_t flags) {
+    g_dbg_l0 = l0;
+    g_dbg_ln = ln;
+    g_dbg_flags = flags;
+}
 
 int lnh_grid_encode_forward(const float *inputs, const void *embeddings, const int32_t *offsets_host, void *outputs,
                             uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void *dy_dx,
@@ -639,6 +949,39 @@ int lnh_grid_encode_backward(const void *grad, const float *inputs, const void *
     return rc;
 }
 
+uint64_t lnh_grid_backward_workspace_size(const int32_t *offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                                          float S, uint32_t H, uint32_t gridtype, int align_corners, int dtype) {
+    if (!offsets_host || L < 1 || L > LNH_MAX_LEVELS || D != 3 || C != 2 || B == 0) return 0;
+    GridMeta m;
+    if (build_meta(m, offsets_host, D, L, S, H, gridtype, align_corners != 0) != 0) return 0;
+    BucketPlan plan;
+    uint32_t nbt = 0;
+    for (uint32_t l = 0; l < L; l++)
+        if ((m.lv[l].hashmap_size + kBucketRows - 1) / kBucketRows > kMaxBucketsPerLevel) return 0;
+    return dtype == LNH_F16 ? plan_buckets<half_t>(plan, m, L, B, D, nbt) : plan_buckets<float>(plan, m, L, B, D, nbt);
+}
+
+int lnh_grid_encode_backward_ws(const void *grad, const float *inputs, const int32_t *offsets_host,
+                                void *grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, int dtype,
+                                void *workspace, uint64_t workspace_bytes, lnh_stream_t stream) {
+    int rc = check_common(inputs, offsets_host, B, D, C, L, dtype);
+    if (rc) return rc;
+    LNH_REQUIRE(grad && grad_embeddings, LNH_ERR_INVALID_ARG, "grid backward: null grad/grad_embeddings");
+    LNH_REQUIRE(D == 3 && C == 2, LNH_ERR_UNSUPPORTED,
+                "grid backward (bucketed): only D == 3, C == 2 (use lnh_grid_encode_backward otherwise)");
+    if (B == 0) return LNH_OK;
+    GridMeta m;
+    LNH_REQUIRE(build_meta(m, offsets_host, D, L, S, H, gridtype, align_corners != 0) == 0, LNH_ERR_INVALID_ARG,
+                "grid: offsets must be increasing and non-negative");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == LNH_F32)
+        return launch_backward_bucketed<float>((const float *)grad, inputs, (float *)grad_embeddings, B, L, m,
+                                               align_corners != 0, interp, workspace, workspace_bytes, s);
+    return launch_backward_bucketed<half_t>((const half_t *)grad, inputs, (half_t *)grad_embeddings, B, L, m,
+                                            align_corners != 0, interp, workspace, workspace_bytes, s);
+}
+
 int lnh_grad_total_variation(const void *inputs, const void *embeddings, void *grad, const int32_t *offsets_host,
                              float weight, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                              uint32_t gridtype, int align_corners, int dtype, lnh_stream_t stream) {
@@ -673,10 +1016,10 @@ int lnh_grid_corner_indices(const float *inputs, const int32_t *offsets_host, ui
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(div_up(B, 256), L), block(256);
     switch (D) {
-        case 2: hipLaunchKernelGGL((k_grid_indices<2>), grid, block, 0, s, inputs, out_idx, B, C, m, (uint32_t)(align_corners != 0)); break;
-        case 3: hipLaunchKernelGGL((k_grid_indices<3>), grid, block, 0, s, inputs, out_idx, B, C, m, (uint32_t)(align_corners != 0)); break;
-        case 4: hipLaunchKernelGGL((k_grid_indices<4>), grid, block, 0, s, inputs, out_idx, B, C, m, (uint32_t)(align_corners != 0)); break;
-        case 5: hipLaunchKernelGGL((k_grid_indices<5>), grid, block, 0, s, inputs, out_idx, B, C, m, (uint32_t)(align_corners != 0)); break;
+        case 2: LNH_LAUNCH((k_grid_indices<2>), grid, block, 0, s, inputs, out_idx, B, C, m, (uint32_t)(align_corners != 0)); break;
+        case 3: LNH_LAUNCH((k_grid_indices<3>), grid, block, 0, s, inputs, out_idx, B, C, m, (uint32_t)(align_corners != 0)); break;
+        case 4: LNH_LAUNCH((k_grid_indices<4>), grid, block, 0, s, inputs, out_idx, B, C, m, (uint32_t)(align_corners != 0)); break;
+        case 5: LNH_LAUNCH((k_grid_indices<5>), grid, block, 0, s, inputs, out_idx, B, C, m, (uint32_t)(align_corners != 0)); break;
     }
     return lnh_check_launch("lnh_grid_corner_indices");
 }

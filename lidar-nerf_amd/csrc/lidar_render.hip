@@ -330,7 +330,7 @@ int lnh_lidar_weights(const float *z, const float *sigma, const float *sample_di
     LNH_REQUIRE(z && sigma && sample_dist && weights, LNH_ERR_INVALID_ARG, "lidar_weights: null pointer");
     LNH_REQUIRE(T >= 1, LNH_ERR_INVALID_ARG, "lidar_weights: T must be >= 1");
     if (N == 0) return LNH_OK;
-    hipLaunchKernelGGL(k_lidar_weights, dim3(div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, z, sigma, sample_dist, N,
+    LNH_LAUNCH(k_lidar_weights, dim3(div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, z, sigma, sample_dist, N,
                        T, density_scale, weights);
     return lnh_check_launch("lnh_lidar_weights");
 }
@@ -345,10 +345,10 @@ int lnh_lidar_composite_forward(const float *z, const float *sigma, const float 
     dim3 grid(div_up(N, 4)), block(256);
     hipStream_t s = (hipStream_t)stream;
     switch (K) {
-        case 1: hipLaunchKernelGGL(k_lidar_composite_fwd<1>, grid, block, 0, s, z, sigma, rgb, sample_dist, N, T, density_scale, weights, weights_sum, depth, image); break;
-        case 2: hipLaunchKernelGGL(k_lidar_composite_fwd<2>, grid, block, 0, s, z, sigma, rgb, sample_dist, N, T, density_scale, weights, weights_sum, depth, image); break;
-        case 3: hipLaunchKernelGGL(k_lidar_composite_fwd<3>, grid, block, 0, s, z, sigma, rgb, sample_dist, N, T, density_scale, weights, weights_sum, depth, image); break;
-        case 4: hipLaunchKernelGGL(k_lidar_composite_fwd<4>, grid, block, 0, s, z, sigma, rgb, sample_dist, N, T, density_scale, weights, weights_sum, depth, image); break;
+        case 1: LNH_LAUNCH(k_lidar_composite_fwd<1>, grid, block, 0, s, z, sigma, rgb, sample_dist, N, T, density_scale, weights, weights_sum, depth, image); break;
+        case 2: LNH_LAUNCH(k_lidar_composite_fwd<2>, grid, block, 0, s, z, sigma, rgb, sample_dist, N, T, density_scale, weights, weights_sum, depth, image); break;
+        case 3: LNH_LAUNCH(k_lidar_composite_fwd<3>, grid, block, 0, s, z, sigma, rgb, sample_dist, N, T, density_scale, weights, weights_sum, depth, image); break;
+        case 4: LNH_LAUNCH(k_lidar_composite_fwd<4>, grid, block, 0, s, z, sigma, rgb, sample_dist, N, T, density_scale, weights, weights_sum, depth, image); break;
         default: lnh_set_error("lidar_composite: K must be 1..4 (got %u)", K); return LNH_ERR_UNSUPPORTED;
     }
     return lnh_check_launch("lnh_lidar_composite_forward");
@@ -365,10 +365,10 @@ int lnh_lidar_composite_backward(const float *grad_weights_sum, const float *gra
     dim3 grid(div_up(N, 4)), block(256);
     hipStream_t s = (hipStream_t)stream;
     switch (K) {
-        case 1: hipLaunchKernelGGL(k_lidar_composite_bwd<1>, grid, block, 0, s, grad_weights_sum, grad_depth, grad_image, z, sigma, rgb, sample_dist, N, T, density_scale, grad_sigma, grad_rgb); break;
-        case 2: hipLaunchKernelGGL(k_lidar_composite_bwd<2>, grid, block, 0, s, grad_weights_sum, grad_depth, grad_image, z, sigma, rgb, sample_dist, N, T, density_scale, grad_sigma, grad_rgb); break;
-        case 3: hipLaunchKernelGGL(k_lidar_composite_bwd<3>, grid, block, 0, s, grad_weights_sum, grad_depth, grad_image, z, sigma, rgb, sample_dist, N, T, density_scale, grad_sigma, grad_rgb); break;
-        case 4: hipLaunchKernelGGL(k_lidar_composite_bwd<4>, grid, block, 0, s, grad_weights_sum, grad_depth, grad_image, z, sigma, rgb, sample_dist, N, T, density_scale, grad_sigma, grad_rgb); break;
+        case 1: LNH_LAUNCH(k_lidar_composite_bwd<1>, grid, block, 0, s, grad_weights_sum, grad_depth, grad_image, z, sigma, rgb, sample_dist, N, T, density_scale, grad_sigma, grad_rgb); break;
+        case 2: LNH_LAUNCH(k_lidar_composite_bwd<2>, grid, block, 0, s, grad_weights_sum, grad_depth, grad_image, z, sigma, rgb, sample_dist, N, T, density_scale, grad_sigma, grad_rgb); break;
+        case 3: LNH_LAUNCH(k_lidar_composite_bwd<3>, grid, block, 0, s, grad_weights_sum, grad_depth, grad_image, z, sigma, rgb, sample_dist, N, T, density_scale, grad_sigma, grad_rgb); break;
+        case 4: LNH_LAUNCH(k_lidar_composite_bwd<4>, grid, block, 0, s, grad_weights_sum, grad_depth, grad_image, z, sigma, rgb, sample_dist, N, T, density_scale, grad_sigma, grad_rgb); break;
         default: lnh_set_error("lidar_composite: K must be 1..4 (got %u)", K); return LNH_ERR_UNSUPPORTED;
     }
     return lnh_check_launch("lnh_lidar_composite_backward");
@@ -390,7 +390,7 @@ int lnh_lidar_resample(const float *z, const float *sigma, const float *sample_d
     hipStream_t s = (hipStream_t)stream;
     if (lds > 64 * 1024)
         hipFuncSetAttribute((const void *)k_lidar_resample, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_lidar_resample, dim3(N), dim3(64), lds, s, z, sigma, sample_dist, u, N, T, n_new, P,
+    LNH_LAUNCH(k_lidar_resample, dim3(N), dim3(64), lds, s, z, sigma, sample_dist, u, N, T, n_new, P,
                        density_scale, new_z, z_out, perm);
     return lnh_check_launch("lnh_lidar_resample");
 }

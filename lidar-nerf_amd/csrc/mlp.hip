@@ -145,7 +145,7 @@ int launch_fwd(const MlpArgs &a, hipStream_t s) {
     constexpr int NT = 4;
     const uint32_t tiles = div_up(a.B, NT * 16 * 4);
     const uint32_t grid = tiles < 1024 ? tiles : 1024;
-    hipLaunchKernelGGL((k_mlp_forward<IN_KS, HT, NHM, NT>), dim3(grid), dim3(256), 0, s, a);
+    LNH_LAUNCH((k_mlp_forward<IN_KS, HT, NHM, NT>), dim3(grid), dim3(256), 0, s, a);
     return lnh_check_launch("lnh_mlp_forward");
 }
 

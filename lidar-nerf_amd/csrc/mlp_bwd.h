@@ -295,7 +295,7 @@ int launch_mlp_backward(const MlpBwdArgs &a, hipStream_t s) {
     const uint32_t grid = steps < 768 ? steps : 768;
     auto k = k_mlp_backward<IN_KS, HT, NHM, NT>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, a);
+    LNH_LAUNCH(k, dim3(grid), dim3(256), lds, s, a);
     return lnh_check_launch("lnh_mlp_backward");
 }
 

@@ -323,7 +323,7 @@ int lnh_near_far_from_aabb(const float *rays_o, const float *rays_d, const float
                            float *nears, float *fars, lnh_stream_t stream) {
     LNH_REQUIRE(rays_o && rays_d && aabb && nears && fars, LNH_ERR_INVALID_ARG, "near_far_from_aabb: null pointer");
     if (N == 0) return LNH_OK;
-    hipLaunchKernelGGL(k_near_far, dim3(div_up(N, 128)), dim3(128), 0, (hipStream_t)stream, rays_o, rays_d, aabb, N,
+    LNH_LAUNCH(k_near_far, dim3(div_up(N, 128)), dim3(128), 0, (hipStream_t)stream, rays_o, rays_d, aabb, N,
                        min_near, nears, fars);
     return lnh_check_launch("lnh_near_far_from_aabb");
 }
@@ -332,7 +332,7 @@ int lnh_sph_from_ray(const float *rays_o, const float *rays_d, float radius, uin
                      lnh_stream_t stream) {
     LNH_REQUIRE(rays_o && rays_d && coords, LNH_ERR_INVALID_ARG, "sph_from_ray: null pointer");
     if (N == 0) return LNH_OK;
-    hipLaunchKernelGGL(k_sph_from_ray, dim3(div_up(N, 128)), dim3(128), 0, (hipStream_t)stream, rays_o, rays_d, radius,
+    LNH_LAUNCH(k_sph_from_ray, dim3(div_up(N, 128)), dim3(128), 0, (hipStream_t)stream, rays_o, rays_d, radius,
                        N, coords);
     return lnh_check_launch("lnh_sph_from_ray");
 }
@@ -340,14 +340,14 @@ int lnh_sph_from_ray(const float *rays_o, const float *rays_d, float radius, uin
 int lnh_morton3D(const int32_t *coords, uint32_t N, int32_t *indices, lnh_stream_t stream) {
     LNH_REQUIRE(coords && indices, LNH_ERR_INVALID_ARG, "morton3D: null pointer");
     if (N == 0) return LNH_OK;
-    hipLaunchKernelGGL(k_morton, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, coords, N, indices);
+    LNH_LAUNCH(k_morton, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, coords, N, indices);
     return lnh_check_launch("lnh_morton3D");
 }
 
 int lnh_morton3D_invert(const int32_t *indices, uint32_t N, int32_t *coords, lnh_stream_t stream) {
     LNH_REQUIRE(coords && indices, LNH_ERR_INVALID_ARG, "morton3D_invert: null pointer");
     if (N == 0) return LNH_OK;
-    hipLaunchKernelGGL(k_morton_invert, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, indices, N, coords);
+    LNH_LAUNCH(k_morton_invert, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, indices, N, coords);
     return lnh_check_launch("lnh_morton3D_invert");
 }
 
@@ -355,7 +355,7 @@ int lnh_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *b
     LNH_REQUIRE(grid && bitfield, LNH_ERR_INVALID_ARG, "packbits: null pointer");
     LNH_REQUIRE(((uintptr_t)grid & 15) == 0, LNH_ERR_INVALID_ARG, "packbits: grid must be 16-byte aligned");
     if (N == 0) return LNH_OK;
-    hipLaunchKernelGGL(k_packbits, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, grid, N, density_thresh,
+    LNH_LAUNCH(k_packbits, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, grid, N, density_thresh,
                        bitfield);
     return lnh_check_launch("lnh_packbits");
 }
@@ -365,7 +365,7 @@ int lnh_occupancy_lookup(const float *xyz, const float *dt, const uint8_t *bitfi
     LNH_REQUIRE(xyz && dt && bitfield && cell_index && occ, LNH_ERR_INVALID_ARG, "occupancy_lookup: null pointer");
     LNH_REQUIRE(C >= 1 && C <= 8 && H >= 1 && H <= 1024, LNH_ERR_INVALID_ARG, "occupancy_lookup: bad cascade / grid size");
     if (N == 0) return LNH_OK;
-    hipLaunchKernelGGL(k_occupancy_lookup, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, xyz, dt, bitfield,
+    LNH_LAUNCH(k_occupancy_lookup, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, xyz, dt, bitfield,
                        bound, N, C, H, cell_index, occ);
     return lnh_check_launch("lnh_occupancy_lookup");
 }
@@ -379,7 +379,7 @@ int lnh_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t
     LNH_REQUIRE(C >= 1 && C <= 8 && H >= 1 && H <= 1024 && max_steps >= 1, LNH_ERR_INVALID_ARG,
                 "march_rays_train: bad cascade / grid size / max_steps");
     if (N == 0) return LNH_OK;
-    hipLaunchKernelGGL(k_march_rays_train, dim3(div_up(N, 64)), dim3(64), 0, (hipStream_t)stream, rays_o, rays_d, grid,
+    LNH_LAUNCH(k_march_rays_train, dim3(div_up(N, 64)), dim3(64), 0, (hipStream_t)stream, rays_o, rays_d, grid,
                        bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays, counter, noises);
     return lnh_check_launch("lnh_march_rays_train");
 }
@@ -390,7 +390,7 @@ int lnh_composite_rays_train_forward(const float *sigmas, const float *rgbs, con
     LNH_REQUIRE(sigmas && rgbs && deltas && rays && weights_sum && depth && image, LNH_ERR_INVALID_ARG,
                 "composite_rays_train_forward: null pointer");
     if (N == 0) return LNH_OK;
-    hipLaunchKernelGGL(k_composite_train_fwd, dim3(div_up(N, 64)), dim3(64), 0, (hipStream_t)stream, sigmas, rgbs,
+    LNH_LAUNCH(k_composite_train_fwd, dim3(div_up(N, 64)), dim3(64), 0, (hipStream_t)stream, sigmas, rgbs,
                        deltas, rays, M, N, T_thresh, weights_sum, depth, image);
     return lnh_check_launch("lnh_composite_rays_train_forward");
 }
@@ -403,7 +403,7 @@ int lnh_composite_rays_train_backward(const float *grad_weights_sum, const float
                     grad_sigmas && grad_rgbs,
                 LNH_ERR_INVALID_ARG, "composite_rays_train_backward: null pointer");
     if (N == 0) return LNH_OK;
-    hipLaunchKernelGGL(k_composite_train_bwd, dim3(div_up(N, 64)), dim3(64), 0, (hipStream_t)stream, grad_weights_sum,
+    LNH_LAUNCH(k_composite_train_bwd, dim3(div_up(N, 64)), dim3(64), 0, (hipStream_t)stream, grad_weights_sum,
                        grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, T_thresh, grad_sigmas,
                        grad_rgbs);
     return lnh_check_launch("lnh_composite_rays_train_backward");

@@ -17,6 +17,7 @@ P, U32, I32, F32 = C.c_void_p, C.c_uint32, C.c_int, C.c_float
 _SIGS = {
     "lnh_grid_encode_forward": [P, P, P, P, U32, U32, U32, U32, F32, U32, P, U32, I32, U32, I32],
     "lnh_grid_encode_backward": [P, P, P, P, P, U32, U32, U32, U32, F32, U32, P, P, U32, I32, U32, I32],
+    "lnh_grid_encode_backward_ws": [P, P, P, P, U32, U32, U32, U32, F32, U32, U32, I32, U32, I32, P, C.c_uint64],
     "lnh_grad_total_variation": [P, P, P, P, F32, U32, U32, U32, U32, F32, U32, U32, I32, I32],
     "lnh_grid_corner_indices": [P, P, P, U32, U32, U32, U32, F32, U32, U32, I32],
     "lnh_freq_encode_forward": [P, U32, U32, U32, U32, P],
@@ -39,7 +40,7 @@ _SIGS = {
     "lnh_lidar_composite_backward": [P, P, P, P, P, P, P, U32, U32, U32, F32, P, P],
     "lnh_lidar_resample": [P, P, P, P, U32, U32, U32, F32, P, P, P],
 }
-EXPORTS = sorted(list(_SIGS) + ["lnh_version", "lnh_last_error", "lnh_arch"])
+EXPORTS = sorted(list(_SIGS) + ["lnh_version", "lnh_last_error", "lnh_arch", "lnh_grid_backward_workspace_size"])
 
 LNH_F32, LNH_F16 = 0, 1
 
@@ -63,6 +64,8 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = sig + [P]
             fn.restype = C.c_int
+        L.lnh_grid_backward_workspace_size.argtypes = [P, U32, U32, U32, U32, F32, U32, U32, I32, I32]
+        L.lnh_grid_backward_workspace_size.restype = C.c_uint64
         L.lnh_last_error.restype = C.c_char_p
         L.lnh_arch.restype = C.c_char_p
         L.lnh_version.restype = C.c_int
@@ -81,10 +84,37 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def call(name, *args):
+# Optional per-entry-point HIP-event timing (bench.py): TIMERS[name] = [(start_event, end_event, tag), ...].
+# Events are recorded on the stream the kernel is launched on (torch's current stream).
+TIMERS = None
+
+
+def enable_timers(names=None):
+    """Start collecting HIP events around calls (all entry points, or only `names`)."""
+    global TIMERS, _TIMED
+    TIMERS, _TIMED = {}, (set(names) if names else None)
+
+
+def disable_timers():
+    global TIMERS
+    t, TIMERS = TIMERS, None
+    return t
+
+
+_TIMED = None
+
+
+def call(name, *args, tag=None):
     """Invoke an entry point on the current stream; raise on any non-zero status."""
     L = lib()
+    timed = TIMERS is not None and (_TIMED is None or name in _TIMED)
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     rc = getattr(L, name)(*args, stream())
+    if timed:
+        e1.record()
+        TIMERS.setdefault(name, []).append((e0, e1, tag))
     if rc != 0:
         raise RuntimeError(f"{name} failed ({rc}): {L.lnh_last_error().decode()}")
 

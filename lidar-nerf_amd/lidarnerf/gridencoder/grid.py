@@ -38,8 +38,21 @@ def grid_forward_raw(inputs, embeddings, offsets_host, S, H, gridtype, align_cor
     dy_dx = torch.empty((B, L * D * C), device=inputs.device, dtype=embeddings.dtype) if want_dy_dx else None
     _hip.call("lnh_grid_encode_forward", inputs.data_ptr(), embeddings.data_ptr(), offsets_host.data_ptr(),
               out.data_ptr(), B, D, C, L, float(S), int(H), _hip.ptr(dy_dx), gridtype, int(align_corners), interp,
-              _hip.dtype_code(embeddings.dtype))
+              _hip.dtype_code(embeddings.dtype), tag=B)
     return out, dy_dx
+
+
+_WORKSPACE = {}  # device -> uint8 scratch tensor for the bucketed backward (grow-only, reused every step)
+
+
+def _workspace(device, nbytes):
+    ws = _WORKSPACE.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = None
+        _WORKSPACE.pop(device, None)
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _WORKSPACE[device] = ws
+    return ws
 
 
 def grid_backward_raw(grad_lbc, inputs, rows, offsets_host, S, H, gridtype, align_corners, interp, dy_dx):
@@ -47,10 +60,21 @@ def grid_backward_raw(grad_lbc, inputs, rows, offsets_host, S, H, gridtype, alig
     L, B, C = grad_lbc.shape
     D = inputs.shape[1]
     ge = torch.zeros((rows, C), device=grad_lbc.device, dtype=grad_lbc.dtype)
+    if dy_dx is None and D == 3 and C == 2:
+        # hot configuration: bucketed scatter-reduce, no atomic adds to HBM (lnh_grid_encode_backward_ws)
+        code = _hip.dtype_code(grad_lbc.dtype)
+        need = _hip.lib().lnh_grid_backward_workspace_size(offsets_host.data_ptr(), B, D, C, L, float(S), int(H),
+                                                           gridtype, int(align_corners), code)
+        if need > 0:
+            ws = _workspace(grad_lbc.device, need)
+            _hip.call("lnh_grid_encode_backward_ws", grad_lbc.data_ptr(), inputs.data_ptr(), offsets_host.data_ptr(),
+                      ge.data_ptr(), B, D, C, L, float(S), int(H), gridtype, int(align_corners), interp, code,
+                      ws.data_ptr(), ws.numel(), tag=B)
+            return ge, None
     gi = torch.zeros((B, D), device=grad_lbc.device, dtype=grad_lbc.dtype) if dy_dx is not None else None
     _hip.call("lnh_grid_encode_backward", grad_lbc.data_ptr(), inputs.data_ptr(), None, offsets_host.data_ptr(),
               ge.data_ptr(), B, D, C, L, float(S), int(H), _hip.ptr(dy_dx), _hip.ptr(gi), gridtype,
-              int(align_corners), interp, _hip.dtype_code(grad_lbc.dtype))
+              int(align_corners), interp, _hip.dtype_code(grad_lbc.dtype), tag=B)
     return ge, gi
 
 

@@ -1,0 +1,71 @@
+"""LiDAR training step: loss of the reference Trainer.train_step (lidarnerf/nerf/utils.py:697-884) and the inner loop
+of train_one_epoch (1206-1226): zero_grad -> autocast(render + loss) -> scaled backward -> [DP all-reduce] ->
+scaler.step(optimizer) -> scaler.update() -> lr_scheduler.step().  Only the LiDAR branch exists in the reference
+path (opt.enable_lidar is forced True, main_lidarnerf.py:229)."""
+import torch
+
+from .. import parallel
+
+
+def lidar_loss(outputs, images_lidar, alpha_d=1000.0, alpha_r=1.0, alpha_i=10.0):
+    """utils.py:712-746 with the default criteria (L1 depth, MSE ray-drop, MSE intensity; main_lidarnerf.py:330-342).
+    images_lidar [B,N,3] = (raydrop, intensity, depth).  Returns (loss, pred_depth, gt_depth)."""
+    gt_raydrop = images_lidar[..., 0]
+    gt_intensity = images_lidar[..., 1] * gt_raydrop
+    gt_depth = images_lidar[..., 2] * gt_raydrop
+    pred_raydrop = outputs["image_lidar"][..., 0]
+    pred_intensity = outputs["image_lidar"][..., 1] * gt_raydrop
+    pred_depth = outputs["depth_lidar"] * gt_raydrop
+    per_ray = (alpha_d * (pred_depth - gt_depth).abs() + alpha_r * (pred_raydrop - gt_raydrop) ** 2
+               + alpha_i * (pred_intensity - gt_intensity) ** 2)
+    return per_ray.mean(), pred_depth, gt_depth
+
+
+def patch_gradient_loss(pred_depth, gt_depth, gt_raydrop, px, py, scale, alpha_grad=100.0):
+    """utils.py:760-876 (grad_loss, non-sobel): |dx| of the prediction vs the SIGNED dx of the ground truth, masked to
+    |gt dx| < 0.01 m and returned rays; only the x term enters the loss (the y terms are computed but unused)."""
+    pred = pred_depth.reshape(-1, 1, px, py) / scale
+    gt = gt_depth.reshape(-1, 1, px, py) / scale
+    rd = gt_raydrop.reshape(-1, 1, px, py)
+    pred_gx = (pred[..., :-1] - pred[..., 1:]).abs()
+    gt_gx = gt[..., :-1] - gt[..., 1:]
+    mask = rd[..., :-1] * (gt_gx.abs() < 0.01)
+    return alpha_grad * (pred_gx * mask - gt_gx * mask).abs().mean()
+
+
+class LidarTrainer:
+    """The hot loop only (no logging / checkpoint / EMA: those are host glue outside the path)."""
+
+    def __init__(self, model, lr=1e-2, iters=30000, fp16=True, alpha_d=1000.0, alpha_r=1.0, alpha_i=10.0,
+                 alpha_grad=100.0, scale=1.0, world_size=1, render_kwargs=None):
+        self.model, self.fp16, self.world = model, fp16, world_size
+        self.alpha = (alpha_d, alpha_r, alpha_i, alpha_grad)
+        self.scale = scale
+        self.render_kwargs = render_kwargs or {}
+        # Adam(betas .9/.99, eps 1e-15) and lr * 0.1^(it/iters) (main_lidarnerf.py:389-391, 408-410)
+        self.optimizer = torch.optim.Adam(model.get_params(lr), betas=(0.9, 0.99), eps=1e-15)
+        self.scheduler = torch.optim.lr_scheduler.LambdaLR(self.optimizer, lambda it: 0.1 ** min(it / iters, 1))
+        self.scaler = torch.amp.GradScaler("cuda", enabled=fp16)
+        self.params = [p for g in self.optimizer.param_groups for p in g["params"]]
+
+    def loss(self, rays_o, rays_d, images_lidar, patch=(1, 1)):
+        out = self.model.render(rays_o, rays_d, cal_lidar_color=True, staged=False, perturb=True,
+                                **self.render_kwargs)
+        ad, ar, ai, ag = self.alpha
+        loss, pred_depth, gt_depth = lidar_loss(out, images_lidar, ad, ar, ai)
+        if patch[0] > 1:
+            loss = loss + patch_gradient_loss(pred_depth, gt_depth, images_lidar[..., 0], patch[0], patch[1],
+                                              self.scale, ag)
+        return loss
+
+    def step(self, rays_o, rays_d, images_lidar, patch=(1, 1)):
+        self.optimizer.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):
+            loss = self.loss(rays_o, rays_d, images_lidar, patch)
+        self.scaler.scale(loss).backward()
+        if self.world > 1:
+            parallel.allreduce_gradients(self.params, self.world)
+        self.scaler.step(self.optimizer)
+        self.scaler.update()
+        self.scheduler.step()
+        return loss

@@ -139,6 +139,46 @@ def test_backward(dt, kind):
     assert np.all(got[want == 0] == 0)
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16])
+@pytest.mark.parametrize("kind", ["random", "rays", "same_cell"])
+def test_backward_bucketed(dt, kind):
+    """lnh_grid_encode_backward_ws (no HBM atomics) must give the same table as the oracle's order-free sum."""
+    from gpu_util import call, dev, host
+    from lidarnerf import _hip
+    if kind == "random":
+        x = _points(5000, 7)
+    elif kind == "rays":
+        x = _ray_points(24, 256, 7)
+    else:  # adversarial: every point in one cell -> one bucket overflows its pool, excess goes through atomics
+        x = (np.random.default_rng(1).random((20000, 3), dtype=np.float32) * 1e-6 + 0.3).astype(np.float32)
+        x[::2] += np.float32(0.11)  # break the runs so the wave merge cannot collapse everything
+    B = x.shape[0]
+    nd = np.float32 if dt == torch.float32 else np.float16
+    g = (np.random.default_rng(8).standard_normal((L, B, CH)) * 0.1).astype(nd)
+    rows = int(OFF[-1])
+    want = c_oracle.grid_backward(g, x, OFF, rows, S, H)
+    code = 0 if dt == torch.float32 else 1
+    offh = torch.from_numpy(OFF)
+    need = _hip.lib().lnh_grid_backward_workspace_size(offh.data_ptr(), B, 3, CH, L, S, H, 0, 0, code)
+    assert need > 0
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    ge = torch.zeros((rows, CH), dtype=dt, device="cuda")
+    call("lnh_grid_encode_backward_ws", dev(g), dev(x), offh, ge, B, 3, CH, L, S, H, 0, 0, 0, code, ws, need)
+    got = host(ge).astype(np.float64)
+    if dt == torch.float32:
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5)
+    elif kind == "same_cell":
+        # pool overflow -> the excess takes the reference's route (packed fp16 atomics into the table): thousands of
+        # fp16 additions per row, each rounding at the running sum's ulp (2^-10 relative)
+        np.testing.assert_allclose(got, want, rtol=0.1, atol=0.05 * np.abs(want).max())
+    else:  # fp32 LDS accumulation, ONE rounding to fp16 per touched row
+        np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-3 * max(1.0, np.abs(want).max() / 10))
+    assert np.all(got[want == 0] == 0)
+    # too-small workspace is an error, not silent corruption
+    with pytest.raises(RuntimeError, match="workspace too small"):
+        call("lnh_grid_encode_backward_ws", dev(g), dev(x), offh, ge, B, 3, CH, L, S, H, 0, 0, 0, code, ws, 1024)
+
+
 def test_backward_full_size_checksum():
     """Full BASELINE size: sum of the gradient table == sum of upstream grads (weights of a cell sum to 1)."""
     from gpu_util import call
