@@ -215,6 +215,55 @@ LNH_API int lnh_lidar_resample(const float *z, const float *sigma, const float *
                                uint32_t N, uint32_t T, uint32_t n_new, float density_scale, float *new_z,
                                float *z_out, int32_t *perm, lnh_stream_t stream);
 
+
+/* ------------------------------------------------------------------ fused LiDAR field step ------------------ */
+/*
+ * The kernels below fuse what lidarnerf/nerf/renderer.py:149-256 + lidarnerf/nerf/network.py:162-237 spread over
+ * dozens of PyTorch launches (sample positions, encoder permutes, trunc_exp, sort/gather merge, masked colour
+ * query).  Semantics are unchanged; see lidar-nerf_amd/csrc/lidar_field.hip for the derivations.
+ *
+ * lnh_lidar_sample_points: x01[N*T,3] = (clip(o + d*z, aabb) + bound) / (2 bound)  (renderer.py:164-167, grid.py:213)
+ */
+LNH_API int lnh_lidar_sample_points(const float *rays_o, const float *rays_d, const float *z, const float *aabb,
+                                    float bound, uint32_t N, uint32_t T, float *x01, lnh_stream_t stream);
+/*
+ * lnh_density_mlp_forward: sigma-net 32 -> 64 -> 16 (ReLU, no bias; network.py:45-59,162-179) on features in the
+ * encoder's level-major layout [16,B,2] (fp16).  Point p = r*T_cur + j writes row r*T_tot + slot_off + j of
+ * h16 [*,16] fp16 (raw outputs: col 0 density pre-activation, cols 1..15 geo_feat) and sigma [*] f32 = exp(h16[.,0])
+ * (trunc_exp forward).  weights flat fp16 [64*32 | 16*64].
+ */
+LNH_API int lnh_density_mlp_forward(const void *features, const void *weights, uint32_t B, uint32_t T_cur,
+                                    uint32_t T_tot, uint32_t slot_off, void *h16, float *sigma, lnh_stream_t stream);
+/* grad_h16 rows addressed like h16 above -> grad_features [16,B,2] fp16, grad_weights fp32 (accumulated). */
+LNH_API int lnh_density_mlp_backward(const void *grad_h16, const void *features, const void *weights, uint32_t B,
+                                     uint32_t T_cur, uint32_t T_tot, uint32_t slot_off, void *grad_features,
+                                     float *grad_weights, lnh_stream_t stream);
+/*
+ * lnh_lidar_merge_weights: sigma_m[n,i] = sigma_pt[n, perm[n,i]] and the compositing weights of the merged samples
+ * (renderer.py:217-243); z [N,T] merged (sorted) depths, perm from lnh_lidar_resample.
+ */
+LNH_API int lnh_lidar_merge_weights(const float *z, const float *sigma_pt, const int32_t *perm,
+                                    const float *sample_dist, uint32_t N, uint32_t T, float density_scale,
+                                    float *sigma_m, float *weights, lnh_stream_t stream);
+/*
+ * lnh_lidar_color_forward: LiDAR colour head (network.py:199-237 with cal_lidar_color=True) on merged samples:
+ * rgb[n,i,0:2] = sigmoid(MLP([freq(d_n) | geo_feat(sample)])) where weights[n,i] > 1e-4, else 0.
+ * h16 [N*T,16] sigma-net rows in point order, perm [N,T], cdir [N,64] f32 = W0[:, :75] freq(d_n) (per ray),
+ * w16 flat fp16: W0g [64,16] (col 0 zero, cols 1..15 = W0[:,75:90]) | W1 [64,64] | W2 padded to [16,64].
+ */
+LNH_API int lnh_lidar_color_forward(const void *h16, const int32_t *perm, const float *weights, const float *cdir,
+                                    const void *w16, uint32_t N, uint32_t T, float *rgb, lnh_stream_t stream);
+/*
+ * lnh_lidar_color_backward: grad_rgb [N,T,2], grad_sigma [N,T] (merged order, from lnh_lidar_composite_backward)
+ * -> grad_h16 [N*T,16] fp16 in POINT order (col 0 = grad_sigma * exp(clamp(pre,-15,15)), activation.py:17-19;
+ * cols 1..15 = colour-head input gradient), grad_w fp32 flat like w16 (accumulated), ray_sum [N,64] f32 = sum over
+ * the ray of d(hidden0) (multiply by freq(d) to get the gradient of W0[:, :75]).
+ */
+LNH_API int lnh_lidar_color_backward(const float *grad_rgb, const float *grad_sigma, const void *h16,
+                                     const int32_t *perm, const float *weights, const float *cdir, const void *w16,
+                                     uint32_t N, uint32_t T, void *grad_h16, float *grad_w, float *ray_sum,
+                                     lnh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,432 @@
+// lidar_field.hip — fused kernels of the LiDAR radiance-field step on gfx950 (the part of the reference that lives in
+// lidarnerf/nerf/renderer.py:149-231 + lidarnerf/nerf/network.py:199-237 as dozens of PyTorch launches):
+//
+//   lnh_lidar_sample_points   rays x z -> sample positions mapped to the encoder's [0,1]^3 (renderer.py:164-167 +
+//                             gridencoder/grid.py:213) in one pass.
+//   lnh_lidar_merge_weights   sigma gathered into merged (sorted) order through the resampler's permutation +
+//                             compositing weights (renderer.py:217-243) — the [N,T+t] sort/gather never happens.
+//   lnh_lidar_color_forward   LiDAR colour head (ray-drop, intensity) for every merged sample whose weight exceeds
+//   lnh_lidar_color_backward  1e-4 (renderer.py:249-256, network.py:199-237) as ONE MFMA kernel each way.
+//
+// Two algebraic moves keep the colour head small:
+//   (1) its first layer sees [freq(d) (75) | geo_feat (15)], and the direction d is constant along a ray, so
+//       W0 [freq(d) | geo] = W0_dir freq(d) + W0_geo geo: the 75-wide part is evaluated ONCE PER RAY (a [N,64]
+//       fp32 bias computed by the caller) and the per-sample matmul shrinks from K=90 to K=16;
+//   (2) the 16-wide sample input is the sigma-net's raw output row itself (col 0 = density pre-activation, cols 1..15
+//       = geo_feat): the weight column for col 0 is zero, so no slicing / concatenation / masked gather is needed —
+//       the row is fetched through the merge permutation straight from where the sigma-net wrote it.
+// Backward: one workgroup per ray; its four waves recompute, back-propagate in registers, cooperate on the weight
+// gradients through LDS (see mlp_bwd.h), and emit the FULL gradient row of the sigma-net output in point order
+// (col 0 = trunc_exp backward of the compositing gradient, lidarnerf/activation.py:17-19), so the merge is undone for
+// free.  The per-ray sum of d(hidden0) gives the gradient of the direction part of W0 after one small GEMM.
+#include "mlp_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ sample points
+__global__ void __launch_bounds__(256)
+k_sample_points(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ z,
+                const float *__restrict__ aabb, float bound, uint32_t N, uint32_t T, float *__restrict__ x01) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * T) return;
+    const uint32_t n = i / T;
+    const float t = z[i];
+    float *o = x01 + (size_t)i * 3;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        // o + d * z  (separate multiply and add: the reference evaluates this with two PyTorch ops), clip to the
+        // aabb, then (x + bound) / (2 bound) as GridEncoder.forward does
+        float p = rays_o[n * 3 + d] + rays_d[n * 3 + d] * t;
+        p = fminf(fmaxf(p, aabb[d]), aabb[3 + d]);
+        o[d] = (p + bound) / (2 * bound);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ merge + weights
+__global__ void __launch_bounds__(256)
+k_merge_weights(const float *__restrict__ z, const float *__restrict__ sigma_pt, const int32_t *__restrict__ perm,
+                const float *__restrict__ sample_dist, uint32_t N, uint32_t T, float density_scale,
+                float *__restrict__ sigma_m, float *__restrict__ weights) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t ray = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (ray >= N) return;
+    const float *zr = z + (size_t)ray * T;
+    const float *sp = sigma_pt + (size_t)ray * T;
+    const int32_t *pr = perm + (size_t)ray * T;
+    const float sd = sample_dist[ray];
+    float carry = 1.0f;
+    for (uint32_t base = 0; base < T; base += 64) {
+        const uint32_t i = base + lane;
+        float alpha = 0.0f, om = 1.0f, sg = 0.0f;
+        if (i < T) {
+            sg = sp[pr[i]];
+            const float zi = zr[i];
+            const float delta = (i + 1 < T) ? (zr[i + 1] - zi) : sd;
+            alpha = 1.0f - expf(-delta * density_scale * sg);
+            om = 1.0f - alpha + 1e-15f;
+        }
+        const float incl = wave_scan_mul(om, lane);
+        float excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.0f;
+        if (i < T) {
+            sigma_m[(size_t)ray * T + i] = sg;
+            weights[(size_t)ray * T + i] = alpha * (carry * excl);
+        }
+        carry *= __shfl(incl, 63, 64);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ colour head
+// flat fp16 weights: W0g [64][16] (col 0 = 0, cols 1..15 = geo columns of the first Linear) | W1 [64][64] | W2 [16][64]
+constexpr int kW0g = 0, kW1 = 64 * 16, kW2 = kW1 + 64 * 64, kWTotal = kW2 + 16 * 64;
+constexpr float kMaskThresh = 1e-4f;  // renderer.py:249
+
+struct ColorArgs {
+    const half_t *h16;      // [N*T,16] sigma-net raw outputs, point order
+    const int32_t *perm;    // [N,T] merged position -> slot of the ray
+    const float *weights;   // [N,T] merged order
+    const float *cdir;      // [N,64] fp32: W0_dir * freq(d) per ray
+    const half_t *W;        // flat fp16 (kWTotal)
+    float *rgb;             // fwd out [N,T,2]
+    const float *g_rgb;     // bwd in  [N,T,2]
+    const float *g_sigma;   // bwd in  [N,T] merged order
+    half_t *g_h16;          // bwd out [N*T,16] point order
+    float *dW;              // bwd out flat fp32 (kWTotal), atomically accumulated
+    float *S;               // bwd out [N,64] fp32: sum over the ray of d(hidden0 pre-activation)
+    uint32_t N, T;
+};
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ void __launch_bounds__(256)
+k_color_forward(ColorArgs a) {
+    constexpr int HT = 4, HS = 2, NT = 4;
+    const uint32_t lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+    half8_t w0[HT], w1[HT][HS], w2[HS];
+#pragma unroll
+    for (int t = 0; t < HT; t++) {
+        w0[t] = load_a_natural(a.W + kW0g, 16, 16 * t + c, 0, g, 16);
+#pragma unroll
+        for (int s = 0; s < HS; s++) w1[t][s] = load_a_nu(a.W + kW1, 64, 16 * t + c, s, g);
+    }
+#pragma unroll
+    for (int s = 0; s < HS; s++) w2[s] = load_a_nu(a.W + kW2, 64, c, s, g);
+
+    const uint32_t total = a.N * a.T;  // < 2^32 (checked by the launcher)
+    for (uint32_t base = wave * NT * 16; base < total; base += nwaves * NT * 16) {
+        float wgt[NT];
+        bool msk[NT];
+        bool any = false;
+#pragma unroll
+        for (int n = 0; n < NT; n++) {
+            const uint32_t m = base + n * 16 + c;
+            wgt[n] = m < total ? a.weights[m] : 0.0f;
+            msk[n] = wgt[n] > kMaskThresh;
+            any |= msk[n];
+        }
+        if (!__any(any)) {  // whole 64-sample span transparent: colour is defined as 0 there
+            if (g == 0) {
+#pragma unroll
+                for (int n = 0; n < NT; n++) {
+                    const uint32_t m = base + n * 16 + c;
+                    if (m < total) *reinterpret_cast<float2 *>(a.rgb + (size_t)m * 2) = make_float2(0.0f, 0.0f);
+                }
+            }
+            continue;
+        }
+#pragma unroll
+        for (int n = 0; n < NT; n++) {
+            const uint32_t m = base + n * 16 + c;
+            const bool valid = m < total;
+            const uint32_t ray = valid ? m / a.T : 0;
+            const size_t src = valid ? (size_t)ray * a.T + (uint32_t)a.perm[m] : 0;
+            const half8_t bx = (valid && g < 2) ? *reinterpret_cast<const half8_t *>(a.h16 + src * 16 + 8 * g) : zero_h8();
+            f32x4 acc[HT];
+#pragma unroll
+            for (int t = 0; t < HT; t++) {
+                acc[t] = valid ? *reinterpret_cast<const f32x4 *>(a.cdir + (size_t)ray * 64 + 16 * t + 4 * g) : zero_f4();
+                acc[t] = MFMA16(w0[t], bx, acc[t]);
+            }
+            half8_t bh[HS];
+#pragma unroll
+            for (int s = 0; s < HS; s++)
+                bh[s] = pack_pair(acc[2 * s], acc[2 * s + 1], [](float v) { return v > 0.0f ? v : 0.0f; });
+#pragma unroll
+            for (int t = 0; t < HT; t++) {
+                acc[t] = zero_f4();
+#pragma unroll
+                for (int s = 0; s < HS; s++) acc[t] = MFMA16(w1[t][s], bh[s], acc[t]);
+            }
+#pragma unroll
+            for (int s = 0; s < HS; s++)
+                bh[s] = pack_pair(acc[2 * s], acc[2 * s + 1], [](float v) { return v > 0.0f ? v : 0.0f; });
+            f32x4 o = zero_f4();
+#pragma unroll
+            for (int s = 0; s < HS; s++) o = MFMA16(w2[s], bh[s], o);
+            if (valid && g == 0) {
+                // the unfused path rounds the MLP output to fp16 before the sigmoid (autocast Linear output)
+                const float r0 = msk[n] ? sigmoidf((float)(half_t)o[0]) : 0.0f;
+                const float r1 = msk[n] ? sigmoidf((float)(half_t)o[1]) : 0.0f;
+                *reinterpret_cast<float2 *>(a.rgb + (size_t)m * 2) = make_float2(r0, r1);
+            }
+        }
+    }
+}
+
+// One workgroup (4 waves) per ray; step = 64 merged samples, wave w owns samples [16w, 16w+16) of the step.
+__global__ void __launch_bounds__(256)
+k_color_backward(ColorArgs a) {
+    constexpr int HT = 4, HS = 2, LDP = 64 + 8;
+    __shared__ __attribute__((aligned(16))) half_t tileG[64 * LDP];  // gradient^T  [channel][sample]
+    __shared__ __attribute__((aligned(16))) half_t tileA[64 * LDP];  // activation^T
+    __shared__ float sred[4][64];
+    const uint32_t wid = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+    const uint32_t col0 = wid * 16;
+
+    half8_t w0[HT], w1[HT][HS], w2[HS];
+    half8_t w2T[HT], w1T[HT][HS], w0T[HS];
+#pragma unroll
+    for (int t = 0; t < HT; t++) {
+        w0[t] = load_a_natural(a.W + kW0g, 16, 16 * t + c, 0, g, 16);
+        w2T[t] = load_at_natural(a.W + kW2, 64, 16 * t + c, 0, g, 16);
+#pragma unroll
+        for (int s = 0; s < HS; s++) {
+            w1[t][s] = load_a_nu(a.W + kW1, 64, 16 * t + c, s, g);
+            w1T[t][s] = load_at_nu(a.W + kW1, 64, 16 * t + c, s, g);
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < HS; s++) {
+        w2[s] = load_a_nu(a.W + kW2, 64, c, s, g);
+        w0T[s] = load_at_nu(a.W + kW0g, 16, c, s, g);  // A[m = input feature c][k = hidden nu]
+    }
+    // weight-gradient tiles owned by this wave (persist over all rays of the workgroup)
+    f32x4 gW2 = zero_f4();       // dW2 rows 0..15, hidden columns [16*wid, +16)
+    f32x4 gW1[HT];               // dW1 row tile q, column tile wid
+    f32x4 gW0 = zero_f4();       // dW0g row tile wid (hidden), 16 input columns
+#pragma unroll
+    for (int q = 0; q < HT; q++) gW1[q] = zero_f4();
+
+    auto put_packed = [&](half_t *tile, const half8_t (&v)[HS]) {
+#pragma unroll
+        for (int s = 0; s < HS; s++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) tile[(16 * (2 * s + (j >> 2)) + 4 * g + (j & 3)) * LDP + col0 + c] = v[s][j];
+    };
+    auto wgrad_tile = [&](f32x4 acc, uint32_t tg, uint32_t ta) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            const half8_t fa = *reinterpret_cast<const half8_t *>(tileG + (16 * tg + c) * LDP + 32 * ks + 8 * g);
+            const half8_t fb = *reinterpret_cast<const half8_t *>(tileA + (16 * ta + c) * LDP + 32 * ks + 8 * g);
+            acc = MFMA16(fa, fb, acc);
+        }
+        return acc;
+    };
+
+    for (uint32_t ray = blockIdx.x; ray < a.N; ray += gridDim.x) {
+        f32x4 cb[HT];
+#pragma unroll
+        for (int t = 0; t < HT; t++) cb[t] = *reinterpret_cast<const f32x4 *>(a.cdir + (size_t)ray * 64 + 16 * t + 4 * g);
+        float ssum[HT][4];
+#pragma unroll
+        for (int t = 0; t < HT; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) ssum[t][r] = 0.0f;
+
+        for (uint32_t step = 0; step < a.T; step += 64) {
+            const uint32_t i = step + col0 + c;
+            const bool valid = i < a.T;
+            const size_t m = (size_t)ray * a.T + (valid ? i : 0);
+            const float wgt = valid ? a.weights[m] : 0.0f;
+            const bool msk = wgt > kMaskThresh;
+            const size_t src = (size_t)ray * a.T + (valid ? (uint32_t)a.perm[m] : 0u);
+            const half8_t bx = (valid && g < 2) ? *reinterpret_cast<const half8_t *>(a.h16 + src * 16 + 8 * g) : zero_h8();
+            // ---- forward recompute
+            f32x4 acc[HT];
+#pragma unroll
+            for (int t = 0; t < HT; t++) acc[t] = MFMA16(w0[t], bx, cb[t]);
+            half8_t bh0[HS], bh1[HS];
+#pragma unroll
+            for (int s = 0; s < HS; s++)
+                bh0[s] = pack_pair(acc[2 * s], acc[2 * s + 1], [](float v) { return v > 0.0f ? v : 0.0f; });
+#pragma unroll
+            for (int t = 0; t < HT; t++) {
+                acc[t] = zero_f4();
+#pragma unroll
+                for (int s = 0; s < HS; s++) acc[t] = MFMA16(w1[t][s], bh0[s], acc[t]);
+            }
+#pragma unroll
+            for (int s = 0; s < HS; s++)
+                bh1[s] = pack_pair(acc[2 * s], acc[2 * s + 1], [](float v) { return v > 0.0f ? v : 0.0f; });
+            f32x4 o = zero_f4();
+#pragma unroll
+            for (int s = 0; s < HS; s++) o = MFMA16(w2[s], bh1[s], o);
+            // ---- output gradient through the sigmoid (only outputs 0,1 exist; lanes g == 0 hold them)
+            half8_t by = zero_h8();
+            if (g == 0 && valid && msk) {
+                const float2 gr = *reinterpret_cast<const float2 *>(a.g_rgb + m * 2);
+                const float r0 = sigmoidf((float)(half_t)o[0]), r1 = sigmoidf((float)(half_t)o[1]);
+                by[0] = (half_t)(gr.x * r0 * (1.0f - r0));
+                by[1] = (half_t)(gr.y * r1 * (1.0f - r1));
+            }
+            // ---- dW2 += dY^T h1
+            if (g < 2) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) tileG[(8 * g + j) * LDP + col0 + c] = by[j];
+            }
+            put_packed(tileA, bh1);
+            __syncthreads();
+            gW2 = wgrad_tile(gW2, 0, wid);
+            __syncthreads();
+            // ---- dH1 = W2^T dY through relu
+            half8_t bd[HS];
+            {
+                f32x4 d[HT];
+#pragma unroll
+                for (int t = 0; t < HT; t++) d[t] = MFMA16(w2T[t], by, zero_f4());
+#pragma unroll
+                for (int s = 0; s < HS; s++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        bd[s][j] = (float)bh1[s][j] > 0.0f ? (half_t)d[2 * s][j] : (half_t)0.0f;
+                        bd[s][4 + j] = (float)bh1[s][4 + j] > 0.0f ? (half_t)d[2 * s + 1][j] : (half_t)0.0f;
+                    }
+            }
+            // ---- dW1 += dH1^T h0
+            put_packed(tileG, bd);
+            put_packed(tileA, bh0);
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < HT; q++) gW1[q] = wgrad_tile(gW1[q], q, wid);
+            __syncthreads();
+            // ---- dH0 = W1^T dH1 through relu
+            {
+                f32x4 d[HT];
+#pragma unroll
+                for (int t = 0; t < HT; t++) {
+                    d[t] = zero_f4();
+#pragma unroll
+                    for (int s = 0; s < HS; s++) d[t] = MFMA16(w1T[t][s], bd[s], d[t]);
+                }
+#pragma unroll
+                for (int s = 0; s < HS; s++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        bd[s][j] = (float)bh0[s][j] > 0.0f ? (half_t)d[2 * s][j] : (half_t)0.0f;
+                        bd[s][4 + j] = (float)bh0[s][4 + j] > 0.0f ? (half_t)d[2 * s + 1][j] : (half_t)0.0f;
+                    }
+#pragma unroll
+                for (int s = 0; s < HS; s++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        ssum[2 * s][j] += (float)bd[s][j];
+                        ssum[2 * s + 1][j] += (float)bd[s][4 + j];
+                    }
+            }
+            // ---- dW0g += dH0^T x  (x = the 16-wide sigma-net row)
+            put_packed(tileG, bd);
+            if (g < 2) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) tileA[(8 * g + j) * LDP + col0 + c] = bx[j];
+            }
+            __syncthreads();
+            gW0 = wgrad_tile(gW0, wid, 0);
+            __syncthreads();
+            // ---- d(sigma-net row) = W0g^T dH0, col 0 <- trunc_exp backward of the compositing gradient
+            f32x4 dx = zero_f4();
+#pragma unroll
+            for (int s = 0; s < HS; s++) dx = MFMA16(w0T[s], bd[s], dx);
+            if (valid) {
+                if (g == 0) {
+                    const float pre = fminf(fmaxf((float)bx[0], -15.0f), 15.0f);
+                    dx[0] = a.g_sigma[m] * expf(pre);
+                }
+                half4_t v = {(half_t)dx[0], (half_t)dx[1], (half_t)dx[2], (half_t)dx[3]};
+                *reinterpret_cast<half4_t *>(a.g_h16 + src * 16 + 4 * g) = v;
+            }
+        }
+        // ---- S[ray][neuron] = sum over the ray's samples of dH0: reduce over the 16 lanes of each g group, then waves
+#pragma unroll
+        for (int t = 0; t < HT; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float v = ssum[t][r];
+                v += __shfl_xor(v, 1, 64);
+                v += __shfl_xor(v, 2, 64);
+                v += __shfl_xor(v, 4, 64);
+                v += __shfl_xor(v, 8, 64);
+                if (c == 0) sred[wid][16 * t + 4 * g + r] = v;
+            }
+        __syncthreads();
+        if (threadIdx.x < 64)
+            a.S[(size_t)ray * 64 + threadIdx.x] = sred[0][threadIdx.x] + sred[1][threadIdx.x] + sred[2][threadIdx.x] +
+                                                  sred[3][threadIdx.x];
+        __syncthreads();
+    }
+    // ---- flush weight gradients (D layout: row 4g+r, col c of each tile)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        unsafeAtomicAdd(a.dW + kW2 + (size_t)(4 * g + r) * 64 + 16 * wid + c, gW2[r]);
+        unsafeAtomicAdd(a.dW + kW0g + (size_t)(16 * wid + 4 * g + r) * 16 + c, gW0[r]);
+#pragma unroll
+        for (int q = 0; q < HT; q++)
+            unsafeAtomicAdd(a.dW + kW1 + (size_t)(16 * q + 4 * g + r) * 64 + 16 * wid + c, gW1[q][r]);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int lnh_lidar_sample_points(const float *rays_o, const float *rays_d, const float *z, const float *aabb, float bound,
+                            uint32_t N, uint32_t T, float *x01, lnh_stream_t stream) {
+    LNH_REQUIRE(rays_o && rays_d && z && aabb && x01, LNH_ERR_INVALID_ARG, "lidar_sample_points: null pointer");
+    LNH_REQUIRE(bound > 0.0f, LNH_ERR_INVALID_ARG, "lidar_sample_points: bound must be positive");
+    if ((uint64_t)N * T == 0) return LNH_OK;
+    LNH_REQUIRE((uint64_t)N * T < 0xffffffffull, LNH_ERR_UNSUPPORTED, "lidar_sample_points: N*T must fit 32 bits");
+    LNH_LAUNCH(k_sample_points, dim3(div_up((uint64_t)N * T, 256)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, z,
+               aabb, bound, N, T, x01);
+    return lnh_check_launch("lnh_lidar_sample_points");
+}
+
+int lnh_lidar_merge_weights(const float *z, const float *sigma_pt, const int32_t *perm, const float *sample_dist,
+                            uint32_t N, uint32_t T, float density_scale, float *sigma_m, float *weights,
+                            lnh_stream_t stream) {
+    LNH_REQUIRE(z && sigma_pt && perm && sample_dist && sigma_m && weights, LNH_ERR_INVALID_ARG,
+                "lidar_merge_weights: null pointer");
+    if (N == 0 || T == 0) return LNH_OK;
+    LNH_LAUNCH(k_merge_weights, dim3(div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, z, sigma_pt, perm, sample_dist, N,
+               T, density_scale, sigma_m, weights);
+    return lnh_check_launch("lnh_lidar_merge_weights");
+}
+
+int lnh_lidar_color_forward(const void *h16, const int32_t *perm, const float *weights, const float *cdir,
+                            const void *w16, uint32_t N, uint32_t T, float *rgb, lnh_stream_t stream) {
+    LNH_REQUIRE(h16 && perm && weights && cdir && w16 && rgb, LNH_ERR_INVALID_ARG, "lidar_color_forward: null pointer");
+    if (N == 0 || T == 0) return LNH_OK;
+    LNH_REQUIRE((uint64_t)N * T < 0xffffffffull, LNH_ERR_UNSUPPORTED, "lidar_color_forward: N*T must fit 32 bits");
+    ColorArgs a{};
+    a.h16 = (const half_t *)h16; a.perm = perm; a.weights = weights; a.cdir = cdir; a.W = (const half_t *)w16;
+    a.rgb = rgb; a.N = N; a.T = T;
+    const uint32_t tiles = div_up((uint64_t)N * T, 4 * 16 * 4);
+    LNH_LAUNCH(k_color_forward, dim3(tiles < 2048 ? tiles : 2048), dim3(256), 0, (hipStream_t)stream, a);
+    return lnh_check_launch("lnh_lidar_color_forward");
+}
+
+int lnh_lidar_color_backward(const float *grad_rgb, const float *grad_sigma, const void *h16, const int32_t *perm,
+                             const float *weights, const float *cdir, const void *w16, uint32_t N, uint32_t T,
+                             void *grad_h16, float *grad_w, float *ray_sum, lnh_stream_t stream) {
+    LNH_REQUIRE(grad_rgb && grad_sigma && h16 && perm && weights && cdir && w16 && grad_h16 && grad_w && ray_sum,
+                LNH_ERR_INVALID_ARG, "lidar_color_backward: null pointer");
+    if (N == 0 || T == 0) return LNH_OK;
+    ColorArgs a{};
+    a.h16 = (const half_t *)h16; a.perm = perm; a.weights = weights; a.cdir = cdir; a.W = (const half_t *)w16;
+    a.g_rgb = grad_rgb; a.g_sigma = grad_sigma; a.g_h16 = (half_t *)grad_h16; a.dW = grad_w; a.S = ray_sum;
+    a.N = N; a.T = T;
+    LNH_LAUNCH(k_color_backward, dim3(N < 2048 ? N : 2048), dim3(256), 0, (hipStream_t)stream, a);
+    return lnh_check_launch("lnh_lidar_color_backward");
+}
+
+}  // extern "C"

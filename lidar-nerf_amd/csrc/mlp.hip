@@ -14,6 +14,7 @@
 int lnh_mlp_backward_nhm0(uint32_t in_ks, const MlpBwdArgs &a, hipStream_t s);
 int lnh_mlp_backward_nhm1(uint32_t in_ks, const MlpBwdArgs &a, hipStream_t s);
 int lnh_mlp_backward_nhm2(uint32_t in_ks, const MlpBwdArgs &a, hipStream_t s);
+int lnh_density_mlp_backward_launch(const MlpBwdArgs &a, hipStream_t s);
 
 namespace {
 
@@ -23,11 +24,13 @@ struct MlpArgs {
     half_t *Y;            // [B, 16]
     half_t *fb;           // NULL or [NHM+1, B, hidden]
     uint32_t B, in_dim, hidden, act, out_act;
+    float *sigma;         // DensityIO only: fp32 exp(out[0]) per destination row
+    IoDims io;
 };
 
 // ---------------------------------------------------------------------------------------------------- forward
 // IN_KS = ceil(in_dim / 32); HT = hidden / 16 (M-tiles); NHM = hidden->hidden matrices; NT = point tiles / iteration
-template <int IN_KS, int HT, int NHM, int NT>
+template <int IN_KS, int HT, int NHM, int NT, typename IO>
 __global__ void __launch_bounds__(256)
 k_mlp_forward(MlpArgs a) {
     constexpr int HS = HT / 2;  // k-steps over a hidden vector
@@ -66,8 +69,7 @@ k_mlp_forward(MlpArgs a) {
 #pragma unroll
             for (int s = 0; s < IN_KS; s++) {
                 const uint32_t k0 = 32 * s + 8 * g;
-                bx[n][s] = (p < a.B && k0 < a.in_dim) ? *reinterpret_cast<const half8_t *>(a.X + p * a.in_dim + k0)
-                                                      : zero_h8();
+                bx[n][s] = (p < a.B && k0 < a.in_dim) ? IO::load_x(a.X, p, k0, a.B, a.in_dim) : zero_h8();
             }
         }
         // ---- layer 0
@@ -134,18 +136,22 @@ k_mlp_forward(MlpArgs a) {
             if (p < a.B) {
                 half4_t v = {(half_t)act_forward(out_act, o[0]), (half_t)act_forward(out_act, o[1]),
                              (half_t)act_forward(out_act, o[2]), (half_t)act_forward(out_act, o[3])};
-                *reinterpret_cast<half4_t *>(a.Y + p * 16 + 4 * g) = v;
+                const uint64_t row = IO::out_row(p, a.io);
+                *reinterpret_cast<half4_t *>(a.Y + row * 16 + 4 * g) = v;
+                if constexpr (IO::kDensity) {
+                    if (g == 0) a.sigma[row] = expf((float)v[0]);
+                }
             }
         }
     }
 }
 
-template <int IN_KS, int HT, int NHM>
+template <int IN_KS, int HT, int NHM, typename IO = RowMajorIO>
 int launch_fwd(const MlpArgs &a, hipStream_t s) {
     constexpr int NT = 4;
     const uint32_t tiles = div_up(a.B, NT * 16 * 4);
     const uint32_t grid = tiles < 1024 ? tiles : 1024;
-    LNH_LAUNCH((k_mlp_forward<IN_KS, HT, NHM, NT>), dim3(grid), dim3(256), 0, s, a);
+    LNH_LAUNCH((k_mlp_forward<IN_KS, HT, NHM, NT, IO>), dim3(grid), dim3(256), 0, s, a);
     return lnh_check_launch("lnh_mlp_forward");
 }
 
@@ -200,7 +206,7 @@ int lnh_mlp_forward(const void *inputs, const void *weights, uint32_t B, uint32_
     if (rc) return rc;
     if (B == 0) return LNH_OK;
     MlpArgs a{(const half_t *)inputs, (const half_t *)weights, (half_t *)outputs, (half_t *)forward_buffer,
-              B, input_dim, hidden_dim, activation, output_activation};
+              B, input_dim, hidden_dim, activation, output_activation, nullptr, IoDims{1, 1, 0}};
     hipStream_t s = (hipStream_t)stream;
     LNH_MLP_FWD_DISPATCH(a)
     return rc;
@@ -218,7 +224,7 @@ int lnh_mlp_backward(const void *grad, const void *inputs, const void *weights, 
     if (rc) return rc;
     if (B == 0) return LNH_OK;
     MlpBwdArgs a{(const half_t *)grad, (const half_t *)inputs, (const half_t *)weights, (half_t *)grad_inputs,
-                 grad_weights, B, input_dim, hidden_dim, activation, output_activation};
+                 grad_weights, B, input_dim, hidden_dim, activation, output_activation, IoDims{1, 1, 0}};
     hipStream_t s = (hipStream_t)stream;
     const uint32_t iks = (input_dim + 31) / 32;
     switch (n_hidden_mats) {
@@ -227,6 +233,31 @@ int lnh_mlp_backward(const void *grad, const void *inputs, const void *weights, 
         default: rc = lnh_mlp_backward_nhm2(iks, a, s); break;
     }
     return rc;
+}
+
+
+int lnh_density_mlp_forward(const void *features, const void *weights, uint32_t B, uint32_t T_cur, uint32_t T_tot,
+                            uint32_t slot_off, void *h16, float *sigma, lnh_stream_t stream) {
+    LNH_REQUIRE(features && weights && h16 && sigma, LNH_ERR_INVALID_ARG, "density mlp forward: null pointer");
+    LNH_REQUIRE(T_cur >= 1 && slot_off + T_cur <= T_tot && B % T_cur == 0, LNH_ERR_INVALID_ARG,
+                "density mlp forward: need B %% T_cur == 0 and slot_off + T_cur <= T_tot");
+    if (B == 0) return LNH_OK;
+    MlpArgs a{(const half_t *)features, (const half_t *)weights, (half_t *)h16, nullptr, B, 32, 64, LNH_ACT_RELU,
+              LNH_ACT_NONE, sigma, IoDims{T_cur, T_tot, slot_off}};
+    return launch_fwd<1, 4, 0, DensityIO>(a, (hipStream_t)stream);
+}
+
+int lnh_density_mlp_backward(const void *grad_h16, const void *features, const void *weights, uint32_t B,
+                             uint32_t T_cur, uint32_t T_tot, uint32_t slot_off, void *grad_features,
+                             float *grad_weights, lnh_stream_t stream) {
+    LNH_REQUIRE(grad_h16 && features && weights && grad_features && grad_weights, LNH_ERR_INVALID_ARG,
+                "density mlp backward: null pointer");
+    LNH_REQUIRE(T_cur >= 1 && slot_off + T_cur <= T_tot && B % T_cur == 0, LNH_ERR_INVALID_ARG,
+                "density mlp backward: need B %% T_cur == 0 and slot_off + T_cur <= T_tot");
+    if (B == 0) return LNH_OK;
+    MlpBwdArgs a{(const half_t *)grad_h16, (const half_t *)features, (const half_t *)weights, (half_t *)grad_features,
+                 grad_weights, B, 32, 64, LNH_ACT_RELU, LNH_ACT_NONE, IoDims{T_cur, T_tot, slot_off}};
+    return lnh_density_mlp_backward_launch(a, (hipStream_t)stream);
 }
 
 }  // extern "C"

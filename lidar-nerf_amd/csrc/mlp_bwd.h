@@ -20,6 +20,7 @@ struct MlpBwdArgs {
     half_t *dX;        // NULL or [B,in_dim]
     float *dW;         // flat fp32, atomically accumulated
     uint32_t B, in_dim, hidden, act, out_act;
+    IoDims io;
 };
 
 template <int IN_KS, int HT, int NHM, int NT>
@@ -37,7 +38,7 @@ struct BwdCfg {
     static constexpr size_t lds_bytes() { return (size_t)(ROWS_G + ROWS_A) * LDP * sizeof(half_t); }
 };
 
-template <int IN_KS, int HT, int NHM, int NT>
+template <int IN_KS, int HT, int NHM, int NT, typename IO>
 __global__ void __launch_bounds__(256)
 k_mlp_backward(MlpBwdArgs a) {
     using Cfg = BwdCfg<IN_KS, HT, NHM, NT>;
@@ -125,9 +126,10 @@ k_mlp_backward(MlpBwdArgs a) {
 #pragma unroll
             for (int s = 0; s < IN_KS; s++) {
                 const uint32_t k0 = 32 * s + 8 * g;
-                bx[n][s] = (p < a.B && k0 < in_dim) ? *reinterpret_cast<const half8_t *>(a.X + p * in_dim + k0) : zero_h8();
+                bx[n][s] = (p < a.B && k0 < in_dim) ? IO::load_x(a.X, p, k0, a.B, in_dim) : zero_h8();
             }
-            by[n] = (p < a.B && g < 2) ? *reinterpret_cast<const half8_t *>(a.dY + p * 16 + 8 * g) : zero_h8();
+            by[n] = (p < a.B && g < 2) ? *reinterpret_cast<const half8_t *>(a.dY + IO::out_row(p, a.io) * 16 + 8 * g)
+                                       : zero_h8();
         }
         half8_t bh[NHM + 1][NT][HS];
 #pragma unroll
@@ -245,10 +247,7 @@ k_mlp_backward(MlpBwdArgs a) {
                     f32x4 acc = zero_f4();
 #pragma unroll
                     for (int s = 0; s < HS; s++) acc = MFMA16(w0T[t][s], bd[n][s], acc);
-                    if (p < a.B && (uint32_t)t < in_tiles) {
-                        half4_t v = {(half_t)acc[0], (half_t)acc[1], (half_t)acc[2], (half_t)acc[3]};
-                        *reinterpret_cast<half4_t *>(a.dX + p * in_dim + 16 * t + 4 * g) = v;
-                    }
+                    if (p < a.B && (uint32_t)t < in_tiles) IO::store_dx(a.dX, p, t, g, a.B, in_dim, acc);
                 }
             }
         }
@@ -286,14 +285,14 @@ k_mlp_backward(MlpBwdArgs a) {
     }
 }
 
-template <int IN_KS, int HT, int NHM>
+template <int IN_KS, int HT, int NHM, typename IO = RowMajorIO>
 int launch_mlp_backward(const MlpBwdArgs &a, hipStream_t s) {
     constexpr int NT = 2;
     using Cfg = BwdCfg<IN_KS, HT, NHM, NT>;
     const size_t lds = Cfg::lds_bytes();
     const uint32_t steps = div_up(a.B, Cfg::PB);
     const uint32_t grid = steps < 768 ? steps : 768;
-    auto k = k_mlp_backward<IN_KS, HT, NHM, NT>;
+    auto k = k_mlp_backward<IN_KS, HT, NHM, NT, IO>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     LNH_LAUNCH(k, dim3(grid), dim3(256), lds, s, a);
     return lnh_check_launch("lnh_mlp_backward");

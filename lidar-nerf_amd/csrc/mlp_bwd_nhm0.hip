@@ -11,3 +11,8 @@ int lnh_mlp_backward_nhm0(uint32_t in_ks, const MlpBwdArgs &a, hipStream_t s) {
     lnh_set_error("fused MLP backward: input_dim > 128 is not instantiated");
     return LNH_ERR_UNSUPPORTED;
 }
+
+// sigma net of the LiDAR field: level-major feature input, strided gradient rows (mlp_common.h DensityIO)
+int lnh_density_mlp_backward_launch(const MlpBwdArgs &a, hipStream_t s) {
+    return launch_mlp_backward<1, 4, 0, DensityIO>(a, s);
+}

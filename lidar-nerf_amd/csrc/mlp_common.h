@@ -109,3 +109,56 @@ __device__ __forceinline__ half8_t pack_pair(const f32x4 &lo, const f32x4 &hi, F
     }
     return r;
 }
+
+// ---------------------------------------------------------------------------------------------------- I/O policies
+// The MLP kernels are templated on an IO policy that says where a point's input row / output row / gradient rows
+// live.  RowMajorIO is the FFMLP layout ([B,in] / [B,16]).  DensityIO is the fused sigma-net of the LiDAR field:
+//   * input  = hash-grid features in the encoder's own level-major layout [L, B, 2] (no [B, L*2] permute copy);
+//   * output = the 16 raw outputs as fp16 at a strided destination row (ray r, slot off + j of a [N, Ttot, 16]
+//     buffer that holds coarse AND fine samples of a ray side by side) + sigma = exp(out[0]) as fp32
+//     (trunc_exp forward, lidarnerf/activation.py:11-13, evaluated on the fp16-rounded pre-activation);
+//   * backward reads the gradient rows from the same strided buffer and writes d(features) level-major.
+struct IoDims {
+    uint32_t T_cur, T_tot, slot_off;  // DensityIO: point p = r*T_cur + j  ->  destination row r*T_tot + slot_off + j
+};
+
+struct RowMajorIO {
+    static constexpr bool kDensity = false;
+    __device__ static __forceinline__ half8_t load_x(const half_t *X, uint64_t p, uint32_t k0, uint32_t B, uint32_t in_dim) {
+        return *reinterpret_cast<const half8_t *>(X + p * in_dim + k0);
+    }
+    __device__ static __forceinline__ uint64_t out_row(uint64_t p, const IoDims &) { return p; }
+    __device__ static __forceinline__ void store_dx(half_t *dX, uint64_t p, uint32_t t, uint32_t g, uint32_t B,
+                                                    uint32_t in_dim, const f32x4 &acc) {
+        half4_t v = {(half_t)acc[0], (half_t)acc[1], (half_t)acc[2], (half_t)acc[3]};
+        *reinterpret_cast<half4_t *>(dX + p * in_dim + 16 * t + 4 * g) = v;
+    }
+};
+
+struct DensityIO {
+    static constexpr bool kDensity = true;
+    // features k0..k0+7 = levels k0/2 .. k0/2+3, two channels each: four 4-byte loads from [L,B,2]
+    __device__ static __forceinline__ half8_t load_x(const half_t *X, uint64_t p, uint32_t k0, uint32_t B, uint32_t in_dim) {
+        half8_t r;
+        const uint32_t l0 = k0 >> 1;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const half2_t v = *reinterpret_cast<const half2_t *>(X + ((uint64_t)(l0 + i) * B + p) * 2);
+            r[2 * i] = v[0];
+            r[2 * i + 1] = v[1];
+        }
+        return r;
+    }
+    __device__ static __forceinline__ uint64_t out_row(uint64_t p, const IoDims &d) {
+        const uint64_t r = p / d.T_cur;
+        return r * d.T_tot + d.slot_off + (p - r * d.T_cur);
+    }
+    // features 16t+4g+r -> levels 8t+2g, 8t+2g+1
+    __device__ static __forceinline__ void store_dx(half_t *dX, uint64_t p, uint32_t t, uint32_t g, uint32_t B,
+                                                    uint32_t in_dim, const f32x4 &acc) {
+        const uint32_t l0 = 8 * t + 2 * g;
+        half2_t a = {(half_t)acc[0], (half_t)acc[1]}, b = {(half_t)acc[2], (half_t)acc[3]};
+        *reinterpret_cast<half2_t *>(dX + ((uint64_t)l0 * B + p) * 2) = a;
+        *reinterpret_cast<half2_t *>(dX + ((uint64_t)(l0 + 1) * B + p) * 2) = b;
+    }
+};

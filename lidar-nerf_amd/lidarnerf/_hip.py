@@ -39,6 +39,12 @@ _SIGS = {
     "lnh_lidar_composite_forward": [P, P, P, P, U32, U32, U32, F32, P, P, P, P],
     "lnh_lidar_composite_backward": [P, P, P, P, P, P, P, U32, U32, U32, F32, P, P],
     "lnh_lidar_resample": [P, P, P, P, U32, U32, U32, F32, P, P, P],
+    "lnh_lidar_sample_points": [P, P, P, P, F32, U32, U32, P],
+    "lnh_density_mlp_forward": [P, P, U32, U32, U32, U32, P, P],
+    "lnh_density_mlp_backward": [P, P, P, U32, U32, U32, U32, P, P],
+    "lnh_lidar_merge_weights": [P, P, P, P, U32, U32, F32, P, P],
+    "lnh_lidar_color_forward": [P, P, P, P, P, U32, U32, P],
+    "lnh_lidar_color_backward": [P, P, P, P, P, P, P, U32, U32, P, P, P],
 }
 EXPORTS = sorted(list(_SIGS) + ["lnh_version", "lnh_last_error", "lnh_arch", "lnh_grid_backward_workspace_size"])
 

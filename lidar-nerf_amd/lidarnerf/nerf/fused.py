@@ -1,0 +1,211 @@
+"""Fused LiDAR render step: the whole `NeRFRenderer.run` + `NeRFNetwork.density/color` chain of the reference
+(lidarnerf/nerf/renderer.py:99-298, lidarnerf/nerf/network.py:162-237) as ~14 kernel launches forward and ~8
+backward, with explicit gradients.
+
+Used by NeRFNetwork.render for the configuration the reference trains (`cal_lidar_color=True`, hash-grid L=16 F=2,
+64-wide sigma net with one hidden layer, 64-wide LiDAR colour net with two, frequency-12 direction encoding) under
+fp16 autocast.  Anything else takes the modular path in renderer.py / network.py, which computes the same values
+from the same kernels' unfused forms.
+
+Forward                                                     kernels (liblidarnerf_hip.so)
+  z = near + (far-near) linspace + perturb                  torch (3 tiny launches)
+  x = (clip(o + d z) + b) / 2b                              lnh_lidar_sample_points
+  feat = hashgrid(x)            [16,B,2] fp16               lnh_grid_encode_forward
+  h16, sigma = sigma_net(feat)  strided into [N,T+t,*]      lnh_density_mlp_forward
+  new_z, z_all, perm = resample(z, sigma)                   lnh_lidar_resample
+  (same three steps for the t new samples)
+  sigma_m, w = merge + weights                              lnh_lidar_merge_weights
+  cdir = W0[:, :75] freq(d)     per RAY                     lnh_freq_encode_forward + one [N,75]x[75,64] GEMM
+  rgb = colour_net(h16[perm], cdir) * (w > 1e-4)            lnh_lidar_color_forward
+  ws, depth, image = composite(sigma_m, rgb, z_all)         lnh_lidar_composite_forward
+Backward runs the mirror image; the hash-table gradient uses the bucketed scatter-reduce (no HBM atomics).
+"""
+import numpy as np
+import torch
+from torch.autograd import Function
+
+from .. import _hip
+from ..gridencoder.grid import _workspace
+
+
+def supported(model, cal_lidar_color, num_steps, upsample_steps):
+    """True when `model` (a NeRFNetwork) has exactly the shapes the fused kernels are specialised for."""
+    try:
+        enc = model.encoder
+        ok = (cal_lidar_color and upsample_steps > 0 and model.bg_radius <= 0
+              and enc.__class__.__name__ == "GridEncoder" and enc.input_dim == 3 and enc.num_levels == 16
+              and enc.level_dim == 2 and enc.gridtype_id == 0 and not enc.align_corners and enc.interp_id == 0
+              and len(model.sigma_net) == 2 and tuple(model.sigma_net[0].weight.shape) == (64, 32)
+              and tuple(model.sigma_net[1].weight.shape) == (16, 64)
+              and len(model.lidar_color_net) == 3 and tuple(model.lidar_color_net[0].weight.shape) == (64, 90)
+              and tuple(model.lidar_color_net[1].weight.shape) == (64, 64)
+              and tuple(model.lidar_color_net[2].weight.shape) == (2, 64)
+              and model.encoder_lidar_dir.__class__.__name__ == "FreqEncoder" and model.encoder_lidar_dir.degree == 12
+              and model.geo_feat_dim == 15 and (num_steps + upsample_steps) % 16 == 0
+              and model.encoder.embeddings.is_cuda)
+        return bool(ok)
+    except AttributeError:
+        return False
+
+
+def _grid_fwd(x01, table16, enc, B):
+    L = enc.num_levels
+    out = torch.empty((L, B, 2), dtype=torch.half, device=x01.device)
+    _hip.call("lnh_grid_encode_forward", x01.data_ptr(), table16.data_ptr(), enc._offsets_host.data_ptr(),
+              out.data_ptr(), B, 3, 2, L, enc.log2_scale, enc.base_resolution, None, 0, 0, 0, _hip.LNH_F16, tag=B)
+    return out
+
+
+def _grid_bwd(g_feat, x01, g_table16, enc, B):
+    L = enc.num_levels
+    off = enc._offsets_host
+    need = _hip.lib().lnh_grid_backward_workspace_size(off.data_ptr(), B, 3, 2, L, enc.log2_scale,
+                                                       enc.base_resolution, 0, 0, _hip.LNH_F16)
+    ws = _workspace(g_feat.device, need)
+    _hip.call("lnh_grid_encode_backward_ws", g_feat.data_ptr(), x01.data_ptr(), off.data_ptr(), g_table16.data_ptr(),
+              B, 3, 2, L, enc.log2_scale, enc.base_resolution, 0, 0, 0, _hip.LNH_F16, ws.data_ptr(), ws.numel(), tag=B)
+
+
+def _no_autocast(fn):
+    """The kernel chain manages precision itself: run the glue ops (casts, the tiny per-ray GEMMs) with autocast off,
+    otherwise fp32 operands of a matmul silently become fp16 tensors handed to kernels that expect fp32."""
+    def wrapped(*args, **kwargs):
+        with torch.autocast("cuda", enabled=False):
+            return fn(*args, **kwargs)
+    return wrapped
+
+
+class FusedLidarRender(Function):
+    @staticmethod
+    @_no_autocast
+    def forward(ctx, rays_o, rays_d, z, u, embeddings, ws0, ws1, wc0, wc1, wc2, model, density_scale):
+        enc = model.encoder
+        dev = rays_o.device
+        N, T = z.shape
+        t_new = u.shape[1]
+        Ttot = T + t_new
+        bound = float(model.bound)
+        aabb = (model.aabb_train if model.training else model.aabb_infer).float().contiguous()
+        nears = torch.full((N,), float(model.min_near_lidar), dtype=torch.float32, device=dev)
+        sd = ((nears * 81.0 - nears) / T).contiguous()  # sample_dist, same fp32 ops as renderer.py:129-156
+
+        table16 = embeddings.detach().to(torch.half).contiguous()
+        wsig16 = torch.cat([ws0.detach().reshape(-1), ws1.detach().reshape(-1)]).to(torch.half).contiguous()
+        # colour head: geo part of the first Linear against the raw 16-wide sigma-net row (col 0 gets weight 0)
+        w0g = torch.cat([torch.zeros((64, 1), device=dev, dtype=wc0.dtype), wc0.detach()[:, 75:90]], dim=1)
+        w2p = torch.nn.functional.pad(wc2.detach(), (0, 0, 0, 14))
+        wcol16 = torch.cat([w0g.reshape(-1), wc1.detach().reshape(-1), w2p.reshape(-1)]).to(torch.half).contiguous()
+
+        h16 = torch.empty((N * Ttot, 16), dtype=torch.half, device=dev)
+        sigma_pt = torch.empty((N, Ttot), dtype=torch.float32, device=dev)
+
+        def density(zz, Tc, off):
+            B = N * Tc
+            x01 = torch.empty((B, 3), dtype=torch.float32, device=dev)
+            _hip.call("lnh_lidar_sample_points", rays_o.data_ptr(), rays_d.data_ptr(), zz.data_ptr(), aabb.data_ptr(),
+                      bound, N, Tc, x01.data_ptr())
+            feat = _grid_fwd(x01, table16, enc, B)
+            _hip.call("lnh_density_mlp_forward", feat.data_ptr(), wsig16.data_ptr(), B, Tc, Ttot, off, h16.data_ptr(),
+                      sigma_pt.data_ptr())
+            return x01, feat
+
+        x01_c, feat_c = density(z, T, 0)
+        sigma_c = sigma_pt[:, :T].contiguous()
+        new_z = torch.empty((N, t_new), dtype=torch.float32, device=dev)
+        z_all = torch.empty((N, Ttot), dtype=torch.float32, device=dev)
+        perm = torch.empty((N, Ttot), dtype=torch.int32, device=dev)
+        _hip.call("lnh_lidar_resample", z.data_ptr(), sigma_c.data_ptr(), sd.data_ptr(), u.data_ptr(), N, T, t_new,
+                  float(density_scale), new_z.data_ptr(), z_all.data_ptr(), perm.data_ptr())
+        x01_f, feat_f = density(new_z, t_new, T)
+
+        sigma_m = torch.empty((N, Ttot), dtype=torch.float32, device=dev)
+        weights = torch.empty((N, Ttot), dtype=torch.float32, device=dev)
+        _hip.call("lnh_lidar_merge_weights", z_all.data_ptr(), sigma_pt.data_ptr(), perm.data_ptr(), sd.data_ptr(), N,
+                  Ttot, float(density_scale), sigma_m.data_ptr(), weights.data_ptr())
+
+        enc_d = torch.empty((N, 75), dtype=torch.float32, device=dev)
+        _hip.call("lnh_freq_encode_forward", rays_d.data_ptr(), N, 3, 12, 75, enc_d.data_ptr())
+        enc_d16 = enc_d.to(torch.half).float()
+        cdir = (enc_d16 @ wc0.detach()[:, :75].to(torch.half).float().t()).contiguous()
+
+        rgb = torch.empty((N, Ttot, 2), dtype=torch.float32, device=dev)
+        _hip.call("lnh_lidar_color_forward", h16.data_ptr(), perm.data_ptr(), weights.data_ptr(), cdir.data_ptr(),
+                  wcol16.data_ptr(), N, Ttot, rgb.data_ptr())
+        ws = torch.empty(N, dtype=torch.float32, device=dev)
+        depth = torch.empty(N, dtype=torch.float32, device=dev)
+        image = torch.empty((N, 2), dtype=torch.float32, device=dev)
+        _hip.call("lnh_lidar_composite_forward", z_all.data_ptr(), sigma_m.data_ptr(), rgb.data_ptr(), sd.data_ptr(), N,
+                  Ttot, 2, float(density_scale), None, ws.data_ptr(), depth.data_ptr(), image.data_ptr())
+
+        ctx.save_for_backward(x01_c, feat_c, x01_f, feat_f, h16, perm, weights, z_all, sigma_m, rgb, sd, cdir, enc_d16,
+                              wsig16, wcol16)
+        ctx.model, ctx.dims, ctx.density_scale = model, (N, T, t_new), density_scale
+        ctx.param_dtypes = (embeddings.dtype, ws0.dtype, ws1.dtype, wc0.dtype, wc1.dtype, wc2.dtype)
+        ctx.mark_non_differentiable(weights, z_all)
+        return ws, depth, image, weights, z_all
+
+    @staticmethod
+    @_no_autocast
+    def backward(ctx, g_ws, g_depth, g_image, _gw, _gz):
+        (x01_c, feat_c, x01_f, feat_f, h16, perm, weights, z_all, sigma_m, rgb, sd, cdir, enc_d16, wsig16,
+         wcol16) = ctx.saved_tensors
+        model, (N, T, t_new), ds = ctx.model, ctx.dims, ctx.density_scale
+        enc = model.encoder
+        dev = h16.device
+        Ttot = T + t_new
+        g_ws, g_depth, g_image = g_ws.contiguous().float(), g_depth.contiguous().float(), g_image.contiguous().float()
+
+        g_sigma = torch.empty((N, Ttot), dtype=torch.float32, device=dev)
+        g_rgb = torch.empty((N, Ttot, 2), dtype=torch.float32, device=dev)
+        _hip.call("lnh_lidar_composite_backward", g_ws.data_ptr(), g_depth.data_ptr(), g_image.data_ptr(),
+                  z_all.data_ptr(), sigma_m.data_ptr(), rgb.data_ptr(), sd.data_ptr(), N, Ttot, 2, float(ds),
+                  g_sigma.data_ptr(), g_rgb.data_ptr())
+
+        g_h16 = torch.empty((N * Ttot, 16), dtype=torch.half, device=dev)
+        g_wcol = torch.zeros(wcol16.numel(), dtype=torch.float32, device=dev)
+        ray_sum = torch.empty((N, 64), dtype=torch.float32, device=dev)
+        _hip.call("lnh_lidar_color_backward", g_rgb.data_ptr(), g_sigma.data_ptr(), h16.data_ptr(), perm.data_ptr(),
+                  weights.data_ptr(), cdir.data_ptr(), wcol16.data_ptr(), N, Ttot, g_h16.data_ptr(), g_wcol.data_ptr(),
+                  ray_sum.data_ptr())
+        g_w0g = g_wcol[:64 * 16].view(64, 16)
+        g_wc0 = torch.cat([ray_sum.t() @ enc_d16, g_w0g[:, 1:16]], dim=1)
+        g_wc1 = g_wcol[64 * 16:64 * 16 + 64 * 64].view(64, 64)
+        g_wc2 = g_wcol[64 * 16 + 64 * 64:].view(16, 64)[:2]
+
+        g_wsig = torch.zeros(wsig16.numel(), dtype=torch.float32, device=dev)
+        g_table16 = torch.zeros((enc.embeddings.shape[0], 2), dtype=torch.half, device=dev)
+        for x01, feat, Tc, off in ((x01_c, feat_c, T, 0), (x01_f, feat_f, t_new, T)):
+            B = N * Tc
+            g_feat = torch.empty((enc.num_levels, B, 2), dtype=torch.half, device=dev)
+            _hip.call("lnh_density_mlp_backward", g_h16.data_ptr(), feat.data_ptr(), wsig16.data_ptr(), B, Tc, Ttot,
+                      off, g_feat.data_ptr(), g_wsig.data_ptr())
+            _grid_bwd(g_feat, x01, g_table16, enc, B)
+
+        dts = ctx.param_dtypes
+        return (None, None, None, None, g_table16.to(dts[0]), g_wsig[:64 * 32].view(64, 32).to(dts[1]),
+                g_wsig[64 * 32:].view(16, 64).to(dts[2]), g_wc0.to(dts[3]), g_wc1.to(dts[4]), g_wc2.to(dts[5]),
+                None, None)
+
+
+def render_lidar(model, rays_o, rays_d, num_steps, upsample_steps, perturb):
+    """Drop-in for NeRFRenderer.run(cal_lidar_color=True) on a supported NeRFNetwork."""
+    prefix = rays_o.shape[:-1]
+    rays_o = rays_o.contiguous().view(-1, 3).float()
+    rays_d = rays_d.contiguous().view(-1, 3).float()
+    N, dev = rays_o.shape[0], rays_o.device
+    nears = torch.full((N, 1), float(model.min_near_lidar), dtype=torch.float32, device=dev)
+    fars = nears * 81.0  # hard-coded 1 m .. 81 m in scene units (renderer.py:129-138)
+    z = nears + (fars - nears) * torch.linspace(0.0, 1.0, num_steps, device=dev).unsqueeze(0)
+    if perturb:
+        z = z + (torch.rand((N, num_steps), device=dev) - 0.5) * ((fars - nears) / num_steps)
+    z = z.contiguous()
+    if model.training:
+        u = torch.rand((N, upsample_steps), device=dev)
+    else:
+        u = torch.linspace(0.5 / upsample_steps, 1.0 - 0.5 / upsample_steps, upsample_steps,
+                           device=dev).expand(N, upsample_steps).contiguous()
+    ws, depth, image, _, _ = FusedLidarRender.apply(
+        rays_o, rays_d, z, u, model.encoder.embeddings, model.sigma_net[0].weight, model.sigma_net[1].weight,
+        model.lidar_color_net[0].weight, model.lidar_color_net[1].weight, model.lidar_color_net[2].weight, model,
+        model.density_scale)
+    return {"depth_lidar": depth.view(*prefix), "image_lidar": image.view(*prefix, 2), "weights_sum_lidar": ws}

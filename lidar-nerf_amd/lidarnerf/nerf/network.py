@@ -12,6 +12,7 @@ import torch.nn.functional as F
 from ..activation import trunc_exp
 from ..encoding import get_encoder
 from ..ffmlp import fused_mlp
+from . import fused
 from .renderer import NeRFRenderer
 
 
@@ -23,8 +24,10 @@ class NeRFNetwork(NeRFRenderer):
     def __init__(self, encoding="hashgrid", encoding_dir="frequency", multires=15, encoding_bg="hashgrid",
                  desired_resolution=2048, log2_hashmap_size=19, num_layers=2, hidden_dim=64, geo_feat_dim=15,
                  num_layers_color=3, hidden_dim_color=64, num_layers_bg=2, hidden_dim_bg=64, out_color_dim=3,
-                 out_lidar_color_dim=2, bound=1, **kwargs):
+                 out_lidar_color_dim=2, bound=1, fused_lidar=True, **kwargs):
         super().__init__(bound, **kwargs)
+        # route LiDAR renders under fp16 autocast through the fused kernel chain (nerf/fused.py) when the shapes match
+        self.fused_lidar = fused_lidar
         self.num_layers, self.hidden_dim, self.geo_feat_dim = num_layers, hidden_dim, geo_feat_dim
         self.out_color_dim, self.out_lidar_color_dim = out_color_dim, out_lidar_color_dim
         self.num_layers_color, self.hidden_dim_color = num_layers_color, hidden_dim_color
@@ -62,6 +65,15 @@ class NeRFNetwork(NeRFRenderer):
             if i != len(net) - 1:
                 h = F.relu(h, inplace=True)
         return h
+
+    def run(self, rays_o, rays_d, cal_lidar_color=False, num_steps=128, upsample_steps=128, bg_color=None,
+            perturb=False, **kwargs):
+        if (self.fused_lidar and rays_o.is_cuda and torch.is_autocast_enabled()
+                and fused.supported(self, cal_lidar_color, num_steps, upsample_steps)):
+            self.out_dim = self.out_lidar_color_dim
+            return fused.render_lidar(self, rays_o, rays_d, num_steps, upsample_steps, perturb)
+        return super().run(rays_o, rays_d, cal_lidar_color=cal_lidar_color, num_steps=num_steps,
+                           upsample_steps=upsample_steps, bg_color=bg_color, perturb=perturb, **kwargs)
 
     def forward(self, x, d):
         dens = self.density(x)
