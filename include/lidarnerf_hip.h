@@ -207,13 +207,14 @@ LNH_API int lnh_lidar_composite_backward(const float *grad_weights_sum, const fl
 /*
  * lnh_lidar_resample: renderer.py:180-231 in one kernel — stage-1 weights, sample_pdf (renderer.py:10-46) with
  * the caller's uniforms u [N,n_new] (linspace for det, rand for training), then the sort/merge of the old and new
- * z values.  Outputs new_z [N,n_new] (unsorted, as sample_pdf returns them), merged z_out [N,T+n_new] ascending
+ * z values.  Outputs new_z [N,n_new] (sorted_new = 0: in sample_pdf's order, exactly what the reference hands to
+ * its second density query; sorted_new = 1: ascending, same set of values), merged z_out [N,T+n_new] ascending
  * and perm [N,T+n_new] int32: the position in concat([old, new]) each merged element came from (= torch.sort's
  * index, renderer.py:218).
  */
 LNH_API int lnh_lidar_resample(const float *z, const float *sigma, const float *sample_dist, const float *u,
-                               uint32_t N, uint32_t T, uint32_t n_new, float density_scale, float *new_z,
-                               float *z_out, int32_t *perm, lnh_stream_t stream);
+                               uint32_t N, uint32_t T, uint32_t n_new, float density_scale, uint32_t sorted_new,
+                               float *new_z, float *z_out, int32_t *perm, lnh_stream_t stream);
 
 
 /* ------------------------------------------------------------------ fused LiDAR field step ------------------ */

@@ -526,12 +526,28 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
     // ---- reserve pool slots: LDS rank per (bucket), one global atomic per touched bucket per workgroup
     uint32_t rank[PPT][NCORN];
 #pragma unroll
-    for (int q = 0; q < PPT; q++)
-        if (emit[q]) {
+    for (int q = 0; q < PPT; q++) {
 #pragma unroll
-            for (uint32_t c = 0; c < (uint32_t)NCORN; c++)
-                rank[q][c] = (dbg & 4) ? threadIdx.x : atomicAdd(&lcnt[row[q][c] >> kBucketRowsLog2], 1u);
+        for (uint32_t c = 0; c < (uint32_t)NCORN; c++) {
+            // On dense (coarse) levels every emitting lane of the wave usually targets the SAME bucket: 64 returning
+            // LDS atomics on one counter serialise, so aggregate — one lane adds the population count, the others
+            // take their rank from the lane mask.  Mixed buckets (hashed levels) fall back to per-lane atomics.
+            const uint32_t bk = row[q][c] >> kBucketRowsLog2;
+            const unsigned long long em = __ballot(emit[q]);
+            if (em == 0ull) continue;  // wave-uniform
+            const int leader = __builtin_ctzll(em);
+            const uint32_t bk0 = __shfl(bk, leader, 64);
+            const bool uniform = __ballot(emit[q] && bk != bk0) == 0ull;
+            if (uniform) {
+                uint32_t base = 0;
+                if (lane == leader) base = atomicAdd(&lcnt[bk0], (uint32_t)__builtin_popcountll(em));
+                base = __shfl(base, leader, 64);
+                rank[q][c] = base + (uint32_t)__builtin_popcountll(em & ((1ull << lane) - 1ull));
+            } else if (emit[q]) {
+                rank[q][c] = atomicAdd(&lcnt[bk], 1u);
+            }
         }
+    }
     __syncthreads();
     if (threadIdx.x < nb) {
         const uint32_t n = lcnt[threadIdx.x];
@@ -558,6 +574,12 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
         }
 }
 
+// A bucket with many entries (coarse dense levels: every ray passes the same few cells) is split over up to
+// kMaxSlices workgroups (blockIdx.y); slices of a split bucket add their partial sums with (few) global atomics, an
+// unsplit bucket owns its rows and uses plain stores.
+constexpr uint32_t kSliceEntries = 96 * 1024;
+constexpr uint32_t kMaxSlices = 16;
+
 template <typename T>
 __global__ void __launch_bounds__(1024)
 k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, const PoolEntry<T> *__restrict__ pool,
@@ -572,13 +594,18 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
         if (bid >= plan.first_bucket[l]) level = l;
     const LevelParams lv = meta.lv[level];
     const uint32_t bk = bid - plan.first_bucket[level], cap = plan.cap[level];
-    const uint32_t n = min(cursor[bid], cap);
-    if (n == 0) return;  // workgroup-uniform
+    const uint32_t n_all = min(cursor[bid], cap);
+    uint32_t slices = (n_all + kSliceEntries - 1) / kSliceEntries;
+    slices = slices > kMaxSlices ? kMaxSlices : slices;
+    if (blockIdx.y >= slices) return;  // workgroup-uniform (also covers n_all == 0)
+    const uint32_t i_begin = (uint32_t)((uint64_t)n_all * blockIdx.y / slices);
+    const uint32_t i_end = (uint32_t)((uint64_t)n_all * (blockIdx.y + 1) / slices);
+    const uint32_t n = i_end - i_begin;
     const uint32_t rows = min(kBucketRows, lv.hashmap_size - bk * kBucketRows);
     for (uint32_t i = threadIdx.x; i < rows * 2; i += blockDim.x) acc[i] = 0ull;
     __syncthreads();
-    const PoolEntry<T> *src = pool + plan.pool_off[level] + (size_t)bk * cap;
-    // One workgroup streams its whole pool: keep UNROLL independent loads in flight per lane.
+    const PoolEntry<T> *src = pool + plan.pool_off[level] + (size_t)bk * cap + i_begin;
+    // One workgroup streams its whole slice: keep UNROLL independent loads in flight per lane.
     constexpr uint32_t UNROLL = 4;
     const uint32_t stride = blockDim.x * UNROLL;
     for (uint32_t i0 = threadIdx.x; i0 < n; i0 += stride) {
@@ -606,10 +633,14 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
         const long long qa = (long long)acc[2 * r], qb = (long long)acc[2 * r + 1];
         if (qa != 0 || qb != 0) {
             const float a = (float)ldexp((double)qa, -K), b = (float)ldexp((double)qb, -K);
-            Vec<T, 2> cur = load_vec<T, 2>(gt + 2 * r);
-            cur.v[0] = (T)((float)cur.v[0] + a);
-            cur.v[1] = (T)((float)cur.v[1] + b);
-            store_vec<T, 2>(gt + 2 * r, cur);
+            if (slices == 1) {
+                Vec<T, 2> cur = load_vec<T, 2>(gt + 2 * r);
+                cur.v[0] = (T)((float)cur.v[0] + a);
+                cur.v[1] = (T)((float)cur.v[1] + b);
+                store_vec<T, 2>(gt + 2 * r, cur);
+            } else {
+                atomic_add_pair(gt + 2 * r, a, b);
+            }
         }
     }
 }
@@ -671,7 +702,7 @@ int launch_backward_bucketed(const T *grad, const float *inputs, T *ge, uint32_t
     if (rc) return rc;
     auto k = k_grid_bwd_reduce<T>;
     const size_t lds = (size_t)kBucketRows * 2 * sizeof(unsigned long long);
-    LNH_LAUNCH(k, dim3(nbt), dim3(1024), lds, s, ge, m, plan, pool, cursor, L);
+    LNH_LAUNCH(k, dim3(nbt, kMaxSlices), dim3(1024), lds, s, ge, m, plan, pool, cursor, L);
     return lnh_check_launch("lnh_grid_encode_backward_ws(reduce)");
 }
 

@@ -187,7 +187,7 @@ k_lidar_composite_bwd(const float *__restrict__ g_ws, const float *__restrict__ 
 __global__ void __launch_bounds__(64)
 k_lidar_resample(const float *__restrict__ z, const float *__restrict__ sigma, const float *__restrict__ sample_dist,
                  const float *__restrict__ u, uint32_t N, uint32_t T, uint32_t n_new, uint32_t P,
-                 float density_scale, float *__restrict__ new_z, float *__restrict__ z_out,
+                 float density_scale, uint32_t sorted_new, float *__restrict__ new_z, float *__restrict__ z_out,
                  int32_t *__restrict__ perm) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float *zs = reinterpret_cast<float *>(smem_raw);
@@ -261,7 +261,7 @@ k_lidar_resample(const float *__restrict__ z, const float *__restrict__ sigma, c
             if (denom < 1e-5f) denom = 1.0f;
             const float t = (uj - cb) / denom;
             s = bb + t * (ba - bb);
-            new_z[(size_t)ray * n_new + j] = s;
+            if (!sorted_new) new_z[(size_t)ray * n_new + j] = s;
         }
         key[j] = s;
         val[j] = (int)j;
@@ -312,7 +312,10 @@ k_lidar_resample(const float *__restrict__ z, const float *__restrict__ sigma, c
     for (uint32_t r = lane; r < n_new; r += 64) {
         const uint32_t pos = (uint32_t)cnt[r] + r;
         zo[pos] = key[r];
-        po[pos] = (int)(T + (uint32_t)val[r]);
+        // sorted_new: the new samples are handed out in ascending order (slot T + r), so that the density pass sees
+        // consecutive lanes = neighbouring positions along the ray, like the coarse samples
+        po[pos] = (int)(T + (sorted_new ? r : (uint32_t)val[r]));
+        if (sorted_new) new_z[(size_t)ray * n_new + r] = key[r];
     }
     __syncthreads();
     for (uint32_t i = lane; i < T + n_new; i += 64) {
@@ -375,8 +378,8 @@ int lnh_lidar_composite_backward(const float *grad_weights_sum, const float *gra
 }
 
 int lnh_lidar_resample(const float *z, const float *sigma, const float *sample_dist, const float *u, uint32_t N,
-                       uint32_t T, uint32_t n_new, float density_scale, float *new_z, float *z_out, int32_t *perm,
-                       lnh_stream_t stream) {
+                       uint32_t T, uint32_t n_new, float density_scale, uint32_t sorted_new, float *new_z, float *z_out,
+                       int32_t *perm, lnh_stream_t stream) {
     LNH_REQUIRE(z && sigma && sample_dist && u && new_z && z_out && perm, LNH_ERR_INVALID_ARG,
                 "lidar_resample: null pointer");
     LNH_REQUIRE(T >= 3, LNH_ERR_INVALID_ARG, "lidar_resample: needs T >= 3 coarse samples (got %u)", T);
@@ -391,7 +394,7 @@ int lnh_lidar_resample(const float *z, const float *sigma, const float *sample_d
     if (lds > 64 * 1024)
         hipFuncSetAttribute((const void *)k_lidar_resample, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     LNH_LAUNCH(k_lidar_resample, dim3(N), dim3(64), lds, s, z, sigma, sample_dist, u, N, T, n_new, P,
-                       density_scale, new_z, z_out, perm);
+                       density_scale, sorted_new, new_z, z_out, perm);
     return lnh_check_launch("lnh_lidar_resample");
 }
 

@@ -115,7 +115,7 @@ class FusedLidarRender(Function):
         z_all = torch.empty((N, Ttot), dtype=torch.float32, device=dev)
         perm = torch.empty((N, Ttot), dtype=torch.int32, device=dev)
         _hip.call("lnh_lidar_resample", z.data_ptr(), sigma_c.data_ptr(), sd.data_ptr(), u.data_ptr(), N, T, t_new,
-                  float(density_scale), new_z.data_ptr(), z_all.data_ptr(), perm.data_ptr())
+                  float(density_scale), 1, new_z.data_ptr(), z_all.data_ptr(), perm.data_ptr())
         x01_f, feat_f = density(new_z, t_new, T)
 
         sigma_m = torch.empty((N, Ttot), dtype=torch.float32, device=dev)

@@ -32,7 +32,7 @@ def lidar_resample(z, sigma, sample_dist, u, density_scale=1.0):
     z_out = torch.empty((N, T + n_new), dtype=torch.float32, device=z.device)
     perm = torch.empty((N, T + n_new), dtype=torch.int32, device=z.device)
     _hip.call("lnh_lidar_resample", z.data_ptr(), sigma.data_ptr(), sample_dist.data_ptr(), u.data_ptr(), N, T, n_new,
-              float(density_scale), new_z.data_ptr(), z_out.data_ptr(), perm.data_ptr())
+              float(density_scale), 0, new_z.data_ptr(), z_out.data_ptr(), perm.data_ptr())
     return new_z, z_out, perm
 
 

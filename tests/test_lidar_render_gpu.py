@@ -83,7 +83,7 @@ def test_resample_merge(det, N, T, n_new):
     new_z = torch.empty((N, n_new), device="cuda")
     z_out = torch.empty((N, T + n_new), device="cuda")
     perm = torch.empty((N, T + n_new), dtype=torch.int32, device="cuda")
-    call("lnh_lidar_resample", z.cuda(), sigma.cuda(), sd.cuda(), u.cuda(), N, T, n_new, 1.0, new_z, z_out, perm)
+    call("lnh_lidar_resample", z.cuda(), sigma.cuda(), sd.cuda(), u.cuda(), N, T, n_new, 1.0, 0, new_z, z_out, perm)
     # cdf is a float32 running sum evaluated in a different association order than torch.cumsum: positions agree to
     # a few ulp of the bin width
     # (an ulp of cdf is amplified by 1/denom inside steep bins, hence the absolute bound of ~4% of a bin width;
@@ -97,6 +97,26 @@ def test_resample_merge(det, N, T, n_new):
     assert torch.equal(z_out, zs)
     assert torch.equal(torch.gather(cat, 1, perm.long()), z_out)
     assert torch.equal(torch.sort(perm, dim=1)[0], torch.arange(T + n_new, device="cuda", dtype=torch.int32).expand(N, -1))
+
+
+def test_resample_sorted_new_samples():
+    """sorted_new = 1: same sample SET, emitted ascending, permutation consistent with the new slot order."""
+    from gpu_util import call
+    N, T, n_new = 33, 768, 64
+    z, sigma, _, sd = _ray_inputs(N, T, 5)
+    u = torch.rand(N, n_new, generator=torch.Generator().manual_seed(6))
+    outs = []
+    for flag in (0, 1):
+        new_z = torch.empty((N, n_new), device="cuda")
+        z_out = torch.empty((N, T + n_new), device="cuda")
+        perm = torch.empty((N, T + n_new), dtype=torch.int32, device="cuda")
+        call("lnh_lidar_resample", z.cuda(), sigma.cuda(), sd.cuda(), u.cuda(), N, T, n_new, 1.0, flag, new_z, z_out, perm)
+        outs.append((new_z, z_out, perm))
+    (nz0, zo0, p0), (nz1, zo1, p1) = outs
+    assert torch.equal(torch.sort(nz0, dim=1)[0], nz1)
+    assert torch.equal(zo0, zo1)
+    cat = torch.cat([z.cuda(), nz1], dim=1)
+    assert torch.equal(torch.gather(cat, 1, p1.long()), zo1)
 
 
 def test_resample_against_reference_golden(golden_dir):
@@ -113,7 +133,7 @@ def test_resample_against_reference_golden(golden_dir):
     new_z = torch.empty((N, 64), device="cuda")
     z_out = torch.empty((N, T + 64), device="cuda")
     perm = torch.empty((N, T + 64), dtype=torch.int32, device="cuda")
-    call("lnh_lidar_resample", z.cuda(), sigma.cuda(), sd.cuda(), u.cuda(), N, T, 64, 1.0, new_z, z_out, perm)
+    call("lnh_lidar_resample", z.cuda(), sigma.cuda(), sd.cuda(), u.cuda(), N, T, 64, 1.0, 0, new_z, z_out, perm)
     nz = new_z.cpu()
     assert torch.all(nz[:, 1:] >= nz[:, :-1])
     assert torch.all(nz >= z[:, :1]) and torch.all(nz <= z[:, -1:])
