@@ -70,3 +70,22 @@ __device__ __forceinline__ float wave_scan_mul(float v, int lane) {
     }
     return v;
 }
+
+// ---- segmented inclusive add-scan over the 64 lanes on the DPP network (6 VALU ops, no LDS/bpermute traffic).
+// `run_start` = first lane of the run this lane belongs to (runs are contiguous lane ranges).  After the four
+// row_shr steps a lane holds the sum over [max(run_start, row_start) .. lane]; row_bcast:15 / :31 carry the partial
+// sums of the preceding 16- / 32-lane blocks into lanes whose run started before their own block.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float lnh_dpp(float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_segscan_add(float v, int lane, int run_start) {
+    float t;
+    t = lnh_dpp<0x111, 0xf>(v); if (lane - 1 >= run_start) v += t;  // row_shr:1 (0 shifted in at row starts)
+    t = lnh_dpp<0x112, 0xf>(v); if (lane - 2 >= run_start) v += t;
+    t = lnh_dpp<0x114, 0xf>(v); if (lane - 4 >= run_start) v += t;
+    t = lnh_dpp<0x118, 0xf>(v); if (lane - 8 >= run_start) v += t;
+    t = lnh_dpp<0x142, 0xa>(v); if ((lane & 16) && run_start < (lane & ~15)) v += t;  // row_bcast:15 -> rows 1,3
+    t = lnh_dpp<0x143, 0xc>(v); if (lane >= 32 && run_start < 32) v += t;             // row_bcast:31 -> rows 2,3
+    return v;
+}

@@ -362,13 +362,7 @@ k_grid_backward(const T *__restrict__ grad, const float *__restrict__ inputs, T 
                     if constexpr (sizeof(T) == 2) v[k] = (float)(half_t)v[k];  // per-contribution rounding (cu:350)
                 }
 #pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-#pragma unroll
-                    for (int k = 0; k < NC; k++) {
-                        float up = __shfl_up(v[k], o, 64);
-                        if (lane - o >= run_start) v[k] += up;
-                    }
-                }
+                for (int k = 0; k < NC; k++) v[k] = wave_segscan_add(v[k], lane, run_start);
                 if (ok && is_tail) {
                     T *p = gt + (size_t)corner_row<D>(cell, lv, c) * C;
                     if constexpr (NC == 2) atomic_add_pair(p, v[0], v[1]);
@@ -509,16 +503,9 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
         }
         if (any_merge && !(dbg & 2)) {  // wave-uniform
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const bool take = lane - o >= run_start;
-#pragma unroll
-                for (uint32_t c = 0; c < (uint32_t)NCORN; c++) {
-                    const float u0 = __shfl_up(v0[q][c], o, 64), u1 = __shfl_up(v1[q][c], o, 64);
-                    if (take) {
-                        v0[q][c] += u0;
-                        v1[q][c] += u1;
-                    }
-                }
+            for (uint32_t c = 0; c < (uint32_t)NCORN; c++) {
+                v0[q][c] = wave_segscan_add(v0[q][c], lane, run_start);
+                v1[q][c] = wave_segscan_add(v1[q][c], lane, run_start);
             }
         }
     }
@@ -537,7 +524,7 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
             if (em == 0ull) continue;  // wave-uniform
             const int leader = __builtin_ctzll(em);
             const uint32_t bk0 = __shfl(bk, leader, 64);
-            const bool uniform = __ballot(emit[q] && bk != bk0) == 0ull;
+            const bool uniform = !(lv.flags & LV_HASH) && __ballot(emit[q] && bk != bk0) == 0ull;
             if (uniform) {
                 uint32_t base = 0;
                 if (lane == leader) base = atomicAdd(&lcnt[bk0], (uint32_t)__builtin_popcountll(em));

@@ -1,0 +1,144 @@
+"""Unit parity of the fused LiDAR-field kernels (lidar_field.hip, DensityIO variants of the MLP kernels) against
+plain PyTorch fp32/fp64 restatements of the same reference arithmetic (renderer.py:164-167, 217-243;
+network.py:162-237; activation.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mlp_ref, render_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def test_sample_points():
+    from gpu_util import call
+    g = torch.Generator().manual_seed(0)
+    N, T = 37, 100
+    o = (torch.rand(N, 3, generator=g) - 0.5).cuda()
+    d = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1).cuda()
+    z = (torch.rand(N, T, generator=g) * 2.5).cuda()  # some samples leave the box -> clipped
+    aabb = torch.tensor([-1.0, -1, -1, 1, 1, 1]).cuda()
+    x01 = torch.empty((N * T, 3), device="cuda")
+    call("lnh_lidar_sample_points", o, d, z, aabb, 1.0, N, T, x01)
+    p = o[:, None, :] + d[:, None, :] * z[..., None]
+    want = (torch.min(torch.max(p, aabb[:3]), aabb[3:]) + 1.0) / 2.0
+    torch.testing.assert_close(x01.view(N, T, 3), want, rtol=0, atol=1e-7)
+    assert float(x01.min()) >= 0.0 and float(x01.max()) <= 1.0
+
+
+def test_merge_weights():
+    from gpu_util import call
+    g = torch.Generator().manual_seed(1)
+    N, T = 29, 832
+    z = torch.sort(torch.rand(N, T, generator=g) * 0.8 + 0.01, dim=1)[0]
+    sigma_pt = torch.rand(N, T, generator=g) * 30
+    perm = torch.stack([torch.randperm(T, generator=g) for _ in range(N)]).int()
+    sd = torch.full((N,), 1e-3)
+    sigma_m = torch.empty((N, T), device="cuda")
+    w = torch.empty((N, T), device="cuda")
+    call("lnh_lidar_merge_weights", z.cuda(), sigma_pt.cuda(), perm.cuda(), sd.cuda(), N, T, 1.0, sigma_m, w)
+    want_sigma = torch.gather(sigma_pt, 1, perm.long())
+    assert torch.equal(sigma_m.cpu(), want_sigma)
+    want_w, _ = render_ref.weights_from_sigma(z, want_sigma, sd[:, None])
+    torch.testing.assert_close(w.cpu(), want_w, rtol=2e-5, atol=1e-7)
+
+
+def _sigma_net(seed):
+    r = np.random.default_rng(seed)
+    w0 = (r.uniform(-1, 1, (64, 32)) * 0.4).astype(np.float16)
+    w1 = (r.uniform(-1, 1, (16, 64)) * 0.3).astype(np.float16)
+    return w0, w1
+
+
+@pytest.mark.parametrize("N,Tc,Ttot,off", [(13, 64, 80, 16), (5, 768, 832, 0), (7, 16, 16, 0)])
+def test_density_mlp_forward_backward(N, Tc, Ttot, off):
+    from gpu_util import call, dev, host
+    B = N * Tc
+    r = np.random.default_rng(2)
+    feat = r.standard_normal((16, B, 2)).astype(np.float16)  # level-major, as the encoder writes it
+    w0, w1 = _sigma_net(3)
+    wflat = np.concatenate([w0.ravel(), w1.ravel()])
+    x_rows = feat.transpose(1, 0, 2).reshape(B, 32)
+    want, _ = mlp_ref.mlp_forward(x_rows, [w0, w1])
+    h16 = torch.full((N * Ttot, 16), float("nan"), dtype=torch.float16, device="cuda")
+    sigma = torch.full((N * Ttot,), float("nan"), device="cuda")
+    call("lnh_density_mlp_forward", dev(feat), dev(wflat), B, Tc, Ttot, off, h16, sigma)
+    rows = (np.arange(B) // Tc) * Ttot + off + (np.arange(B) % Tc)
+    got = host(h16).astype(np.float64)
+    np.testing.assert_allclose(got[rows], want, rtol=2e-3, atol=4e-3)
+    untouched = np.setdiff1d(np.arange(N * Ttot), rows)
+    assert np.isnan(got[untouched]).all()  # strided destination: other slots are not written
+    # sigma = exp(fp16-rounded pre-activation) exactly (trunc_exp forward)
+    np.testing.assert_allclose(host(sigma)[rows], np.exp(got[rows, 0]).astype(np.float32), rtol=2e-6)
+    # backward
+    gy = (r.standard_normal((N * Ttot, 16)) * 0.1).astype(np.float16)
+    gx_want, dws = mlp_ref.mlp_backward(x_rows, [w0, w1], gy[rows])
+    gfeat = torch.empty((16, B, 2), dtype=torch.float16, device="cuda")
+    gw = torch.zeros(wflat.size, dtype=torch.float32, device="cuda")
+    call("lnh_density_mlp_backward", dev(gy), dev(feat), dev(wflat), B, Tc, Ttot, off, gfeat, gw)
+    got_gx = host(gfeat).astype(np.float64).transpose(1, 0, 2).reshape(B, 32)
+    np.testing.assert_allclose(got_gx, gx_want, rtol=5e-3, atol=2e-3)
+    dw_want = np.concatenate([d.ravel() for d in dws])
+    np.testing.assert_allclose(host(gw), dw_want, rtol=5e-3, atol=2e-3 * np.abs(dw_want).max())
+
+
+def _color_reference(h16, perm, weights, cdir, W0g, W1, W2, g_rgb=None, g_sigma=None):
+    """fp64 autograd restatement of the colour head on merged samples (+ trunc_exp backward column)."""
+    N, T = perm.shape
+    x = h16.view(N, T, 16).double().requires_grad_(True)
+    xg = torch.gather(x, 1, perm.long().unsqueeze(-1).expand(-1, -1, 16))
+    params = [p.half().double().requires_grad_(True) for p in (W0g, W1, W2)]
+    cd = cdir.double().requires_grad_(True)
+    rh = lambda t: t + (t.half().double() - t).detach()  # fp16 storage rounding, straight-through gradient
+    h0 = rh(torch.relu(xg @ params[0].t() + cd[:, None, :]))
+    h1 = rh(torch.relu(h0 @ params[1].t()))
+    o = rh(h1 @ params[2].t())
+    mask = (weights > 1e-4)[..., None]
+    rgb = torch.sigmoid(o) * mask
+    if g_rgb is None:
+        return rgb.detach()
+    (rgb * g_rgb.double()).sum().backward()
+    gx = x.grad.clone()
+    pre = x.detach()[..., 0].clamp(-15, 15)
+    g_sig_pt = torch.zeros(N, T, dtype=torch.float64)
+    g_sig_pt.scatter_(1, perm.long(), g_sigma.double())  # merged -> point order
+    gx[..., 0] = g_sig_pt * torch.exp(pre)
+    return rgb.detach(), gx, [p.grad for p in params], cd.grad
+
+
+@pytest.mark.parametrize("N,T", [(8, 64), (5, 832), (3, 48)])
+def test_color_head_forward_backward(N, T):
+    from gpu_util import call
+    g = torch.Generator().manual_seed(N + T)
+    h16 = (torch.randn(N * T, 16, generator=g) * 0.5).half()
+    perm = torch.stack([torch.randperm(T, generator=g) for _ in range(N)]).int()
+    weights = torch.rand(N, T, generator=g) * 2.5e-4  # ~60 % of the samples above the 1e-4 mask threshold
+    weights[0] = 0.0  # a fully masked ray
+    cdir = torch.randn(N, 64, generator=g)
+    W0g = torch.cat([torch.zeros(64, 1), torch.randn(64, 15, generator=g) * 0.3], 1)
+    W1 = torch.randn(64, 64, generator=g) * 0.2
+    W2 = torch.randn(2, 64, generator=g) * 0.2
+    w16 = torch.cat([W0g.reshape(-1), W1.reshape(-1), torch.nn.functional.pad(W2, (0, 0, 0, 14)).reshape(-1)]).half()
+    rgb = torch.empty((N, T, 2), device="cuda")
+    call("lnh_lidar_color_forward", h16.cuda(), perm.cuda(), weights.cuda(), cdir.cuda(), w16.cuda(), N, T, rgb)
+    g_rgb = torch.randn(N, T, 2, generator=g)
+    g_sigma = torch.randn(N, T, generator=g)
+    want_rgb, want_gx, want_gw, want_gcd = _color_reference(h16, perm, weights, cdir, W0g, W1, W2, g_rgb, g_sigma)
+    torch.testing.assert_close(rgb.cpu().double(), want_rgb, rtol=2e-3, atol=2e-3)
+    assert float(rgb[0].abs().max()) == 0.0
+    g_h16 = torch.full((N * T, 16), float("nan"), dtype=torch.float16, device="cuda")
+    g_w = torch.zeros(w16.numel(), device="cuda")
+    S = torch.empty((N, 64), device="cuda")
+    call("lnh_lidar_color_backward", g_rgb.cuda(), g_sigma.cuda(), h16.cuda(), perm.cuda(), weights.cuda(), cdir.cuda(),
+         w16.cuda(), N, T, g_h16, g_w, S)
+    got_gx = g_h16.cpu().double().view(N, T, 16)
+    assert torch.isfinite(got_gx).all()  # every point row written exactly once
+    scale = want_gx.abs().max().item()
+    torch.testing.assert_close(got_gx, want_gx, rtol=1e-2, atol=4e-3 * scale)
+    gw = g_w.cpu().double()
+    for got, want in ((gw[:1024].view(64, 16), want_gw[0]), (gw[1024:1024 + 4096].view(64, 64), want_gw[1]),
+                      (gw[1024 + 4096:].view(16, 64)[:2], want_gw[2])):
+        torch.testing.assert_close(got, want, rtol=1e-2, atol=5e-3 * want.abs().max().item())
+    assert float(gw[1024 + 4096:].view(16, 64)[2:].abs().max()) == 0.0  # padded output rows get no gradient
+    # per-ray sum of d(hidden0) == gradient w.r.t. the per-ray direction bias
+    torch.testing.assert_close(S.cpu().double(), want_gcd, rtol=1e-2, atol=5e-3 * want_gcd.abs().max().item())

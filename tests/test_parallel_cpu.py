@@ -1,0 +1,58 @@
+"""Data-parallel path on CPU: 2 processes, gloo.  DP invariant: after the gradient all-reduce every rank holds the
+mean of the per-rank gradients == the gradient of the mean loss over the concatenated batch."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from lidarnerf import parallel
+    r, l, w = parallel.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(0)
+    big = torch.nn.Parameter(torch.zeros(1 << 20))           # "hash table": reduced on its own
+    small = [torch.nn.Parameter(torch.zeros(64, 32)), torch.nn.Parameter(torch.zeros(16, 64))]  # coalesced
+    if rank == 1:
+        big.data.fill_(5.0)  # replicas start different; broadcast must fix that
+    mod = torch.nn.ParameterList([big] + small)
+    parallel.broadcast_parameters(mod)
+    assert float(big.data.abs().max()) == 0.0
+    x = torch.full((4,), float(rank + 1))
+    loss = (big[:4] * x).sum() + sum((p * (rank + 1)).sum() for p in small)
+    loss.backward()
+    parallel.allreduce_gradients([big] + small, world)
+    torch.testing.assert_close(big.grad[:4], torch.full((4,), 1.5))
+    for p in small:
+        torch.testing.assert_close(p.grad, torch.full_like(p, 1.5))
+    a, b = parallel.shard_rays(67980, rank, world)
+    assert (a, b) == ((0, 33990) if rank == 0 else (33990, 67980))
+    assert parallel.max_over_ranks(float(rank), "cpu") == float(world - 1)
+    dist.barrier()
+    dist.destroy_process_group()
+    out.put(rank)
+
+
+def test_dp_gradient_allreduce_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1]
