@@ -425,7 +425,9 @@ int lnh_lidar_color_backward(const float *grad_rgb, const float *grad_sigma, con
     a.h16 = (const half_t *)h16; a.perm = perm; a.weights = weights; a.cdir = cdir; a.W = (const half_t *)w16;
     a.g_rgb = grad_rgb; a.g_sigma = grad_sigma; a.g_h16 = (half_t *)grad_h16; a.dW = grad_w; a.S = ray_sum;
     a.N = N; a.T = T;
-    LNH_LAUNCH(k_color_backward, dim3(N < 2048 ? N : 2048), dim3(256), 0, (hipStream_t)stream, a);
+    // persistent workgroups: each flushes 6144 weight-gradient partials with device atomics (~20 G/s chip-wide), so
+    // keep the workgroup count near the CU count rather than one per ray
+    LNH_LAUNCH(k_color_backward, dim3(N < 512 ? N : 512), dim3(256), 0, (hipStream_t)stream, a);
     return lnh_check_launch("lnh_lidar_color_backward");
 }
 

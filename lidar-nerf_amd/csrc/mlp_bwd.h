@@ -291,7 +291,7 @@ int launch_mlp_backward(const MlpBwdArgs &a, hipStream_t s) {
     using Cfg = BwdCfg<IN_KS, HT, NHM, NT>;
     const size_t lds = Cfg::lds_bytes();
     const uint32_t steps = div_up(a.B, Cfg::PB);
-    const uint32_t grid = steps < 768 ? steps : 768;
+    const uint32_t grid = steps < 512 ? steps : 512;  // each workgroup ends with one atomic per weight: keep them few
     auto k = k_mlp_backward<IN_KS, HT, NHM, NT, IO>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     LNH_LAUNCH(k, dim3(grid), dim3(256), lds, s, a);

@@ -43,7 +43,11 @@ class LidarTrainer:
         self.scale = scale
         self.render_kwargs = render_kwargs or {}
         # Adam(betas .9/.99, eps 1e-15) and lr * 0.1^(it/iters) (main_lidarnerf.py:389-391, 408-410)
-        self.optimizer = torch.optim.Adam(model.get_params(lr), betas=(0.9, 0.99), eps=1e-15)
+        # get_params returns generators: materialise them; one fused kernel for all parameter groups on the GPU
+        params = [dict(g, params=list(g["params"])) for g in model.get_params(lr)]
+        params = [g for g in params if len(g["params"])]
+        on_gpu = all(p.is_cuda for g in params for p in g["params"])
+        self.optimizer = torch.optim.Adam(params, betas=(0.9, 0.99), eps=1e-15, fused=on_gpu)
         self.scheduler = torch.optim.lr_scheduler.LambdaLR(self.optimizer, lambda it: 0.1 ** min(it / iters, 1))
         self.scaler = torch.amp.GradScaler("cuda", enabled=fp16)
         self.params = [p for g in self.optimizer.param_groups for p in g["params"]]
