@@ -89,3 +89,28 @@ __device__ __forceinline__ float wave_segscan_add(float v, int lane, int run_sta
     t = lnh_dpp<0x143, 0xc>(v); if (lane >= 32 && run_start < 32) v += t;             // row_bcast:31 -> rows 2,3
     return v;
 }
+
+// Same scan for MANY values of one lane: the six "take" decisions depend only on (lane, run_start), so they are
+// turned into 0/1 multipliers once and every step becomes ONE v_fmac_f32 with a DPP source operand.
+struct SegScanMask {
+    float m[6];
+};
+__device__ __forceinline__ SegScanMask wave_segscan_mask(int lane, int run_start) {
+    SegScanMask k;
+    k.m[0] = (lane - 1 >= run_start) ? 1.0f : 0.0f;
+    k.m[1] = (lane - 2 >= run_start) ? 1.0f : 0.0f;
+    k.m[2] = (lane - 4 >= run_start) ? 1.0f : 0.0f;
+    k.m[3] = (lane - 8 >= run_start) ? 1.0f : 0.0f;
+    k.m[4] = ((lane & 16) && run_start < (lane & ~15)) ? 1.0f : 0.0f;
+    k.m[5] = (lane >= 32 && run_start < 32) ? 1.0f : 0.0f;
+    return k;
+}
+__device__ __forceinline__ float wave_segscan_add(float v, const SegScanMask &k) {
+    v = fmaf(lnh_dpp<0x111, 0xf>(v), k.m[0], v);
+    v = fmaf(lnh_dpp<0x112, 0xf>(v), k.m[1], v);
+    v = fmaf(lnh_dpp<0x114, 0xf>(v), k.m[2], v);
+    v = fmaf(lnh_dpp<0x118, 0xf>(v), k.m[3], v);
+    v = fmaf(lnh_dpp<0x142, 0xa>(v), k.m[4], v);
+    v = fmaf(lnh_dpp<0x143, 0xc>(v), k.m[5], v);
+    return v;
+}

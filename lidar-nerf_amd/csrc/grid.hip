@@ -391,16 +391,16 @@ k_grid_backward(const T *__restrict__ grad, const float *__restrict__ inputs, T 
 //           the pool of the table BUCKET they belong to (bucket = 8192 consecutive rows of one level); slots are
 //           reserved with LDS counters + ONE global atomic per bucket per workgroup, so the pool writes of a
 //           workgroup are contiguous per bucket;
-//   pass 2 (k_grid_bwd_reduce): one workgroup per bucket accumulates its pool in a 64 KiB LDS image and adds the
+//   pass 2 (k_grid_bwd_reduce): one workgroup per bucket accumulates its pool in a 128 KiB LDS image and adds the
 //           touched rows into the gradient table with plain stores — it owns those rows.  The LDS image is 64-bit
 //           FIXED POINT: measured on MI355X, ds_add_f32 sustains ~100 G adds/s chip-wide while ds_add_u64 keeps up
 //           with the 6 TB/s pool stream (scratch/ldsbench), and integer accumulation makes the sum exact and
 //           order-independent (fp16 contributions are multiples of 2^-24, so scale 2^24 loses nothing).
 // A bucket whose pool overflows (adversarial, non-uniform input) falls back to global atomics for the excess in
 // pass 1, which completes before pass 2 starts (kernel boundary), so the result is always the full sum.
-constexpr uint32_t kBucketRowsLog2 = 12;
+constexpr uint32_t kBucketRowsLog2 = 13;
 constexpr uint32_t kBucketRows = 1u << kBucketRowsLog2;
-constexpr uint32_t kMaxBucketsPerLevel = 128;
+constexpr uint32_t kMaxBucketsPerLevel = 64;
 
 struct BucketPlan {
     uint32_t first_bucket[LNH_MAX_LEVELS + 1];  // prefix sum of buckets per level
@@ -441,19 +441,24 @@ __device__ __forceinline__ void entry_get(const PoolEntry<float> &e, float &a, f
 // PPT points per thread (same level, 1024 points apart so that lanes stay consecutive samples): every workgroup
 // reserves its pool slots with ONE global atomic per touched bucket for 1024*PPT points — the cursor atomics are
 // device atomics too (~20 G/s), so fewer, larger reservations matter.
-template <typename T, int D, int PPT>
-__global__ void __launch_bounds__(1024)
+template <typename T, int D, int PPT, int NTHREADS>
+__global__ void __launch_bounds__(NTHREADS)
 k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs, T *__restrict__ grad_table,
                    uint32_t B, GridMeta meta, BucketPlan plan, PoolEntry<T> *__restrict__ pool,
                    uint32_t *__restrict__ cursor, uint32_t align, uint32_t interp, uint32_t dbg) {
     constexpr int C = 2, NCORN = 1 << D;
     __shared__ uint32_t lcnt[kMaxBucketsPerLevel];
-    __shared__ uint32_t lbase[kMaxBucketsPerLevel];
+    __shared__ uint32_t lbase[kMaxBucketsPerLevel];       // first reserved pool slot per bucket (global)
+    __shared__ uint32_t lstart[kMaxBucketsPerLevel + 1];  // first staging slot per bucket (workgroup-local)
+    __shared__ PoolEntry<T> stage[NTHREADS * PPT * NCORN];
     const uint32_t level = blockIdx.y;
     const LevelParams lv = meta.lv[level];
     const uint32_t fb = plan.first_bucket[level], nb = plan.first_bucket[level + 1] - fb, cap = plan.cap[level];
     const int lane = threadIdx.x & 63;
-    if (threadIdx.x < kMaxBucketsPerLevel) lcnt[threadIdx.x] = 0;
+    if (threadIdx.x < kMaxBucketsPerLevel) {
+        lcnt[threadIdx.x] = 0;
+        lbase[threadIdx.x] = 0;
+    }
 
     float v0[PPT][NCORN], v1[PPT][NCORN];
     uint32_t row[PPT][NCORN];
@@ -502,10 +507,11 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
             row[q][c] = ok ? corner_row<D>(cell, lv, c) : 0u;
         }
         if (any_merge && !(dbg & 2)) {  // wave-uniform
+            const SegScanMask sm = wave_segscan_mask(lane, run_start);
 #pragma unroll
             for (uint32_t c = 0; c < (uint32_t)NCORN; c++) {
-                v0[q][c] = wave_segscan_add(v0[q][c], lane, run_start);
-                v1[q][c] = wave_segscan_add(v1[q][c], lane, run_start);
+                v0[q][c] = wave_segscan_add(v0[q][c], sm);
+                v1[q][c] = wave_segscan_add(v1[q][c], sm);
             }
         }
     }
@@ -520,11 +526,15 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
             // LDS atomics on one counter serialise, so aggregate — one lane adds the population count, the others
             // take their rank from the lane mask.  Mixed buckets (hashed levels) fall back to per-lane atomics.
             const uint32_t bk = row[q][c] >> kBucketRowsLog2;
+            if (lv.flags & LV_HASH) {  // workgroup-uniform: hashed level, buckets are mixed -> per-lane atomics
+                if (emit[q]) rank[q][c] = atomicAdd(&lcnt[bk], 1u);
+                continue;
+            }
             const unsigned long long em = __ballot(emit[q]);
             if (em == 0ull) continue;  // wave-uniform
             const int leader = __builtin_ctzll(em);
             const uint32_t bk0 = __shfl(bk, leader, 64);
-            const bool uniform = !(lv.flags & LV_HASH) && __ballot(emit[q] && bk != bk0) == 0ull;
+            const bool uniform = __ballot(emit[q] && bk != bk0) == 0ull;
             if (uniform) {
                 uint32_t base = 0;
                 if (lane == leader) base = atomicAdd(&lcnt[bk0], (uint32_t)__builtin_popcountll(em));
@@ -536,29 +546,53 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
         }
     }
     __syncthreads();
-    if (threadIdx.x < nb) {
-        const uint32_t n = lcnt[threadIdx.x];
-        lbase[threadIdx.x] = n ? atomicAdd(&cursor[fb + threadIdx.x], n) : 0u;
+    // global reservation + exclusive scan of the workgroup's bucket counts (first wave; 128 counters = 2 per lane)
+    if (threadIdx.x < 64) {
+        static_assert(kMaxBucketsPerLevel == 64, "one bucket counter per lane of the first wave");
+        const uint32_t n0 = lcnt[lane];
+        if ((uint32_t)lane < nb && n0) lbase[lane] = atomicAdd(&cursor[fb + lane], n0);
+        uint32_t incl = n0;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += up;
+        }
+        lstart[lane] = incl - n0;
+        if (lane == 63) lstart[kMaxBucketsPerLevel] = incl;
     }
     __syncthreads();
-    PoolEntry<T> *lp = pool + plan.pool_off[level];
-    T *gt = grad_table + (size_t)lv.offset * C;
+    // ---- stage the entries in LDS grouped by bucket, then stream them out: consecutive lanes write consecutive pool
+    //      slots (a per-lane scatter of 8-byte stores costs one cache-line transaction per lane)
 #pragma unroll
     for (int q = 0; q < PPT; q++)
         if (emit[q]) {
 #pragma unroll
             for (uint32_t c = 0; c < (uint32_t)NCORN; c++) {
-                const uint32_t bk = row[q][c] >> kBucketRowsLog2;
-                const uint32_t pos = lbase[bk] + rank[q][c];
-                if (pos < cap) {
-                    PoolEntry<T> e;
-                    entry_set(e, row[q][c] & (kBucketRows - 1), v0[q][c], v1[q][c]);
-                    if (!(dbg & 8) || v0[q][c] == 12345.0f) lp[(size_t)bk * cap + pos] = e;
-                } else {  // pool overflow: exact but slow
-                    atomic_add_pair(gt + (size_t)row[q][c] * C, v0[q][c], v1[q][c]);
-                }
+                PoolEntry<T> e;
+                entry_set(e, row[q][c] & (kBucketRows - 1), v0[q][c], v1[q][c]);
+                stage[lstart[row[q][c] >> kBucketRowsLog2] + rank[q][c]] = e;
             }
         }
+    __syncthreads();
+    PoolEntry<T> *lp = pool + plan.pool_off[level];
+    T *gt = grad_table + (size_t)lv.offset * C;
+    const uint32_t total = lstart[kMaxBucketsPerLevel];
+    for (uint32_t pos = threadIdx.x; pos < total; pos += blockDim.x) {
+        uint32_t lo = 0, hi = kMaxBucketsPerLevel;  // last bucket whose start is <= pos
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (lstart[mid] <= pos) lo = mid; else hi = mid;
+        }
+        const uint32_t bk = lo, gpos = lbase[bk] + (pos - lstart[bk]);
+        const PoolEntry<T> e = stage[pos];
+        if (gpos < cap) {
+            lp[(size_t)bk * cap + gpos] = e;
+        } else {  // pool overflow: exact but slow
+            float a, b2;
+            entry_get(e, a, b2);
+            atomic_add_pair(gt + ((size_t)bk * kBucketRows + e.row) * C, a, b2);
+        }
+    }
 }
 
 // A bucket with many entries (coarse dense levels: every ray passes the same few cells) is split over up to
@@ -682,13 +716,20 @@ int launch_backward_bucketed(const T *grad, const float *inputs, T *ge, uint32_t
         lnh_set_error("grid backward: hipMemsetAsync failed");
         return LNH_ERR_LAUNCH;
     }
-    constexpr int PPT = 2;
-    LNH_LAUNCH((k_grid_bwd_scatter<T, 3, PPT>), dim3(div_up(B, 1024 * PPT), L), dim3(1024), 0, s, grad, inputs, ge, B, m,
+    // 1024 threads x 1 point: the per-workgroup cost that matters is the one returning device atomic per touched
+    // bucket (measured: 256- and 512-thread workgroups are 2.3x / 1.5x slower), and 8 entries/thread keep the LDS
+    // staging buffer at 64 KiB (two workgroups per CU)
+    LNH_LAUNCH((k_grid_bwd_scatter<T, 3, 1, 1024>), dim3(div_up(B, 1024), L), dim3(1024), 0, s, grad, inputs, ge, B, m,
                plan, pool, cursor, align, interp, g_dbg_flags);
     int rc = lnh_check_launch("lnh_grid_encode_backward_ws(scatter)");
     if (rc) return rc;
     auto k = k_grid_bwd_reduce<T>;
     const size_t lds = (size_t)kBucketRows * 2 * sizeof(unsigned long long);
+    static bool attr_set = false;  // 128 KiB of dynamic LDS needs the opt-in once per process
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
     LNH_LAUNCH(k, dim3(nbt, kMaxSlices), dim3(1024), lds, s, ge, m, plan, pool, cursor, L);
     return lnh_check_launch("lnh_grid_encode_backward_ws(reduce)");
 }
