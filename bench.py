@@ -122,6 +122,7 @@ def main():
         print(f"[bench] WORLD_SIZE={world} differs from --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP extension is the product path (no CPU fallback)")
+    local = local % torch.cuda.device_count()  # (functional tests run several ranks on one GPU)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     _hip.lib()  # fail loudly now if the extension is missing

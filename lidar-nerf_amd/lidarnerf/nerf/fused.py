@@ -24,7 +24,7 @@ import numpy as np
 import torch
 from torch.autograd import Function
 
-from .. import _hip
+from .. import _hip, parallel
 from ..gridencoder.grid import _workspace
 
 
@@ -181,6 +181,10 @@ class FusedLidarRender(Function):
                       off, g_feat.data_ptr(), g_wsig.data_ptr())
             _grid_bwd(g_feat, x01, g_table16, enc, B)
 
+        # data parallel: the table gradient goes on the wire as fp16, overlapped with nothing else left to do here
+        handle = parallel.allreduce_half_table(g_table16, enc.embeddings)
+        if handle is not None:
+            handle.wait()
         dts = ctx.param_dtypes
         return (None, None, None, None, g_table16.to(dts[0]), g_wsig[:64 * 32].view(64, 32).to(dts[1]),
                 g_wsig[64 * 32:].view(16, 64).to(dts[2]), g_wc0.to(dts[3]), g_wc1.to(dts[4]), g_wc2.to(dts[5]),

@@ -16,17 +16,19 @@ import torch.distributed as dist
 
 
 def init_from_env(backend=None):
-    """Initialise torch.distributed from torchrun-style env vars; returns (rank, local_rank, world_size)."""
+    """Initialise torch.distributed from torchrun-style env vars; returns (rank, local_rank, world_size).
+    LNH_DIST_BACKEND overrides the backend (tests run two ranks on one GPU with gloo; RCCL refuses that)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
+        backend = backend or os.environ.get("LNH_DIST_BACKEND")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
 
@@ -47,6 +49,9 @@ def allreduce_gradients(params, world=None, small_numel=1 << 20):
     for p in params:
         if p.grad is None:
             continue
+        if getattr(p, "_lnh_grad_reduced", False):  # already averaged inside backward (fp16 table gradient)
+            p._lnh_grad_reduced = False
+            continue
         (big if p.grad.numel() >= small_numel else small).append(p.grad)
     handles = [dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True) for g in big]
     if small:
@@ -61,6 +66,23 @@ def allreduce_gradients(params, world=None, small_numel=1 << 20):
     for h, g in zip(handles, big):
         h.wait()
         g.div_(world)
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def allreduce_half_table(g_table16, param):
+    """Average the hash-table gradient over ranks WHILE IT IS STILL fp16 (27 MB instead of 55 MB on the wire; the
+    kernels produce it in fp16 anyway).  Returns a handle to wait on; marks `param` so allreduce_gradients skips it.
+    An fp16 overflow of the sum surfaces as inf, which GradScaler turns into a skipped step + smaller scale, exactly
+    as it does for a single-rank overflow."""
+    w = world_size()
+    if w <= 1:
+        return None
+    g_table16.div_(w)  # pre-divide: keeps the sum inside fp16 range whenever the per-rank values are
+    param._lnh_grad_reduced = True
+    return dist.all_reduce(g_table16, op=dist.ReduceOp.SUM, async_op=True)
 
 
 def broadcast_parameters(module, src=0):

@@ -37,6 +37,16 @@ def _worker(rank, world, port, out):
     torch.testing.assert_close(big.grad[:4], torch.full((4,), 1.5))
     for p in small:
         torch.testing.assert_close(p.grad, torch.full_like(p, 1.5))
+    # fp16 table-gradient path used by the fused backward
+    tbl = torch.nn.Parameter(torch.zeros(8, 2))
+    g16 = torch.full((8, 2), float(rank + 1) * 2.0, dtype=torch.float16)
+    h = parallel.allreduce_half_table(g16, tbl)
+    h.wait()
+    torch.testing.assert_close(g16, torch.full((8, 2), 3.0, dtype=torch.float16))
+    tbl.grad = g16.float()
+    parallel.allreduce_gradients([tbl], world)  # must NOT reduce it a second time
+    torch.testing.assert_close(tbl.grad, torch.full((8, 2), 3.0))
+    assert tbl._lnh_grad_reduced is False
     a, b = parallel.shard_rays(67980, rank, world)
     assert (a, b) == ((0, 33990) if rank == 0 else (33990, 67980))
     assert parallel.max_over_ranks(float(rank), "cpu") == float(world - 1)
