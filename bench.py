@@ -146,7 +146,9 @@ def main():
     sync()
     _hip.enable_timers(["lnh_grid_encode_forward", "lnh_grid_encode_backward", "lnh_grid_encode_backward_ws", "lnh_mlp_forward", "lnh_mlp_backward",
                         "lnh_lidar_composite_forward", "lnh_lidar_composite_backward", "lnh_lidar_resample",
-                        "lnh_lidar_weights", "lnh_freq_encode_forward"])
+                        "lnh_lidar_weights", "lnh_freq_encode_forward", "lnh_density_mlp_forward",
+                        "lnh_density_mlp_backward", "lnh_lidar_color_forward", "lnh_lidar_color_backward",
+                        "lnh_lidar_merge_weights", "lnh_lidar_sample_points"])
     t0 = time.perf_counter()
     for s in range(args.steps):
         loss = trainer.step(*batches[(args.warmup + s) % len(batches)])

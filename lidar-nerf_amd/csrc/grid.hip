@@ -212,8 +212,36 @@ k_grid_forward(const float *__restrict__ inputs, const T *__restrict__ table, T 
     if (ok) {
         // issue all 2^D gathers before consuming any of them
         Vec<T, C> g[1 << D];
+        if constexpr (D == 3 && C == 2) {
+            // The two x-neighbours of a cell edge are adjacent table rows whenever the x term is dense (row, row+1) or
+            // the hashed x coordinate is even ((x ^ h) and ((x+1) ^ h) differ in bit 0 only): fetch such a pair with ONE
+            // load of 2 rows.  The gather rate of this kernel is set by distinct cache lines per wave instruction
+            // (measured ~1 line/clk/CU), so halving the accesses of most pairs is a direct win.
+            const bool hash = lv.flags & LV_HASH;
+            const bool x_dense = !hash && (lv.flags & 15u) >= 1 && (lv.flags & LV_NOWRAP);
+            const bool pair_ok = x_dense || (hash && (lv.flags & LV_POW2) && !(cell.term[0][0] & 1u));
 #pragma unroll
-        for (uint32_t c = 0; c < (1u << D); c++) g[c] = load_vec<T, C>(tab + (size_t)corner_row<D>(cell, lv, c) * C);
+            for (uint32_t yz = 0; yz < 4; yz++) {
+                const uint32_t c0 = yz << 1, c1 = c0 | 1u;
+                const uint32_t r0 = corner_row<D>(cell, lv, c0);
+                if (pair_ok) {
+                    const uint32_t lo = x_dense ? r0 : (r0 & ~1u);
+                    const Vec<T, 4> pr = load_vec<T, 4>(tab + (size_t)lo * C);
+                    const bool swap = !x_dense && (r0 & 1u);  // hashed, r0 odd: r1 = r0 ^ 1 is the lower row
+                    g[c0].v[0] = swap ? pr.v[2] : pr.v[0];
+                    g[c0].v[1] = swap ? pr.v[3] : pr.v[1];
+                    g[c1].v[0] = swap ? pr.v[0] : pr.v[2];
+                    g[c1].v[1] = swap ? pr.v[1] : pr.v[3];
+                } else {
+                    g[c0] = load_vec<T, C>(tab + (size_t)r0 * C);
+                    g[c1] = load_vec<T, C>(tab + (size_t)corner_row<D>(cell, lv, c1) * C);
+                }
+            }
+        } else {
+#pragma unroll
+            for (uint32_t c = 0; c < (1u << D); c++)
+                g[c] = load_vec<T, C>(tab + (size_t)corner_row<D>(cell, lv, c) * C);
+        }
 #pragma unroll
         for (uint32_t c = 0; c < (1u << D); c++) {
             const float w = corner_weight<D>(cell, c);
@@ -471,13 +499,17 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
 #pragma unroll
         for (int d = 0; d < D; d++) x[d] = in_range ? inputs[(size_t)b * D + d] : -1.0f;
         Cell<D> cell;
-        const bool ok = in_range && locate<D>(x, lv, align != 0, interp, cell);
+        bool ok = in_range && locate<D>(x, lv, align != 0, interp, cell);
         float g0 = 0.0f, g1 = 0.0f;
         if (ok) {
             const Vec<T, 2> gv = load_vec<T, 2>(grad + ((size_t)level * B + b) * C);
             g0 = (float)gv.v[0];
             g1 = (float)gv.v[1];
         }
+        // a sample whose upstream gradient is exactly zero (fp16 underflow behind an opaque surface, masked-out
+        // rays) contributes nothing: drop it here instead of moving 8 zero entries through the pool
+        (void)0;
+        ok = ok && (g0 != 0.0f || g1 != 0.0f);
         // ---- wave run-merge (see k_grid_backward)
         uint32_t key[D];
 #pragma unroll

@@ -146,11 +146,10 @@ k_mlp_forward(MlpArgs a) {
     }
 }
 
-template <int IN_KS, int HT, int NHM, typename IO = RowMajorIO>
+template <int IN_KS, int HT, int NHM, typename IO = RowMajorIO, int NT = 4>
 int launch_fwd(const MlpArgs &a, hipStream_t s) {
-    constexpr int NT = 4;
     const uint32_t tiles = div_up(a.B, NT * 16 * 4);
-    const uint32_t grid = tiles < 1024 ? tiles : 1024;
+    const uint32_t grid = tiles < 2048 ? tiles : 2048;
     LNH_LAUNCH((k_mlp_forward<IN_KS, HT, NHM, NT, IO>), dim3(grid), dim3(256), 0, s, a);
     return lnh_check_launch("lnh_mlp_forward");
 }
@@ -244,7 +243,7 @@ int lnh_density_mlp_forward(const void *features, const void *weights, uint32_t 
     if (B == 0) return LNH_OK;
     MlpArgs a{(const half_t *)features, (const half_t *)weights, (half_t *)h16, nullptr, B, 32, 64, LNH_ACT_RELU,
               LNH_ACT_NONE, sigma, IoDims{T_cur, T_tot, slot_off}};
-    return launch_fwd<1, 4, 0, DensityIO>(a, (hipStream_t)stream);
+    return launch_fwd<1, 4, 0, DensityIO, 2>(a, (hipStream_t)stream);
 }
 
 int lnh_density_mlp_backward(const void *grad_h16, const void *features, const void *weights, uint32_t B,
