@@ -223,18 +223,32 @@ LNH_API int lnh_lidar_resample(const float *z, const float *sigma, const float *
  * dozens of PyTorch launches (sample positions, encoder permutes, trunc_exp, sort/gather merge, masked colour
  * query).  Semantics are unchanged; see lidar-nerf_amd/csrc/lidar_field.hip for the derivations.
  *
- * lnh_lidar_sample_points: x01[N*T,3] = (clip(o + d*z, aabb) + bound) / (2 bound)  (renderer.py:164-167, grid.py:213)
+ * lnh_lidar_sample_points: (clip(o + d*z, aabb) + bound) / (2 bound)  (renderer.py:164-167, grid.py:213) for z [N,T],
+ * written to row n*T_tot + slot_off + j of x01 (T_tot = T, slot_off = 0: plain [N*T,3]).
  */
 LNH_API int lnh_lidar_sample_points(const float *rays_o, const float *rays_d, const float *z, const float *aabb,
-                                    float bound, uint32_t N, uint32_t T, float *x01, lnh_stream_t stream);
+                                    float bound, uint32_t N, uint32_t T, uint32_t T_tot, uint32_t slot_off, float *x01,
+                                    lnh_stream_t stream);
+/*
+ * lnh_grid_encode_forward_mapped: lnh_grid_encode_forward (D = 3, hash, linear) whose launch index b = r*T_cur + j
+ * reads position row r*T_tot + slot_off + j of inputs_all [B_all,3] and writes the same row of
+ * outputs_all [L, B_all, C] — coarse and importance samples of a ray share one buffer, so the backward pass is ONE
+ * launch over B_all points.
+ */
+LNH_API int lnh_grid_encode_forward_mapped(const float *inputs_all, const void *embeddings, const int32_t *offsets_host,
+                                           void *outputs_all, uint32_t B, uint32_t T_cur, uint32_t T_tot,
+                                           uint32_t slot_off, uint32_t B_all, uint32_t C, uint32_t L, float S,
+                                           uint32_t H, int dtype, lnh_stream_t stream);
 /*
  * lnh_density_mlp_forward: sigma-net 32 -> 64 -> 16 (ReLU, no bias; network.py:45-59,162-179) on features in the
  * encoder's level-major layout [16,B,2] (fp16).  Point p = r*T_cur + j writes row r*T_tot + slot_off + j of
  * h16 [*,16] fp16 (raw outputs: col 0 density pre-activation, cols 1..15 geo_feat) and sigma [*] f32 = exp(h16[.,0])
- * (trunc_exp forward).  weights flat fp16 [64*32 | 16*64].
+ * (trunc_exp forward).  weights flat fp16 [64*32 | 16*64].  feat_rows = 0: features is [16,B,2] indexed by p;
+ * feat_rows = B_all: features is [16,B_all,2] indexed by the destination row (lnh_grid_encode_forward_mapped).
  */
 LNH_API int lnh_density_mlp_forward(const void *features, const void *weights, uint32_t B, uint32_t T_cur,
-                                    uint32_t T_tot, uint32_t slot_off, void *h16, float *sigma, lnh_stream_t stream);
+                                    uint32_t T_tot, uint32_t slot_off, uint32_t feat_rows, void *h16, float *sigma,
+                                    lnh_stream_t stream);
 /* grad_h16 rows addressed like h16 above -> grad_features [16,B,2] fp16, grad_weights fp32 (accumulated). */
 LNH_API int lnh_density_mlp_backward(const void *grad_h16, const void *features, const void *weights, uint32_t B,
                                      uint32_t T_cur, uint32_t T_tot, uint32_t slot_off, void *grad_features,

@@ -32,6 +32,9 @@ struct LevelParams {
 struct GridMeta {
     LevelParams lv[LNH_MAX_LEVELS];
 };
+struct RowMap {
+    uint32_t T_cur, T_tot, slot_off, B_all;
+};
 enum { LV_HASH = 16, LV_POW2 = 32, LV_NOWRAP = 64 };
 
 // gridencoder.cu:55-57 (spatial-hash primes); folded to immediates after unrolling
@@ -194,16 +197,21 @@ __device__ __forceinline__ void store_vec(T *p, const Vec<T, C> &r) {
 template <typename T, int D, int C, bool DYDX>
 __global__ void __launch_bounds__(256)
 k_grid_forward(const float *__restrict__ inputs, const T *__restrict__ table, T *__restrict__ outputs,
-               T *__restrict__ dy_dx, uint32_t B, uint32_t L, GridMeta meta, uint32_t align, uint32_t interp) {
+               T *__restrict__ dy_dx, uint32_t B, uint32_t L, GridMeta meta, uint32_t align, uint32_t interp,
+               RowMap map) {
     const uint32_t level = blockIdx.y;
     const LevelParams lv = meta.lv[level];
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
+    const uint32_t b0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b0 >= B) return;
+    // optional row map: launch index b0 = r*T_cur + j addresses row r*T_tot + slot_off + j of buffers holding
+    // B_all rows (coarse and fine samples of a ray side by side); identity when T_cur == 0
+    const uint32_t b = map.T_cur ? (b0 / map.T_cur) * map.T_tot + map.slot_off + b0 % map.T_cur : b0;
+    const uint32_t Bs = map.T_cur ? map.B_all : B;
     float x[D];
 #pragma unroll
     for (int d = 0; d < D; d++) x[d] = inputs[(size_t)b * D + d];
     const T *tab = table + (size_t)lv.offset * C;
-    T *out = outputs + ((size_t)level * B + b) * C;
+    T *out = outputs + ((size_t)level * Bs + b) * C;
     Cell<D> cell;
     Vec<T, C> res;
 #pragma unroll
@@ -867,15 +875,15 @@ k_grad_tv(const T *__restrict__ inputs, const T *__restrict__ table, T *__restri
 
 template <typename T, int D>
 int launch_forward_c(const float *inputs, const T *emb, T *out, T *dy_dx, uint32_t B, uint32_t C, uint32_t L,
-                     const GridMeta &m, uint32_t align, uint32_t interp, hipStream_t s) {
+                     const GridMeta &m, uint32_t align, uint32_t interp, hipStream_t s, RowMap map = RowMap{0, 0, 0, 0}) {
     dim3 grid(div_up(B, 256), L), block(256);
 #define LNH_FWD(CC)                                                                                               \
     if (dy_dx)                                                                                                    \
         LNH_LAUNCH((k_grid_forward<T, D, CC, true>), grid, block, 0, s, inputs, emb, out, dy_dx, B, L, m, \
-                           align, interp);                                                                        \
+                           align, interp, map);                                                                   \
     else                                                                                                          \
         LNH_LAUNCH((k_grid_forward<T, D, CC, false>), grid, block, 0, s, inputs, emb, out, dy_dx, B, L, m, \
-                           align, interp);
+                           align, interp, map);
     switch (C) {
         case 1: LNH_FWD(1) break;
         case 2: LNH_FWD(2) break;
@@ -1007,6 +1015,28 @@ int lnh_grid_encode_forward(const float *inputs, const void *embeddings, const i
                                                         (half_t *)dy_dx, B, C, L, m, align_corners != 0, interp, s)))
     }
     return rc;
+}
+
+int lnh_grid_encode_forward_mapped(const float *inputs_all, const void *embeddings, const int32_t *offsets_host,
+                                   void *outputs_all, uint32_t B, uint32_t T_cur, uint32_t T_tot, uint32_t slot_off,
+                                   uint32_t B_all, uint32_t C, uint32_t L, float S, uint32_t H, int dtype,
+                                   lnh_stream_t stream) {
+    int rc = check_common(inputs_all, offsets_host, B, 3, C, L, dtype);
+    if (rc) return rc;
+    LNH_REQUIRE(embeddings && outputs_all, LNH_ERR_INVALID_ARG, "grid forward (mapped): null embeddings/outputs");
+    LNH_REQUIRE(T_cur >= 1 && slot_off + T_cur <= T_tot && B % T_cur == 0 && (uint64_t)(B / T_cur) * T_tot <= B_all,
+                LNH_ERR_INVALID_ARG, "grid forward (mapped): inconsistent row map");
+    if (B == 0) return LNH_OK;
+    GridMeta m;
+    LNH_REQUIRE(build_meta(m, offsets_host, 3, L, S, H, 0, false) == 0, LNH_ERR_INVALID_ARG,
+                "grid: offsets must be increasing and non-negative");
+    const RowMap map{T_cur, T_tot, slot_off, B_all};
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == LNH_F32)
+        return launch_forward_c<float, 3>(inputs_all, (const float *)embeddings, (float *)outputs_all, nullptr, B, C, L, m,
+                                          0, 0, s, map);
+    return launch_forward_c<half_t, 3>(inputs_all, (const half_t *)embeddings, (half_t *)outputs_all, nullptr, B, C, L, m, 0,
+                                       0, s, map);
 }
 
 int lnh_grid_encode_backward(const void *grad, const float *inputs, const void *embeddings,

@@ -26,12 +26,13 @@ namespace {
 // ------------------------------------------------------------------------------------------------ sample points
 __global__ void __launch_bounds__(256)
 k_sample_points(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ z,
-                const float *__restrict__ aabb, float bound, uint32_t N, uint32_t T, float *__restrict__ x01) {
+                const float *__restrict__ aabb, float bound, uint32_t N, uint32_t T, uint32_t T_tot, uint32_t slot_off,
+                float *__restrict__ x01) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N * T) return;
     const uint32_t n = i / T;
     const float t = z[i];
-    float *o = x01 + (size_t)i * 3;
+    float *o = x01 + ((size_t)n * T_tot + slot_off + (i - n * T)) * 3;  // row n*T_tot + slot_off + j
 #pragma unroll
     for (int d = 0; d < 3; d++) {
         // o + d * z  (separate multiply and add: the reference evaluates this with two PyTorch ops), clip to the
@@ -381,13 +382,14 @@ k_color_backward(ColorArgs a) {
 extern "C" {
 
 int lnh_lidar_sample_points(const float *rays_o, const float *rays_d, const float *z, const float *aabb, float bound,
-                            uint32_t N, uint32_t T, float *x01, lnh_stream_t stream) {
+                            uint32_t N, uint32_t T, uint32_t T_tot, uint32_t slot_off, float *x01, lnh_stream_t stream) {
     LNH_REQUIRE(rays_o && rays_d && z && aabb && x01, LNH_ERR_INVALID_ARG, "lidar_sample_points: null pointer");
     LNH_REQUIRE(bound > 0.0f, LNH_ERR_INVALID_ARG, "lidar_sample_points: bound must be positive");
+    LNH_REQUIRE(slot_off + T <= T_tot, LNH_ERR_INVALID_ARG, "lidar_sample_points: slot_off + T must be <= T_tot");
     if ((uint64_t)N * T == 0) return LNH_OK;
     LNH_REQUIRE((uint64_t)N * T < 0xffffffffull, LNH_ERR_UNSUPPORTED, "lidar_sample_points: N*T must fit 32 bits");
     LNH_LAUNCH(k_sample_points, dim3(div_up((uint64_t)N * T, 256)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, z,
-               aabb, bound, N, T, x01);
+               aabb, bound, N, T, T_tot, slot_off, x01);
     return lnh_check_launch("lnh_lidar_sample_points");
 }
 
@@ -427,7 +429,7 @@ int lnh_lidar_color_backward(const float *grad_rgb, const float *grad_sigma, con
     a.N = N; a.T = T;
     // persistent workgroups: each flushes 6144 weight-gradient partials with device atomics (~20 G/s chip-wide), so
     // keep the workgroup count near the CU count rather than one per ray
-    LNH_LAUNCH(k_color_backward, dim3(N < 512 ? N : 512), dim3(256), 0, (hipStream_t)stream, a);
+    LNH_LAUNCH(k_color_backward, dim3(N < 256 ? N : 256), dim3(256), 0, (hipStream_t)stream, a);
     return lnh_check_launch("lnh_lidar_color_backward");
 }
 

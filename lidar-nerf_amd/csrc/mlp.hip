@@ -69,7 +69,7 @@ k_mlp_forward(MlpArgs a) {
 #pragma unroll
             for (int s = 0; s < IN_KS; s++) {
                 const uint32_t k0 = 32 * s + 8 * g;
-                bx[n][s] = (p < a.B && k0 < a.in_dim) ? IO::load_x(a.X, p, k0, a.B, a.in_dim) : zero_h8();
+                bx[n][s] = (p < a.B && k0 < a.in_dim) ? IO::load_x(a.X, p, k0, a.B, a.in_dim, a.io) : zero_h8();
             }
         }
         // ---- layer 0
@@ -205,7 +205,7 @@ int lnh_mlp_forward(const void *inputs, const void *weights, uint32_t B, uint32_
     if (rc) return rc;
     if (B == 0) return LNH_OK;
     MlpArgs a{(const half_t *)inputs, (const half_t *)weights, (half_t *)outputs, (half_t *)forward_buffer,
-              B, input_dim, hidden_dim, activation, output_activation, nullptr, IoDims{1, 1, 0}};
+              B, input_dim, hidden_dim, activation, output_activation, nullptr, IoDims{1, 1, 0, 0}};
     hipStream_t s = (hipStream_t)stream;
     LNH_MLP_FWD_DISPATCH(a)
     return rc;
@@ -223,7 +223,7 @@ int lnh_mlp_backward(const void *grad, const void *inputs, const void *weights, 
     if (rc) return rc;
     if (B == 0) return LNH_OK;
     MlpBwdArgs a{(const half_t *)grad, (const half_t *)inputs, (const half_t *)weights, (half_t *)grad_inputs,
-                 grad_weights, B, input_dim, hidden_dim, activation, output_activation, IoDims{1, 1, 0}};
+                 grad_weights, B, input_dim, hidden_dim, activation, output_activation, IoDims{1, 1, 0, 0}};
     hipStream_t s = (hipStream_t)stream;
     const uint32_t iks = (input_dim + 31) / 32;
     switch (n_hidden_mats) {
@@ -236,26 +236,27 @@ int lnh_mlp_backward(const void *grad, const void *inputs, const void *weights, 
 
 
 int lnh_density_mlp_forward(const void *features, const void *weights, uint32_t B, uint32_t T_cur, uint32_t T_tot,
-                            uint32_t slot_off, void *h16, float *sigma, lnh_stream_t stream) {
+                            uint32_t slot_off, uint32_t feat_rows, void *h16, float *sigma, lnh_stream_t stream) {
     LNH_REQUIRE(features && weights && h16 && sigma, LNH_ERR_INVALID_ARG, "density mlp forward: null pointer");
     LNH_REQUIRE(T_cur >= 1 && slot_off + T_cur <= T_tot && B % T_cur == 0, LNH_ERR_INVALID_ARG,
                 "density mlp forward: need B %% T_cur == 0 and slot_off + T_cur <= T_tot");
     if (B == 0) return LNH_OK;
     MlpArgs a{(const half_t *)features, (const half_t *)weights, (half_t *)h16, nullptr, B, 32, 64, LNH_ACT_RELU,
-              LNH_ACT_NONE, sigma, IoDims{T_cur, T_tot, slot_off}};
+              LNH_ACT_NONE, sigma, IoDims{T_cur, T_tot, slot_off, feat_rows}};
     return launch_fwd<1, 4, 0, DensityIO, 2>(a, (hipStream_t)stream);
 }
 
 int lnh_density_mlp_backward(const void *grad_h16, const void *features, const void *weights, uint32_t B,
                              uint32_t T_cur, uint32_t T_tot, uint32_t slot_off, void *grad_features,
                              float *grad_weights, lnh_stream_t stream) {
+    const uint32_t feat_rows = 0;
     LNH_REQUIRE(grad_h16 && features && weights && grad_features && grad_weights, LNH_ERR_INVALID_ARG,
                 "density mlp backward: null pointer");
     LNH_REQUIRE(T_cur >= 1 && slot_off + T_cur <= T_tot && B % T_cur == 0, LNH_ERR_INVALID_ARG,
                 "density mlp backward: need B %% T_cur == 0 and slot_off + T_cur <= T_tot");
     if (B == 0) return LNH_OK;
     MlpBwdArgs a{(const half_t *)grad_h16, (const half_t *)features, (const half_t *)weights, (half_t *)grad_features,
-                 grad_weights, B, 32, 64, LNH_ACT_RELU, LNH_ACT_NONE, IoDims{T_cur, T_tot, slot_off}};
+                 grad_weights, B, 32, 64, LNH_ACT_RELU, LNH_ACT_NONE, IoDims{T_cur, T_tot, slot_off, feat_rows}};
     return lnh_density_mlp_backward_launch(a, (hipStream_t)stream);
 }
 

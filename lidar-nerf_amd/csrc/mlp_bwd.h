@@ -126,7 +126,7 @@ k_mlp_backward(MlpBwdArgs a) {
 #pragma unroll
             for (int s = 0; s < IN_KS; s++) {
                 const uint32_t k0 = 32 * s + 8 * g;
-                bx[n][s] = (p < a.B && k0 < in_dim) ? IO::load_x(a.X, p, k0, a.B, in_dim) : zero_h8();
+                bx[n][s] = (p < a.B && k0 < in_dim) ? IO::load_x(a.X, p, k0, a.B, in_dim, a.io) : zero_h8();
             }
             by[n] = (p < a.B && g < 2) ? *reinterpret_cast<const half8_t *>(a.dY + IO::out_row(p, a.io) * 16 + 8 * g)
                                        : zero_h8();
@@ -283,6 +283,189 @@ k_mlp_backward(MlpBwdArgs a) {
             for (int r = 0; r < 4; r++) unsafeAtomicAdd(dWo + (size_t)(4 * g + r) * hidden + 16 * i + c, gWo[q][r]);
         }
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------------- wave-independent
+// Backward for ONE-hidden-layer nets (NHM = 0: the sigma net) without LDS transposes or workgroup barriers.
+//
+// The MFMA operand layouts are symmetric (A: row = lane&15, B: column = lane&15, same k enumeration), so swapping
+// the two operands of a product yields the TRANSPOSED result in the accumulator layout:
+//      MFMA(A = W, B = X^T)  ->  D[channel 4g+r][point c]      ("channel-major", feeds the next layer as B operand)
+//      MFMA(A = X^T-as-A, B = W-as-B)  ->  D[point 4g+r][channel c]   ("point-major")
+// and a point-major accumulator tile IS a wgrad operand fragment: dW[o][i] = sum_p dH[p][o] * act[p][i] contracts over
+// points, i.e. needs lane (g, o) to hold dH[points 4g+r][o] — exactly D[point 4g+r][channel c = o].  So every wave
+// recomputes its 32 points once in each orientation (MFMA time is negligible here) and accumulates ALL weight-gradient
+// tiles of the net in its own registers; quantities that are not products (dY, x) are transposed by multiplying with an
+// identity fragment.  Waves never wait for each other; the four partial sums of a workgroup are combined through LDS
+// once at the end of the kernel and flushed with one atomic per weight.
+template <int IN_KS, int HT, typename IO>
+__global__ void __launch_bounds__(512)
+k_mlp_backward_wi(MlpBwdArgs a) {
+    constexpr int HS = HT / 2, IT = IN_KS * 2, NT = 2;
+    __shared__ float red[(HT + HT * IT) * 256];
+    const uint32_t wid = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+    const uint32_t hidden = HT * 16, in_dim = a.in_dim, act = a.act, in_tiles = in_dim / 16;
+    const bool want_dx = a.dX != nullptr;
+    const uint32_t nw = blockDim.x >> 6;
+    const uint32_t wave = blockIdx.x * nw + wid, nwaves = gridDim.x * nw;
+
+    const half_t *W0 = a.W;
+    const half_t *Wo = W0 + (size_t)hidden * in_dim;
+    half8_t w0[HT][IN_KS], woT[HT], w0T[IT][HS], ident[IT];
+#pragma unroll
+    for (int t = 0; t < HT; t++) {
+#pragma unroll
+        for (int s = 0; s < IN_KS; s++) w0[t][s] = load_a_natural(W0, in_dim, 16 * t + c, s, g, in_dim);
+        woT[t] = load_at_natural(Wo, hidden, 16 * t + c, 0, g, 16);
+    }
+#pragma unroll
+    for (int t = 0; t < IT; t++) {
+#pragma unroll
+        for (int s = 0; s < HS; s++)
+            w0T[t][s] = (want_dx && (uint32_t)t < in_tiles) ? load_at_nu(W0, in_dim, 16 * t + c, s, g) : zero_h8();
+        // identity fragment selecting natural-k element (16 t' + c) with t' = t & 1 inside a 32-wide k-step:
+        // element j of lane (g, c) is k = 8g + j
+#pragma unroll
+        for (int j = 0; j < 8; j++) ident[t][j] = (8 * g + j == 16 * (t & 1) + c) ? (half_t)1.0f : (half_t)0.0f;
+    }
+    f32x4 gWo[HT], gW0[HT][IT];
+#pragma unroll
+    for (int t = 0; t < HT; t++) {
+        gWo[t] = zero_f4();
+#pragma unroll
+        for (int i = 0; i < IT; i++) gW0[t][i] = zero_f4();
+    }
+    auto pack2 = [](const f32x4 &lo, const f32x4 &hi) {
+        half8_t r = {(half_t)lo[0], (half_t)lo[1], (half_t)lo[2], (half_t)lo[3],
+                     (half_t)hi[0], (half_t)hi[1], (half_t)hi[2], (half_t)hi[3]};
+        return r;
+    };
+
+    for (uint64_t base = (uint64_t)wave * NT * 16; base < a.B; base += (uint64_t)nwaves * NT * 16) {
+        half8_t bx[NT][IN_KS], by[NT];
+#pragma unroll
+        for (int n = 0; n < NT; n++) {
+            const uint64_t p = base + n * 16 + c;
+#pragma unroll
+            for (int s = 0; s < IN_KS; s++) {
+                const uint32_t k0 = 32 * s + 8 * g;
+                bx[n][s] = (p < a.B && k0 < in_dim) ? IO::load_x(a.X, p, k0, a.B, in_dim, a.io) : zero_h8();
+            }
+            by[n] = (p < a.B && g < 2) ? *reinterpret_cast<const half8_t *>(a.dY + IO::out_row(p, a.io) * 16 + 8 * g)
+                                       : zero_h8();
+        }
+        // ---- channel-major chain: hidden, its gradient, dX
+        half8_t bd[NT][HS];
+#pragma unroll
+        for (int n = 0; n < NT; n++) {
+            f32x4 h[HT], d[HT];
+#pragma unroll
+            for (int t = 0; t < HT; t++) {
+                h[t] = zero_f4();
+#pragma unroll
+                for (int s = 0; s < IN_KS; s++) h[t] = MFMA16(w0[t][s], bx[n][s], h[t]);
+                d[t] = MFMA16(woT[t], by[n], zero_f4());
+            }
+#pragma unroll
+            for (int s = 0; s < HS; s++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float p0 = (float)(half_t)act_forward(act, h[2 * s][j]);
+                    const float p1 = (float)(half_t)act_forward(act, h[2 * s + 1][j]);
+                    bd[n][s][j] = (half_t)act_backward_post(act, d[2 * s][j], p0);
+                    bd[n][s][4 + j] = (half_t)act_backward_post(act, d[2 * s + 1][j], p1);
+                }
+            if (want_dx) {
+                const uint64_t p = base + n * 16 + c;
+#pragma unroll
+                for (int t = 0; t < IT; t++) {
+                    f32x4 acc = zero_f4();
+#pragma unroll
+                    for (int s = 0; s < HS; s++) acc = MFMA16(w0T[t][s], bd[n][s], acc);
+                    if (p < a.B && (uint32_t)t < in_tiles) IO::store_dx(a.dX, p, t, g, a.B, in_dim, acc);
+                }
+            }
+        }
+        // ---- point-major operands + weight gradients
+        f32x4 dy_pm[NT];
+#pragma unroll
+        for (int n = 0; n < NT; n++) dy_pm[n] = MFMA16(by[n], ident[0], zero_f4());  // D[point][output c]
+        const half8_t fa_y = pack2(dy_pm[0], dy_pm[1]);
+        half8_t fx[IT];
+#pragma unroll
+        for (int i = 0; i < IT; i++) {
+            f32x4 x_pm[NT];
+#pragma unroll
+            for (int n = 0; n < NT; n++) x_pm[n] = MFMA16(bx[n][i >> 1], ident[i], zero_f4());  // D[point][feature 16i+c]
+            fx[i] = pack2(x_pm[0], x_pm[1]);
+        }
+#pragma unroll
+        for (int t = 0; t < HT; t++) {
+            f32x4 h_pm[NT], d_pm[NT];
+#pragma unroll
+            for (int n = 0; n < NT; n++) {
+                h_pm[n] = zero_f4();
+#pragma unroll
+                for (int s = 0; s < IN_KS; s++) h_pm[n] = MFMA16(bx[n][s], w0[t][s], h_pm[n]);  // D[point][channel 16t+c]
+                d_pm[n] = MFMA16(by[n], woT[t], zero_f4());
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float post = (float)(half_t)act_forward(act, h_pm[n][r]);
+                    h_pm[n][r] = post;
+                    d_pm[n][r] = act_backward_post(act, d_pm[n][r], post);
+                }
+            }
+            const half8_t fh = pack2(h_pm[0], h_pm[1]), fd = pack2(d_pm[0], d_pm[1]);
+            gWo[t] = MFMA16(fa_y, fh, gWo[t]);  // dWo[o][16t + c]
+#pragma unroll
+            for (int i = 0; i < IT; i++) gW0[t][i] = MFMA16(fd, fx[i], gW0[t][i]);  // dW0[16t + .][16i + c]
+        }
+    }
+
+    // ---- combine the waves of the workgroup through LDS, then one atomic per weight.  The whole gradient is only
+    //      ~100 cache lines, so device atomics on it serialise: keep the number of flushing workgroups ~ #CUs.
+    constexpr int NTILE = HT + HT * IT;
+    for (uint32_t w = 0; w < nw; w++) {
+        if (wid == w) {
+#pragma unroll
+            for (int t = 0; t < HT; t++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float *q = red + (t * 4 + r) * 64 + lane;
+                    *q = (w == 0 ? 0.0f : *q) + gWo[t][r];
+                }
+#pragma unroll
+                for (int i = 0; i < IT; i++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        float *q = red + ((HT + t * IT + i) * 4 + r) * 64 + lane;
+                        *q = (w == 0 ? 0.0f : *q) + gW0[t][i][r];
+                    }
+            }
+        }
+        __syncthreads();
+    }
+    float *dW0 = a.dW;
+    float *dWo = dW0 + (size_t)hidden * in_dim;
+    for (uint32_t e = threadIdx.x; e < NTILE * 256; e += blockDim.x) {
+        const uint32_t tile = e >> 8, r = (e >> 6) & 3, ln = e & 63, gg = ln >> 4, cc = ln & 15;
+        const float v = red[e];
+        if (tile < HT) {
+            unsafeAtomicAdd(dWo + (size_t)(4 * gg + r) * hidden + 16 * tile + cc, v);
+        } else {
+            const uint32_t t = (tile - HT) / IT, i = (tile - HT) % IT;
+            if (i < in_tiles) unsafeAtomicAdd(dW0 + (size_t)(16 * t + 4 * gg + r) * in_dim + 16 * i + cc, v);
+        }
+    }
+}
+
+template <int IN_KS, int HT, typename IO = RowMajorIO>
+int launch_mlp_backward_wi(const MlpBwdArgs &a, hipStream_t s) {
+    const uint32_t iters = div_up(a.B, 8 * 32);
+    const uint32_t grid = iters < 256 ? iters : 256;
+    LNH_LAUNCH((k_mlp_backward_wi<IN_KS, HT, IO>), dim3(grid), dim3(512), 0, s, a);
+    return lnh_check_launch("lnh_mlp_backward");
 }
 
 template <int IN_KS, int HT, int NHM, typename IO = RowMajorIO>

@@ -3,8 +3,8 @@
 
 int lnh_mlp_backward_nhm0(uint32_t in_ks, const MlpBwdArgs &a, hipStream_t s) {
     switch (in_ks) {
-        case 1: return launch_mlp_backward<1, 4, 0>(a, s);
-        case 2: return launch_mlp_backward<2, 4, 0>(a, s);
+        case 1: return launch_mlp_backward_wi<1, 4>(a, s);
+        case 2: return launch_mlp_backward_wi<2, 4>(a, s);
         case 3: return launch_mlp_backward<3, 4, 0>(a, s);
         case 4: return launch_mlp_backward<4, 4, 0>(a, s);
     }
@@ -14,5 +14,5 @@ int lnh_mlp_backward_nhm0(uint32_t in_ks, const MlpBwdArgs &a, hipStream_t s) {
 
 // sigma net of the LiDAR field: level-major feature input, strided gradient rows (mlp_common.h DensityIO)
 int lnh_density_mlp_backward_launch(const MlpBwdArgs &a, hipStream_t s) {
-    return launch_mlp_backward<1, 4, 0, DensityIO>(a, s);
+    return launch_mlp_backward_wi<1, 4, DensityIO>(a, s);
 }

@@ -120,11 +120,14 @@ __device__ __forceinline__ half8_t pack_pair(const f32x4 &lo, const f32x4 &hi, F
 //   * backward reads the gradient rows from the same strided buffer and writes d(features) level-major.
 struct IoDims {
     uint32_t T_cur, T_tot, slot_off;  // DensityIO: point p = r*T_cur + j  ->  destination row r*T_tot + slot_off + j
+    uint32_t feat_rows;               // DensityIO: != 0 -> the feature buffer has feat_rows rows per level and is
+                                      //            addressed by the destination row too (coarse + fine in one buffer)
 };
 
 struct RowMajorIO {
     static constexpr bool kDensity = false;
-    __device__ static __forceinline__ half8_t load_x(const half_t *X, uint64_t p, uint32_t k0, uint32_t B, uint32_t in_dim) {
+    __device__ static __forceinline__ half8_t load_x(const half_t *X, uint64_t p, uint32_t k0, uint32_t B, uint32_t in_dim,
+                                                     const IoDims &) {
         return *reinterpret_cast<const half8_t *>(X + p * in_dim + k0);
     }
     __device__ static __forceinline__ uint64_t out_row(uint64_t p, const IoDims &) { return p; }
@@ -137,10 +140,17 @@ struct RowMajorIO {
 
 struct DensityIO {
     static constexpr bool kDensity = true;
+    __device__ static __forceinline__ uint64_t out_row(uint64_t p, const IoDims &d) {
+        const uint64_t r = p / d.T_cur;
+        return r * d.T_tot + d.slot_off + (p - r * d.T_cur);
+    }
     // features k0..k0+7 = levels k0/2 .. k0/2+3, two channels each: four 4-byte loads from [L,B,2]
-    __device__ static __forceinline__ half8_t load_x(const half_t *X, uint64_t p, uint32_t k0, uint32_t B, uint32_t in_dim) {
+    __device__ static __forceinline__ half8_t load_x(const half_t *X, uint64_t p0, uint32_t k0, uint32_t B0, uint32_t in_dim,
+                                                     const IoDims &d) {
         half8_t r;
         const uint32_t l0 = k0 >> 1;
+        const uint64_t p = d.feat_rows ? out_row(p0, d) : p0;
+        const uint64_t B = d.feat_rows ? d.feat_rows : B0;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const half2_t v = *reinterpret_cast<const half2_t *>(X + ((uint64_t)(l0 + i) * B + p) * 2);
@@ -148,10 +158,6 @@ struct DensityIO {
             r[2 * i + 1] = v[1];
         }
         return r;
-    }
-    __device__ static __forceinline__ uint64_t out_row(uint64_t p, const IoDims &d) {
-        const uint64_t r = p / d.T_cur;
-        return r * d.T_tot + d.slot_off + (p - r * d.T_cur);
     }
     // features 16t+4g+r -> levels 8t+2g, 8t+2g+1
     __device__ static __forceinline__ void store_dx(half_t *dX, uint64_t p, uint32_t t, uint32_t g, uint32_t B,

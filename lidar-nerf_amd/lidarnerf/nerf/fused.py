@@ -98,25 +98,31 @@ class FusedLidarRender(Function):
 
         h16 = torch.empty((N * Ttot, 16), dtype=torch.half, device=dev)
         sigma_pt = torch.empty((N, Ttot), dtype=torch.float32, device=dev)
+        # coarse and importance samples of a ray live side by side (slots 0..T-1 | T..T+t-1) in ONE set of buffers, so
+        # the backward pass is a single launch chain over all N*(T+t) points
+        B_all = N * Ttot
+        L = enc.num_levels
+        x01 = torch.empty((B_all, 3), dtype=torch.float32, device=dev)
+        feat = torch.empty((L, B_all, 2), dtype=torch.half, device=dev)
 
         def density(zz, Tc, off):
             B = N * Tc
-            x01 = torch.empty((B, 3), dtype=torch.float32, device=dev)
             _hip.call("lnh_lidar_sample_points", rays_o.data_ptr(), rays_d.data_ptr(), zz.data_ptr(), aabb.data_ptr(),
-                      bound, N, Tc, x01.data_ptr())
-            feat = _grid_fwd(x01, table16, enc, B)
-            _hip.call("lnh_density_mlp_forward", feat.data_ptr(), wsig16.data_ptr(), B, Tc, Ttot, off, h16.data_ptr(),
-                      sigma_pt.data_ptr())
-            return x01, feat
+                      bound, N, Tc, Ttot, off, x01.data_ptr())
+            _hip.call("lnh_grid_encode_forward_mapped", x01.data_ptr(), table16.data_ptr(),
+                      enc._offsets_host.data_ptr(), feat.data_ptr(), B, Tc, Ttot, off, B_all, 2, L, enc.log2_scale,
+                      enc.base_resolution, _hip.LNH_F16, tag=B)
+            _hip.call("lnh_density_mlp_forward", feat.data_ptr(), wsig16.data_ptr(), B, Tc, Ttot, off, B_all,
+                      h16.data_ptr(), sigma_pt.data_ptr())
 
-        x01_c, feat_c = density(z, T, 0)
+        density(z, T, 0)
         sigma_c = sigma_pt[:, :T].contiguous()
         new_z = torch.empty((N, t_new), dtype=torch.float32, device=dev)
         z_all = torch.empty((N, Ttot), dtype=torch.float32, device=dev)
         perm = torch.empty((N, Ttot), dtype=torch.int32, device=dev)
         _hip.call("lnh_lidar_resample", z.data_ptr(), sigma_c.data_ptr(), sd.data_ptr(), u.data_ptr(), N, T, t_new,
                   float(density_scale), 1, new_z.data_ptr(), z_all.data_ptr(), perm.data_ptr())
-        x01_f, feat_f = density(new_z, t_new, T)
+        density(new_z, t_new, T)
 
         sigma_m = torch.empty((N, Ttot), dtype=torch.float32, device=dev)
         weights = torch.empty((N, Ttot), dtype=torch.float32, device=dev)
@@ -137,8 +143,7 @@ class FusedLidarRender(Function):
         _hip.call("lnh_lidar_composite_forward", z_all.data_ptr(), sigma_m.data_ptr(), rgb.data_ptr(), sd.data_ptr(), N,
                   Ttot, 2, float(density_scale), None, ws.data_ptr(), depth.data_ptr(), image.data_ptr())
 
-        ctx.save_for_backward(x01_c, feat_c, x01_f, feat_f, h16, perm, weights, z_all, sigma_m, rgb, sd, cdir, enc_d16,
-                              wsig16, wcol16)
+        ctx.save_for_backward(x01, feat, h16, perm, weights, z_all, sigma_m, rgb, sd, cdir, enc_d16, wsig16, wcol16)
         ctx.model, ctx.dims, ctx.density_scale = model, (N, T, t_new), density_scale
         ctx.param_dtypes = (embeddings.dtype, ws0.dtype, ws1.dtype, wc0.dtype, wc1.dtype, wc2.dtype)
         ctx.mark_non_differentiable(weights, z_all)
@@ -147,8 +152,7 @@ class FusedLidarRender(Function):
     @staticmethod
     @_no_autocast
     def backward(ctx, g_ws, g_depth, g_image, _gw, _gz):
-        (x01_c, feat_c, x01_f, feat_f, h16, perm, weights, z_all, sigma_m, rgb, sd, cdir, enc_d16, wsig16,
-         wcol16) = ctx.saved_tensors
+        x01, feat, h16, perm, weights, z_all, sigma_m, rgb, sd, cdir, enc_d16, wsig16, wcol16 = ctx.saved_tensors
         model, (N, T, t_new), ds = ctx.model, ctx.dims, ctx.density_scale
         enc = model.encoder
         dev = h16.device
@@ -174,12 +178,11 @@ class FusedLidarRender(Function):
 
         g_wsig = torch.zeros(wsig16.numel(), dtype=torch.float32, device=dev)
         g_table16 = torch.zeros((enc.embeddings.shape[0], 2), dtype=torch.half, device=dev)
-        for x01, feat, Tc, off in ((x01_c, feat_c, T, 0), (x01_f, feat_f, t_new, T)):
-            B = N * Tc
-            g_feat = torch.empty((enc.num_levels, B, 2), dtype=torch.half, device=dev)
-            _hip.call("lnh_density_mlp_backward", g_h16.data_ptr(), feat.data_ptr(), wsig16.data_ptr(), B, Tc, Ttot,
-                      off, g_feat.data_ptr(), g_wsig.data_ptr())
-            _grid_bwd(g_feat, x01, g_table16, enc, B)
+        B_all = N * Ttot
+        g_feat = torch.empty((enc.num_levels, B_all, 2), dtype=torch.half, device=dev)
+        _hip.call("lnh_density_mlp_backward", g_h16.data_ptr(), feat.data_ptr(), wsig16.data_ptr(), B_all, Ttot, Ttot, 0,
+                  g_feat.data_ptr(), g_wsig.data_ptr())
+        _grid_bwd(g_feat, x01, g_table16, enc, B_all)
 
         # data parallel: the table gradient goes on the wire as fp16, overlapped with nothing else left to do here
         handle = parallel.allreduce_half_table(g_table16, enc.embeddings)

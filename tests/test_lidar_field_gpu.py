@@ -19,7 +19,7 @@ def test_sample_points():
     z = (torch.rand(N, T, generator=g) * 2.5).cuda()  # some samples leave the box -> clipped
     aabb = torch.tensor([-1.0, -1, -1, 1, 1, 1]).cuda()
     x01 = torch.empty((N * T, 3), device="cuda")
-    call("lnh_lidar_sample_points", o, d, z, aabb, 1.0, N, T, x01)
+    call("lnh_lidar_sample_points", o, d, z, aabb, 1.0, N, T, T, 0, x01)
     p = o[:, None, :] + d[:, None, :] * z[..., None]
     want = (torch.min(torch.max(p, aabb[:3]), aabb[3:]) + 1.0) / 2.0
     torch.testing.assert_close(x01.view(N, T, 3), want, rtol=0, atol=1e-7)
@@ -62,7 +62,7 @@ def test_density_mlp_forward_backward(N, Tc, Ttot, off):
     want, _ = mlp_ref.mlp_forward(x_rows, [w0, w1])
     h16 = torch.full((N * Ttot, 16), float("nan"), dtype=torch.float16, device="cuda")
     sigma = torch.full((N * Ttot,), float("nan"), device="cuda")
-    call("lnh_density_mlp_forward", dev(feat), dev(wflat), B, Tc, Ttot, off, h16, sigma)
+    call("lnh_density_mlp_forward", dev(feat), dev(wflat), B, Tc, Ttot, off, 0, h16, sigma)
     rows = (np.arange(B) // Tc) * Ttot + off + (np.arange(B) % Tc)
     got = host(h16).astype(np.float64)
     np.testing.assert_allclose(got[rows], want, rtol=2e-3, atol=4e-3)
