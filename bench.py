@@ -144,7 +144,7 @@ def main():
     for s in range(args.warmup):
         trainer.step(*batches[s % len(batches)])
     sync()
-    _hip.enable_timers(["lnh_grid_encode_forward", "lnh_grid_encode_backward", "lnh_grid_encode_backward_ws", "lnh_mlp_forward", "lnh_mlp_backward",
+    _hip.enable_timers(["lnh_grid_encode_forward", "lnh_grid_encode_forward_mapped", "lnh_grid_encode_backward", "lnh_grid_encode_backward_ws", "lnh_mlp_forward", "lnh_mlp_backward",
                         "lnh_lidar_composite_forward", "lnh_lidar_composite_backward", "lnh_lidar_resample",
                         "lnh_lidar_weights", "lnh_freq_encode_forward", "lnh_density_mlp_forward",
                         "lnh_density_mlp_backward", "lnh_lidar_color_forward", "lnh_lidar_color_backward",
@@ -168,9 +168,10 @@ def main():
         units = [t for _, _, t in evs if t]
         kernels[name] = {"calls": len(ms), "total_ms": round(sum(ms), 3), "avg_us": round(1e3 * sum(ms) / len(ms), 2),
                          "points": int(sum(units)) if units else None}
-    dom = max(("lnh_grid_encode_forward", "lnh_grid_encode_backward", "lnh_grid_encode_backward_ws"),
+    dom = max(("lnh_grid_encode_forward", "lnh_grid_encode_forward_mapped", "lnh_grid_encode_backward",
+               "lnh_grid_encode_backward_ws"),
               key=lambda k: kernels.get(k, {}).get("total_ms", 0))
-    per_pt = GRID_FWD_BYTES if dom.endswith("forward") else GRID_BWD_BYTES
+    per_pt = GRID_FWD_BYTES if "forward" in dom else GRID_BWD_BYTES
     k = kernels[dom]
     avg_points = k["points"] / k["calls"]
     achieved = per_pt * k["points"] / (k["total_ms"] * 1e-3) / 1e9  # GB/s over all launches of that kernel

@@ -123,7 +123,8 @@ k_color_forward(ColorArgs a) {
 #pragma unroll
         for (int n = 0; n < NT; n++) {
             const uint32_t m = base + n * 16 + c;
-            wgt[n] = m < total ? a.weights[m] : 0.0f;
+            const float wv = a.weights[m < total ? m : 0];  // unconditional load + select
+            wgt[n] = m < total ? wv : 0.0f;
             msk[n] = wgt[n] > kMaskThresh;
             any |= msk[n];
         }
@@ -141,15 +142,15 @@ k_color_forward(ColorArgs a) {
         for (int n = 0; n < NT; n++) {
             const uint32_t m = base + n * 16 + c;
             const bool valid = m < total;
-            const uint32_t ray = valid ? m / a.T : 0;
-            const size_t src = valid ? (size_t)ray * a.T + (uint32_t)a.perm[m] : 0;
-            const half8_t bx = (valid && g < 2) ? *reinterpret_cast<const half8_t *>(a.h16 + src * 16 + 8 * g) : zero_h8();
+            const uint32_t mc = valid ? m : 0, ray = mc / a.T;
+            const size_t src = (size_t)ray * a.T + (uint32_t)a.perm[mc];
+            const half8_t bxl = *reinterpret_cast<const half8_t *>(a.h16 + src * 16 + (g < 2 ? 8 * g : 0));
+            const half8_t bx = (valid && g < 2) ? bxl : zero_h8();
             f32x4 acc[HT];
 #pragma unroll
-            for (int t = 0; t < HT; t++) {
-                acc[t] = valid ? *reinterpret_cast<const f32x4 *>(a.cdir + (size_t)ray * 64 + 16 * t + 4 * g) : zero_f4();
-                acc[t] = MFMA16(w0[t], bx, acc[t]);
-            }
+            for (int t = 0; t < HT; t++) acc[t] = *reinterpret_cast<const f32x4 *>(a.cdir + (size_t)ray * 64 + 16 * t + 4 * g);
+#pragma unroll
+            for (int t = 0; t < HT; t++) acc[t] = MFMA16(w0[t], bx, acc[t]);
             half8_t bh[HS];
 #pragma unroll
             for (int s = 0; s < HS; s++)
@@ -226,24 +227,78 @@ k_color_backward(ColorArgs a) {
         return acc;
     };
 
-    for (uint32_t ray = blockIdx.x; ray < a.N; ray += gridDim.x) {
-        f32x4 cb[HT];
+    // The per-sample operands form a dependent chain (perm -> sigma-net row) of HBM round trips; left in program order
+    // they cost ~4 exposed latencies per 64-sample step.  The (ray, step) iteration space of the workgroup is therefore
+    // flattened and software-pipelined: stage A (weights, perm, incoming gradients) runs two iterations ahead, stage B
+    // (the gathered sigma-net row) one iteration ahead.  All loads are unconditional from clamped addresses.
+    struct StageA {
+        bool valid;
+        size_t m;
+        uint32_t ray, slot;
+        float wgt, gs;
+        float2 gr;
+    };
+    const uint32_t nsteps = (a.T + 63) / 64;
+    const uint32_t nrays = blockIdx.x < a.N ? (a.N - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const uint32_t K = nrays * nsteps;
+    auto load_a = [&](uint32_t k) {
+        StageA A;
+        const uint32_t rr = k / nsteps, i = (k - rr * nsteps) * 64 + col0 + c;
+        const uint32_t ray = blockIdx.x + rr * gridDim.x;
+        A.valid = k < K && i < a.T;
+        A.ray = ray;
+        A.m = A.valid ? (size_t)ray * a.T + i : 0;
+        A.wgt = a.weights[A.m];
+        A.slot = (uint32_t)a.perm[A.m];
+        A.gs = a.g_sigma[A.m];
+        A.gr = *reinterpret_cast<const float2 *>(a.g_rgb + A.m * 2);
+        return A;
+    };
+    auto src_of = [&](const StageA &A) { return A.valid ? (size_t)A.ray * a.T + A.slot : (size_t)0; };
+    auto load_b = [&](const StageA &A) {
+        return *reinterpret_cast<const half8_t *>(a.h16 + src_of(A) * 16 + (g < 2 ? 8 * g : 0));
+    };
+    auto load_cb = [&](uint32_t ray, f32x4 (&cb)[HT]) {
+        const uint32_t r = ray < a.N ? ray : 0;
 #pragma unroll
-        for (int t = 0; t < HT; t++) cb[t] = *reinterpret_cast<const f32x4 *>(a.cdir + (size_t)ray * 64 + 16 * t + 4 * g);
-        float ssum[HT][4];
-#pragma unroll
-        for (int t = 0; t < HT; t++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) ssum[t][r] = 0.0f;
+        for (int t = 0; t < HT; t++) cb[t] = *reinterpret_cast<const f32x4 *>(a.cdir + (size_t)r * 64 + 16 * t + 4 * g);
+    };
+    StageA A0 = load_a(0), A1 = load_a(1);
+    half8_t B0 = load_b(A0);
+    f32x4 cb[HT], cb_next[HT];
+    load_cb(blockIdx.x, cb_next);
+    float ssum[HT][4];
 
-        for (uint32_t step = 0; step < a.T; step += 64) {
-            const uint32_t i = step + col0 + c;
-            const bool valid = i < a.T;
-            const size_t m = (size_t)ray * a.T + (valid ? i : 0);
-            const float wgt = valid ? a.weights[m] : 0.0f;
+    for (uint32_t k = 0; k < K; k++) {
+        const uint32_t rr = k / nsteps, sidx = k - rr * nsteps;
+        const uint32_t ray = blockIdx.x + rr * gridDim.x;
+        const StageA A2 = load_a(k + 2);
+        const half8_t B1 = load_b(A1);
+        if (sidx == 0) {
+#pragma unroll
+            for (int t = 0; t < HT; t++) {
+                cb[t] = cb_next[t];
+#pragma unroll
+                for (int r = 0; r < 4; r++) ssum[t][r] = 0.0f;
+            }
+            load_cb(ray + gridDim.x, cb_next);
+        }
+        {
+            const bool valid = A0.valid;
+            const size_t m = A0.m;
+            const float wgt = valid ? A0.wgt : 0.0f;
             const bool msk = wgt > kMaskThresh;
-            const size_t src = (size_t)ray * a.T + (valid ? (uint32_t)a.perm[m] : 0u);
-            const half8_t bx = (valid && g < 2) ? *reinterpret_cast<const half8_t *>(a.h16 + src * 16 + 8 * g) : zero_h8();
+            const size_t src = src_of(A0);
+            const half8_t bx = (valid && g < 2) ? B0 : zero_h8();
+            // whole 64-sample step transparent (the forward defines colour as 0 there): no colour gradient exists, only
+            // the compositing gradient of sigma flows back
+            if (!__syncthreads_or(valid && msk)) {
+                if (valid) {
+                    half4_t v = {(half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f};
+                    if (g == 0) v[0] = (half_t)(A0.gs * expf(fminf(fmaxf((float)bx[0], -15.0f), 15.0f)));
+                    *reinterpret_cast<half4_t *>(a.g_h16 + src * 16 + 4 * g) = v;
+                }
+            } else {
             // ---- forward recompute
             f32x4 acc[HT];
 #pragma unroll
@@ -267,7 +322,7 @@ k_color_backward(ColorArgs a) {
             // ---- output gradient through the sigmoid (only outputs 0,1 exist; lanes g == 0 hold them)
             half8_t by = zero_h8();
             if (g == 0 && valid && msk) {
-                const float2 gr = *reinterpret_cast<const float2 *>(a.g_rgb + m * 2);
+                const float2 gr = A0.gr;
                 const float r0 = sigmoidf((float)(half_t)o[0]), r1 = sigmoidf((float)(half_t)o[1]);
                 by[0] = (half_t)(gr.x * r0 * (1.0f - r0));
                 by[1] = (half_t)(gr.y * r1 * (1.0f - r1));
@@ -342,12 +397,17 @@ k_color_backward(ColorArgs a) {
             if (valid) {
                 if (g == 0) {
                     const float pre = fminf(fmaxf((float)bx[0], -15.0f), 15.0f);
-                    dx[0] = a.g_sigma[m] * expf(pre);
+                    dx[0] = A0.gs * expf(pre);
                 }
                 half4_t v = {(half_t)dx[0], (half_t)dx[1], (half_t)dx[2], (half_t)dx[3]};
                 *reinterpret_cast<half4_t *>(a.g_h16 + src * 16 + 4 * g) = v;
             }
         }
+        }
+        A0 = A1;
+        A1 = A2;
+        B0 = B1;
+        if (sidx + 1 < nsteps) continue;
         // ---- S[ray][neuron] = sum over the ray's samples of dH0: reduce over the 16 lanes of each g group, then waves
 #pragma unroll
         for (int t = 0; t < HT; t++)

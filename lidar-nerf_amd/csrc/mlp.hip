@@ -30,9 +30,11 @@ struct MlpArgs {
 
 // ---------------------------------------------------------------------------------------------------- forward
 // IN_KS = ceil(in_dim / 32); HT = hidden / 16 (M-tiles); NHM = hidden->hidden matrices; NT = point tiles / iteration
-template <int IN_KS, int HT, int NHM, int NT, typename IO>
+// FAST = (hidden activation ReLU, no output activation), resolved at compile time; otherwise runtime switches.
+template <int IN_KS, int HT, int NHM, int NT, typename IO, bool FAST>
 __global__ void __launch_bounds__(256)
 k_mlp_forward(MlpArgs a) {
+    constexpr int ACT = FAST ? (int)LNH_ACT_RELU : -1;
     constexpr int HS = HT / 2;  // k-steps over a hidden vector
     const uint32_t lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -69,7 +71,11 @@ k_mlp_forward(MlpArgs a) {
 #pragma unroll
             for (int s = 0; s < IN_KS; s++) {
                 const uint32_t k0 = 32 * s + 8 * g;
-                bx[n][s] = (p < a.B && k0 < a.in_dim) ? IO::load_x(a.X, p, k0, a.B, a.in_dim, a.io) : zero_h8();
+                // unconditional load from a clamped address + register select (a predicated load would make hipcc
+                // branch around every load and drain vmcnt per element)
+                const bool ok = p < a.B && k0 < a.in_dim;
+                const half8_t v = IO::load_x(a.X, ok ? p : 0, ok ? k0 : 0, a.B, a.in_dim, a.io);
+                bx[n][s] = ok ? v : zero_h8();
             }
         }
         // ---- layer 0
@@ -88,7 +94,7 @@ k_mlp_forward(MlpArgs a) {
             for (int n = 0; n < NT; n++)
 #pragma unroll
                 for (int s = 0; s < HS; s++)
-                    bh[n][s] = pack_pair(acc[2 * s][n], acc[2 * s + 1][n], [&](float v) { return act_forward(act, v); });
+                    bh[n][s] = pack_pair(acc[2 * s][n], acc[2 * s + 1][n], [&](float v) { return act_fwd<ACT>(act, v); });
         }
         auto save_hidden = [&](int layer) {
             if (!a.fb) return;
@@ -123,7 +129,7 @@ k_mlp_forward(MlpArgs a) {
             for (int n = 0; n < NT; n++)
 #pragma unroll
                 for (int s = 0; s < HS; s++)
-                    bh[n][s] = pack_pair(acc[2 * s][n], acc[2 * s + 1][n], [&](float v) { return act_forward(act, v); });
+                    bh[n][s] = pack_pair(acc[2 * s][n], acc[2 * s + 1][n], [&](float v) { return act_fwd<ACT>(act, v); });
             save_hidden(m + 1);
         }
         // ---- output layer (16 padded outputs)
@@ -134,8 +140,11 @@ k_mlp_forward(MlpArgs a) {
             for (int s = 0; s < HS; s++) o = MFMA16(wo[s], bh[n][s], o);
             const uint64_t p = base + n * 16 + c;
             if (p < a.B) {
-                half4_t v = {(half_t)act_forward(out_act, o[0]), (half_t)act_forward(out_act, o[1]),
-                             (half_t)act_forward(out_act, o[2]), (half_t)act_forward(out_act, o[3])};
+                if (!FAST && out_act != LNH_ACT_NONE) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o[r] = act_forward(out_act, o[r]);
+                }
+                half4_t v = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
                 const uint64_t row = IO::out_row(p, a.io);
                 *reinterpret_cast<half4_t *>(a.Y + row * 16 + 4 * g) = v;
                 if constexpr (IO::kDensity) {
@@ -150,7 +159,11 @@ template <int IN_KS, int HT, int NHM, typename IO = RowMajorIO, int NT = 4>
 int launch_fwd(const MlpArgs &a, hipStream_t s) {
     const uint32_t tiles = div_up(a.B, NT * 16 * 4);
     const uint32_t grid = tiles < 2048 ? tiles : 2048;
-    LNH_LAUNCH((k_mlp_forward<IN_KS, HT, NHM, NT, IO>), dim3(grid), dim3(256), 0, s, a);
+    if (a.act == LNH_ACT_RELU && a.out_act == LNH_ACT_NONE) {
+        LNH_LAUNCH((k_mlp_forward<IN_KS, HT, NHM, NT, IO, true>), dim3(grid), dim3(256), 0, s, a);
+    } else {
+        LNH_LAUNCH((k_mlp_forward<IN_KS, HT, NHM, NT, IO, false>), dim3(grid), dim3(256), 0, s, a);
+    }
     return lnh_check_launch("lnh_mlp_forward");
 }
 

@@ -38,7 +38,7 @@ struct BwdCfg {
     static constexpr size_t lds_bytes() { return (size_t)(ROWS_G + ROWS_A) * LDP * sizeof(half_t); }
 };
 
-template <int IN_KS, int HT, int NHM, int NT, typename IO>
+template <int IN_KS, int HT, int NHM, int NT, typename IO, int ACT>
 __global__ void __launch_bounds__(256)
 k_mlp_backward(MlpBwdArgs a) {
     using Cfg = BwdCfg<IN_KS, HT, NHM, NT>;
@@ -126,10 +126,14 @@ k_mlp_backward(MlpBwdArgs a) {
 #pragma unroll
             for (int s = 0; s < IN_KS; s++) {
                 const uint32_t k0 = 32 * s + 8 * g;
-                bx[n][s] = (p < a.B && k0 < in_dim) ? IO::load_x(a.X, p, k0, a.B, in_dim, a.io) : zero_h8();
+                // unconditional loads from clamped addresses + register selects (see mlp.hip)
+                const bool ok = p < a.B && k0 < in_dim;
+                const half8_t v = IO::load_x(a.X, ok ? p : 0, ok ? k0 : 0, a.B, in_dim, a.io);
+                bx[n][s] = ok ? v : zero_h8();
             }
-            by[n] = (p < a.B && g < 2) ? *reinterpret_cast<const half8_t *>(a.dY + IO::out_row(p, a.io) * 16 + 8 * g)
-                                       : zero_h8();
+            const bool oky = p < a.B && g < 2;
+            const half8_t vy = *reinterpret_cast<const half8_t *>(a.dY + IO::out_row(oky ? p : 0, a.io) * 16 + (oky ? 8 * g : 0));
+            by[n] = oky ? vy : zero_h8();
         }
         half8_t bh[NHM + 1][NT][HS];
 #pragma unroll
@@ -143,7 +147,7 @@ k_mlp_backward(MlpBwdArgs a) {
             }
 #pragma unroll
             for (int s = 0; s < HS; s++)
-                bh[0][n][s] = pack_pair(acc[2 * s], acc[2 * s + 1], [&](float v) { return act_forward(act, v); });
+                bh[0][n][s] = pack_pair(acc[2 * s], acc[2 * s + 1], [&](float v) { return act_fwd<ACT>(act, v); });
         }
 #pragma unroll
         for (int m = 0; m < NHM; m++)
@@ -158,7 +162,7 @@ k_mlp_backward(MlpBwdArgs a) {
                 }
 #pragma unroll
                 for (int s = 0; s < HS; s++)
-                    bh[m + 1][n][s] = pack_pair(acc[2 * s], acc[2 * s + 1], [&](float v) { return act_forward(act, v); });
+                    bh[m + 1][n][s] = pack_pair(acc[2 * s], acc[2 * s + 1], [&](float v) { return act_fwd<ACT>(act, v); });
             }
 
         // ---- output matrix: dWo[o][i] += sum_p dY[p][o] h_last[p][i]
@@ -188,8 +192,8 @@ k_mlp_backward(MlpBwdArgs a) {
             for (int s = 0; s < HS; s++)
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    bd[n][s][j] = (half_t)act_backward_post(act, acc[2 * s][j], (float)bh[NHM][n][s][j]);
-                    bd[n][s][4 + j] = (half_t)act_backward_post(act, acc[2 * s + 1][j], (float)bh[NHM][n][s][4 + j]);
+                    bd[n][s][j] = (half_t)act_bwd<ACT>(act, acc[2 * s][j], (float)bh[NHM][n][s][j]);
+                    bd[n][s][4 + j] = (half_t)act_bwd<ACT>(act, acc[2 * s + 1][j], (float)bh[NHM][n][s][4 + j]);
                 }
         }
         // ---- hidden matrices, last to first
@@ -217,8 +221,8 @@ k_mlp_backward(MlpBwdArgs a) {
                 for (int s = 0; s < HS; s++)
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        bd[n][s][j] = (half_t)act_backward_post(act, acc[2 * s][j], (float)bh[m][n][s][j]);
-                        bd[n][s][4 + j] = (half_t)act_backward_post(act, acc[2 * s + 1][j], (float)bh[m][n][s][4 + j]);
+                        bd[n][s][j] = (half_t)act_bwd<ACT>(act, acc[2 * s][j], (float)bh[m][n][s][j]);
+                        bd[n][s][4 + j] = (half_t)act_bwd<ACT>(act, acc[2 * s + 1][j], (float)bh[m][n][s][4 + j]);
                     }
             }
         }
@@ -299,7 +303,7 @@ k_mlp_backward(MlpBwdArgs a) {
 // tiles of the net in its own registers; quantities that are not products (dY, x) are transposed by multiplying with an
 // identity fragment.  Waves never wait for each other; the four partial sums of a workgroup are combined through LDS
 // once at the end of the kernel and flushed with one atomic per weight.
-template <int IN_KS, int HT, typename IO>
+template <int IN_KS, int HT, typename IO, int ACT>
 __global__ void __launch_bounds__(512)
 k_mlp_backward_wi(MlpBwdArgs a) {
     constexpr int HS = HT / 2, IT = IN_KS * 2, NT = 2;
@@ -350,10 +354,14 @@ k_mlp_backward_wi(MlpBwdArgs a) {
 #pragma unroll
             for (int s = 0; s < IN_KS; s++) {
                 const uint32_t k0 = 32 * s + 8 * g;
-                bx[n][s] = (p < a.B && k0 < in_dim) ? IO::load_x(a.X, p, k0, a.B, in_dim, a.io) : zero_h8();
+                // unconditional loads from clamped addresses + register selects (see mlp.hip)
+                const bool ok = p < a.B && k0 < in_dim;
+                const half8_t v = IO::load_x(a.X, ok ? p : 0, ok ? k0 : 0, a.B, in_dim, a.io);
+                bx[n][s] = ok ? v : zero_h8();
             }
-            by[n] = (p < a.B && g < 2) ? *reinterpret_cast<const half8_t *>(a.dY + IO::out_row(p, a.io) * 16 + 8 * g)
-                                       : zero_h8();
+            const bool oky = p < a.B && g < 2;
+            const half8_t vy = *reinterpret_cast<const half8_t *>(a.dY + IO::out_row(oky ? p : 0, a.io) * 16 + (oky ? 8 * g : 0));
+            by[n] = oky ? vy : zero_h8();
         }
         // ---- channel-major chain: hidden, its gradient, dX
         half8_t bd[NT][HS];
@@ -371,10 +379,10 @@ k_mlp_backward_wi(MlpBwdArgs a) {
             for (int s = 0; s < HS; s++)
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const float p0 = (float)(half_t)act_forward(act, h[2 * s][j]);
-                    const float p1 = (float)(half_t)act_forward(act, h[2 * s + 1][j]);
-                    bd[n][s][j] = (half_t)act_backward_post(act, d[2 * s][j], p0);
-                    bd[n][s][4 + j] = (half_t)act_backward_post(act, d[2 * s + 1][j], p1);
+                    const float p0 = (float)(half_t)act_fwd<ACT>(act, h[2 * s][j]);
+                    const float p1 = (float)(half_t)act_fwd<ACT>(act, h[2 * s + 1][j]);
+                    bd[n][s][j] = (half_t)act_bwd<ACT>(act, d[2 * s][j], p0);
+                    bd[n][s][4 + j] = (half_t)act_bwd<ACT>(act, d[2 * s + 1][j], p1);
                 }
             if (want_dx) {
                 const uint64_t p = base + n * 16 + c;
@@ -411,9 +419,9 @@ k_mlp_backward_wi(MlpBwdArgs a) {
                 d_pm[n] = MFMA16(by[n], woT[t], zero_f4());
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const float post = (float)(half_t)act_forward(act, h_pm[n][r]);
+                    const float post = (float)(half_t)act_fwd<ACT>(act, h_pm[n][r]);
                     h_pm[n][r] = post;
-                    d_pm[n][r] = act_backward_post(act, d_pm[n][r], post);
+                    d_pm[n][r] = act_bwd<ACT>(act, d_pm[n][r], post);
                 }
             }
             const half8_t fh = pack2(h_pm[0], h_pm[1]), fd = pack2(d_pm[0], d_pm[1]);
@@ -464,7 +472,11 @@ template <int IN_KS, int HT, typename IO = RowMajorIO>
 int launch_mlp_backward_wi(const MlpBwdArgs &a, hipStream_t s) {
     const uint32_t iters = div_up(a.B, 8 * 32);
     const uint32_t grid = iters < 256 ? iters : 256;
-    LNH_LAUNCH((k_mlp_backward_wi<IN_KS, HT, IO>), dim3(grid), dim3(512), 0, s, a);
+    if (a.act == LNH_ACT_RELU) {
+        LNH_LAUNCH((k_mlp_backward_wi<IN_KS, HT, IO, (int)LNH_ACT_RELU>), dim3(grid), dim3(512), 0, s, a);
+    } else {
+        LNH_LAUNCH((k_mlp_backward_wi<IN_KS, HT, IO, -1>), dim3(grid), dim3(512), 0, s, a);
+    }
     return lnh_check_launch("lnh_mlp_backward");
 }
 
@@ -475,7 +487,8 @@ int launch_mlp_backward(const MlpBwdArgs &a, hipStream_t s) {
     const size_t lds = Cfg::lds_bytes();
     const uint32_t steps = div_up(a.B, Cfg::PB);
     const uint32_t grid = steps < 512 ? steps : 512;  // each workgroup ends with one atomic per weight: keep them few
-    auto k = k_mlp_backward<IN_KS, HT, NHM, NT, IO>;
+    auto k = a.act == LNH_ACT_RELU ? k_mlp_backward<IN_KS, HT, NHM, NT, IO, (int)LNH_ACT_RELU>
+                                   : k_mlp_backward<IN_KS, HT, NHM, NT, IO, -1>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     LNH_LAUNCH(k, dim3(grid), dim3(256), lds, s, a);
     return lnh_check_launch("lnh_mlp_backward");

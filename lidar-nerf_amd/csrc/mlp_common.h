@@ -51,6 +51,20 @@ __device__ __forceinline__ float act_backward_post(uint32_t a, float g, float po
     }
 }
 
+// Compile-time activation selector: ACT >= 0 folds the switch away (the per-element runtime switch costs one scalar
+// branch per value — ~1000 branches per tile iteration — and fences the MFMA schedule); ACT < 0 keeps it for the
+// rarely used activations.
+template <int ACT>
+__device__ __forceinline__ float act_fwd(uint32_t rt, float x) {
+    if constexpr (ACT >= 0) return act_forward((uint32_t)ACT, x);
+    else return act_forward(rt, x);
+}
+template <int ACT>
+__device__ __forceinline__ float act_bwd(uint32_t rt, float g, float post) {
+    if constexpr (ACT >= 0) return act_backward_post((uint32_t)ACT, g, post);
+    else return act_backward_post(rt, g, post);
+}
+
 __device__ __forceinline__ half8_t zero_h8() {
     half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
     return z;
@@ -141,8 +155,8 @@ struct RowMajorIO {
 struct DensityIO {
     static constexpr bool kDensity = true;
     __device__ static __forceinline__ uint64_t out_row(uint64_t p, const IoDims &d) {
-        const uint64_t r = p / d.T_cur;
-        return r * d.T_tot + d.slot_off + (p - r * d.T_cur);
+        const uint32_t p32 = (uint32_t)p, r = p32 / d.T_cur;  // B is 32-bit: no 64-bit software division
+        return (uint64_t)r * d.T_tot + d.slot_off + (p32 - r * d.T_cur);
     }
     // features k0..k0+7 = levels k0/2 .. k0/2+3, two channels each: four 4-byte loads from [L,B,2]
     __device__ static __forceinline__ half8_t load_x(const half_t *X, uint64_t p0, uint32_t k0, uint32_t B0, uint32_t in_dim,
