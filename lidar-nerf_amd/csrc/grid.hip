@@ -465,6 +465,22 @@ __device__ __forceinline__ void entry_set(PoolEntry<float> &e, uint32_t row, flo
     e.v0 = a;
     e.v1 = b;
 }
+// value * 2^24 of an fp16 number as an exact 64-bit integer, from its bits (no double-precision round trip):
+// normal: (1024 | m) << (e - 1), subnormal: m
+__device__ __forceinline__ long long half_to_fixed24(half_t h) {
+    const uint32_t bits = __builtin_bit_cast(unsigned short, h);
+    const uint32_t e = (bits >> 10) & 31u, mant = bits & 1023u;
+    const unsigned long long mag = e ? ((unsigned long long)(1024u | mant) << (e - 1u)) : (unsigned long long)mant;
+    return (bits & 0x8000u) ? -(long long)mag : (long long)mag;
+}
+__device__ __forceinline__ void entry_fixed(const PoolEntry<half_t> &e, int, long long &qa, long long &qb) {
+    qa = half_to_fixed24(e.v[0]);
+    qb = half_to_fixed24(e.v[1]);
+}
+__device__ __forceinline__ void entry_fixed(const PoolEntry<float> &e, int K, long long &qa, long long &qb) {
+    qa = (long long)ldexp((double)e.v0, K);
+    qb = (long long)ldexp((double)e.v1, K);
+}
 __device__ __forceinline__ void entry_get(const PoolEntry<half_t> &e, float &a, float &b) {
     a = (float)e.v[0];
     b = (float)e.v[1];
@@ -481,13 +497,16 @@ template <typename T, int D, int PPT, int NTHREADS>
 __global__ void __launch_bounds__(NTHREADS)
 k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs, T *__restrict__ grad_table,
                    uint32_t B, GridMeta meta, BucketPlan plan, PoolEntry<T> *__restrict__ pool,
-                   uint32_t *__restrict__ cursor, uint32_t align, uint32_t interp, uint32_t dbg) {
+                   uint32_t *__restrict__ cursor, uint32_t align, uint32_t interp, uint32_t dbg, uint32_t n_levels) {
     constexpr int C = 2, NCORN = 1 << D;
+    __shared__ uint2 lout[kMaxBucketsPerLevel];           // per bucket: {pool slot - staging slot, staging slots that fit}
     __shared__ uint32_t lcnt[kMaxBucketsPerLevel];
     __shared__ uint32_t lbase[kMaxBucketsPerLevel];       // first reserved pool slot per bucket (global)
     __shared__ uint32_t lstart[kMaxBucketsPerLevel + 1];  // first staging slot per bucket (workgroup-local)
     __shared__ PoolEntry<T> stage[NTHREADS * PPT * NCORN];
-    const uint32_t level = blockIdx.y;
+    // level-fastest workgroup order: concurrently resident workgroups work on the same points at different levels
+    // (the coordinates stay in L2, the cursor atomics spread over all levels' counters instead of 64 hot words)
+    const uint32_t level = blockIdx.x % n_levels, chunk = blockIdx.x / n_levels;
     const LevelParams lv = meta.lv[level];
     const uint32_t fb = plan.first_bucket[level], nb = plan.first_bucket[level + 1] - fb, cap = plan.cap[level];
     const int lane = threadIdx.x & 63;
@@ -501,19 +520,19 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
     bool emit[PPT];
 #pragma unroll
     for (int q = 0; q < PPT; q++) {
-        const uint32_t b = (blockIdx.x * PPT + q) * blockDim.x + threadIdx.x;
+        const uint32_t b = (chunk * PPT + q) * blockDim.x + threadIdx.x;
         const bool in_range = b < B;
+        const uint32_t bc = in_range ? b : 0;  // unconditional loads from a clamped index + selects
         float x[D];
 #pragma unroll
-        for (int d = 0; d < D; d++) x[d] = in_range ? inputs[(size_t)b * D + d] : -1.0f;
+        for (int d = 0; d < D; d++) {
+            const float xv = inputs[(size_t)bc * D + d];
+            x[d] = in_range ? xv : -1.0f;
+        }
+        const Vec<T, 2> gv = load_vec<T, 2>(grad + ((size_t)level * B + bc) * C);
         Cell<D> cell;
         bool ok = in_range && locate<D>(x, lv, align != 0, interp, cell);
-        float g0 = 0.0f, g1 = 0.0f;
-        if (ok) {
-            const Vec<T, 2> gv = load_vec<T, 2>(grad + ((size_t)level * B + b) * C);
-            g0 = (float)gv.v[0];
-            g1 = (float)gv.v[1];
-        }
+        const float g0 = ok ? (float)gv.v[0] : 0.0f, g1 = ok ? (float)gv.v[1] : 0.0f;
         // a sample whose upstream gradient is exactly zero (fp16 underflow behind an opaque surface, masked-out
         // rays) contributes nothing: drop it here instead of moving 8 zero entries through the pool
         (void)0;
@@ -597,8 +616,11 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
             const uint32_t up = __shfl_up(incl, o, 64);
             if (lane >= o) incl += up;
         }
-        lstart[lane] = incl - n0;
+        const uint32_t st = incl - n0, base = lbase[lane];
+        lstart[lane] = st;
         if (lane == 63) lstart[kMaxBucketsPerLevel] = incl;
+        // staging slot pos of bucket bk goes to pool slot bk*cap + base + (pos - st) while base + (pos - st) < cap
+        lout[lane] = make_uint2((uint32_t)lane * cap + base - st, base < cap ? st + min(cap - base, 0x10000u) : st);
     }
     __syncthreads();
     // ---- stage the entries in LDS grouped by bucket, then stream them out: consecutive lanes write consecutive pool
@@ -609,7 +631,7 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
 #pragma unroll
             for (uint32_t c = 0; c < (uint32_t)NCORN; c++) {
                 PoolEntry<T> e;
-                entry_set(e, row[q][c] & (kBucketRows - 1), v0[q][c], v1[q][c]);
+                entry_set(e, row[q][c], v0[q][c], v1[q][c]);  // full row: its high bits name the bucket at write-out
                 stage[lstart[row[q][c] >> kBucketRowsLog2] + rank[q][c]] = e;
             }
         }
@@ -618,15 +640,12 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
     T *gt = grad_table + (size_t)lv.offset * C;
     const uint32_t total = lstart[kMaxBucketsPerLevel];
     for (uint32_t pos = threadIdx.x; pos < total; pos += blockDim.x) {
-        uint32_t lo = 0, hi = kMaxBucketsPerLevel;  // last bucket whose start is <= pos
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (lstart[mid] <= pos) lo = mid; else hi = mid;
-        }
-        const uint32_t bk = lo, gpos = lbase[bk] + (pos - lstart[bk]);
-        const PoolEntry<T> e = stage[pos];
-        if (gpos < cap) {
-            lp[(size_t)bk * cap + gpos] = e;
+        PoolEntry<T> e = stage[pos];
+        const uint32_t bk = e.row >> kBucketRowsLog2;
+        const uint2 o = lout[bk];
+        e.row &= kBucketRows - 1;
+        if (pos < o.y) {
+            lp[o.x + pos] = e;
         } else {  // pool overflow: exact but slow
             float a, b2;
             entry_get(e, a, b2);
@@ -680,9 +699,8 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
         for (uint32_t u = 0; u < UNROLL; u++) {
             const uint32_t i = i0 + u * blockDim.x;
             if (i < n) {
-                float a, b;
-                entry_get(e[u], a, b);
-                const long long qa = (long long)ldexp((double)a, K), qb = (long long)ldexp((double)b, K);
+                long long qa, qb;
+                entry_fixed(e[u], K, qa, qb);
                 atomicAdd(&acc[e[u].row * 2], (unsigned long long)qa);  // ds_add_u64
                 atomicAdd(&acc[e[u].row * 2 + 1], (unsigned long long)qb);
             }
@@ -744,6 +762,11 @@ int launch_backward_bucketed(const T *grad, const float *inputs, T *ge, uint32_t
         return LNH_ERR_INVALID_ARG;
     }
     for (uint32_t l = 0; l < L; l++)
+        if ((uint64_t)plan.cap[l] * (plan.first_bucket[l + 1] - plan.first_bucket[l]) > 0xffffffffull) {
+            lnh_set_error("grid backward (bucketed): B = %u is too large for 32-bit pool slots", B);
+            return LNH_ERR_UNSUPPORTED;
+        }
+    for (uint32_t l = 0; l < L; l++)
         if (plan.first_bucket[l + 1] - plan.first_bucket[l] > kMaxBucketsPerLevel) {
             lnh_set_error("grid backward (bucketed): level %u has more than %u buckets", l, kMaxBucketsPerLevel);
             return LNH_ERR_UNSUPPORTED;
@@ -759,8 +782,8 @@ int launch_backward_bucketed(const T *grad, const float *inputs, T *ge, uint32_t
     // 1024 threads x 1 point: the per-workgroup cost that matters is the one returning device atomic per touched
     // bucket (measured: 256- and 512-thread workgroups are 2.3x / 1.5x slower), and 8 entries/thread keep the LDS
     // staging buffer at 64 KiB (two workgroups per CU)
-    LNH_LAUNCH((k_grid_bwd_scatter<T, 3, 1, 1024>), dim3(div_up(B, 1024), L), dim3(1024), 0, s, grad, inputs, ge, B, m,
-               plan, pool, cursor, align, interp, g_dbg_flags);
+    LNH_LAUNCH((k_grid_bwd_scatter<T, 3, 1, 1024>), dim3(div_up(B, 1024) * L), dim3(1024), 0, s, grad, inputs, ge, B, m,
+               plan, pool, cursor, align, interp, g_dbg_flags, L);
     int rc = lnh_check_launch("lnh_grid_encode_backward_ws(scatter)");
     if (rc) return rc;
     auto k = k_grid_bwd_reduce<T>;
