@@ -18,6 +18,7 @@ typedef float float4_t __attribute__((ext_vector_type(4)));
 
 // thread-local last-error string (lnh_last_error)
 void lnh_set_error(const char *fmt, ...);
+int lnh_cu_count();  // compute units of the current device (cached per device); 256 on MI355X
 
 #define LNH_REQUIRE(cond, code, ...)     \
     do {                                 \
@@ -104,6 +105,53 @@ __device__ __forceinline__ SegScanMask wave_segscan_mask(int lane, int run_start
     k.m[4] = ((lane & 16) && run_start < (lane & ~15)) ? 1.0f : 0.0f;
     k.m[5] = (lane >= 32 && run_start < 32) ? 1.0f : 0.0f;
     return k;
+}
+// Row-local variant: runs never cross a 16-lane DPP row (the caller starts a new run at every row start), so the scan
+// is the four row_shr steps only — pure VALU, no cross-row broadcast.
+__device__ __forceinline__ float row_segscan_add(float v, const SegScanMask &k) {
+    v = fmaf(lnh_dpp<0x111, 0xf>(v), k.m[0], v);
+    v = fmaf(lnh_dpp<0x112, 0xf>(v), k.m[1], v);
+    v = fmaf(lnh_dpp<0x114, 0xf>(v), k.m[2], v);
+    v = fmaf(lnh_dpp<0x118, 0xf>(v), k.m[3], v);
+    return v;
+}
+// The same two scans over N values at once, as explicit v_fmac_f32_dpp: ONE instruction per value and step (the
+// compiler's lowering of the intrinsic form is v_mov_b32 + v_mov_b32_dpp + half a v_pk_fma_f32).  Steps are emitted
+// value-interleaved, so the 2-wait-state "VALU write -> DPP read" hazard of a value's next step is covered by the
+// other values' instructions (N >= 3); the leading s_nop covers the producers of the first step.
+template <int N>
+__device__ __forceinline__ void row_segscan_add_n(float (&v)[N], const SegScanMask &k) {
+    static_assert(N >= 3, "needs >= 2 independent instructions between the steps of one value");
+    asm volatile("s_nop 1");
+#pragma unroll
+    for (int i = 0; i < N; i++)
+        asm volatile("v_fmac_f32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(v[i]) : "v"(k.m[0]));
+#pragma unroll
+    for (int i = 0; i < N; i++)
+        asm volatile("v_fmac_f32_dpp %0, %0, %1 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(v[i]) : "v"(k.m[1]));
+#pragma unroll
+    for (int i = 0; i < N; i++)
+        asm volatile("v_fmac_f32_dpp %0, %0, %1 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(v[i]) : "v"(k.m[2]));
+#pragma unroll
+    for (int i = 0; i < N; i++)
+        asm volatile("v_fmac_f32_dpp %0, %0, %1 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(v[i]) : "v"(k.m[3]));
+}
+template <int N>
+__device__ __forceinline__ void cross_segscan_add_n(float (&v)[N], const SegScanMask &k) {
+    static_assert(N >= 3, "needs >= 2 independent instructions between the steps of one value");
+    asm volatile("s_nop 1");
+#pragma unroll
+    for (int i = 0; i < N; i++)
+        asm volatile("v_fmac_f32_dpp %0, %0, %1 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v[i]) : "v"(k.m[4]));
+#pragma unroll
+    for (int i = 0; i < N; i++)
+        asm volatile("v_fmac_f32_dpp %0, %0, %1 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v[i]) : "v"(k.m[5]));
+}
+// the two cross-row steps that complete row_segscan_add to the full-wave scan
+__device__ __forceinline__ float cross_segscan_add(float v, const SegScanMask &k) {
+    v = fmaf(lnh_dpp<0x142, 0xa>(v), k.m[4], v);
+    v = fmaf(lnh_dpp<0x143, 0xc>(v), k.m[5], v);
+    return v;
 }
 __device__ __forceinline__ float wave_segscan_add(float v, const SegScanMask &k) {
     v = fmaf(lnh_dpp<0x111, 0xf>(v), k.m[0], v);

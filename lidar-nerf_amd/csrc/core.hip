@@ -10,6 +10,18 @@ void lnh_set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+int lnh_cu_count() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cached[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+
 extern "C" {
 int lnh_version(void) { return 100; }
 const char *lnh_last_error(void) { return g_err; }

@@ -505,11 +505,13 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
     __shared__ uint32_t lstart[kMaxBucketsPerLevel + 1];  // first staging slot per bucket (workgroup-local)
     __shared__ PoolEntry<T> stage[NTHREADS * PPT * NCORN];
     // level-fastest workgroup order: concurrently resident workgroups work on the same points at different levels
-    // (the coordinates stay in L2, the cursor atomics spread over all levels' counters instead of 64 hot words)
+    // (the coordinates stay in L2, the cursor atomics spread over all levels' counters instead of 64 hot words).
+    // (A persistent-workgroup variant of this kernel was measured 1.5x SLOWER: the hardware dispatcher overlaps the
+    // phases of independent workgroups better than a barrier-separated item loop does.)
+    const int lane = threadIdx.x & 63;
     const uint32_t level = blockIdx.x % n_levels, chunk = blockIdx.x / n_levels;
     const LevelParams lv = meta.lv[level];
     const uint32_t fb = plan.first_bucket[level], nb = plan.first_bucket[level + 1] - fb, cap = plan.cap[level];
-    const int lane = threadIdx.x & 63;
     if (threadIdx.x < kMaxBucketsPerLevel) {
         lcnt[threadIdx.x] = 0;
         lbase[threadIdx.x] = 0;
@@ -537,21 +539,29 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
         // rays) contributes nothing: drop it here instead of moving 8 zero entries through the pool
         (void)0;
         ok = ok && (g0 != 0.0f || g1 != 0.0f);
-        // ---- wave run-merge (see k_grid_backward)
+        // ---- run-merge inside 16-lane rows: consecutive lanes are consecutive samples of a ray, which share their cell
+        //      on the coarser levels.  Runs are cut at DPP row starts (pure-VALU row_shr scan, no cross-row traffic), and
+        //      a wave with fewer than kMinMerges mergeable lanes skips the scan altogether — on the fine levels almost
+        //      every wave has SOME coincidental pair, and scanning 16 values to save one or two entries does not pay.
+        constexpr int kMinMerges = 8;
         uint32_t key[D];
 #pragma unroll
         for (int d = 0; d < D; d++) key[d] = ok ? cell.term[d][0] : 0xffffffffu - lane;
-        bool same_prev = true;
+        // dense (coarse) levels: runs span whole waves and every entry lands in the same few buckets, so there the
+        // full-wave scan (two extra cross-row steps) is worth its price
+        const bool row_local = (lv.flags & LV_HASH) != 0;  // workgroup-uniform
+        bool same_prev = row_local ? (lane & 15) != 0 : lane != 0;
 #pragma unroll
         for (int d = 0; d < D; d++) {
-            const uint32_t up = __shfl_up(key[d], 1, 64);
+            // wave_shr:1 (0x138): previous lane across rows
+            const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key[d], 0x138, 0xf, 0xf, false);
             same_prev &= (up == key[d]);
         }
-        same_prev &= lane > 0;
-        const unsigned long long heads = __ballot(!same_prev);
+        unsigned long long heads = __ballot(!same_prev);
+        const bool any_merge = !(dbg & 2) && __builtin_popcountll(~heads) >= kMinMerges;  // wave-uniform
+        if (!any_merge) heads = ~0ull;
         const unsigned long long below = heads & ((2ull << lane) - 1ull);
         const int run_start = 63 - __builtin_clzll(below);
-        const bool any_merge = (~heads) != 0ull;
         const unsigned long long heads_above = (lane == 63) ? 0ull : (heads >> (lane + 1));
         emit[q] = ok && ((lane == 63) || (heads_above & 1ull));
 #pragma unroll
@@ -565,12 +575,20 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
             }
             row[q][c] = ok ? corner_row<D>(cell, lv, c) : 0u;
         }
-        if (any_merge && !(dbg & 2)) {  // wave-uniform
+        if (any_merge) {  // wave-uniform
             const SegScanMask sm = wave_segscan_mask(lane, run_start);
+            float vv[2 * NCORN];
 #pragma unroll
             for (uint32_t c = 0; c < (uint32_t)NCORN; c++) {
-                v0[q][c] = wave_segscan_add(v0[q][c], sm);
-                v1[q][c] = wave_segscan_add(v1[q][c], sm);
+                vv[2 * c] = v0[q][c];
+                vv[2 * c + 1] = v1[q][c];
+            }
+            row_segscan_add_n(vv, sm);
+            if (!row_local) cross_segscan_add_n(vv, sm);
+#pragma unroll
+            for (uint32_t c = 0; c < (uint32_t)NCORN; c++) {
+                v0[q][c] = vv[2 * c];
+                v1[q][c] = vv[2 * c + 1];
             }
         }
     }
@@ -585,6 +603,7 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
             // LDS atomics on one counter serialise, so aggregate — one lane adds the population count, the others
             // take their rank from the lane mask.  Mixed buckets (hashed levels) fall back to per-lane atomics.
             const uint32_t bk = row[q][c] >> kBucketRowsLog2;
+            if (dbg & 1024) { rank[q][c] = c; continue; }
             if (lv.flags & LV_HASH) {  // workgroup-uniform: hashed level, buckets are mixed -> per-lane atomics
                 if (emit[q]) rank[q][c] = atomicAdd(&lcnt[bk], 1u);
                 continue;
@@ -609,7 +628,7 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
     if (threadIdx.x < 64) {
         static_assert(kMaxBucketsPerLevel == 64, "one bucket counter per lane of the first wave");
         const uint32_t n0 = lcnt[lane];
-        if ((uint32_t)lane < nb && n0) lbase[lane] = atomicAdd(&cursor[fb + lane], n0);
+        if ((uint32_t)lane < nb && n0 && !(dbg & 512)) lbase[lane] = atomicAdd(&cursor[fb + lane], n0);
         uint32_t incl = n0;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -627,7 +646,7 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
     //      slots (a per-lane scatter of 8-byte stores costs one cache-line transaction per lane)
 #pragma unroll
     for (int q = 0; q < PPT; q++)
-        if (emit[q]) {
+        if (emit[q] && !(dbg & 2048)) {
 #pragma unroll
             for (uint32_t c = 0; c < (uint32_t)NCORN; c++) {
                 PoolEntry<T> e;
@@ -638,7 +657,7 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
     __syncthreads();
     PoolEntry<T> *lp = pool + plan.pool_off[level];
     T *gt = grad_table + (size_t)lv.offset * C;
-    const uint32_t total = lstart[kMaxBucketsPerLevel];
+    const uint32_t total = (dbg & 256) ? 0 : lstart[kMaxBucketsPerLevel];
     for (uint32_t pos = threadIdx.x; pos < total; pos += blockDim.x) {
         PoolEntry<T> e = stage[pos];
         const uint32_t bk = e.row >> kBucketRowsLog2;
@@ -663,7 +682,7 @@ constexpr uint32_t kMaxSlices = 16;
 template <typename T>
 __global__ void __launch_bounds__(1024)
 k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, const PoolEntry<T> *__restrict__ pool,
-                  const uint32_t *__restrict__ cursor, uint32_t L) {
+                  const uint32_t *__restrict__ cursor, uint32_t L, uint32_t dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     unsigned long long *acc = reinterpret_cast<unsigned long long *>(smem_raw);  // [kBucketRows][2] fixed point
     // fp16 contributions are exact multiples of 2^-24; fp32 ones get 2^-40 resolution and +-8e6 of range
@@ -675,7 +694,8 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
     const LevelParams lv = meta.lv[level];
     const uint32_t bk = bid - plan.first_bucket[level], cap = plan.cap[level];
     const uint32_t n_all = min(cursor[bid], cap);
-    uint32_t slices = (n_all + kSliceEntries - 1) / kSliceEntries;
+    const uint32_t slice_entries = (dbg & 32) ? kSliceEntries * 8 : ((dbg & 128) ? kSliceEntries / 2 : kSliceEntries);
+    uint32_t slices = (n_all + slice_entries - 1) / slice_entries;
     slices = slices > kMaxSlices ? kMaxSlices : slices;
     if (blockIdx.y >= slices) return;  // workgroup-uniform (also covers n_all == 0)
     const uint32_t i_begin = (uint32_t)((uint64_t)n_all * blockIdx.y / slices);
@@ -684,29 +704,66 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
     const uint32_t rows = min(kBucketRows, lv.hashmap_size - bk * kBucketRows);
     for (uint32_t i = threadIdx.x; i < rows * 2; i += blockDim.x) acc[i] = 0ull;
     __syncthreads();
-    const PoolEntry<T> *src = pool + plan.pool_off[level] + (size_t)bk * cap + i_begin;
-    // One workgroup streams its whole slice: keep UNROLL independent loads in flight per lane.
-    constexpr uint32_t UNROLL = 4;
-    const uint32_t stride = blockDim.x * UNROLL;
-    for (uint32_t i0 = threadIdx.x; i0 < n; i0 += stride) {
-        PoolEntry<T> e[UNROLL];
+    // One workgroup streams its whole slice; what bounds it is the number of bytes in flight per CU, so every lane keeps
+    // UNROLL independent loads outstanding (unconditional, from clamped indices: a predicated load would be branched
+    // around and waited for one by one).
+    if constexpr (sizeof(PoolEntry<T>) == 8) {
+        // 8-byte entries: 16-byte loads of aligned entry PAIRS; entries outside [a_begin, a_end) are masked
+        constexpr uint32_t UNROLL = 8;
+        const uint64_t a_begin = plan.pool_off[level] + (uint64_t)bk * cap + i_begin, a_end = a_begin + n;
+        const uint64_t p_begin = a_begin >> 1, p_end = (a_end + 1) >> 1;  // pairs [p_begin, p_end)
+        const uint4 *src2 = reinterpret_cast<const uint4 *>(pool);
+        const uint32_t npairs = (uint32_t)(p_end - p_begin), stride = blockDim.x * UNROLL;
+        for (uint32_t j0 = threadIdx.x; j0 < npairs; j0 += stride) {
+            uint4 raw[UNROLL];
 #pragma unroll
-        for (uint32_t u = 0; u < UNROLL; u++) {  // unconditional (clamped) loads: a predicated load would be
-            const uint32_t i = i0 + u * blockDim.x;  // branched around and waited for one by one
-            e[u] = src[i < n ? i : n - 1];
+            for (uint32_t u = 0; u < UNROLL; u++) {
+                const uint32_t j = j0 + u * blockDim.x;
+                raw[u] = src2[p_begin + (j < npairs ? j : npairs - 1)];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < UNROLL; u++) {
+                const uint32_t j = j0 + u * blockDim.x;
+                const uint64_t e0 = (p_begin + j) * 2;
+                const uint32_t w[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    if (j < npairs && e0 + h >= a_begin && e0 + h < a_end && !(dbg & 16)) {
+                        PoolEntry<T> e;
+                        __builtin_memcpy(&e, &w[2 * h], 8);
+                        long long qa, qb;
+                        entry_fixed(e, K, qa, qb);
+                        atomicAdd(&acc[e.row * 2], (unsigned long long)qa);  // ds_add_u64
+                        atomicAdd(&acc[e.row * 2 + 1], (unsigned long long)qb);
+                    }
+                }
+            }
         }
+    } else {
+        constexpr uint32_t UNROLL = 8;
+        const PoolEntry<T> *src = pool + plan.pool_off[level] + (size_t)bk * cap + i_begin;
+        const uint32_t stride = blockDim.x * UNROLL;
+        for (uint32_t i0 = threadIdx.x; i0 < n; i0 += stride) {
+            PoolEntry<T> e[UNROLL];
 #pragma unroll
-        for (uint32_t u = 0; u < UNROLL; u++) {
-            const uint32_t i = i0 + u * blockDim.x;
-            if (i < n) {
-                long long qa, qb;
-                entry_fixed(e[u], K, qa, qb);
-                atomicAdd(&acc[e[u].row * 2], (unsigned long long)qa);  // ds_add_u64
-                atomicAdd(&acc[e[u].row * 2 + 1], (unsigned long long)qb);
+            for (uint32_t u = 0; u < UNROLL; u++) {
+                const uint32_t i = i0 + u * blockDim.x;
+                e[u] = src[i < n ? i : n - 1];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < UNROLL; u++) {
+                const uint32_t i = i0 + u * blockDim.x;
+                if (i < n) {
+                    long long qa, qb;
+                    entry_fixed(e[u], K, qa, qb);
+                    atomicAdd(&acc[e[u].row * 2], (unsigned long long)qa);  // ds_add_u64
+                    atomicAdd(&acc[e[u].row * 2 + 1], (unsigned long long)qb);
+                }
             }
         }
     }
     __syncthreads();
+    if (dbg & 64) return;
     T *gt = grad_table + ((size_t)lv.offset + (size_t)bk * kBucketRows) * 2;
     for (uint32_t r = threadIdx.x; r < rows; r += blockDim.x) {
         const long long qa = (long long)acc[2 * r], qb = (long long)acc[2 * r + 1];
@@ -746,7 +803,7 @@ uint64_t plan_buckets(BucketPlan &plan, const GridMeta &m, uint32_t L, uint32_t 
     plan.first_bucket[L] = nbt;
     total_buckets = nbt;
     const uint64_t cursor_bytes = ((uint64_t)nbt * 4 + 255) / 256 * 256;
-    return cursor_bytes + slots * sizeof(PoolEntry<T>);
+    return cursor_bytes + slots * sizeof(PoolEntry<T>) + 16;  // + one pad entry: the reduce pass reads aligned pairs
 }
 
 template <typename T>
@@ -793,7 +850,7 @@ int launch_backward_bucketed(const T *grad, const float *inputs, T *ge, uint32_t
         (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    LNH_LAUNCH(k, dim3(nbt, kMaxSlices), dim3(1024), lds, s, ge, m, plan, pool, cursor, L);
+    LNH_LAUNCH(k, dim3(nbt, kMaxSlices), dim3(1024), lds, s, ge, m, plan, pool, cursor, L, g_dbg_flags);
     return lnh_check_launch("lnh_grid_encode_backward_ws(reduce)");
 }
 
