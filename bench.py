@@ -175,6 +175,18 @@ def main():
     k = kernels[dom]
     avg_points = k["points"] / k["calls"]
     achieved = per_pt * k["points"] / (k["total_ms"] * 1e-3) / 1e9  # GB/s over all launches of that kernel
+    # HBM bytes per launch from the committed PMC pass of this same command (profiles/collect.sh); bench.py itself
+    # cannot run rocprofv3, so the number is only reported when that file exists and names the dominant kernels
+    traffic, traffic_src = None, None
+    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc.json")
+    if os.path.exists(pmc_path) and args.rays == 4096:
+        pk = json.load(open(pmc_path)).get("kernels", {})
+        names = {"lnh_grid_encode_backward_ws": ("k_grid_bwd_scatter", "k_grid_bwd_reduce"),
+                 "lnh_grid_encode_forward_mapped": ("k_grid_forward",), "lnh_grid_encode_forward": ("k_grid_forward",)}
+        parts = [pk.get(n, {}).get("hbm_bytes_per_launch") for n in names.get(dom, ())]
+        if parts and all(p is not None for p in parts):
+            traffic = int(sum(parts))
+            traffic_src = "profiles/r01_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, " + " + ".join(names[dom]) + ")"
     result = {
         "metric": "train rays/sec (encode+MLP+composite+bwd), KITTI-360 66x1030",
         "value": round(rays_total / elapsed, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps,
@@ -186,7 +198,8 @@ def main():
                    "samples_per_ray": NUM_STEPS + UPSAMPLE, "parallelism": f"dp{world}",
                    "optimizer": "Adam + GradScaler (in timed region)", "final_loss": round(loss_val, 5)},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(per_pt * avg_points),
                      "bytes_per_point": per_pt, "points_per_launch": int(avg_points),
                      "avg_launch_us": k["avg_us"]},
         "kernels": kernels,
