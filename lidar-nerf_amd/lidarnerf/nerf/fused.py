@@ -28,21 +28,31 @@ from .. import _hip, parallel
 from ..gridencoder.grid import _workspace
 
 
+class FieldSpec:
+    """What the fused chain needs from a field, independent of how the module stores it (`network.NeRFNetwork` keeps
+    nn.Linear stacks + `encoder.embeddings`, `network_tcnn.NeRFNetwork` keeps flat tcnn-style `params` vectors):
+    tensors that take part in autograd (possibly views of Parameters) + the per-ray direction features."""
+
+    def __init__(self, grid, table, ws0, ws1, wc0, wc1, wc2, n_dir, dir_features, n_color_mats=3, table_param=None):
+        self.grid, self.table, self.ws0, self.ws1 = grid, table, ws0, ws1
+        self.table_param = table_param if table_param is not None else table  # the Parameter DP bookkeeping marks
+        self.wc0, self.wc1, self.wc2, self.n_dir, self.dir_features = wc0, wc1, wc2, n_dir, dir_features
+        self.n_color_mats = n_color_mats
+
+
 def supported(model, cal_lidar_color, num_steps, upsample_steps):
-    """True when `model` (a NeRFNetwork) has exactly the shapes the fused kernels are specialised for."""
+    """True when `model` has exactly the shapes the fused kernels are specialised for."""
     try:
-        enc = model.encoder
+        sp = model.fused_spec()
+        enc = sp.grid
         ok = (cal_lidar_color and upsample_steps > 0 and model.bg_radius <= 0
-              and enc.__class__.__name__ == "GridEncoder" and enc.input_dim == 3 and enc.num_levels == 16
+              and enc.input_dim == 3 and enc.num_levels == 16
               and enc.level_dim == 2 and enc.gridtype_id == 0 and not enc.align_corners and enc.interp_id == 0
-              and len(model.sigma_net) == 2 and tuple(model.sigma_net[0].weight.shape) == (64, 32)
-              and tuple(model.sigma_net[1].weight.shape) == (16, 64)
-              and len(model.lidar_color_net) == 3 and tuple(model.lidar_color_net[0].weight.shape) == (64, 90)
-              and tuple(model.lidar_color_net[1].weight.shape) == (64, 64)
-              and tuple(model.lidar_color_net[2].weight.shape) == (2, 64)
-              and model.encoder_lidar_dir.__class__.__name__ == "FreqEncoder" and model.encoder_lidar_dir.degree == 12
+              and tuple(sp.ws0.shape) == (64, 32) and tuple(sp.ws1.shape) == (16, 64)
+              and sp.n_color_mats == 3 and 1 <= sp.n_dir <= 128 and tuple(sp.wc0.shape) == (64, sp.n_dir + 15)
+              and tuple(sp.wc1.shape) == (64, 64) and tuple(sp.wc2.shape) == (2, 64)
               and model.geo_feat_dim == 15 and (num_steps + upsample_steps) % 16 == 0
-              and model.encoder.embeddings.is_cuda)
+              and sp.table.is_cuda)
         return bool(ok)
     except AttributeError:
         return False
@@ -78,8 +88,9 @@ def _no_autocast(fn):
 class FusedLidarRender(Function):
     @staticmethod
     @_no_autocast
-    def forward(ctx, rays_o, rays_d, z, u, embeddings, ws0, ws1, wc0, wc1, wc2, model, density_scale):
-        enc = model.encoder
+    def forward(ctx, rays_o, rays_d, z, u, embeddings, ws0, ws1, wc0, wc1, wc2, model, density_scale, spec):
+        enc = spec.grid
+        kd = spec.n_dir
         dev = rays_o.device
         N, T = z.shape
         t_new = u.shape[1]
@@ -92,7 +103,7 @@ class FusedLidarRender(Function):
         table16 = embeddings.detach().to(torch.half).contiguous()
         wsig16 = torch.cat([ws0.detach().reshape(-1), ws1.detach().reshape(-1)]).to(torch.half).contiguous()
         # colour head: geo part of the first Linear against the raw 16-wide sigma-net row (col 0 gets weight 0)
-        w0g = torch.cat([torch.zeros((64, 1), device=dev, dtype=wc0.dtype), wc0.detach()[:, 75:90]], dim=1)
+        w0g = torch.cat([torch.zeros((64, 1), device=dev, dtype=wc0.dtype), wc0.detach()[:, kd:kd + 15]], dim=1)
         w2p = torch.nn.functional.pad(wc2.detach(), (0, 0, 0, 14))
         wcol16 = torch.cat([w0g.reshape(-1), wc1.detach().reshape(-1), w2p.reshape(-1)]).to(torch.half).contiguous()
 
@@ -129,10 +140,9 @@ class FusedLidarRender(Function):
         _hip.call("lnh_lidar_merge_weights", z_all.data_ptr(), sigma_pt.data_ptr(), perm.data_ptr(), sd.data_ptr(), N,
                   Ttot, float(density_scale), sigma_m.data_ptr(), weights.data_ptr())
 
-        enc_d = torch.empty((N, 75), dtype=torch.float32, device=dev)
-        _hip.call("lnh_freq_encode_forward", rays_d.data_ptr(), N, 3, 12, 75, enc_d.data_ptr())
+        enc_d = spec.dir_features(rays_d)  # [N, kd] fp32, constant along a ray
         enc_d16 = enc_d.to(torch.half).float()
-        cdir = (enc_d16 @ wc0.detach()[:, :75].to(torch.half).float().t()).contiguous()
+        cdir = (enc_d16 @ wc0.detach()[:, :kd].to(torch.half).float().t()).contiguous()
 
         rgb = torch.empty((N, Ttot, 2), dtype=torch.float32, device=dev)
         _hip.call("lnh_lidar_color_forward", h16.data_ptr(), perm.data_ptr(), weights.data_ptr(), cdir.data_ptr(),
@@ -144,7 +154,8 @@ class FusedLidarRender(Function):
                   Ttot, 2, float(density_scale), None, ws.data_ptr(), depth.data_ptr(), image.data_ptr())
 
         ctx.save_for_backward(x01, feat, h16, perm, weights, z_all, sigma_m, rgb, sd, cdir, enc_d16, wsig16, wcol16)
-        ctx.model, ctx.dims, ctx.density_scale = model, (N, T, t_new), density_scale
+        ctx.model, ctx.dims, ctx.density_scale, ctx.enc = model, (N, T, t_new), density_scale, enc
+        ctx.table_param = spec.table_param
         ctx.param_dtypes = (embeddings.dtype, ws0.dtype, ws1.dtype, wc0.dtype, wc1.dtype, wc2.dtype)
         ctx.mark_non_differentiable(weights, z_all)
         return ws, depth, image, weights, z_all
@@ -154,7 +165,7 @@ class FusedLidarRender(Function):
     def backward(ctx, g_ws, g_depth, g_image, _gw, _gz):
         x01, feat, h16, perm, weights, z_all, sigma_m, rgb, sd, cdir, enc_d16, wsig16, wcol16 = ctx.saved_tensors
         model, (N, T, t_new), ds = ctx.model, ctx.dims, ctx.density_scale
-        enc = model.encoder
+        enc = ctx.enc
         dev = h16.device
         Ttot = T + t_new
         g_ws, g_depth, g_image = g_ws.contiguous().float(), g_depth.contiguous().float(), g_image.contiguous().float()
@@ -177,7 +188,7 @@ class FusedLidarRender(Function):
         g_wc2 = g_wcol[64 * 16 + 64 * 64:].view(16, 64)[:2]
 
         g_wsig = torch.zeros(wsig16.numel(), dtype=torch.float32, device=dev)
-        g_table16 = torch.zeros((enc.embeddings.shape[0], 2), dtype=torch.half, device=dev)
+        g_table16 = torch.zeros((int(enc._offsets_host[-1]), 2), dtype=torch.half, device=dev)
         B_all = N * Ttot
         g_feat = torch.empty((enc.num_levels, B_all, 2), dtype=torch.half, device=dev)
         _hip.call("lnh_density_mlp_backward", g_h16.data_ptr(), feat.data_ptr(), wsig16.data_ptr(), B_all, Ttot, Ttot, 0,
@@ -185,13 +196,13 @@ class FusedLidarRender(Function):
         _grid_bwd(g_feat, x01, g_table16, enc, B_all)
 
         # data parallel: the table gradient goes on the wire as fp16, overlapped with nothing else left to do here
-        handle = parallel.allreduce_half_table(g_table16, enc.embeddings)
+        handle = parallel.allreduce_half_table(g_table16, ctx.table_param)
         if handle is not None:
             handle.wait()
         dts = ctx.param_dtypes
         return (None, None, None, None, g_table16.to(dts[0]), g_wsig[:64 * 32].view(64, 32).to(dts[1]),
                 g_wsig[64 * 32:].view(16, 64).to(dts[2]), g_wc0.to(dts[3]), g_wc1.to(dts[4]), g_wc2.to(dts[5]),
-                None, None)
+                None, None, None)
 
 
 def render_lidar(model, rays_o, rays_d, num_steps, upsample_steps, perturb):
@@ -211,8 +222,7 @@ def render_lidar(model, rays_o, rays_d, num_steps, upsample_steps, perturb):
     else:
         u = torch.linspace(0.5 / upsample_steps, 1.0 - 0.5 / upsample_steps, upsample_steps,
                            device=dev).expand(N, upsample_steps).contiguous()
-    ws, depth, image, _, _ = FusedLidarRender.apply(
-        rays_o, rays_d, z, u, model.encoder.embeddings, model.sigma_net[0].weight, model.sigma_net[1].weight,
-        model.lidar_color_net[0].weight, model.lidar_color_net[1].weight, model.lidar_color_net[2].weight, model,
-        model.density_scale)
+    sp = model.fused_spec()
+    ws, depth, image, _, _ = FusedLidarRender.apply(rays_o, rays_d, z, u, sp.table, sp.ws0, sp.ws1, sp.wc0, sp.wc1,
+                                                    sp.wc2, model, model.density_scale, sp)
     return {"depth_lidar": depth.view(*prefix), "image_lidar": image.view(*prefix, 2), "weights_sum_lidar": ws}

@@ -66,6 +66,25 @@ class NeRFNetwork(NeRFRenderer):
                 h = F.relu(h, inplace=True)
         return h
 
+    # ---- what the fused LiDAR chain (nerf/fused.py) needs to know about this field
+    def _lidar_dir_features(self, d):
+        """[N,3] unit directions -> [N,75] fp32 frequency features (HIP encoder, network.py:215 feeds raw directions)."""
+        from .. import _hip
+        n = d.shape[0]
+        out = torch.empty((n, 75), dtype=torch.float32, device=d.device)
+        _hip.call("lnh_freq_encode_forward", d.data_ptr(), n, 3, 12, 75, out.data_ptr())
+        return out
+
+    def fused_spec(self):
+        if self.encoder.__class__.__name__ != "GridEncoder" or len(self.sigma_net) != 2 \
+                or self.encoder_lidar_dir.__class__.__name__ != "FreqEncoder" or self.encoder_lidar_dir.degree != 12:
+            raise AttributeError("field is not fusable")
+        c = self.lidar_color_net
+        return fused.FieldSpec(grid=self.encoder, table=self.encoder.embeddings, ws0=self.sigma_net[0].weight,
+                               ws1=self.sigma_net[1].weight, wc0=c[0].weight,
+                               wc1=c[1].weight if len(c) == 3 else None, wc2=c[-1].weight, n_dir=75,
+                               dir_features=self._lidar_dir_features, n_color_mats=len(c))
+
     def run(self, rays_o, rays_d, cal_lidar_color=False, num_steps=128, upsample_steps=128, bg_color=None,
             perturb=False, **kwargs):
         if (self.fused_lidar and rays_o.is_cuda and torch.is_autocast_enabled()

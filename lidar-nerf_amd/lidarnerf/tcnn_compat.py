@@ -1,0 +1,191 @@
+"""tiny-cuda-nn shaped modules on top of the HIP kernels, so that the reference's `network_tcnn.NeRFNetwork`
+(lidarnerf/nerf/network_tcnn.py:46-132) — the backend `main_lidarnerf.py -L` really selects — runs without
+tinycudann.  Only the two entry points that file uses exist: `Encoding(n_input_dims, encoding_config)` and
+`Network(n_input_dims, n_output_dims, network_config)`, with tcnn's conventions: inputs in [0,1], a flat fp32 `params`
+Parameter per module (state-dict key `<name>.params`), `n_output_dims`, fp16 outputs under autocast.
+
+PARITY UNPINNED: tiny-cuda-nn is an external, unversioned dependency of the reference (readme.md:74-76) whose source is
+not in the tree.  HashGrid / SphericalHarmonics reuse the in-tree encoders' arithmetic (torch-ngp's gridencoder and
+shencoder are restatements of tcnn's); Frequency follows tcnn's published layout (72 = 3 * 12 * 2 outputs,
+out[dim*2K + 2k + p] = sin(2^k * pi * x[dim] + p * pi/2)); FullyFusedMLP uses tcnn's weight order (first matrix
+[n_neurons, pad16(n_in)], hidden matrices, last matrix [pad16(n_out), n_neurons], all row-major, bias-free).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .ffmlp import fused_mlp
+from .gridencoder import GridEncoder
+from .shencoder import SHEncoder
+
+
+def _pad16(n):
+    return (n + 15) // 16 * 16
+
+
+class _HashGrid(GridEncoder):
+    """GridEncoder whose table is exposed as tcnn's flat `params` vector."""
+
+    def __init__(self, cfg, n_input_dims):
+        super().__init__(input_dim=n_input_dims, num_levels=int(cfg.get("n_levels", 16)),
+                         level_dim=int(cfg.get("n_features_per_level", 2)),
+                         per_level_scale=float(cfg.get("per_level_scale", 2.0)),
+                         base_resolution=int(cfg.get("base_resolution", 16)),
+                         log2_hashmap_size=int(cfg.get("log2_hashmap_size", 19)), desired_resolution=None,
+                         gridtype="hash", align_corners=False,
+                         interpolation="smoothstep" if str(cfg.get("interpolation", "Linear")).lower() == "smoothstep"
+                         else "linear")
+        flat = self.embeddings.data.reshape(-1).clone()
+        del self.embeddings
+        self.params = nn.Parameter(flat)
+        offs = self.offsets  # tcnn checkpoints hold nothing but `params`: keep the level offsets out of the state dict
+        del self.offsets
+        self.register_buffer("offsets", offs, persistent=False)
+
+    @property
+    def embeddings(self):  # [rows, level_dim] view; gradients flow into `params`
+        return self.params.view(-1, self.level_dim)
+
+    def reset_parameters(self):
+        if "params" in self._parameters:
+            self.params.data.uniform_(-1e-4, 1e-4)
+        else:
+            super().reset_parameters()
+
+
+class Encoding(nn.Module):
+    """tcnn.Encoding(n_input_dims, encoding_config): otype HashGrid | Frequency | SphericalHarmonics | Identity."""
+
+    def __init__(self, n_input_dims, encoding_config, dtype=None, seed=1337):
+        super().__init__()
+        self.n_input_dims = int(n_input_dims)
+        self.encoding_config = dict(encoding_config)
+        otype = str(encoding_config.get("otype", "")).lower()
+        self.otype = otype
+        if otype in ("hashgrid", "grid"):
+            self.impl = _HashGrid(encoding_config, self.n_input_dims)
+            self.n_output_dims = self.impl.output_dim
+        elif otype == "frequency":
+            self.degree = int(encoding_config.get("n_frequencies", encoding_config.get("degree", 12)))
+            self.impl = None
+            self.n_output_dims = self.n_input_dims * self.degree * 2
+        elif otype == "sphericalharmonics":
+            if self.n_input_dims != 3:
+                raise RuntimeError("SphericalHarmonics encoding needs 3 input dims")
+            self.impl = SHEncoder(input_dim=3, degree=int(encoding_config.get("degree", 4)))
+            self.n_output_dims = self.impl.output_dim
+        elif otype == "identity":
+            self.impl = None
+            self.n_output_dims = self.n_input_dims
+        else:
+            raise RuntimeError(f"tcnn_compat.Encoding: unsupported otype {encoding_config.get('otype')!r}")
+
+    # tcnn modules own ONE flat parameter called `params` (empty for parameter-free encodings)
+    @property
+    def params(self):
+        if self.otype in ("hashgrid", "grid"):
+            return self.impl.params
+        return torch.zeros(0)
+
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        sd = super().state_dict(*args, destination=destination, prefix=prefix, keep_vars=keep_vars)
+        key = prefix + "impl.params"
+        if key in sd:  # tcnn checkpoints call it `<module>.params`
+            sd[prefix + "params"] = sd.pop(key)
+        elif prefix + "params" not in sd:  # parameter-free encodings still own an (empty) `params` in tcnn
+            sd[prefix + "params"] = torch.zeros(0)
+        return sd
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        if prefix + "params" in state_dict and self.otype in ("hashgrid", "grid"):
+            state_dict[prefix + "impl.params"] = state_dict.pop(prefix + "params")
+        elif prefix + "params" in state_dict:
+            state_dict.pop(prefix + "params")  # parameter-free encodings store an empty tensor
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def frequency(self, x):
+        """[M, D] in [0,1] -> [M, D*2K] fp32: out[d*2K + 2k + p] = sin(2^k * pi * x_d + p*pi/2)."""
+        k = torch.arange(self.degree, device=x.device, dtype=torch.float32)
+        arg = x.float().unsqueeze(-1) * (torch.exp2(k) * math.pi)  # [M, D, K]
+        phase = torch.tensor([0.0, 0.5 * math.pi], device=x.device)
+        return torch.sin(arg.unsqueeze(-1) + phase).reshape(x.shape[0], -1)
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("tcnn_compat.Encoding: input must be a CUDA (ROCm) tensor")
+        if self.otype in ("hashgrid", "grid"):
+            return self.impl(x * 2.0 - 1.0, bound=1)  # GridEncoder maps [-b, b] -> [0, 1] itself
+        if self.otype == "frequency":
+            return self.frequency(x.reshape(-1, self.n_input_dims)).view(*x.shape[:-1], self.n_output_dims)
+        if self.otype == "sphericalharmonics":
+            return self.impl(x * 2.0 - 1.0)  # tcnn's SH takes [0,1] and maps it back to [-1,1]
+        return x
+
+
+_ACT = {"relu": 0, "exponential": 1, "sine": 2, "sigmoid": 3, "squareplus": 4, "softplus": 5, "none": 6}
+
+
+class Network(nn.Module):
+    """tcnn.Network(n_input_dims, n_output_dims, network_config) with otype FullyFusedMLP / CutlassMLP."""
+
+    def __init__(self, n_input_dims, n_output_dims, network_config, seed=1337):
+        super().__init__()
+        self.n_input_dims, self.n_output_dims = int(n_input_dims), int(n_output_dims)
+        self.network_config = dict(network_config)
+        self.n_neurons = int(network_config.get("n_neurons", 64))
+        self.n_hidden_layers = int(network_config.get("n_hidden_layers", 1))
+        act = str(network_config.get("activation", "ReLU")).lower()
+        out_act = str(network_config.get("output_activation", "None")).lower()
+        if act not in _ACT or out_act != "none":
+            raise RuntimeError("tcnn_compat.Network: activation must be one of %s and output_activation None"
+                               % sorted(_ACT))
+        if self.n_hidden_layers < 1:
+            raise RuntimeError("tcnn_compat.Network: n_hidden_layers >= 1")
+        self.activation = _ACT[act]
+        self.in_pad, self.out_pad = _pad16(self.n_input_dims), _pad16(self.n_output_dims)
+        n = self.n_neurons
+        self._shapes = [(n, self.in_pad)] + [(n, n)] * (self.n_hidden_layers - 1) + [(self.out_pad, n)]
+        total = sum(a * b for a, b in self._shapes)
+        g = torch.Generator().manual_seed(seed)
+        flat = torch.empty(total)
+        off = 0
+        for (o, i) in self._shapes:  # xavier-uniform per matrix, as tcnn initialises
+            lim = math.sqrt(6.0 / (o + i))
+            flat[off:off + o * i] = (torch.rand(o * i, generator=g) * 2 - 1) * lim
+            off += o * i
+        self.params = nn.Parameter(flat)
+
+    def matrices(self):
+        """Views [out, in] of the flat parameter vector (padded shapes)."""
+        mats, off = [], 0
+        for (o, i) in self._shapes:
+            mats.append(self.params[off:off + o * i].view(o, i))
+            off += o * i
+        return mats
+
+    def forward(self, x):
+        if not x.is_cuda:  # like tinycudann itself: GPU tensors only, no host fallback
+            raise RuntimeError("tcnn_compat.Network: input must be a CUDA (ROCm) tensor")
+        lead = x.shape[:-1]
+        x = x.reshape(-1, self.n_input_dims)
+        mats = self.matrices()
+        if self.n_neurons == 64 and self.out_pad == 16 and self.in_pad <= 128 and len(mats) <= 4:
+            xp = torch.nn.functional.pad(x, (0, self.in_pad - self.n_input_dims)) if self.in_pad != self.n_input_dims else x
+            y = fused_mlp(xp, mats, activation=self.activation, inference=not torch.is_grad_enabled())
+        else:
+            if self.activation != 0:
+                raise RuntimeError("tcnn_compat.Network: only ReLU outside the fused 64-wide configuration")
+            h = torch.nn.functional.pad(x, (0, self.in_pad - self.n_input_dims)).to(self.params.dtype)
+            for k, m in enumerate(mats):
+                h = h @ m.t()
+                if k != len(mats) - 1:
+                    h = torch.relu(h)
+            y = h
+        return y[:, :self.n_output_dims].view(*lead, self.n_output_dims)
+
+
+def per_level_scale(desired_resolution, bound, base_resolution=16, n_levels=16):
+    """network_tcnn.py:39-41"""
+    return float(np.exp2(np.log2(desired_resolution * bound / base_resolution) / (n_levels - 1)))

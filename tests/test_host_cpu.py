@@ -105,3 +105,42 @@ def test_lidar_loss_matches_restated_train_step():
     pl = patch_gradient_loss(pd, gd, gt[..., 0], 2, 8, 0.01)
     want_p = render_ref.patch_grad_loss(depth[0], gt[0], 2, 8, 0.01)
     torch.testing.assert_close(pl, want_p)
+
+
+def test_tcnn_facade_api_and_state_dict_layout():
+    """network_tcnn.NeRFNetwork (the class `-L` selects, network_tcnn.py:10-219) without tinycudann: constructor
+    arguments, module names, tcnn's one-flat-`params`-per-module state dict, widths, GPU-only modules."""
+    from lidarnerf import tcnn_compat
+    from lidarnerf.nerf.network_tcnn import NeRFNetwork
+    net = NeRFNetwork(encoding="hashgrid", desired_resolution=32768, log2_hashmap_size=19, n_features_per_level=2,
+                      bound=1, min_near_lidar=0.01, density_scale=1)
+    sd = net.state_dict()
+    assert {"encoder.params", "sigma_net.params", "encoder_dir.params", "encoder_lidar_dir.params", "color_net.params",
+            "lidar_color_net.params", "aabb_train", "aabb_infer"} <= set(sd.keys())
+    assert not any(".impl." in k for k in sd)
+    assert sd["encoder.params"].numel() == 6837544 * 2 and sd["encoder_lidar_dir.params"].numel() == 0
+    assert net.encoder.n_output_dims == 32 and net.encoder_dir.n_output_dims == 16
+    assert net.encoder_lidar_dir.n_output_dims == 72 and net.in_dim_lidar_color == 87
+    assert sd["sigma_net.params"].numel() == 64 * 32 + 16 * 64
+    assert sd["lidar_color_net.params"].numel() == 64 * 96 + 64 * 64 + 16 * 64   # input padded 87 -> 96, output 2 -> 16
+    assert sd["color_net.params"].numel() == 64 * 32 + 64 * 64 + 16 * 64
+    assert abs(tcnn_compat.per_level_scale(32768, 1) - 1.6624757922855755) < 1e-12
+    # round trip through a tcnn-shaped checkpoint
+    net2 = NeRFNetwork(encoding="hashgrid", desired_resolution=32768, bound=1, min_near_lidar=0.01)
+    missing, unexpected = net2.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    assert torch.equal(net2.encoder.impl.params.data, net.encoder.impl.params.data)
+    groups = [g for g in net.get_params(1e-2)]
+    assert len(groups) == 6 and sum(len(list(g["params"])) for g in groups) == 4
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="CUDA"):
+            net.sigma_net(torch.rand(4, 32))
+        with pytest.raises(RuntimeError, match="CUDA"):
+            net.encoder_lidar_dir(torch.rand(4, 3))
+    # tcnn Frequency layout: out[d*2K + 2k + p] = sin(2^k pi x_d + p pi/2)
+    x = torch.tensor([[0.25, 0.5, 0.8]])
+    f = net.encoder_lidar_dir.frequency(x)[0]
+    assert f.shape == (72,)
+    for (dd, k, ph) in [(0, 0, 0), (0, 0, 1), (1, 3, 0), (2, 11, 1)]:
+        want = np.sin(np.float32(2.0 ** k * np.pi) * np.float32(x[0, dd]) + ph * np.pi / 2)
+        assert abs(float(f[dd * 24 + 2 * k + ph]) - want) < 2e-3 * max(1.0, 2.0 ** k * 1e-3)
