@@ -261,6 +261,29 @@ LNH_API int lnh_lidar_merge_weights(const float *z, const float *sigma_pt, const
                                     const float *sample_dist, uint32_t N, uint32_t T, float density_scale,
                                     float *sigma_m, float *weights, lnh_stream_t stream);
 /*
+ * Element-wise stages around the field that the reference leaves to dozens of PyTorch launches (one launch each here).
+ * lnh_lidar_coarse_samples: z[n,i] = near + (far-near)*linspace(0,1,T)[i] (+ (u[n,i]-0.5)*(far-near)/T when u != NULL)
+ *   (renderer.py:147-161; linspace evaluated symmetrically like torch.linspace).
+ * lnh_lidar_dir_term: per-ray direction term of the colour head's first Linear (network.py:215-221):
+ *   features16[n,k] = fp16-rounded dir_features[n,k] (kept as f32), cdir[n,o] = sum_k features16[n,k]*fp16(w0[o*ldw+k]),
+ *   o < 64, K <= 128.
+ * lnh_lidar_pack_weights: fp32 master matrices (row strides ld_*) -> flat fp16 vectors of lnh_density_mlp_* (wsig16:
+ *   [64,32 | 16,64]) and lnh_lidar_color_* (wcol16: W0g [64,16] = (0 | wc0[:, n_dir:n_dir+15]) | wc1 [64,64] | wc2 -> [16,64]).
+ * lnh_lidar_loss: nerf/utils.py:712-746 default criteria, loss = mean_n(alpha_d*|d-gd| + alpha_r*(r-gr)^2 +
+ *   alpha_i*(i-gi)^2) with predictions/targets masked by gt ray-drop; gt [N,3] = (raydrop, intensity, depth); also
+ *   writes d loss/d depth [N] and d loss/d image [N,2].
+ */
+LNH_API int lnh_lidar_coarse_samples(const float *u, uint32_t N, uint32_t T, float near, float far, float *z,
+                                     lnh_stream_t stream);
+LNH_API int lnh_lidar_dir_term(const float *dir_features, const float *w0, uint32_t ldw, uint32_t N, uint32_t K,
+                               float *features16, float *cdir, lnh_stream_t stream);
+LNH_API int lnh_lidar_pack_weights(const float *ws0, uint32_t ld_s0, const float *ws1, uint32_t ld_s1,
+                                   const float *wc0, uint32_t ld_c0, uint32_t n_dir, const float *wc1, uint32_t ld_c1,
+                                   const float *wc2, uint32_t ld_c2, void *wsig16, void *wcol16, lnh_stream_t stream);
+LNH_API int lnh_lidar_loss(const float *depth, const float *image, const float *gt, uint32_t N, float alpha_d,
+                           float alpha_r, float alpha_i, float *loss, float *grad_depth, float *grad_image,
+                           lnh_stream_t stream);
+/*
  * lnh_lidar_color_forward: LiDAR colour head (network.py:199-237 with cal_lidar_color=True) on merged samples:
  * rgb[n,i,0:2] = sigmoid(MLP([freq(d_n) | geo_feat(sample)])) where weights[n,i] > 1e-4, else 0.
  * h16 [N*T,16] sigma-net rows in point order, perm [N,T], cdir [N,64] f32 = W0[:, :75] freq(d_n) (per ray),

@@ -1,0 +1,154 @@
+// lidar_glue.hip — the small element-wise stages around the LiDAR field that the reference leaves to ~100 PyTorch
+// launches per step (renderer.py:129-161 sampling set-up, network.py:215-221 direction term, nerf/utils.py:712-746
+// loss).  Each is one launch here; none of them is bandwidth- or compute-relevant, the point is the launch count.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ coarse samples
+// z[n,i] = near + (far - near) * lin_i (+ (u[n,i] - 0.5) * (far - near) / T), lin = torch.linspace(0, 1, T)
+// (renderer.py:147-161).  torch.linspace is evaluated symmetrically (start + step*i in the lower half, end -
+// step*(T-1-i) in the upper half); the same form is used here so that both paths draw identical samples.
+__global__ void __launch_bounds__(256)
+k_coarse_samples(const float *__restrict__ u, uint32_t N, uint32_t T, float near, float far, float *__restrict__ z) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * T) return;
+    const uint32_t i = idx % T;
+    const float step = T > 1 ? 1.0f / (float)(T - 1) : 0.0f;
+    const float lin = i < T / 2 ? step * (float)i : 1.0f - step * (float)(T - 1 - i);
+    float v = near + (far - near) * lin;
+    if (u) v = v + (u[idx] - 0.5f) * ((far - near) / (float)T);
+    z[idx] = v;
+}
+
+// ------------------------------------------------------------------------------------------------ direction term
+// enc16[n,k] = fp16-rounded direction feature; cdir[n,o] = sum_k enc16[n,k] * fp16(W0[o,k])  (fp32 accumulate).
+// One workgroup = 4 rays x 64 outputs; the feature row of a ray is broadcast through LDS.
+__global__ void __launch_bounds__(256)
+k_dir_term(const float *__restrict__ enc, const float *__restrict__ W0, uint32_t ldw, uint32_t N, uint32_t K,
+           float *__restrict__ enc16, float *__restrict__ cdir) {
+    __shared__ float row[4][128];
+    const uint32_t r = threadIdx.x >> 6, o = threadIdx.x & 63;
+    const uint32_t n = blockIdx.x * 4 + r;
+    const bool valid = n < N;
+    for (uint32_t k = o; k < K; k += 64) {
+        const float v = (float)(half_t)enc[(size_t)(valid ? n : 0) * K + k];
+        row[r][k] = v;
+        if (valid) enc16[(size_t)n * K + k] = v;
+    }
+    __syncthreads();
+    float acc = 0.0f;
+    const float *w = W0 + (size_t)o * ldw;
+    for (uint32_t k = 0; k < K; k++) acc = fmaf(row[r][k], (float)(half_t)w[k], acc);
+    if (valid) cdir[(size_t)n * 64 + o] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------ weight packing
+// fp32 master weights (possibly strided views) -> the flat fp16 vectors the fused kernels read:
+//   wsig = [ws0 (64x32) | ws1 (16x64)],  wcol = [W0g (64x16: col 0 zero, cols 1..15 = wc0[:, kd:kd+15]) | wc1 | wc2 padded to 16 rows]
+struct PackArgs {
+    const float *ws0, *ws1, *wc0, *wc1, *wc2;
+    uint32_t ld_s0, ld_s1, ld_c0, ld_c1, ld_c2, kd;
+    half_t *wsig, *wcol;
+};
+__global__ void __launch_bounds__(256)
+k_pack_weights(PackArgs a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr uint32_t nS0 = 64 * 32, nS1 = 16 * 64, nC0 = 64 * 16, nC1 = 64 * 64, nC2 = 16 * 64;
+    if (i < nS0) {
+        a.wsig[i] = (half_t)a.ws0[(i / 32) * a.ld_s0 + i % 32];
+    } else if (i < nS0 + nS1) {
+        const uint32_t j = i - nS0;
+        a.wsig[i] = (half_t)a.ws1[(j / 64) * a.ld_s1 + j % 64];
+    }
+    if (i < nC0) {
+        const uint32_t o = i / 16, c = i % 16;
+        a.wcol[i] = c == 0 ? (half_t)0.0f : (half_t)a.wc0[o * a.ld_c0 + a.kd + c - 1];
+    } else if (i < nC0 + nC1) {
+        const uint32_t j = i - nC0;
+        a.wcol[i] = (half_t)a.wc1[(j / 64) * a.ld_c1 + j % 64];
+    } else if (i < nC0 + nC1 + nC2) {
+        const uint32_t j = i - nC0 - nC1, o = j / 64;
+        a.wcol[i] = o < 2 ? (half_t)a.wc2[o * a.ld_c2 + j % 64] : (half_t)0.0f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ loss
+// nerf/utils.py:712-746 with the default criteria: per ray
+//   l = a_d |pd - gd| + a_r (pr - gr)^2 + a_i (pi - gi)^2,  pd = depth * gr, gd = gt_depth * gr, pi = intensity * gr,
+// loss = mean(l).  Emits the loss and d loss / d depth, d loss / d image in the same pass.
+__global__ void __launch_bounds__(256)
+k_lidar_loss(const float *__restrict__ depth, const float *__restrict__ image, const float *__restrict__ gt, uint32_t N,
+             float a_d, float a_r, float a_i, float *__restrict__ loss, float *__restrict__ g_depth,
+             float *__restrict__ g_image) {
+    __shared__ float part[4];
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    float l = 0.0f;
+    if (n < N) {
+        const float gr = gt[n * 3], gi = gt[n * 3 + 1] * gr, gd = gt[n * 3 + 2] * gr;
+        const float pr = image[n * 2], pi = image[n * 2 + 1] * gr, pd = depth[n] * gr;
+        const float dd = pd - gd, dr = pr - gr, di = pi - gi;
+        l = a_d * fabsf(dd) + a_r * dr * dr + a_i * di * di;
+        const float inv = 1.0f / (float)N;
+        const float sgn = dd > 0.0f ? 1.0f : (dd < 0.0f ? -1.0f : 0.0f);  // torch: sign(0) = 0
+        g_depth[n] = a_d * sgn * gr * inv;
+        g_image[n * 2] = 2.0f * a_r * dr * inv;
+        g_image[n * 2 + 1] = 2.0f * a_i * di * gr * inv;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = l;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(loss, (part[0] + part[1] + part[2] + part[3]) / (float)N);
+}
+
+}  // namespace
+
+extern "C" {
+
+int lnh_lidar_coarse_samples(const float *u, uint32_t N, uint32_t T, float near, float far, float *z,
+                             lnh_stream_t stream) {
+    LNH_REQUIRE(z, LNH_ERR_INVALID_ARG, "lidar_coarse_samples: null pointer");
+    if ((uint64_t)N * T == 0) return LNH_OK;
+    LNH_REQUIRE((uint64_t)N * T < 0xffffffffull, LNH_ERR_UNSUPPORTED, "lidar_coarse_samples: N*T must fit 32 bits");
+    LNH_LAUNCH(k_coarse_samples, dim3(div_up((uint64_t)N * T, 256)), dim3(256), 0, (hipStream_t)stream, u, N, T, near,
+               far, z);
+    return lnh_check_launch("lnh_lidar_coarse_samples");
+}
+
+int lnh_lidar_dir_term(const float *dir_features, const float *w0, uint32_t ldw, uint32_t N, uint32_t K,
+                       float *features16, float *cdir, lnh_stream_t stream) {
+    LNH_REQUIRE(dir_features && w0 && features16 && cdir, LNH_ERR_INVALID_ARG, "lidar_dir_term: null pointer");
+    LNH_REQUIRE(K >= 1 && K <= 128 && ldw >= K, LNH_ERR_INVALID_ARG, "lidar_dir_term: need 1 <= K <= 128 and ldw >= K");
+    if (N == 0) return LNH_OK;
+    LNH_LAUNCH(k_dir_term, dim3(div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, dir_features, w0, ldw, N, K,
+               features16, cdir);
+    return lnh_check_launch("lnh_lidar_dir_term");
+}
+
+int lnh_lidar_pack_weights(const float *ws0, uint32_t ld_s0, const float *ws1, uint32_t ld_s1, const float *wc0,
+                           uint32_t ld_c0, uint32_t n_dir, const float *wc1, uint32_t ld_c1, const float *wc2,
+                           uint32_t ld_c2, void *wsig16, void *wcol16, lnh_stream_t stream) {
+    LNH_REQUIRE(ws0 && ws1 && wc0 && wc1 && wc2 && wsig16 && wcol16, LNH_ERR_INVALID_ARG,
+                "lidar_pack_weights: null pointer");
+    LNH_REQUIRE(ld_s0 >= 32 && ld_s1 >= 64 && ld_c0 >= n_dir + 15 && ld_c1 >= 64 && ld_c2 >= 64, LNH_ERR_INVALID_ARG,
+                "lidar_pack_weights: leading dimension smaller than the row");
+    PackArgs a{ws0, ws1, wc0, wc1, wc2, ld_s0, ld_s1, ld_c0, ld_c1, ld_c2, n_dir, (half_t *)wsig16, (half_t *)wcol16};
+    LNH_LAUNCH(k_pack_weights, dim3(div_up(64 * 16 + 64 * 64 + 16 * 64, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return lnh_check_launch("lnh_lidar_pack_weights");
+}
+
+int lnh_lidar_loss(const float *depth, const float *image, const float *gt, uint32_t N, float alpha_d, float alpha_r,
+                   float alpha_i, float *loss, float *grad_depth, float *grad_image, lnh_stream_t stream) {
+    LNH_REQUIRE(depth && image && gt && loss && grad_depth && grad_image, LNH_ERR_INVALID_ARG,
+                "lidar_loss: null pointer");
+    (void)hipGetLastError();
+    LNH_REQUIRE(hipMemsetAsync(loss, 0, sizeof(float), (hipStream_t)stream) == hipSuccess, LNH_ERR_LAUNCH,
+                "lidar_loss: hipMemsetAsync failed");
+    if (N == 0) return LNH_OK;
+    LNH_LAUNCH(k_lidar_loss, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, depth, image, gt, N, alpha_d,
+               alpha_r, alpha_i, loss, grad_depth, grad_image);
+    return lnh_check_launch("lnh_lidar_loss");
+}
+
+}  // extern "C"

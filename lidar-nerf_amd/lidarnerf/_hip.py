@@ -45,6 +45,10 @@ _SIGS = {
     "lnh_density_mlp_backward": [P, P, P, U32, U32, U32, U32, P, P],
     "lnh_lidar_merge_weights": [P, P, P, P, U32, U32, F32, P, P],
     "lnh_lidar_color_forward": [P, P, P, P, P, U32, U32, P],
+    "lnh_lidar_coarse_samples": [P, U32, U32, F32, F32, P],
+    "lnh_lidar_dir_term": [P, P, U32, U32, U32, P, P],
+    "lnh_lidar_pack_weights": [P, U32, P, U32, P, U32, U32, P, U32, P, U32, P, P],
+    "lnh_lidar_loss": [P, P, P, U32, F32, F32, F32, P, P, P],
     "lnh_lidar_color_backward": [P, P, P, P, P, P, P, U32, U32, P, P, P],
 }
 EXPORTS = sorted(list(_SIGS) + ["lnh_version", "lnh_last_error", "lnh_arch", "lnh_grid_backward_workspace_size"])

@@ -97,15 +97,21 @@ class FusedLidarRender(Function):
         Ttot = T + t_new
         bound = float(model.bound)
         aabb = (model.aabb_train if model.training else model.aabb_infer).float().contiguous()
-        nears = torch.full((N,), float(model.min_near_lidar), dtype=torch.float32, device=dev)
-        sd = ((nears * 81.0 - nears) / T).contiguous()  # sample_dist, same fp32 ops as renderer.py:129-156
+        # sample_dist = (fars - nears) / T with the fp32 roundings of renderer.py:129-156, formed on the host
+        near32 = np.float32(model.min_near_lidar)
+        sd = torch.full((N,), float((np.float32(near32 * np.float32(81.0)) - near32) / np.float32(T)),
+                        dtype=torch.float32, device=dev)
 
         table16 = embeddings.detach().to(torch.half).contiguous()
-        wsig16 = torch.cat([ws0.detach().reshape(-1), ws1.detach().reshape(-1)]).to(torch.half).contiguous()
-        # colour head: geo part of the first Linear against the raw 16-wide sigma-net row (col 0 gets weight 0)
-        w0g = torch.cat([torch.zeros((64, 1), device=dev, dtype=wc0.dtype), wc0.detach()[:, kd:kd + 15]], dim=1)
-        w2p = torch.nn.functional.pad(wc2.detach(), (0, 0, 0, 14))
-        wcol16 = torch.cat([w0g.reshape(-1), wc1.detach().reshape(-1), w2p.reshape(-1)]).to(torch.half).contiguous()
+        # fp32 master matrices (possibly strided views of flat parameter vectors) -> the flat fp16 vectors of the
+        # kernels, one launch: wsig16 = [ws0 | ws1]; wcol16 = [(0 | wc0[:, kd:kd+15]) | wc1 | wc2 padded to 16 rows]
+        wsig16 = torch.empty(64 * 32 + 16 * 64, dtype=torch.half, device=dev)
+        wcol16 = torch.empty(64 * 16 + 64 * 64 + 16 * 64, dtype=torch.half, device=dev)
+        mats = [m.detach() if m.dtype == torch.float32 and m.stride(-1) == 1 else m.detach().float().contiguous()
+                for m in (ws0, ws1, wc0, wc1, wc2)]
+        _hip.call("lnh_lidar_pack_weights", mats[0].data_ptr(), mats[0].stride(0), mats[1].data_ptr(),
+                  mats[1].stride(0), mats[2].data_ptr(), mats[2].stride(0), kd, mats[3].data_ptr(), mats[3].stride(0),
+                  mats[4].data_ptr(), mats[4].stride(0), wsig16.data_ptr(), wcol16.data_ptr())
 
         h16 = torch.empty((N * Ttot, 16), dtype=torch.half, device=dev)
         sigma_pt = torch.empty((N, Ttot), dtype=torch.float32, device=dev)
@@ -140,9 +146,11 @@ class FusedLidarRender(Function):
         _hip.call("lnh_lidar_merge_weights", z_all.data_ptr(), sigma_pt.data_ptr(), perm.data_ptr(), sd.data_ptr(), N,
                   Ttot, float(density_scale), sigma_m.data_ptr(), weights.data_ptr())
 
-        enc_d = spec.dir_features(rays_d)  # [N, kd] fp32, constant along a ray
-        enc_d16 = enc_d.to(torch.half).float()
-        cdir = (enc_d16 @ wc0.detach()[:, :kd].to(torch.half).float().t()).contiguous()
+        enc_d = spec.dir_features(rays_d).contiguous()  # [N, kd] fp32, constant along a ray
+        enc_d16 = torch.empty_like(enc_d)                # the same, rounded to fp16 (what the MLP would see)
+        cdir = torch.empty((N, 64), dtype=torch.float32, device=dev)
+        _hip.call("lnh_lidar_dir_term", enc_d.data_ptr(), mats[2].data_ptr(), mats[2].stride(0), N, kd,
+                  enc_d16.data_ptr(), cdir.data_ptr())
 
         rgb = torch.empty((N, Ttot, 2), dtype=torch.float32, device=dev)
         _hip.call("lnh_lidar_color_forward", h16.data_ptr(), perm.data_ptr(), weights.data_ptr(), cdir.data_ptr(),
@@ -211,12 +219,14 @@ def render_lidar(model, rays_o, rays_d, num_steps, upsample_steps, perturb):
     rays_o = rays_o.contiguous().view(-1, 3).float()
     rays_d = rays_d.contiguous().view(-1, 3).float()
     N, dev = rays_o.shape[0], rays_o.device
-    nears = torch.full((N, 1), float(model.min_near_lidar), dtype=torch.float32, device=dev)
-    fars = nears * 81.0  # hard-coded 1 m .. 81 m in scene units (renderer.py:129-138)
-    z = nears + (fars - nears) * torch.linspace(0.0, 1.0, num_steps, device=dev).unsqueeze(0)
-    if perturb:
-        z = z + (torch.rand((N, num_steps), device=dev) - 0.5) * ((fars - nears) / num_steps)
-    z = z.contiguous()
+    # near = min_near_lidar, far = 81 * near: hard-coded 1 m .. 81 m in scene units (renderer.py:129-138); the fp32
+    # products are formed exactly as the tensor code of the reference forms them
+    near = torch.tensor(float(model.min_near_lidar), dtype=torch.float32)
+    far = near * 81.0
+    z = torch.empty((N, num_steps), dtype=torch.float32, device=dev)
+    noise = torch.rand((N, num_steps), device=dev) if perturb else None
+    _hip.call("lnh_lidar_coarse_samples", noise.data_ptr() if perturb else None, N, num_steps, float(near), float(far),
+              z.data_ptr())
     if model.training:
         u = torch.rand((N, upsample_steps), device=dev)
     else:

@@ -21,6 +21,35 @@ def lidar_loss(outputs, images_lidar, alpha_d=1000.0, alpha_r=1.0, alpha_i=10.0)
     return per_ray.mean(), pred_depth, gt_depth
 
 
+class _FusedLidarLoss(torch.autograd.Function):
+    """lidar_loss as ONE kernel that also emits d loss / d (depth, image); backward only scales by the upstream scalar."""
+
+    @staticmethod
+    def forward(ctx, depth, image, gt, ad, ar, ai):
+        from .. import _hip
+        n = depth.numel()
+        depth, image, gt = depth.reshape(n).float().contiguous(), image.reshape(n, 2).float().contiguous(), \
+            gt.reshape(n, 3).float().contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=depth.device)
+        g_depth, g_image = torch.empty_like(depth), torch.empty_like(image)
+        _hip.call("lnh_lidar_loss", depth.data_ptr(), image.data_ptr(), gt.data_ptr(), n, float(ad), float(ar), float(ai),
+                  loss.data_ptr(), g_depth.data_ptr(), g_image.data_ptr())
+        ctx.save_for_backward(g_depth, g_image)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        g_depth, g_image = ctx.saved_tensors
+        return g_depth * g, g_image * g, None, None, None, None
+
+
+def fused_lidar_loss(outputs, images_lidar, alpha_d=1000.0, alpha_r=1.0, alpha_i=10.0):
+    """lidar_loss through the single-launch kernel (GPU tensors only); same value and gradients."""
+    depth, image = outputs["depth_lidar"], outputs["image_lidar"]
+    loss = _FusedLidarLoss.apply(depth.reshape(-1), image.reshape(-1, 2), images_lidar, alpha_d, alpha_r, alpha_i)
+    return loss
+
+
 def patch_gradient_loss(pred_depth, gt_depth, gt_raydrop, px, py, scale, alpha_grad=100.0):
     """utils.py:760-876 (grad_loss, non-sobel): |dx| of the prediction vs the SIGNED dx of the ground truth, masked to
     |gt dx| < 0.01 m and returned rays; only the x term enters the loss (the y terms are computed but unused)."""
@@ -56,6 +85,8 @@ class LidarTrainer:
         out = self.model.render(rays_o, rays_d, cal_lidar_color=True, staged=False, perturb=True,
                                 **self.render_kwargs)
         ad, ar, ai, ag = self.alpha
+        if patch[0] <= 1 and out["depth_lidar"].is_cuda:
+            return fused_lidar_loss(out, images_lidar, ad, ar, ai)
         loss, pred_depth, gt_depth = lidar_loss(out, images_lidar, ad, ar, ai)
         if patch[0] > 1:
             loss = loss + patch_gradient_loss(pred_depth, gt_depth, images_lidar[..., 0], patch[0], patch[1],

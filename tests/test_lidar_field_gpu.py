@@ -142,3 +142,68 @@ def test_color_head_forward_backward(N, T):
     assert float(gw[1024 + 4096:].view(16, 64)[2:].abs().max()) == 0.0  # padded output rows get no gradient
     # per-ray sum of d(hidden0) == gradient w.r.t. the per-ray direction bias
     torch.testing.assert_close(S.cpu().double(), want_gcd, rtol=1e-2, atol=5e-3 * want_gcd.abs().max().item())
+
+
+# ---------------------------------------------------------------------------------------------- glue kernels
+def test_coarse_samples_match_torch_linspace_form():
+    from lidarnerf import _hip
+    N, T = 37, 768
+    near = float(np.float32(0.0107848535))
+    far = float(np.float32(near) * np.float32(81.0))
+    u = torch.rand(N, T, device="cuda")
+    z = torch.empty(N, T, device="cuda")
+    for noise in (None, u):
+        _hip.call("lnh_lidar_coarse_samples", None if noise is None else noise.data_ptr(), N, T, near, far, z.data_ptr())
+        nears = torch.full((N, 1), near, device="cuda")
+        fars = torch.full((N, 1), far, device="cuda")
+        want = nears + (fars - nears) * torch.linspace(0.0, 1.0, T, device="cuda").unsqueeze(0)
+        if noise is not None:
+            want = want + (noise - 0.5) * ((fars - nears) / T)
+        torch.testing.assert_close(z, want, rtol=0, atol=1e-7)  # same fp32 expression; linspace itself within 1 ulp
+
+
+def test_dir_term_and_weight_packing():
+    from lidarnerf import _hip
+    torch.manual_seed(0)
+    N, K = 1001, 75
+    enc = torch.randn(N, K, device="cuda")
+    big = torch.randn(64, 96, device="cuda") * 0.2          # strided view, like the tcnn-shaped flat parameter
+    wc0 = big[:, :K + 15]
+    enc16 = torch.empty_like(enc)
+    cdir = torch.empty(N, 64, device="cuda")
+    _hip.call("lnh_lidar_dir_term", enc.data_ptr(), wc0.data_ptr(), wc0.stride(0), N, K, enc16.data_ptr(), cdir.data_ptr())
+    want16 = enc.half().float()
+    assert torch.equal(enc16, want16)
+    want = want16.double() @ wc0[:, :K].half().double().t()
+    torch.testing.assert_close(cdir.double(), want, rtol=1e-5, atol=1e-5)
+    ws0, ws1 = torch.randn(64, 32, device="cuda"), torch.randn(16, 64, device="cuda")
+    wc1, wc2 = torch.randn(64, 64, device="cuda"), torch.randn(2, 64, device="cuda")
+    wsig = torch.empty(64 * 32 + 16 * 64, dtype=torch.half, device="cuda")
+    wcol = torch.empty(64 * 16 + 64 * 64 + 16 * 64, dtype=torch.half, device="cuda")
+    _hip.call("lnh_lidar_pack_weights", ws0.data_ptr(), 32, ws1.data_ptr(), 64, wc0.data_ptr(), wc0.stride(0), K,
+              wc1.data_ptr(), 64, wc2.data_ptr(), 64, wsig.data_ptr(), wcol.data_ptr())
+    assert torch.equal(wsig, torch.cat([ws0.reshape(-1), ws1.reshape(-1)]).half())
+    w0g = torch.cat([torch.zeros(64, 1, device="cuda"), wc0[:, K:K + 15]], dim=1)
+    w2p = torch.nn.functional.pad(wc2, (0, 0, 0, 14))
+    assert torch.equal(wcol, torch.cat([w0g.reshape(-1), wc1.reshape(-1), w2p.reshape(-1)]).half())
+
+
+def test_fused_lidar_loss_matches_train_step_loss():
+    from lidarnerf.nerf.train_step import fused_lidar_loss, lidar_loss
+    torch.manual_seed(1)
+    N = 4099
+    depth = torch.rand(1, N, device="cuda", requires_grad=True)
+    image = torch.rand(1, N, 2, device="cuda", requires_grad=True)
+    gt = torch.rand(1, N, 3, device="cuda")
+    gt[..., 0] = (gt[..., 0] > 0.3).float()
+    with torch.no_grad():
+        depth[0, :5] = gt[0, :5, 2]  # exact ties: sign(0) = 0
+    want, _, _ = lidar_loss({"depth_lidar": depth, "image_lidar": image}, gt)
+    (want * 3.0).backward()
+    gd, gi = depth.grad.clone(), image.grad.clone()
+    depth.grad = image.grad = None
+    got = fused_lidar_loss({"depth_lidar": depth, "image_lidar": image}, gt)
+    (got * 3.0).backward()
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(depth.grad, gd, rtol=1e-6, atol=1e-9)
+    torch.testing.assert_close(image.grad, gi, rtol=1e-5, atol=1e-9)
