@@ -277,6 +277,10 @@ LNH_API int lnh_lidar_coarse_samples(const float *u, uint32_t N, uint32_t T, flo
                                      lnh_stream_t stream);
 LNH_API int lnh_lidar_dir_term(const float *dir_features, const float *w0, uint32_t ldw, uint32_t N, uint32_t K,
                                float *features16, float *cdir, lnh_stream_t stream);
+/* grad_w0[o*ldw + k] += sum_n ray_sum[n,o] * features16[n,k]  (ray_sum [N,64] from lnh_lidar_color_backward);
+ * scratch: ceil(N/32) * 64 * 128 floats. */
+LNH_API int lnh_lidar_dir_term_backward(const float *ray_sum, const float *features16, uint32_t N, uint32_t K,
+                                        float *scratch, float *grad_w0, uint32_t ldw, lnh_stream_t stream);
 LNH_API int lnh_lidar_pack_weights(const float *ws0, uint32_t ld_s0, const float *ws1, uint32_t ld_s1,
                                    const float *wc0, uint32_t ld_c0, uint32_t n_dir, const float *wc1, uint32_t ld_c1,
                                    const float *wc2, uint32_t ld_c2, void *wsig16, void *wcol16, lnh_stream_t stream);

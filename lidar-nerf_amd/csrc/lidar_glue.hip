@@ -43,6 +43,52 @@ k_dir_term(const float *__restrict__ enc, const float *__restrict__ W0, uint32_t
     if (valid) cdir[(size_t)n * 64 + o] = acc;
 }
 
+// d cdir / d W0_dir:  gW[o, k] += sum_n S[n, o] * enc16[n, k]  (S = per-ray sum of dH0 from the colour backward).
+// A library GEMM with M = 64, N = K <= 128 and a 4096-long reduction runs as one tile for ~43 us.  Two tiny passes
+// instead: every workgroup reduces a 32-ray chunk (staged in LDS) to a [64, 128] partial in scratch, then one thread
+// per output sums the partials.  (Atomics instead of the second pass were measured slower: 64*K addresses are so
+// few cache lines that device atomics on them serialise.)
+constexpr int kDirChunk = 32;
+__global__ void __launch_bounds__(256)
+k_dir_term_backward_partial(const float *__restrict__ S, const float *__restrict__ enc16, uint32_t N, uint32_t K,
+                            float *__restrict__ partial) {
+    constexpr int KPT = 32, CH = kDirChunk;  // k values per thread (k = kg + 4*j), rays per workgroup
+    __shared__ float sS[CH][64];
+    __shared__ float sE[CH][128];
+    const uint32_t o = threadIdx.x & 63, kg = threadIdx.x >> 6;
+    const uint32_t n0 = blockIdx.x * CH, cnt = min((uint32_t)CH, N - n0);
+    for (uint32_t i = threadIdx.x; i < CH * 64; i += 256) {  // coalesced staging, zero-filled beyond the valid part
+        const uint32_t r = i >> 6;
+        sS[r][i & 63] = r < cnt ? S[(size_t)(n0 + r) * 64 + (i & 63)] : 0.0f;
+    }
+    for (uint32_t i = threadIdx.x; i < CH * 128; i += 256) {
+        const uint32_t r = i >> 7, k = i & 127;
+        sE[r][k] = (r < cnt && k < K) ? enc16[(size_t)(n0 + r) * K + k] : 0.0f;
+    }
+    __syncthreads();
+    float acc[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; j++) acc[j] = 0.0f;
+    for (uint32_t r = 0; r < CH; r++) {
+        const float s = sS[r][o];
+#pragma unroll
+        for (int j = 0; j < KPT; j++) acc[j] = fmaf(s, sE[r][kg + 4 * j], acc[j]);  // wave-uniform address: broadcast
+    }
+    float *out = partial + (size_t)blockIdx.x * 64 * 128;
+#pragma unroll
+    for (int j = 0; j < KPT; j++) out[(kg + 4 * j) * 64 + o] = acc[j];  // [k][o]: consecutive lanes, consecutive floats
+}
+__global__ void __launch_bounds__(256)
+k_dir_term_backward_sum(const float *__restrict__ partial, uint32_t chunks, uint32_t K, float *__restrict__ gW,
+                        uint32_t ldw) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // i = k*64 + o
+    if (i >= K * 64) return;
+    float a = 0.0f;  // blockIdx.y strides over the chunks: 8-way split keeps the dependent-load chain short
+    for (uint32_t c = blockIdx.y; c < chunks; c += gridDim.y) a += partial[(size_t)c * 64 * 128 + i];
+    const uint32_t k = i >> 6, o = i & 63;
+    unsafeAtomicAdd(gW + (size_t)o * ldw + k, a);
+}
+
 // ------------------------------------------------------------------------------------------------ weight packing
 // fp32 master weights (possibly strided views) -> the flat fp16 vectors the fused kernels read:
 //   wsig = [ws0 (64x32) | ws1 (16x64)],  wcol = [W0g (64x16: col 0 zero, cols 1..15 = wc0[:, kd:kd+15]) | wc1 | wc2 padded to 16 rows]
@@ -124,6 +170,22 @@ int lnh_lidar_dir_term(const float *dir_features, const float *w0, uint32_t ldw,
     LNH_LAUNCH(k_dir_term, dim3(div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, dir_features, w0, ldw, N, K,
                features16, cdir);
     return lnh_check_launch("lnh_lidar_dir_term");
+}
+
+int lnh_lidar_dir_term_backward(const float *ray_sum, const float *features16, uint32_t N, uint32_t K, float *scratch,
+                                float *grad_w0, uint32_t ldw, lnh_stream_t stream) {
+    LNH_REQUIRE(ray_sum && features16 && grad_w0 && scratch, LNH_ERR_INVALID_ARG, "lidar_dir_term_backward: null pointer");
+    LNH_REQUIRE(K >= 1 && K <= 128 && ldw >= K, LNH_ERR_INVALID_ARG,
+                "lidar_dir_term_backward: need 1 <= K <= 128 and ldw >= K");
+    if (N == 0) return LNH_OK;
+    const uint32_t chunks = div_up(N, kDirChunk);
+    LNH_LAUNCH(k_dir_term_backward_partial, dim3(chunks), dim3(256), 0, (hipStream_t)stream, ray_sum, features16, N, K,
+               scratch);
+    int rc = lnh_check_launch("lnh_lidar_dir_term_backward(partial)");
+    if (rc) return rc;
+    LNH_LAUNCH(k_dir_term_backward_sum, dim3(div_up(K * 64, 256), chunks < 8 ? chunks : 8), dim3(256), 0, (hipStream_t)stream, scratch, chunks, K,
+               grad_w0, ldw);
+    return lnh_check_launch("lnh_lidar_dir_term_backward(sum)");
 }
 
 int lnh_lidar_pack_weights(const float *ws0, uint32_t ld_s0, const float *ws1, uint32_t ld_s1, const float *wc0,

@@ -191,7 +191,12 @@ class FusedLidarRender(Function):
                   weights.data_ptr(), cdir.data_ptr(), wcol16.data_ptr(), N, Ttot, g_h16.data_ptr(), g_wcol.data_ptr(),
                   ray_sum.data_ptr())
         g_w0g = g_wcol[:64 * 16].view(64, 16)
-        g_wc0 = torch.cat([ray_sum.t() @ enc_d16, g_w0g[:, 1:16]], dim=1)
+        kd = enc_d16.shape[1]
+        g_wc0 = torch.zeros((64, kd + 15), dtype=torch.float32, device=dev)
+        scratch = torch.empty(((N + 31) // 32) * 64 * 128, dtype=torch.float32, device=dev)
+        _hip.call("lnh_lidar_dir_term_backward", ray_sum.data_ptr(), enc_d16.data_ptr(), N, kd, scratch.data_ptr(),
+                  g_wc0.data_ptr(), kd + 15)
+        g_wc0[:, kd:] = g_w0g[:, 1:16]
         g_wc1 = g_wcol[64 * 16:64 * 16 + 64 * 64].view(64, 64)
         g_wc2 = g_wcol[64 * 16 + 64 * 64:].view(16, 64)[:2]
 
