@@ -21,8 +21,16 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 # -ffp-contract=off: fused multiply-adds are written explicitly (fmaf) where the reference's compiler fuses them, so
 # integer results derived from float math (cell indices, step counts) are reproducible against the CPU oracle.
+# -amdgpu-mfma-vgpr-form: let v_mfma write architectural VGPRs.  By default hipcc puts EVERY MFMA destination into an
+# AGPR and copies it back with v_accvgpr_read before the VALU can touch it (4 moves per MFMA); the tiny-MLP kernels apply
+# an activation to every MFMA result, so those copies were ~35 % of their instruction stream.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=off",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+
+
+MFMA_VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+# hipcc (ROCm 7.2) crashes on the 2-hidden-matrix backward instantiations with that option: they keep the default
+NO_VGPR_FORM = {"mlp_bwd_nhm2.hip"}
 
 
 def _newer(src, deps, out):
@@ -37,7 +45,8 @@ def _compile(src, force):
     deps = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
     if not force and not _newer(src, deps, out):
         return out, False
-    cmd = [HIPCC] + FLAGS + ["-c", src, "-o", out]
+    extra = [] if os.path.basename(src) in NO_VGPR_FORM else MFMA_VGPR_FORM
+    cmd = [HIPCC] + FLAGS + extra + ["-c", src, "-o", out]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")

@@ -177,267 +177,6 @@ k_color_forward(ColorArgs a) {
     }
 }
 
-// One workgroup (4 waves) per ray; step = 64 merged samples, wave w owns samples [16w, 16w+16) of the step.
-__global__ void __launch_bounds__(256)
-k_color_backward(ColorArgs a) {
-    constexpr int HT = 4, HS = 2, LDP = 64 + 8;
-    __shared__ __attribute__((aligned(16))) half_t tileG[64 * LDP];  // gradient^T  [channel][sample]
-    __shared__ __attribute__((aligned(16))) half_t tileA[64 * LDP];  // activation^T
-    __shared__ float sred[4][64];
-    const uint32_t wid = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
-    const uint32_t col0 = wid * 16;
-
-    half8_t w0[HT], w1[HT][HS], w2[HS];
-    half8_t w2T[HT], w1T[HT][HS], w0T[HS];
-#pragma unroll
-    for (int t = 0; t < HT; t++) {
-        w0[t] = load_a_natural(a.W + kW0g, 16, 16 * t + c, 0, g, 16);
-        w2T[t] = load_at_natural(a.W + kW2, 64, 16 * t + c, 0, g, 16);
-#pragma unroll
-        for (int s = 0; s < HS; s++) {
-            w1[t][s] = load_a_nu(a.W + kW1, 64, 16 * t + c, s, g);
-            w1T[t][s] = load_at_nu(a.W + kW1, 64, 16 * t + c, s, g);
-        }
-    }
-#pragma unroll
-    for (int s = 0; s < HS; s++) {
-        w2[s] = load_a_nu(a.W + kW2, 64, c, s, g);
-        w0T[s] = load_at_nu(a.W + kW0g, 16, c, s, g);  // A[m = input feature c][k = hidden nu]
-    }
-    // weight-gradient tiles owned by this wave (persist over all rays of the workgroup)
-    f32x4 gW2 = zero_f4();       // dW2 rows 0..15, hidden columns [16*wid, +16)
-    f32x4 gW1[HT];               // dW1 row tile q, column tile wid
-    f32x4 gW0 = zero_f4();       // dW0g row tile wid (hidden), 16 input columns
-#pragma unroll
-    for (int q = 0; q < HT; q++) gW1[q] = zero_f4();
-
-    auto put_packed = [&](half_t *tile, const half8_t (&v)[HS]) {
-#pragma unroll
-        for (int s = 0; s < HS; s++)
-#pragma unroll
-            for (int j = 0; j < 8; j++) tile[(16 * (2 * s + (j >> 2)) + 4 * g + (j & 3)) * LDP + col0 + c] = v[s][j];
-    };
-    auto wgrad_tile = [&](f32x4 acc, uint32_t tg, uint32_t ta) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-            const half8_t fa = *reinterpret_cast<const half8_t *>(tileG + (16 * tg + c) * LDP + 32 * ks + 8 * g);
-            const half8_t fb = *reinterpret_cast<const half8_t *>(tileA + (16 * ta + c) * LDP + 32 * ks + 8 * g);
-            acc = MFMA16(fa, fb, acc);
-        }
-        return acc;
-    };
-
-    // The per-sample operands form a dependent chain (perm -> sigma-net row) of HBM round trips; left in program order
-    // they cost ~4 exposed latencies per 64-sample step.  The (ray, step) iteration space of the workgroup is therefore
-    // flattened and software-pipelined: stage A (weights, perm, incoming gradients) runs two iterations ahead, stage B
-    // (the gathered sigma-net row) one iteration ahead.  All loads are unconditional from clamped addresses.
-    struct StageA {
-        bool valid;
-        size_t m;
-        uint32_t ray, slot;
-        float wgt, gs;
-        float2 gr;
-    };
-    const uint32_t nsteps = (a.T + 63) / 64;
-    const uint32_t nrays = blockIdx.x < a.N ? (a.N - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-    const uint32_t K = nrays * nsteps;
-    auto load_a = [&](uint32_t k) {
-        StageA A;
-        const uint32_t rr = k / nsteps, i = (k - rr * nsteps) * 64 + col0 + c;
-        const uint32_t ray = blockIdx.x + rr * gridDim.x;
-        A.valid = k < K && i < a.T;
-        A.ray = ray;
-        A.m = A.valid ? (size_t)ray * a.T + i : 0;
-        A.wgt = a.weights[A.m];
-        A.slot = (uint32_t)a.perm[A.m];
-        A.gs = a.g_sigma[A.m];
-        A.gr = *reinterpret_cast<const float2 *>(a.g_rgb + A.m * 2);
-        return A;
-    };
-    auto src_of = [&](const StageA &A) { return A.valid ? (size_t)A.ray * a.T + A.slot : (size_t)0; };
-    auto load_b = [&](const StageA &A) {
-        return *reinterpret_cast<const half8_t *>(a.h16 + src_of(A) * 16 + (g < 2 ? 8 * g : 0));
-    };
-    auto load_cb = [&](uint32_t ray, f32x4 (&cb)[HT]) {
-        const uint32_t r = ray < a.N ? ray : 0;
-#pragma unroll
-        for (int t = 0; t < HT; t++) cb[t] = *reinterpret_cast<const f32x4 *>(a.cdir + (size_t)r * 64 + 16 * t + 4 * g);
-    };
-    StageA A0 = load_a(0), A1 = load_a(1);
-    half8_t B0 = load_b(A0);
-    f32x4 cb[HT], cb_next[HT];
-    load_cb(blockIdx.x, cb_next);
-    float ssum[HT][4];
-
-    for (uint32_t k = 0; k < K; k++) {
-        const uint32_t rr = k / nsteps, sidx = k - rr * nsteps;
-        const uint32_t ray = blockIdx.x + rr * gridDim.x;
-        const StageA A2 = load_a(k + 2);
-        const half8_t B1 = load_b(A1);
-        if (sidx == 0) {
-#pragma unroll
-            for (int t = 0; t < HT; t++) {
-                cb[t] = cb_next[t];
-#pragma unroll
-                for (int r = 0; r < 4; r++) ssum[t][r] = 0.0f;
-            }
-            load_cb(ray + gridDim.x, cb_next);
-        }
-        {
-            const bool valid = A0.valid;
-            const size_t m = A0.m;
-            const float wgt = valid ? A0.wgt : 0.0f;
-            const bool msk = wgt > kMaskThresh;
-            const size_t src = src_of(A0);
-            const half8_t bx = (valid && g < 2) ? B0 : zero_h8();
-            // whole 64-sample step transparent (the forward defines colour as 0 there): no colour gradient exists, only
-            // the compositing gradient of sigma flows back
-            if (!__syncthreads_or(valid && msk)) {
-                if (valid) {
-                    half4_t v = {(half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f};
-                    if (g == 0) v[0] = (half_t)(A0.gs * expf(fminf(fmaxf((float)bx[0], -15.0f), 15.0f)));
-                    *reinterpret_cast<half4_t *>(a.g_h16 + src * 16 + 4 * g) = v;
-                }
-            } else {
-            // ---- forward recompute
-            f32x4 acc[HT];
-#pragma unroll
-            for (int t = 0; t < HT; t++) acc[t] = MFMA16(w0[t], bx, cb[t]);
-            half8_t bh0[HS], bh1[HS];
-#pragma unroll
-            for (int s = 0; s < HS; s++)
-                bh0[s] = pack_pair(acc[2 * s], acc[2 * s + 1], [](float v) { return v > 0.0f ? v : 0.0f; });
-#pragma unroll
-            for (int t = 0; t < HT; t++) {
-                acc[t] = zero_f4();
-#pragma unroll
-                for (int s = 0; s < HS; s++) acc[t] = MFMA16(w1[t][s], bh0[s], acc[t]);
-            }
-#pragma unroll
-            for (int s = 0; s < HS; s++)
-                bh1[s] = pack_pair(acc[2 * s], acc[2 * s + 1], [](float v) { return v > 0.0f ? v : 0.0f; });
-            f32x4 o = zero_f4();
-#pragma unroll
-            for (int s = 0; s < HS; s++) o = MFMA16(w2[s], bh1[s], o);
-            // ---- output gradient through the sigmoid (only outputs 0,1 exist; lanes g == 0 hold them)
-            half8_t by = zero_h8();
-            if (g == 0 && valid && msk) {
-                const float2 gr = A0.gr;
-                const float r0 = sigmoidf((float)(half_t)o[0]), r1 = sigmoidf((float)(half_t)o[1]);
-                by[0] = (half_t)(gr.x * r0 * (1.0f - r0));
-                by[1] = (half_t)(gr.y * r1 * (1.0f - r1));
-            }
-            // ---- dW2 += dY^T h1
-            if (g < 2) {
-#pragma unroll
-                for (int j = 0; j < 8; j++) tileG[(8 * g + j) * LDP + col0 + c] = by[j];
-            }
-            put_packed(tileA, bh1);
-            __syncthreads();
-            gW2 = wgrad_tile(gW2, 0, wid);
-            __syncthreads();
-            // ---- dH1 = W2^T dY through relu
-            half8_t bd[HS];
-            {
-                f32x4 d[HT];
-#pragma unroll
-                for (int t = 0; t < HT; t++) d[t] = MFMA16(w2T[t], by, zero_f4());
-#pragma unroll
-                for (int s = 0; s < HS; s++)
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        bd[s][j] = (float)bh1[s][j] > 0.0f ? (half_t)d[2 * s][j] : (half_t)0.0f;
-                        bd[s][4 + j] = (float)bh1[s][4 + j] > 0.0f ? (half_t)d[2 * s + 1][j] : (half_t)0.0f;
-                    }
-            }
-            // ---- dW1 += dH1^T h0
-            put_packed(tileG, bd);
-            put_packed(tileA, bh0);
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < HT; q++) gW1[q] = wgrad_tile(gW1[q], q, wid);
-            __syncthreads();
-            // ---- dH0 = W1^T dH1 through relu
-            {
-                f32x4 d[HT];
-#pragma unroll
-                for (int t = 0; t < HT; t++) {
-                    d[t] = zero_f4();
-#pragma unroll
-                    for (int s = 0; s < HS; s++) d[t] = MFMA16(w1T[t][s], bd[s], d[t]);
-                }
-#pragma unroll
-                for (int s = 0; s < HS; s++)
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        bd[s][j] = (float)bh0[s][j] > 0.0f ? (half_t)d[2 * s][j] : (half_t)0.0f;
-                        bd[s][4 + j] = (float)bh0[s][4 + j] > 0.0f ? (half_t)d[2 * s + 1][j] : (half_t)0.0f;
-                    }
-#pragma unroll
-                for (int s = 0; s < HS; s++)
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        ssum[2 * s][j] += (float)bd[s][j];
-                        ssum[2 * s + 1][j] += (float)bd[s][4 + j];
-                    }
-            }
-            // ---- dW0g += dH0^T x  (x = the 16-wide sigma-net row)
-            put_packed(tileG, bd);
-            if (g < 2) {
-#pragma unroll
-                for (int j = 0; j < 8; j++) tileA[(8 * g + j) * LDP + col0 + c] = bx[j];
-            }
-            __syncthreads();
-            gW0 = wgrad_tile(gW0, wid, 0);
-            __syncthreads();
-            // ---- d(sigma-net row) = W0g^T dH0, col 0 <- trunc_exp backward of the compositing gradient
-            f32x4 dx = zero_f4();
-#pragma unroll
-            for (int s = 0; s < HS; s++) dx = MFMA16(w0T[s], bd[s], dx);
-            if (valid) {
-                if (g == 0) {
-                    const float pre = fminf(fmaxf((float)bx[0], -15.0f), 15.0f);
-                    dx[0] = A0.gs * expf(pre);
-                }
-                half4_t v = {(half_t)dx[0], (half_t)dx[1], (half_t)dx[2], (half_t)dx[3]};
-                *reinterpret_cast<half4_t *>(a.g_h16 + src * 16 + 4 * g) = v;
-            }
-        }
-        }
-        A0 = A1;
-        A1 = A2;
-        B0 = B1;
-        if (sidx + 1 < nsteps) continue;
-        // ---- S[ray][neuron] = sum over the ray's samples of dH0: reduce over the 16 lanes of each g group, then waves
-#pragma unroll
-        for (int t = 0; t < HT; t++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                float v = ssum[t][r];
-                v += __shfl_xor(v, 1, 64);
-                v += __shfl_xor(v, 2, 64);
-                v += __shfl_xor(v, 4, 64);
-                v += __shfl_xor(v, 8, 64);
-                if (c == 0) sred[wid][16 * t + 4 * g + r] = v;
-            }
-        __syncthreads();
-        if (threadIdx.x < 64)
-            a.S[(size_t)ray * 64 + threadIdx.x] = sred[0][threadIdx.x] + sred[1][threadIdx.x] + sred[2][threadIdx.x] +
-                                                  sred[3][threadIdx.x];
-        __syncthreads();
-    }
-    // ---- flush weight gradients (D layout: row 4g+r, col c of each tile)
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        unsafeAtomicAdd(a.dW + kW2 + (size_t)(4 * g + r) * 64 + 16 * wid + c, gW2[r]);
-        unsafeAtomicAdd(a.dW + kW0g + (size_t)(16 * wid + 4 * g + r) * 16 + c, gW0[r]);
-#pragma unroll
-        for (int q = 0; q < HT; q++)
-            unsafeAtomicAdd(a.dW + kW1 + (size_t)(16 * q + 4 * g + r) * 64 + 16 * wid + c, gW1[q][r]);
-    }
-}
-
-
 // Wave-independent colour-head backward: one WAVE per ray at a time, 32 merged samples per iteration, no LDS tiles and
 // no barriers in the sample loop.  Weight gradients contract over samples, so their MFMA operands are the TRANSPOSES of
 // what the layer chain leaves in registers; a transpose of a packed fp16 fragment is one MFMA against an identity
@@ -497,7 +236,10 @@ k_color_backward_wi(ColorArgs a) {
         return r;
     };
 
-    // software pipeline over the flattened (ray, step) space of this wave (see k_color_backward)
+    // The per-sample operands form a dependent chain (perm -> sigma-net row) of HBM round trips; left in program order
+    // they cost ~4 exposed latencies per step.  The (ray, step) iteration space of the wave is therefore flattened and
+    // software-pipelined: stage A (weights, perm, incoming gradients) runs two iterations ahead, stage B (the gathered
+    // sigma-net row) one iteration ahead.  All loads are unconditional from clamped addresses.
     struct StageA {
         bool valid[NT];
         uint32_t ray, m[NT], slot[NT];
@@ -710,13 +452,10 @@ k_color_backward_wi(ColorArgs a) {
 #undef WF
 }
 
+
 }  // namespace
 
-static int g_color_bwd_variant = 1;  // 1 = wave-independent, 0 = workgroup-cooperative (tuning switch)
-
 extern "C" {
-
-__attribute__((visibility("default"))) void lnh_debug_color_bwd_variant(int v) { g_color_bwd_variant = v; }
 
 int lnh_lidar_sample_points(const float *rays_o, const float *rays_d, const float *z, const float *aabb, float bound,
                             uint32_t N, uint32_t T, uint32_t T_tot, uint32_t slot_off, float *x01, lnh_stream_t stream) {
@@ -767,12 +506,8 @@ int lnh_lidar_color_backward(const float *grad_rgb, const float *grad_sigma, con
     a.N = N; a.T = T;
     // persistent workgroups: each flushes 6144 weight-gradient partials with device atomics (~20 G/s chip-wide), so
     // keep the workgroup count near the CU count rather than one per ray
-    if (g_color_bwd_variant) {
-        const uint32_t wgs = (N + 3) / 4;
-        LNH_LAUNCH(k_color_backward_wi, dim3(wgs < 256 ? wgs : 256), dim3(256), 0, (hipStream_t)stream, a);
-    } else {
-        LNH_LAUNCH(k_color_backward, dim3(N < 256 ? N : 256), dim3(256), 0, (hipStream_t)stream, a);
-    }
+    const uint32_t wgs = (N + 3) / 4;
+    LNH_LAUNCH(k_color_backward_wi, dim3(wgs < 256 ? wgs : 256), dim3(256), 0, (hipStream_t)stream, a);
     return lnh_check_launch("lnh_lidar_color_backward");
 }
 
