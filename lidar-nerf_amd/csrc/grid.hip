@@ -441,7 +441,8 @@ constexpr uint32_t kMaxBucketsPerLevel = 64;
 struct BucketPlan {
     uint32_t first_bucket[LNH_MAX_LEVELS + 1];  // prefix sum of buckets per level
     uint32_t cap[LNH_MAX_LEVELS];               // pool slots per bucket of that level
-    uint64_t pool_off[LNH_MAX_LEVELS];          // first pool slot of that level
+    uint64_t pool_off[LNH_MAX_LEVELS];          // byte offset of that level's pool region (16-byte aligned)
+    uint64_t rows_off[LNH_MAX_LEVELS];          // fp16 tables: byte offset of the level's row-index array (SoA pool)
 };
 
 template <typename T>
@@ -481,6 +482,8 @@ __device__ __forceinline__ void entry_fixed(const PoolEntry<float> &e, int K, lo
     qa = (long long)ldexp((double)e.v0, K);
     qb = (long long)ldexp((double)e.v1, K);
 }
+__device__ __forceinline__ half2_t pool_value(const PoolEntry<half_t> &e) { return e.v; }
+__device__ __forceinline__ half2_t pool_value(const PoolEntry<float> &) { return half2_t{0, 0}; }  // (unused)
 __device__ __forceinline__ void entry_get(const PoolEntry<half_t> &e, float &a, float &b) {
     a = (float)e.v[0];
     b = (float)e.v[1];
@@ -655,7 +658,12 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
             }
         }
     __syncthreads();
-    PoolEntry<T> *lp = pool + plan.pool_off[level];
+    // fp16 tables keep the pool as two streams (4-byte value pairs | 2-byte bucket-local rows): 6 bytes per entry
+    // instead of 8 through HBM, twice
+    char *pool_bytes = reinterpret_cast<char *>(pool);
+    PoolEntry<T> *lp = reinterpret_cast<PoolEntry<T> *>(pool_bytes + plan.pool_off[level]);
+    half2_t *lvals = reinterpret_cast<half2_t *>(pool_bytes + plan.pool_off[level]);
+    unsigned short *lrows = reinterpret_cast<unsigned short *>(pool_bytes + plan.rows_off[level]);
     T *gt = grad_table + (size_t)lv.offset * C;
     const uint32_t total = (dbg & 256) ? 0 : lstart[kMaxBucketsPerLevel];
     for (uint32_t pos = threadIdx.x; pos < total; pos += blockDim.x) {
@@ -664,7 +672,12 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
         const uint2 o = lout[bk];
         e.row &= kBucketRows - 1;
         if (pos < o.y) {
-            lp[o.x + pos] = e;
+            if constexpr (sizeof(T) == 2) {
+                lvals[o.x + pos] = pool_value(e);
+                lrows[o.x + pos] = (unsigned short)e.row;
+            } else {
+                lp[o.x + pos] = e;
+            }
         } else {  // pool overflow: exact but slow
             float a, b2;
             entry_get(e, a, b2);
@@ -707,41 +720,64 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
     // One workgroup streams its whole slice; what bounds it is the number of bytes in flight per CU, so every lane keeps
     // UNROLL independent loads outstanding (unconditional, from clamped indices: a predicated load would be branched
     // around and waited for one by one).
-    if constexpr (sizeof(PoolEntry<T>) == 8) {
-        // 8-byte entries: 16-byte loads of aligned entry PAIRS; entries outside [a_begin, a_end) are masked
-        constexpr uint32_t UNROLL = 8;
-        const uint64_t a_begin = plan.pool_off[level] + (uint64_t)bk * cap + i_begin, a_end = a_begin + n;
-        const uint64_t p_begin = a_begin >> 1, p_end = (a_end + 1) >> 1;  // pairs [p_begin, p_end)
-        const uint4 *src2 = reinterpret_cast<const uint4 *>(pool);
-        const uint32_t npairs = (uint32_t)(p_end - p_begin), stride = blockDim.x * UNROLL;
-        for (uint32_t j0 = threadIdx.x; j0 < npairs; j0 += stride) {
-            uint4 raw[UNROLL];
+    if constexpr (sizeof(T) == 2) {
+        // fp16 tables: two streams, read as aligned QUADS of entries (16 bytes of values + 8 bytes of rows per load
+        // pair); slots outside [a_begin, a_end) are masked
+        constexpr uint32_t UNROLL = 4;
+        const char *pool_bytes = reinterpret_cast<const char *>(pool);
+        const uint4 *vals4 = reinterpret_cast<const uint4 *>(pool_bytes + plan.pool_off[level]);
+        const uint2 *rows4 = reinterpret_cast<const uint2 *>(pool_bytes + plan.rows_off[level]);
+        const uint32_t a_begin = bk * cap + i_begin, a_end = a_begin + n;  // level-relative slots (< 2^32, checked)
+        const uint32_t q_begin = a_begin >> 2, q_end = (a_end + 3) >> 2;
+        const uint32_t nquads = q_end - q_begin, stride = blockDim.x * UNROLL;
+        // double-buffered: the loads of batch i+1 are in flight while the LDS adds of batch i execute
+        uint4 rv[2][UNROLL];
+        uint2 rr[2][UNROLL];
+        auto fetch = [&](uint32_t j0, uint4 (&v)[UNROLL], uint2 (&r)[UNROLL]) {
 #pragma unroll
             for (uint32_t u = 0; u < UNROLL; u++) {
-                const uint32_t j = j0 + u * blockDim.x;
-                raw[u] = src2[p_begin + (j < npairs ? j : npairs - 1)];
+                const uint32_t j = j0 + u * blockDim.x, q = q_begin + (j < nquads ? j : nquads - 1);
+                v[u] = vals4[q];
+                r[u] = rows4[q];
             }
+        };
+        auto consume = [&](uint32_t j0, const uint4 (&v)[UNROLL], const uint2 (&r)[UNROLL]) {
 #pragma unroll
             for (uint32_t u = 0; u < UNROLL; u++) {
                 const uint32_t j = j0 + u * blockDim.x;
-                const uint64_t e0 = (p_begin + j) * 2;
-                const uint32_t w[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
+                const uint32_t e0 = (q_begin + j) * 4;
+                const uint32_t vw[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                const uint32_t rw[2] = {r[u].x, r[u].y};
 #pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    if (j < npairs && e0 + h >= a_begin && e0 + h < a_end && !(dbg & 16)) {
+                for (int h = 0; h < 4; h++) {
+                    if (j < nquads && e0 + h >= a_begin && e0 + h < a_end && !(dbg & 16)) {
                         PoolEntry<T> e;
-                        __builtin_memcpy(&e, &w[2 * h], 8);
+                        e.v = __builtin_bit_cast(half2_t, vw[h]);
+                        const uint32_t row = (rw[h >> 1] >> (16 * (h & 1))) & 0xffffu;
                         long long qa, qb;
                         entry_fixed(e, K, qa, qb);
-                        atomicAdd(&acc[e.row * 2], (unsigned long long)qa);  // ds_add_u64
-                        atomicAdd(&acc[e.row * 2 + 1], (unsigned long long)qb);
+                        atomicAdd(&acc[row * 2], (unsigned long long)qa);  // ds_add_u64
+                        atomicAdd(&acc[row * 2 + 1], (unsigned long long)qb);
                     }
                 }
             }
+        };
+        if (nquads) fetch(threadIdx.x, rv[0], rr[0]);
+        uint32_t j0 = threadIdx.x;
+        while (j0 < nquads) {  // unrolled by two so that the buffer index is a compile-time constant
+            const uint32_t j1 = j0 + stride;
+            if (j1 < nquads) fetch(j1, rv[1], rr[1]);
+            consume(j0, rv[0], rr[0]);
+            if (j1 >= nquads) break;
+            const uint32_t j2 = j1 + stride;
+            if (j2 < nquads) fetch(j2, rv[0], rr[0]);
+            consume(j1, rv[1], rr[1]);
+            j0 = j2;
         }
     } else {
         constexpr uint32_t UNROLL = 8;
-        const PoolEntry<T> *src = pool + plan.pool_off[level] + (size_t)bk * cap + i_begin;
+        const PoolEntry<T> *src = reinterpret_cast<const PoolEntry<T> *>(reinterpret_cast<const char *>(pool) +
+                                                                         plan.pool_off[level]) + (size_t)bk * cap + i_begin;
         const uint32_t stride = blockDim.x * UNROLL;
         for (uint32_t i0 = threadIdx.x; i0 < n; i0 += stride) {
             PoolEntry<T> e[UNROLL];
@@ -785,7 +821,7 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
 template <typename T>
 uint64_t plan_buckets(BucketPlan &plan, const GridMeta &m, uint32_t L, uint32_t B, uint32_t D, uint32_t &total_buckets) {
     const uint64_t per_level = (uint64_t)B << D;  // worst-case entries of one level
-    uint64_t slots = 0;
+    uint64_t bytes = 0;
     uint32_t nbt = 0;
     for (uint32_t l = 0; l < L; l++) {
         const uint32_t nb = (m.lv[l].hashmap_size + kBucketRows - 1) / kBucketRows;
@@ -796,14 +832,22 @@ uint64_t plan_buckets(BucketPlan &plan, const GridMeta &m, uint32_t L, uint32_t 
         if (cap > per_level) cap = per_level;
         if (cap > 0xffffffffull) cap = 0xffffffffull;
         plan.cap[l] = (uint32_t)cap;
-        plan.pool_off[l] = slots;
-        slots += cap * nb;
+        const uint64_t slots = cap * nb;
+        plan.pool_off[l] = bytes;
+        if (sizeof(T) == 2) {  // values (4 B) | rows (2 B), each stream padded so that aligned quad reads stay inside
+            const uint64_t vals_bytes = (slots * 4 + 16 + 15) / 16 * 16;
+            plan.rows_off[l] = bytes + vals_bytes;
+            bytes += vals_bytes + (slots * 2 + 8 + 15) / 16 * 16;
+        } else {
+            plan.rows_off[l] = 0;
+            bytes += (slots * sizeof(PoolEntry<T>) + 15) / 16 * 16;
+        }
         nbt += nb;
     }
     plan.first_bucket[L] = nbt;
     total_buckets = nbt;
     const uint64_t cursor_bytes = ((uint64_t)nbt * 4 + 255) / 256 * 256;
-    return cursor_bytes + slots * sizeof(PoolEntry<T>) + 16;  // + one pad entry: the reduce pass reads aligned pairs
+    return cursor_bytes + bytes;
 }
 
 template <typename T>
