@@ -14,6 +14,7 @@
 //     coarse levels, where one cell spans many consecutive samples of a ray) are summed with a segmented shuffle
 //     scan and only the run tail issues the atomic.
 #include "common.h"
+#include <type_traits>
 
 #include <cmath>
 
@@ -197,10 +198,10 @@ __device__ __forceinline__ void store_vec(T *p, const Vec<T, C> &r) {
 template <typename T, int D, int C, bool DYDX>
 __global__ void __launch_bounds__(256)
 k_grid_forward(const float *__restrict__ inputs, const T *__restrict__ table, T *__restrict__ outputs,
-               T *__restrict__ dy_dx, uint32_t B, uint32_t L, GridMeta meta, uint32_t align, uint32_t interp,
+               T *__restrict__ dy_dx, uint32_t B, uint32_t L, GridMeta meta, uint32_t align_rt, uint32_t interp_rt,
                RowMap map) {
     const uint32_t level = blockIdx.y;
-    const LevelParams lv = meta.lv[level];
+    const LevelParams lv_rt = meta.lv[level];
     const uint32_t b0 = blockIdx.x * blockDim.x + threadIdx.x;
     if (b0 >= B) return;
     // optional row map: launch index b0 = r*T_cur + j addresses row r*T_tot + slot_off + j of buffers holding
@@ -210,8 +211,18 @@ k_grid_forward(const float *__restrict__ inputs, const T *__restrict__ table, T 
     float x[D];
 #pragma unroll
     for (int d = 0; d < D; d++) x[d] = inputs[(size_t)b * D + d];
-    const T *tab = table + (size_t)lv.offset * C;
+    const T *tab = table + (size_t)lv_rt.offset * C;
     T *out = outputs + ((size_t)level * Bs + b) * C;
+    // The level class is workgroup-uniform.  The two classes that make up the usual configuration (hashed power-of-two
+    // level / dense level indexed in all D dimensions, both with linear interpolation and align_corners = false) get
+    // their own straight-line copy of the body with the flags as compile-time constants; everything else takes the
+    // generic copy with run-time branches.
+    auto body = [&](auto mode_c) {
+    constexpr int MODE = decltype(mode_c)::value;
+    LevelParams lv = lv_rt;
+    if constexpr (MODE == 1) lv.flags = LV_HASH | LV_POW2;
+    if constexpr (MODE == 2) lv.flags = LV_NOWRAP | (uint32_t)D;
+    const uint32_t align = MODE ? 0u : align_rt, interp = MODE ? 0u : interp_rt;
     Cell<D> cell;
     Vec<T, C> res;
 #pragma unroll
@@ -300,6 +311,12 @@ k_grid_forward(const float *__restrict__ inputs, const T *__restrict__ table, T 
             store_vec<T, C>(dd + gd * C, rg);
         }
     }
+    };
+    const bool plain = align_rt == 0 && interp_rt == 0;
+    if (plain && (lv_rt.flags & (LV_HASH | LV_POW2)) == (LV_HASH | LV_POW2)) body(std::integral_constant<int, 1>{});
+    else if (plain && !(lv_rt.flags & LV_HASH) && (lv_rt.flags & LV_NOWRAP) && (lv_rt.flags & 15u) == (uint32_t)D)
+        body(std::integral_constant<int, 2>{});
+    else body(std::integral_constant<int, 0>{});
 }
 
 // Debug kernel for the bit-exact index contract.
@@ -500,7 +517,7 @@ template <typename T, int D, int PPT, int NTHREADS>
 __global__ void __launch_bounds__(NTHREADS)
 k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs, T *__restrict__ grad_table,
                    uint32_t B, GridMeta meta, BucketPlan plan, PoolEntry<T> *__restrict__ pool,
-                   uint32_t *__restrict__ cursor, uint32_t align, uint32_t interp, uint32_t dbg, uint32_t n_levels) {
+                   uint32_t *__restrict__ cursor, uint32_t align_rt, uint32_t interp_rt, uint32_t dbg, uint32_t n_levels) {
     constexpr int C = 2, NCORN = 1 << D;
     __shared__ uint2 lout[kMaxBucketsPerLevel];           // per bucket: {pool slot - staging slot, staging slots that fit}
     __shared__ uint32_t lcnt[kMaxBucketsPerLevel];
@@ -513,8 +530,15 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
     // phases of independent workgroups better than a barrier-separated item loop does.)
     const int lane = threadIdx.x & 63;
     const uint32_t level = blockIdx.x % n_levels, chunk = blockIdx.x / n_levels;
-    const LevelParams lv = meta.lv[level];
+    const LevelParams lv_rt = meta.lv[level];
     const uint32_t fb = plan.first_bucket[level], nb = plan.first_bucket[level + 1] - fb, cap = plan.cap[level];
+    // level class resolved at compile time for the two usual classes (see k_grid_forward)
+    auto body = [&](auto mode_c) {
+    constexpr int MODE = decltype(mode_c)::value;
+    LevelParams lv = lv_rt;
+    if constexpr (MODE == 1) lv.flags = LV_HASH | LV_POW2;
+    if constexpr (MODE == 2) lv.flags = LV_NOWRAP | (uint32_t)D;
+    const uint32_t align = MODE ? 0u : align_rt, interp = MODE ? 0u : interp_rt;
     if (threadIdx.x < kMaxBucketsPerLevel) {
         lcnt[threadIdx.x] = 0;
         lbase[threadIdx.x] = 0;
@@ -684,6 +708,12 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
             atomic_add_pair(gt + ((size_t)bk * kBucketRows + e.row) * C, a, b2);
         }
     }
+    };
+    const bool plain = align_rt == 0 && interp_rt == 0;
+    if (plain && (lv_rt.flags & (LV_HASH | LV_POW2)) == (LV_HASH | LV_POW2)) body(std::integral_constant<int, 1>{});
+    else if (plain && !(lv_rt.flags & LV_HASH) && (lv_rt.flags & LV_NOWRAP) && (lv_rt.flags & 15u) == (uint32_t)D)
+        body(std::integral_constant<int, 2>{});
+    else body(std::integral_constant<int, 0>{});
 }
 
 // A bucket with many entries (coarse dense levels: every ray passes the same few cells) is split over up to
