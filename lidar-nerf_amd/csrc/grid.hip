@@ -238,22 +238,41 @@ k_grid_forward(const float *__restrict__ inputs, const T *__restrict__ table, T 
             // (measured ~1 line/clk/CU), so halving the accesses of most pairs is a direct win.
             const bool hash = lv.flags & LV_HASH;
             const bool x_dense = !hash && (lv.flags & 15u) >= 1 && (lv.flags & LV_NOWRAP);
-            const bool pair_ok = x_dense || (hash && (lv.flags & LV_POW2) && !(cell.term[0][0] & 1u));
+            const bool hash_pair = hash && (lv.flags & LV_POW2);   // level-uniform
+            const bool x_odd = cell.term[0][0] & 1u;               // per lane
+            // All loads first, every use after the loop, and no per-lane branch around a load: a consumer (or the end of
+            // a divergent region) pins an s_waitcnt and serialises the four (y,z) iterations into dependent round trips.
+            //   pair[yz]: the aligned row pair holding corner c0 (hashed levels) / rows r0, r0+1 (dense x)
+            //   solo[yz]: corner c1 on its own, fetched only where it is not the sibling of c0 (hashed level, odd x)
+            Vec<T, 4> pair[4];
+            Vec<T, C> solo[4];
+            uint32_t r0s[4];
 #pragma unroll
             for (uint32_t yz = 0; yz < 4; yz++) {
                 const uint32_t c0 = yz << 1, c1 = c0 | 1u;
                 const uint32_t r0 = corner_row<D>(cell, lv, c0);
-                if (pair_ok) {
-                    const uint32_t lo = x_dense ? r0 : (r0 & ~1u);
-                    const Vec<T, 4> pr = load_vec<T, 4>(tab + (size_t)lo * C);
-                    const bool swap = !x_dense && (r0 & 1u);  // hashed, r0 odd: r1 = r0 ^ 1 is the lower row
-                    g[c0].v[0] = swap ? pr.v[2] : pr.v[0];
-                    g[c0].v[1] = swap ? pr.v[3] : pr.v[1];
-                    g[c1].v[0] = swap ? pr.v[0] : pr.v[2];
-                    g[c1].v[1] = swap ? pr.v[1] : pr.v[3];
+                r0s[yz] = r0;
+                if (x_dense || hash_pair) {
+                    pair[yz] = load_vec<T, 4>(tab + (size_t)(x_dense ? r0 : (r0 & ~1u)) * C);
+                    // lanes whose c1 IS the sibling read row 0 instead (one broadcast line): selecting the address
+                    // keeps the load unconditional — an exec-masked load would be waited for at the end of its branch
+                    if (hash_pair)
+                        solo[yz] = load_vec<T, C>(tab + (size_t)(x_odd ? corner_row<D>(cell, lv, c1) : 0u) * C);
                 } else {
                     g[c0] = load_vec<T, C>(tab + (size_t)r0 * C);
                     g[c1] = load_vec<T, C>(tab + (size_t)corner_row<D>(cell, lv, c1) * C);
+                }
+            }
+            if (x_dense || hash_pair) {
+#pragma unroll
+                for (uint32_t yz = 0; yz < 4; yz++) {
+                    const uint32_t c0 = yz << 1, c1 = c0 | 1u;
+                    const bool swap = hash_pair && (r0s[yz] & 1u);  // hashed, r0 odd: its sibling r0 ^ 1 is the lower row
+                    const bool own = hash_pair && x_odd;
+                    g[c0].v[0] = swap ? pair[yz].v[2] : pair[yz].v[0];
+                    g[c0].v[1] = swap ? pair[yz].v[3] : pair[yz].v[1];
+                    g[c1].v[0] = own ? solo[yz].v[0] : (swap ? pair[yz].v[0] : pair[yz].v[2]);
+                    g[c1].v[1] = own ? solo[yz].v[1] : (swap ? pair[yz].v[1] : pair[yz].v[3]);
                 }
             }
         } else {
