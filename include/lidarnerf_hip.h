@@ -306,6 +306,19 @@ LNH_API int lnh_lidar_color_backward(const float *grad_rgb, const float *grad_si
                                      uint32_t N, uint32_t T, void *grad_h16, float *grad_w, float *ray_sum,
                                      lnh_stream_t stream);
 
+/* ---- range image <-> point cloud (lidarnerf/convert.py:99-160, 194-237) ---------------------------
+ * lnh_lidar_to_pano: points [N,4] f32 (x,y,z,intensity) in the sensor frame -> pano [H,W] f32 (distance of the nearest
+ *   point per pixel, 0 = empty) and intensities [H,W] f32; lidar_K = (fov_up, fov) in degrees; points with
+ *   dist >= max_depth or outside the image are dropped; ties keep the earlier point.  keys_scratch: H*W*8 bytes.
+ * lnh_pano_to_lidar: pano (+ optional intensities) -> points [H*W,4] and valid [H*W] u8 (pano != 0); the caller
+ *   compacts in pixel order.
+ */
+LNH_API int lnh_lidar_to_pano(const float *points, uint32_t N, uint32_t H, uint32_t W, float fov_up, float fov,
+                              float max_depth, void *keys_scratch, float *pano, float *intensities,
+                              lnh_stream_t stream);
+LNH_API int lnh_pano_to_lidar(const float *pano, const float *intensities, uint32_t H, uint32_t W, float fov_up,
+                              float fov, float *points, uint8_t *valid, lnh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,6 +11,9 @@ Vectors:
   G3 get_lidar_rays    lidarnerf/dataset/base_dataset.py:16-105  full 66x1030 grid (subsampled) + patch indices
   G4 FreqEncoder       lidarnerf/encoding.py:6-47            pure-torch fwd/bwd, degree 12
   G5 trunc_exp         lidarnerf/activation.py:6-20          fwd/bwd incl. the clamp region
+  G6 convert           lidarnerf/convert.py:99-160, 194-237  lidar_to_pano_with_intensities (per-point loop) on a
+                       synthetic 20 k-point sweep incl. ties, out-of-range and beyond-max-depth points, and
+                       pano_to_lidar_with_intensities of the result
 """
 import os
 import sys
@@ -164,8 +167,27 @@ def g5():
                         g=g.numpy(), gx=x.grad.numpy())
 
 
+def g6():
+    from lidarnerf.convert import lidar_to_pano_with_intensities, pano_to_lidar_with_intensities
+    rng = np.random.default_rng(7)
+    H, W, K = 66, 1030, (2.0, 26.9)
+    n = 20000
+    az = rng.uniform(-np.pi, np.pi, n)
+    el = np.deg2rad(rng.uniform(-30.0, 6.0, n))          # some rays outside the 26.9 deg field of view
+    d = rng.uniform(0.5, 95.0, n)                          # some beyond max_depth = 80
+    pts = np.stack([d * np.cos(el) * np.cos(az), d * np.cos(el) * np.sin(az), d * np.sin(el),
+                    rng.uniform(0, 1, n)], 1).astype(np.float32)
+    pts[100:200] = pts[0:100]                              # exact duplicates: the first one must win
+    pts[100:200, 3] += 1.0
+    pts[300:400, :3] = pts[200:300, :3] * np.float32(0.5)  # same pixel, nearer: the later one must win
+    pano, inten = lidar_to_pano_with_intensities(pts, H, W, K, max_depth=80)
+    back = pano_to_lidar_with_intensities(pano.astype(np.float32), inten.astype(np.float32), K)
+    np.savez_compressed(os.path.join(OUT, "g6_convert.npz"), pts=pts, H=H, W=W, K=np.array(K), pano=pano,
+                        intensities=inten, back=back)
+
+
 if __name__ == "__main__":
-    g1(); g2(); g3(); g4(); g5()
+    g1(); g2(); g3(); g4(); g5(); g6()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

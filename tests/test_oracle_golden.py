@@ -87,3 +87,16 @@ def test_g5_trunc_exp(golden_dir):
     y.backward(torch.from_numpy(g["g"]))
     np.testing.assert_array_equal(y.detach().numpy(), g["y"])
     np.testing.assert_array_equal(x.grad.numpy(), g["gx"])
+
+
+def test_g6_convert_oracle_matches_reference_bit_exactly(golden_dir):
+    """oracle/convert_ref.py (vectorised) vs the reference's per-point loop (lidarnerf/convert.py:99-160, 194-237)."""
+    from oracle import convert_ref
+    g = _load(golden_dir, "g6_convert.npz")
+    H, W, K = int(g["H"]), int(g["W"]), tuple(float(v) for v in g["K"])
+    pano, inten = convert_ref.lidar_to_pano_with_intensities(g["pts"], H, W, K, 80)
+    assert np.array_equal(pano, g["pano"]) and np.array_equal(inten, g["intensities"])
+    assert (pano != 0).sum() > 10000
+    back = convert_ref.pano_to_lidar_with_intensities(g["pano"].astype(np.float32),
+                                                      g["intensities"].astype(np.float32), K)
+    assert np.array_equal(back, g["back"])
