@@ -319,6 +319,12 @@ LNH_API int lnh_lidar_to_pano(const float *points, uint32_t N, uint32_t H, uint3
 LNH_API int lnh_pano_to_lidar(const float *pano, const float *intensities, uint32_t H, uint32_t W, float fov_up,
                               float fov, float *points, uint8_t *valid, lnh_stream_t stream);
 
+/* ---- evaluation: nearest-neighbour pass of the chamfer distance (extern/chamfer3D/chamfer3D.cu:9-138)
+ * dist[j] = min_k |xyz1[j] - xyz2[k]|^2 (squared), idx[j] = the first k attaining it; xyz* are [n,3] / [m,3] f32.
+ */
+LNH_API int lnh_chamfer_nn(const float *xyz1, uint32_t n, const float *xyz2, uint32_t m, float *dist, int32_t *idx,
+                           lnh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

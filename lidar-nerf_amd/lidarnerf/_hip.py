@@ -51,6 +51,7 @@ _SIGS = {
     "lnh_lidar_pack_weights": [P, U32, P, U32, P, U32, U32, P, U32, P, U32, P, P],
     "lnh_lidar_to_pano": [P, U32, U32, U32, F32, F32, F32, P, P, P],
     "lnh_pano_to_lidar": [P, P, U32, U32, F32, F32, P, P],
+    "lnh_chamfer_nn": [P, U32, P, U32, P, P],
     "lnh_lidar_loss": [P, P, P, U32, F32, F32, F32, P, P, P],
     "lnh_lidar_color_backward": [P, P, P, P, P, P, P, U32, U32, P, P, P],
 }

@@ -189,3 +189,11 @@ def composite_rays_train_backward(grad_ws, grad_img, sigmas, rgbs, deltas, rays,
     lib().lnh_oracle_composite_rays_train_backward(_p(gws), _p(gi), _p(s), _p(c), _p(dl), _p(r), _p(ws), _p(img),
                                                    C.c_uint32(M), C.c_uint32(N), C.c_float(T_thresh), _p(gs), _p(gc))
     return gs, gc
+
+
+def chamfer_nn(xyz1, xyz2):
+    a, b = _f32(xyz1), _f32(xyz2)
+    n, m = a.shape[0], b.shape[0]
+    dist, idx = np.zeros(n, np.float32), np.zeros(n, np.int32)
+    lib().lnh_oracle_chamfer_nn(_p(a), C.c_uint32(n), _p(b), C.c_uint32(m), _p(dist), _p(idx))
+    return dist, idx

@@ -623,3 +623,21 @@ ORACLE_API void lnh_oracle_composite_rays_train_backward(const float *grad_weigh
         }
     }
 }
+
+/* ---- chamfer nearest neighbour: extern/chamfer3D/chamfer3D.cu:9-138 (semantics: squared distance, first minimal
+ * index; x*x + y*y + z*z with the two contractions nvcc applies by default). */
+ORACLE_API void lnh_oracle_chamfer_nn(const float *xyz1, uint32_t n, const float *xyz2, uint32_t m, float *dist,
+                                      int32_t *idx) {
+    for (uint32_t j = 0; j < n; j++) {
+        const float x1 = xyz1[j * 3], y1 = xyz1[j * 3 + 1], z1 = xyz1[j * 3 + 2];
+        float best = 0.0f;
+        int32_t best_i = 0;
+        for (uint32_t k = 0; k < m; k++) {
+            const float dx = xyz2[k * 3] - x1, dy = xyz2[k * 3 + 1] - y1, dz = xyz2[k * 3 + 2] - z1;
+            const float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+            if (k == 0 || d < best) { best = d; best_i = (int32_t)k; }
+        }
+        dist[j] = best;
+        idx[j] = best_i;
+    }
+}
