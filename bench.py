@@ -196,7 +196,7 @@ def main():
         "config": {"workload": "KITTI-360 seq 1908 shaped: hash-grid L=16 F=2 (2^19 rows, res 16..32768) + 64-wide "
                                "fused MLPs, 66x1030 range image", "rays_per_gpu_per_step": args.rays,
                    "samples_per_ray": NUM_STEPS + UPSAMPLE, "parallelism": f"dp{world}",
-                   "optimizer": "Adam + GradScaler (in timed region)", "final_loss": round(loss_val, 5)},
+                   "optimizer": "Adam + dynamic loss scaling, in the timed region (hash table: fused lnh_adam_table_step; MLPs: torch fused Adam)", "final_loss": round(loss_val, 5)},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(per_pt * avg_points),

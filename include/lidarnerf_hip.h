@@ -325,6 +325,18 @@ LNH_API int lnh_pano_to_lidar(const float *pano, const float *intensities, uint3
 LNH_API int lnh_chamfer_nn(const float *xyz1, uint32_t n, const float *xyz2, uint32_t m, float *dist, int32_t *idx,
                            lnh_stream_t stream);
 
+/* ---- optimizer step of the hash table (nerf/utils.py:1206-1226: GradScaler + torch.optim.Adam, fused) ------------
+ * lnh_grad_check_f16: *found_inf = 1 if any of the n fp16 gradient values is inf / nan (never clears it).
+ * lnh_adam_table_step: torch.optim.Adam (no weight decay / amsgrad) on fp32 param / exp_avg / exp_avg_sq with the
+ *   fp16 gradient scaled by *inv_scale; also writes the fp16 copy of the updated parameters.  *found_inf != 0 skips
+ *   the whole update.  The step counter t lives on the device, double-buffered: reads *step_in, writes *step_out.
+ */
+LNH_API int lnh_grad_check_f16(const void *grad16, uint64_t n, float *found_inf, lnh_stream_t stream);
+LNH_API int lnh_adam_table_step(float *param, float *exp_avg, float *exp_avg_sq, const void *grad16, void *param16,
+                                uint64_t n, double lr, double beta1, double beta2, double eps,
+                                const float *inv_scale, const float *found_inf, const float *step_in,
+                                float *step_out, lnh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

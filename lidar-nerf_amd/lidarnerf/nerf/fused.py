@@ -102,7 +102,11 @@ class FusedLidarRender(Function):
         sd = torch.full((N,), float((np.float32(near32 * np.float32(81.0)) - near32) / np.float32(T)),
                         dtype=torch.float32, device=dev)
 
-        table16 = embeddings.detach().to(torch.half).contiguous()
+        # fp16 copy of the table: maintained by the fused table optimizer when there is one (train_step.LidarTrainer),
+        # otherwise cast here (the autocast rule of grid.py:54-57)
+        table16 = getattr(spec.table_param, "_lnh_table16", None)
+        if table16 is None:
+            table16 = embeddings.detach().to(torch.half).contiguous()
         # fp32 master matrices (possibly strided views of flat parameter vectors) -> the flat fp16 vectors of the
         # kernels, one launch: wsig16 = [ws0 | ws1]; wcol16 = [(0 | wc0[:, kd:kd+15]) | wc1 | wc2 padded to 16 rows]
         wsig16 = torch.empty(64 * 32 + 16 * 64, dtype=torch.half, device=dev)
@@ -213,7 +217,13 @@ class FusedLidarRender(Function):
         if handle is not None:
             handle.wait()
         dts = ctx.param_dtypes
-        return (None, None, None, None, g_table16.to(dts[0]), g_wsig[:64 * 32].view(64, 32).to(dts[1]),
+        if getattr(ctx.table_param, "_lnh_keep_grad16", False):
+            # the fused table optimizer consumes the fp16 gradient directly: no fp32 copy, no .grad on the table
+            ctx.table_param._lnh_grad16 = g_table16
+            g_table = None
+        else:
+            g_table = g_table16.to(dts[0])
+        return (None, None, None, None, g_table, g_wsig[:64 * 32].view(64, 32).to(dts[1]),
                 g_wsig[64 * 32:].view(16, 64).to(dts[2]), g_wc0.to(dts[3]), g_wc1.to(dts[4]), g_wc2.to(dts[5]),
                 None, None, None)
 

@@ -63,10 +63,16 @@ def patch_gradient_loss(pred_depth, gt_depth, gt_raydrop, px, py, scale, alpha_g
 
 
 class LidarTrainer:
-    """The hot loop only (no logging / checkpoint / EMA: those are host glue outside the path)."""
+    """The hot loop only (no logging / checkpoint / EMA: those are host glue outside the path).
+
+    fused_table_optimizer (default on for fp16 + a fusable field on the GPU): the 13.7 M-parameter hash table — 99.8 %
+    of all parameters — leaves torch.optim.Adam / GradScaler and is stepped by ONE kernel (lnh_adam_table_step) that
+    reads the fp16 gradient the backward kernels produce and writes the fp32 master table, its moments and the fp16
+    copy of the next step.  Same arithmetic as torch's fused Adam, same GradScaler contract (dynamic loss scale, inf/nan
+    => the step is skipped for EVERY parameter and the scale backs off); the MLP parameters stay on torch's Adam."""
 
     def __init__(self, model, lr=1e-2, iters=30000, fp16=True, alpha_d=1000.0, alpha_r=1.0, alpha_i=10.0,
-                 alpha_grad=100.0, scale=1.0, world_size=1, render_kwargs=None):
+                 alpha_grad=100.0, scale=1.0, world_size=1, render_kwargs=None, fused_table_optimizer=True):
         self.model, self.fp16, self.world = model, fp16, world_size
         self.alpha = (alpha_d, alpha_r, alpha_i, alpha_grad)
         self.scale = scale
@@ -74,8 +80,24 @@ class LidarTrainer:
         # Adam(betas .9/.99, eps 1e-15) and lr * 0.1^(it/iters) (main_lidarnerf.py:389-391, 408-410)
         # get_params returns generators: materialise them; one fused kernel for all parameter groups on the GPU
         params = [dict(g, params=list(g["params"])) for g in model.get_params(lr)]
-        params = [g for g in params if len(g["params"])]
         on_gpu = all(p.is_cuda for g in params for p in g["params"])
+        self.table = None
+        if fused_table_optimizer and fp16 and on_gpu and hasattr(model, "fused_spec"):
+            try:
+                tp = model.fused_spec().table_param
+            except AttributeError:
+                tp = None
+            if tp is not None and tp.dtype == torch.float32 and tp.is_contiguous() and tp.numel() % 4 == 0:
+                self.table = tp
+                params = [dict(g, params=[p for p in g["params"] if p is not tp]) for g in params]
+                self.t_m, self.t_v = torch.zeros_like(tp), torch.zeros_like(tp)
+                self.t_steps = [torch.zeros((), device=tp.device), torch.zeros((), device=tp.device)]
+                self.t_flip = 0
+                tp._lnh_keep_grad16 = True
+                tp._lnh_table16 = tp.detach().to(torch.half).reshape(-1, 2).contiguous()
+                self.loss_scale = torch.full((), 65536.0, dtype=torch.float32, device=tp.device)
+                self.growth_tracker = torch.zeros((), dtype=torch.int32, device=tp.device)
+        params = [g for g in params if len(g["params"])]
         self.optimizer = torch.optim.Adam(params, betas=(0.9, 0.99), eps=1e-15, fused=on_gpu)
         self.scheduler = torch.optim.lr_scheduler.LambdaLR(self.optimizer, lambda it: 0.1 ** min(it / iters, 1))
         self.scaler = torch.amp.GradScaler("cuda", enabled=fp16)
@@ -93,7 +115,45 @@ class LidarTrainer:
                                               self.scale, ag)
         return loss
 
+    def _step_fused_table(self, rays_o, rays_d, images_lidar, patch):
+        from .. import _hip
+        tp = self.table
+        self.optimizer.zero_grad(set_to_none=True)
+        tp._lnh_grad16 = None
+        with torch.autocast("cuda", dtype=torch.float16):
+            loss = self.loss(rays_o, rays_d, images_lidar, patch)
+        (loss * self.loss_scale).backward()
+        if self.world > 1:
+            parallel.allreduce_gradients(self.params, self.world)
+        # --- GradScaler.step / update, with the table handled by the fused kernels
+        found_inf = torch.zeros((), dtype=torch.float32, device=tp.device)
+        inv_scale = self.loss_scale.reciprocal()
+        grads = [p.grad for p in self.params if p.grad is not None]
+        if grads:
+            torch._amp_foreach_non_finite_check_and_unscale_(grads, found_inf, inv_scale)
+        g16 = tp._lnh_grad16
+        if g16 is None:
+            raise RuntimeError("fused table optimizer: the backward pass produced no fp16 table gradient "
+                               "(render did not go through the fused LiDAR chain)")
+        _hip.call("lnh_grad_check_f16", g16.data_ptr(), g16.numel(), found_inf.data_ptr())
+        self.optimizer.grad_scale, self.optimizer.found_inf = None, found_inf
+        try:
+            self.optimizer.step()
+        finally:
+            del self.optimizer.grad_scale, self.optimizer.found_inf
+        lr = float(self.optimizer.param_groups[0]["lr"])
+        s_in, s_out = self.t_steps[self.t_flip], self.t_steps[1 - self.t_flip]
+        _hip.call("lnh_adam_table_step", tp.data_ptr(), self.t_m.data_ptr(), self.t_v.data_ptr(), g16.data_ptr(),
+                  tp._lnh_table16.data_ptr(), tp.numel(), lr, 0.9, 0.99, 1e-15, inv_scale.data_ptr(),
+                  found_inf.data_ptr(), s_in.data_ptr(), s_out.data_ptr())
+        self.t_flip = 1 - self.t_flip
+        torch._amp_update_scale_(self.loss_scale, self.growth_tracker, found_inf, 2.0, 0.5, 2000)
+        self.scheduler.step()
+        return loss
+
     def step(self, rays_o, rays_d, images_lidar, patch=(1, 1)):
+        if self.table is not None:
+            return self._step_fused_table(rays_o, rays_d, images_lidar, patch)
         self.optimizer.zero_grad(set_to_none=True)
         with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):
             loss = self.loss(rays_o, rays_d, images_lidar, patch)
