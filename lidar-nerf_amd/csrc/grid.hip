@@ -764,7 +764,10 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
     const uint32_t i_end = (uint32_t)((uint64_t)n_all * (blockIdx.y + 1) / slices);
     const uint32_t n = i_end - i_begin;
     const uint32_t rows = min(kBucketRows, lv.hashmap_size - bk * kBucketRows);
-    for (uint32_t i = threadIdx.x; i < rows * 2; i += blockDim.x) acc[i] = 0ull;
+    // channel-planar image: acc[row] | acc[kBucketRows + row].  With the two channels of a row interleaved, each
+    // ds_add_u64 instruction of a wave would touch only every other pair of banks (row*4 + {0,1} mod 32) and pay twice
+    // the conflicts; planar, the 64 random rows of an instruction spread over all 32 banks.
+    for (uint32_t i = threadIdx.x; i < kBucketRows * 2; i += blockDim.x) acc[i] = 0ull;
     __syncthreads();
     // One workgroup streams its whole slice; what bounds it is the number of bytes in flight per CU, so every lane keeps
     // UNROLL independent loads outstanding (unconditional, from clamped indices: a predicated load would be branched
@@ -805,8 +808,8 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
                         const uint32_t row = (rw[h >> 1] >> (16 * (h & 1))) & 0xffffu;
                         long long qa, qb;
                         entry_fixed(e, K, qa, qb);
-                        atomicAdd(&acc[row * 2], (unsigned long long)qa);  // ds_add_u64
-                        atomicAdd(&acc[row * 2 + 1], (unsigned long long)qb);
+                        atomicAdd(&acc[row], (unsigned long long)qa);  // ds_add_u64
+                        atomicAdd(&acc[kBucketRows + row], (unsigned long long)qb);
                     }
                 }
             }
@@ -841,8 +844,8 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
                 if (i < n) {
                     long long qa, qb;
                     entry_fixed(e[u], K, qa, qb);
-                    atomicAdd(&acc[e[u].row * 2], (unsigned long long)qa);  // ds_add_u64
-                    atomicAdd(&acc[e[u].row * 2 + 1], (unsigned long long)qb);
+                    atomicAdd(&acc[e[u].row], (unsigned long long)qa);  // ds_add_u64
+                    atomicAdd(&acc[kBucketRows + e[u].row], (unsigned long long)qb);
                 }
             }
         }
@@ -851,7 +854,7 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
     if (dbg & 64) return;
     T *gt = grad_table + ((size_t)lv.offset + (size_t)bk * kBucketRows) * 2;
     for (uint32_t r = threadIdx.x; r < rows; r += blockDim.x) {
-        const long long qa = (long long)acc[2 * r], qb = (long long)acc[2 * r + 1];
+        const long long qa = (long long)acc[r], qb = (long long)acc[kBucketRows + r];
         if (qa != 0 || qb != 0) {
             const float a = (float)ldexp((double)qa, -K), b = (float)ldexp((double)qb, -K);
             if (slices == 1) {
