@@ -589,7 +589,7 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
         //      on the coarser levels.  Runs are cut at DPP row starts (pure-VALU row_shr scan, no cross-row traffic), and
         //      a wave with fewer than kMinMerges mergeable lanes skips the scan altogether — on the fine levels almost
         //      every wave has SOME coincidental pair, and scanning 16 values to save one or two entries does not pay.
-        constexpr int kMinMerges = 8;
+        constexpr int kMinMerges = 8;  // (4 / 16 / 24 measured within noise of each other)
         uint32_t key[D];
 #pragma unroll
         for (int d = 0; d < D; d++) key[d] = ok ? cell.term[d][0] : 0xffffffffu - lane;
@@ -649,7 +649,6 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
             // LDS atomics on one counter serialise, so aggregate — one lane adds the population count, the others
             // take their rank from the lane mask.  Mixed buckets (hashed levels) fall back to per-lane atomics.
             const uint32_t bk = row[q][c] >> kBucketRowsLog2;
-            if (dbg & 1024) { rank[q][c] = c; continue; }
             if (lv.flags & LV_HASH) {  // workgroup-uniform: hashed level, buckets are mixed -> per-lane atomics
                 if (emit[q]) rank[q][c] = atomicAdd(&lcnt[bk], 1u);
                 continue;
@@ -674,7 +673,7 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
     if (threadIdx.x < 64) {
         static_assert(kMaxBucketsPerLevel == 64, "one bucket counter per lane of the first wave");
         const uint32_t n0 = lcnt[lane];
-        if ((uint32_t)lane < nb && n0 && !(dbg & 512)) lbase[lane] = atomicAdd(&cursor[fb + lane], n0);
+        if ((uint32_t)lane < nb && n0) lbase[lane] = atomicAdd(&cursor[fb + lane], n0);
         uint32_t incl = n0;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -692,7 +691,7 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
     //      slots (a per-lane scatter of 8-byte stores costs one cache-line transaction per lane)
 #pragma unroll
     for (int q = 0; q < PPT; q++)
-        if (emit[q] && !(dbg & 2048)) {
+        if (emit[q]) {
 #pragma unroll
             for (uint32_t c = 0; c < (uint32_t)NCORN; c++) {
                 PoolEntry<T> e;
@@ -708,7 +707,7 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
     half2_t *lvals = reinterpret_cast<half2_t *>(pool_bytes + plan.pool_off[level]);
     unsigned short *lrows = reinterpret_cast<unsigned short *>(pool_bytes + plan.rows_off[level]);
     T *gt = grad_table + (size_t)lv.offset * C;
-    const uint32_t total = (dbg & 256) ? 0 : lstart[kMaxBucketsPerLevel];
+    const uint32_t total = lstart[kMaxBucketsPerLevel];
     for (uint32_t pos = threadIdx.x; pos < total; pos += blockDim.x) {
         PoolEntry<T> e = stage[pos];
         const uint32_t bk = e.row >> kBucketRowsLog2;
@@ -756,9 +755,7 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
     const LevelParams lv = meta.lv[level];
     const uint32_t bk = bid - plan.first_bucket[level], cap = plan.cap[level];
     const uint32_t n_all = min(cursor[bid], cap);
-    const uint32_t slice_entries = (dbg & 32) ? kSliceEntries * 8 : (dbg & 128) ? kSliceEntries / 2 :
-                                   (dbg & 4096) ? kSliceEntries * 2 : (dbg & 8192) ? kSliceEntries * 4 : kSliceEntries;
-    uint32_t slices = (n_all + slice_entries - 1) / slice_entries;
+    uint32_t slices = (n_all + kSliceEntries - 1) / kSliceEntries;
     slices = slices > kMaxSlices ? kMaxSlices : slices;
     if (blockIdx.y >= slices) return;  // workgroup-uniform (also covers n_all == 0)
     const uint32_t i_begin = (uint32_t)((uint64_t)n_all * blockIdx.y / slices);
@@ -803,7 +800,7 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
                 const uint32_t rw[2] = {r[u].x, r[u].y};
 #pragma unroll
                 for (int h = 0; h < 4; h++) {
-                    if (j < nquads && e0 + h >= a_begin && e0 + h < a_end && !(dbg & 16)) {
+                    if (j < nquads && e0 + h >= a_begin && e0 + h < a_end) {
                         PoolEntry<T> e;
                         e.v = __builtin_bit_cast(half2_t, vw[h]);
                         const uint32_t row = (rw[h >> 1] >> (16 * (h & 1))) & 0xffffu;
@@ -852,7 +849,6 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
         }
     }
     __syncthreads();
-    if (dbg & 64) return;
     T *gt = grad_table + ((size_t)lv.offset + (size_t)bk * kBucketRows) * 2;
     for (uint32_t r = threadIdx.x; r < rows; r += blockDim.x) {
         const long long qa = (long long)acc[r], qb = (long long)acc[kBucketRows + r];
