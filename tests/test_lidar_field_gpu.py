@@ -50,7 +50,8 @@ def _sigma_net(seed):
     return w0, w1
 
 
-@pytest.mark.parametrize("N,Tc,Ttot,off", [(13, 64, 80, 16), (5, 768, 832, 0), (7, 16, 16, 0)])
+# (420, 768, ...): 322 560 points > one pass of the persistent grids (forward 262 144, backward 65 536 per pass)
+@pytest.mark.parametrize("N,Tc,Ttot,off", [(13, 64, 80, 16), (5, 768, 832, 0), (7, 16, 16, 0), (420, 768, 832, 64)])
 def test_density_mlp_forward_backward(N, Tc, Ttot, off):
     from gpu_util import call, dev, host
     B = N * Tc
@@ -77,7 +78,11 @@ def test_density_mlp_forward_backward(N, Tc, Ttot, off):
     gw = torch.zeros(wflat.size, dtype=torch.float32, device="cuda")
     call("lnh_density_mlp_backward", dev(gy), dev(feat), dev(wflat), B, Tc, Ttot, off, gfeat, gw)
     got_gx = host(gfeat).astype(np.float64).transpose(1, 0, 2).reshape(B, 32)
-    np.testing.assert_allclose(got_gx, gx_want, rtol=5e-3, atol=2e-3)
+    # fp16 storage of the hidden layer: a pre-activation within an fp16 ulp of 0 flips its ReLU mask, which moves a few
+    # elements in ten million beyond the bulk tolerance
+    bad = np.abs(got_gx - gx_want) > 2e-3 + 5e-3 * np.abs(gx_want)
+    assert bad.mean() < 1e-5, bad.sum()
+    np.testing.assert_allclose(got_gx, gx_want, rtol=5e-3, atol=1e-2)
     dw_want = np.concatenate([d.ravel() for d in dws])
     np.testing.assert_allclose(host(gw), dw_want, rtol=5e-3, atol=2e-3 * np.abs(dw_want).max())
 
@@ -106,7 +111,9 @@ def _color_reference(h16, perm, weights, cdir, W0g, W1, W2, g_rgb=None, g_sigma=
     return rgb.detach(), gx, [p.grad for p in params], cd.grad
 
 
-@pytest.mark.parametrize("N,T", [(8, 64), (5, 832), (3, 48)])
+# (2100, 64): more rays than resident waves (256 workgroups x 4), so waves walk SEVERAL rays — the flattened, software-
+# pipelined (ray, step) loop crosses ray boundaries (direction-term reload, per-ray S write)
+@pytest.mark.parametrize("N,T", [(8, 64), (5, 832), (3, 48), (2100, 64)])
 def test_color_head_forward_backward(N, T):
     from gpu_util import call
     g = torch.Generator().manual_seed(N + T)
