@@ -189,14 +189,16 @@ class FusedLidarRender(Function):
                   g_sigma.data_ptr(), g_rgb.data_ptr())
 
         g_h16 = torch.empty((N * Ttot, 16), dtype=torch.half, device=dev)
-        g_wcol = torch.zeros(wcol16.numel(), dtype=torch.float32, device=dev)
+        kd = enc_d16.shape[1]
+        n_col, n_sig, n_c0 = wcol16.numel(), wsig16.numel(), 64 * (kd + 15)
+        zeros = torch.zeros(n_col + n_sig + n_c0, dtype=torch.float32, device=dev)  # one fill for all small gradients
+        g_wcol, g_wsig = zeros[:n_col], zeros[n_col:n_col + n_sig]
         ray_sum = torch.empty((N, 64), dtype=torch.float32, device=dev)
         _hip.call("lnh_lidar_color_backward", g_rgb.data_ptr(), g_sigma.data_ptr(), h16.data_ptr(), perm.data_ptr(),
                   weights.data_ptr(), cdir.data_ptr(), wcol16.data_ptr(), N, Ttot, g_h16.data_ptr(), g_wcol.data_ptr(),
                   ray_sum.data_ptr())
         g_w0g = g_wcol[:64 * 16].view(64, 16)
-        kd = enc_d16.shape[1]
-        g_wc0 = torch.zeros((64, kd + 15), dtype=torch.float32, device=dev)
+        g_wc0 = zeros[n_col + n_sig:].view(64, kd + 15)
         scratch = torch.empty(((N + 31) // 32) * 64 * 128, dtype=torch.float32, device=dev)
         _hip.call("lnh_lidar_dir_term_backward", ray_sum.data_ptr(), enc_d16.data_ptr(), N, kd, scratch.data_ptr(),
                   g_wc0.data_ptr(), kd + 15)
@@ -204,7 +206,6 @@ class FusedLidarRender(Function):
         g_wc1 = g_wcol[64 * 16:64 * 16 + 64 * 64].view(64, 64)
         g_wc2 = g_wcol[64 * 16 + 64 * 64:].view(16, 64)[:2]
 
-        g_wsig = torch.zeros(wsig16.numel(), dtype=torch.float32, device=dev)
         g_table16 = torch.zeros((int(enc._offsets_host[-1]), 2), dtype=torch.half, device=dev)
         B_all = N * Ttot
         g_feat = torch.empty((enc.num_levels, B_all, 2), dtype=torch.half, device=dev)
@@ -239,11 +240,15 @@ def render_lidar(model, rays_o, rays_d, num_steps, upsample_steps, perturb):
     near = torch.tensor(float(model.min_near_lidar), dtype=torch.float32)
     far = near * 81.0
     z = torch.empty((N, num_steps), dtype=torch.float32, device=dev)
-    noise = torch.rand((N, num_steps), device=dev) if perturb else None
-    _hip.call("lnh_lidar_coarse_samples", noise.data_ptr() if perturb else None, N, num_steps, float(near), float(far),
+    # one random draw serves the stratified perturbation (first N*num_steps values) and, in training mode, the
+    # importance-sampling positions u (the rest)
+    n_noise = N * num_steps if perturb else 0
+    n_u = N * upsample_steps if model.training else 0
+    rnd = torch.rand(n_noise + n_u, device=dev) if n_noise + n_u else None
+    _hip.call("lnh_lidar_coarse_samples", rnd.data_ptr() if perturb else None, N, num_steps, float(near), float(far),
               z.data_ptr())
     if model.training:
-        u = torch.rand((N, upsample_steps), device=dev)
+        u = rnd[n_noise:].view(N, upsample_steps)
     else:
         u = torch.linspace(0.5 / upsample_steps, 1.0 - 0.5 / upsample_steps, upsample_steps,
                            device=dev).expand(N, upsample_steps).contiguous()
