@@ -205,15 +205,22 @@ k_lidar_resample(const float *__restrict__ z, const float *__restrict__ sigma, c
     const uint32_t nb = T - 1;  // number of bins (z_mid entries) = cdf entries
     const uint32_t nw = T - 2;  // number of pdf weights: weights[1:-1]
 
+    // 0) the ray's z and sigma rows into LDS with all loads in flight at once (zo[] doubles as the sigma scratch): the
+    //    scan loop below would otherwise pay one HBM round trip per 64-sample chunk, and this kernel is one wave per
+    //    ray, i.e. pure latency
+    float *sg = zo;
+#pragma unroll 4
+    for (uint32_t i = lane; i < T; i += 64) {
+        zs[i] = zr[i];
+        sg[i] = sr[i];
+    }
+    __syncthreads();
     // 1) stage-1 weights (renderer.py:180-194); keep w in cdf[] scratch (shifted: cdf[i] = w_i for i in 1..T-2)
     float carry = 1.0f, wsum = 0.0f;
     for (uint32_t base = 0; base < T; base += 64) {
         const uint32_t i = base + lane;
         float zi = 0, delta, alpha = 0.0f, om = 1.0f, e;
-        if (i < T) {
-            sample_alpha(zr, sr, i, T, sd, density_scale, zi, delta, alpha, om, e);
-            zs[i] = zi;
-        }
+        if (i < T) sample_alpha(zs, sg, i, T, sd, density_scale, zi, delta, alpha, om, e);
         const float incl = wave_scan_mul(om, lane);
         float excl = __shfl_up(incl, 1, 64);
         if (lane == 0) excl = 1.0f;
