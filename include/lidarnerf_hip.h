@@ -84,6 +84,13 @@ LNH_API int lnh_grid_encode_backward_ws(const void *grad, const float *inputs, c
                                         void *grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
                                         uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, int dtype,
                                         void *workspace, uint64_t workspace_bytes, lnh_stream_t stream);
+/* Same, restricted to the levels [level_begin, level_end): rows of other levels are not touched.  Lets a data-parallel
+ * caller hand the gradient of finished levels to the all-reduce while later levels are still being reduced. */
+LNH_API int lnh_grid_encode_backward_ws_levels(const void *grad, const float *inputs, const int32_t *offsets_host,
+                                               void *grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                                               float S, uint32_t H, uint32_t gridtype, int align_corners,
+                                               uint32_t interp, int dtype, void *workspace, uint64_t workspace_bytes,
+                                               uint32_t level_begin, uint32_t level_end, lnh_stream_t stream);
 /*
  * Replaces grad_total_variation  gridencoder.h:43-55 (gridencoder.cu:695-910): adds the TV-regulariser gradient
  * of the cells visited by `inputs` into `grad` (same layout as embeddings).

@@ -536,7 +536,8 @@ template <typename T, int D, int PPT, int NTHREADS>
 __global__ void __launch_bounds__(NTHREADS)
 k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs, T *__restrict__ grad_table,
                    uint32_t B, GridMeta meta, BucketPlan plan, PoolEntry<T> *__restrict__ pool,
-                   uint32_t *__restrict__ cursor, uint32_t align_rt, uint32_t interp_rt, uint32_t dbg, uint32_t n_levels) {
+                   uint32_t *__restrict__ cursor, uint32_t align_rt, uint32_t interp_rt, uint32_t dbg, uint32_t n_levels,
+                   uint32_t level0) {
     constexpr int C = 2, NCORN = 1 << D;
     __shared__ uint2 lout[kMaxBucketsPerLevel];           // per bucket: {pool slot - staging slot, staging slots that fit}
     __shared__ uint32_t lcnt[kMaxBucketsPerLevel];
@@ -548,7 +549,7 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
     // (A persistent-workgroup variant of this kernel was measured 1.5x SLOWER: the hardware dispatcher overlaps the
     // phases of independent workgroups better than a barrier-separated item loop does.)
     const int lane = threadIdx.x & 63;
-    const uint32_t level = blockIdx.x % n_levels, chunk = blockIdx.x / n_levels;
+    const uint32_t level = level0 + blockIdx.x % n_levels, chunk = blockIdx.x / n_levels;  // window [level0, +n_levels)
     const LevelParams lv_rt = meta.lv[level];
     const uint32_t fb = plan.first_bucket[level], nb = plan.first_bucket[level + 1] - fb, cap = plan.cap[level];
     // level class resolved at compile time for the two usual classes (see k_grid_forward)
@@ -743,12 +744,12 @@ constexpr uint32_t kMaxSlices = 16;
 template <typename T>
 __global__ void __launch_bounds__(1024)
 k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, const PoolEntry<T> *__restrict__ pool,
-                  const uint32_t *__restrict__ cursor, uint32_t L, uint32_t dbg) {
+                  const uint32_t *__restrict__ cursor, uint32_t L, uint32_t dbg, uint32_t bucket0) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     unsigned long long *acc = reinterpret_cast<unsigned long long *>(smem_raw);  // [kBucketRows][2] fixed point
     // fp16 contributions are exact multiples of 2^-24; fp32 ones get 2^-40 resolution and +-8e6 of range
     constexpr int K = sizeof(T) == 2 ? 24 : 40;
-    const uint32_t bid = blockIdx.x;
+    const uint32_t bid = bucket0 + blockIdx.x;
     uint32_t level = 0;
     for (uint32_t l = 0; l < L; l++)
         if (bid >= plan.first_bucket[l]) level = l;
@@ -902,7 +903,9 @@ uint64_t plan_buckets(BucketPlan &plan, const GridMeta &m, uint32_t L, uint32_t 
 template <typename T>
 int launch_backward_bucketed(const T *grad, const float *inputs, T *ge, uint32_t B, uint32_t L, const GridMeta &m,
                              uint32_t align, uint32_t interp, void *workspace, uint64_t workspace_bytes,
-                             hipStream_t s) {
+                             hipStream_t s, uint32_t level_begin = 0, uint32_t level_end = 0xffffffffu) {
+    if (level_end > L) level_end = L;
+    if (level_begin >= level_end) return LNH_OK;
     BucketPlan plan;
     uint32_t nbt = 0;
     const uint64_t need = plan_buckets<T>(plan, m, L, B, 3, nbt);
@@ -932,8 +935,9 @@ int launch_backward_bucketed(const T *grad, const float *inputs, T *ge, uint32_t
     // 1024 threads x 1 point: the per-workgroup cost that matters is the one returning device atomic per touched
     // bucket (measured: 256- and 512-thread workgroups are 2.3x / 1.5x slower), and 8 entries/thread keep the LDS
     // staging buffer at 64 KiB (two workgroups per CU)
-    LNH_LAUNCH((k_grid_bwd_scatter<T, 3, 1, 1024>), dim3(div_up(B, 1024) * L), dim3(1024), 0, s, grad, inputs, ge, B, m,
-               plan, pool, cursor, align, interp, g_dbg_flags, L);
+    const uint32_t n_win = level_end - level_begin;
+    LNH_LAUNCH((k_grid_bwd_scatter<T, 3, 1, 1024>), dim3(div_up(B, 1024) * n_win), dim3(1024), 0, s, grad, inputs, ge, B,
+               m, plan, pool, cursor, align, interp, g_dbg_flags, n_win, level_begin);
     int rc = lnh_check_launch("lnh_grid_encode_backward_ws(scatter)");
     if (rc) return rc;
     auto k = k_grid_bwd_reduce<T>;
@@ -943,7 +947,8 @@ int launch_backward_bucketed(const T *grad, const float *inputs, T *ge, uint32_t
         (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    LNH_LAUNCH(k, dim3(nbt, kMaxSlices), dim3(1024), lds, s, ge, m, plan, pool, cursor, L, g_dbg_flags);
+    const uint32_t b0 = plan.first_bucket[level_begin], b1 = plan.first_bucket[level_end];
+    LNH_LAUNCH(k, dim3(b1 - b0, kMaxSlices), dim3(1024), lds, s, ge, m, plan, pool, cursor, L, g_dbg_flags, b0);
     return lnh_check_launch("lnh_grid_encode_backward_ws(reduce)");
 }
 
@@ -1274,6 +1279,32 @@ int lnh_grid_encode_backward_ws(const void *grad, const float *inputs, const int
                                                align_corners != 0, interp, workspace, workspace_bytes, s);
     return launch_backward_bucketed<half_t>((const half_t *)grad, inputs, (half_t *)grad_embeddings, B, L, m,
                                             align_corners != 0, interp, workspace, workspace_bytes, s);
+}
+
+int lnh_grid_encode_backward_ws_levels(const void *grad, const float *inputs, const int32_t *offsets_host,
+                                       void *grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                       uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, int dtype,
+                                       void *workspace, uint64_t workspace_bytes, uint32_t level_begin,
+                                       uint32_t level_end, lnh_stream_t stream) {
+    int rc = check_common(inputs, offsets_host, B, D, C, L, dtype);
+    if (rc) return rc;
+    LNH_REQUIRE(grad && grad_embeddings, LNH_ERR_INVALID_ARG, "grid backward: null grad/grad_embeddings");
+    LNH_REQUIRE(D == 3 && C == 2, LNH_ERR_UNSUPPORTED,
+                "grid backward (bucketed): only D == 3, C == 2 (use lnh_grid_encode_backward otherwise)");
+    LNH_REQUIRE(level_begin <= level_end && level_end <= L, LNH_ERR_INVALID_ARG,
+                "grid backward: need level_begin <= level_end <= L");
+    if (B == 0) return LNH_OK;
+    GridMeta m;
+    LNH_REQUIRE(build_meta(m, offsets_host, D, L, S, H, gridtype, align_corners != 0) == 0, LNH_ERR_INVALID_ARG,
+                "grid: offsets must be increasing and non-negative");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == LNH_F32)
+        return launch_backward_bucketed<float>((const float *)grad, inputs, (float *)grad_embeddings, B, L, m,
+                                               align_corners != 0, interp, workspace, workspace_bytes, s, level_begin,
+                                               level_end);
+    return launch_backward_bucketed<half_t>((const half_t *)grad, inputs, (half_t *)grad_embeddings, B, L, m,
+                                            align_corners != 0, interp, workspace, workspace_bytes, s, level_begin,
+                                            level_end);
 }
 
 int lnh_grad_total_variation(const void *inputs, const void *embeddings, void *grad, const int32_t *offsets_host,

@@ -76,6 +76,31 @@ def _grid_bwd(g_feat, x01, g_table16, enc, B):
               B, 3, 2, L, enc.log2_scale, enc.base_resolution, 0, 0, 0, _hip.LNH_F16, ws.data_ptr(), ws.numel(), tag=B)
 
 
+# Data parallel: level windows of the table gradient.  The gradient of a window is final as soon as its scatter + reduce
+# pair has run, so its all-reduce (fp16, RCCL's own stream) overlaps with the kernels of the following windows; only the
+# last window's ~23 % of the 27 MB stays exposed.  Windows are cut so that each holds a similar number of pool entries.
+_DP_LEVEL_WINDOWS = ((0, 7), (7, 10), (10, 13), (13, 16))
+
+
+def _grid_bwd_overlapped(g_feat, x01, g_table16, enc, B, table_param):
+    """_grid_bwd + parallel.allreduce_half_table, pipelined over level windows.  Returns the handles to wait on."""
+    L = enc.num_levels
+    off = enc._offsets_host
+    need = _hip.lib().lnh_grid_backward_workspace_size(off.data_ptr(), B, 3, 2, L, enc.log2_scale,
+                                                       enc.base_resolution, 0, 0, _hip.LNH_F16)
+    ws = _workspace(g_feat.device, need)
+    windows = _DP_LEVEL_WINDOWS if L == 16 else ((0, L),)
+    handles = []
+    for l0, l1 in windows:
+        _hip.call("lnh_grid_encode_backward_ws_levels", g_feat.data_ptr(), x01.data_ptr(), off.data_ptr(),
+                  g_table16.data_ptr(), B, 3, 2, L, enc.log2_scale, enc.base_resolution, 0, 0, 0, _hip.LNH_F16,
+                  ws.data_ptr(), ws.numel(), l0, l1)
+        h = parallel.allreduce_half_table(g_table16[int(off[l0]):int(off[l1])], table_param)
+        if h is not None:
+            handles.append(h)
+    return handles
+
+
 def _no_autocast(fn):
     """The kernel chain manages precision itself: run the glue ops (casts, the tiny per-ray GEMMs) with autocast off,
     otherwise fp32 operands of a matmul silently become fp16 tensors handed to kernels that expect fp32."""
@@ -211,12 +236,13 @@ class FusedLidarRender(Function):
         g_feat = torch.empty((enc.num_levels, B_all, 2), dtype=torch.half, device=dev)
         _hip.call("lnh_density_mlp_backward", g_h16.data_ptr(), feat.data_ptr(), wsig16.data_ptr(), B_all, Ttot, Ttot, 0,
                   g_feat.data_ptr(), g_wsig.data_ptr())
-        _grid_bwd(g_feat, x01, g_table16, enc, B_all)
-
-        # data parallel: the table gradient goes on the wire as fp16, overlapped with nothing else left to do here
-        handle = parallel.allreduce_half_table(g_table16, ctx.table_param)
-        if handle is not None:
-            handle.wait()
+        if parallel.world_size() > 1:
+            # data parallel: the table gradient goes on the wire as fp16, window by window, behind the kernels of the
+            # following windows
+            for handle in _grid_bwd_overlapped(g_feat, x01, g_table16, enc, B_all, ctx.table_param):
+                handle.wait()
+        else:
+            _grid_bwd(g_feat, x01, g_table16, enc, B_all)
         dts = ctx.param_dtypes
         if getattr(ctx.table_param, "_lnh_keep_grad16", False):
             # the fused table optimizer consumes the fp16 gradient directly: no fp32 copy, no .grad on the table

@@ -179,6 +179,38 @@ def test_backward_bucketed(dt, kind):
         call("lnh_grid_encode_backward_ws", dev(g), dev(x), offh, ge, B, 3, CH, L, S, H, 0, 0, 0, code, ws, 1024)
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16])
+def test_backward_bucketed_level_windows(dt):
+    """lnh_grid_encode_backward_ws_levels over consecutive windows == the one-shot call, bit for bit (the bucketed sum
+    is order-independent), and a window leaves the rows of the other levels alone."""
+    from gpu_util import call, dev
+    from lidarnerf import _hip
+    x = _ray_points(40, 256, 3)
+    B = x.shape[0]
+    nd = np.float32 if dt == torch.float32 else np.float16
+    g = (np.random.default_rng(4).standard_normal((L, B, CH)) * 0.1).astype(nd)
+    rows = int(OFF[-1])
+    code = 0 if dt == torch.float32 else 1
+    offh = torch.from_numpy(OFF)
+    need = _hip.lib().lnh_grid_backward_workspace_size(offh.data_ptr(), B, 3, CH, L, S, H, 0, 0, code)
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    full = torch.zeros((rows, CH), dtype=dt, device="cuda")
+    call("lnh_grid_encode_backward_ws", dev(g), dev(x), offh, full, B, 3, CH, L, S, H, 0, 0, 0, code, ws, need)
+    part = torch.zeros((rows, CH), dtype=dt, device="cuda")
+    gd, xd = dev(g), dev(x)
+    windows = [(0, 7), (7, 10), (10, 13), (13, L)] if L == 16 else [(0, L // 2), (L // 2, L)]
+    for k, (l0, l1) in enumerate(windows):
+        call("lnh_grid_encode_backward_ws_levels", gd, xd, offh, part, B, 3, CH, L, S, H, 0, 0, 0, code, ws, need, l0, l1)
+        done = int(OFF[l1])
+        assert torch.equal(part[:done], full[:done])
+        assert float(part[done:].abs().max()) == 0.0 if done < rows else True
+    assert torch.equal(part, full)
+    call("lnh_grid_encode_backward_ws_levels", gd, xd, offh, part, B, 3, CH, L, S, H, 0, 0, 0, code, ws, need, 5, 5)  # empty
+    assert torch.equal(part, full)
+    with pytest.raises(RuntimeError, match="level_begin"):
+        call("lnh_grid_encode_backward_ws_levels", gd, xd, offh, part, B, 3, CH, L, S, H, 0, 0, 0, code, ws, need, 3, L + 1)
+
+
 def test_backward_full_size_checksum():
     """Full BASELINE size: sum of the gradient table == sum of upstream grads (weights of a cell sum to 1)."""
     from gpu_util import call
