@@ -210,6 +210,26 @@ def main():
                      "avg_launch_us": k["avg_us"]},
         "kernels": kernels,
     }
+    # secondary number of SURVEY §8(d): full-frame evaluation (67 980 rays of a 66 x 1030 range image, staged in
+    # chunks of 4096, no perturbation, no gradient) — reported beside the headline metric, never instead of it
+    if world == 1:
+        model.eval()
+        frame = make_batch(poses, 0, 66 * 1030, rank, device)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            for _ in range(2):
+                model.render(frame[0], frame[1], cal_lidar_color=True, staged=True, max_ray_batch=4096, perturb=False,
+                             num_steps=NUM_STEPS, upsample_steps=UPSAMPLE)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                model.render(frame[0], frame[1], cal_lidar_color=True, staged=True, max_ray_batch=4096, perturb=False,
+                             num_steps=NUM_STEPS, upsample_steps=UPSAMPLE)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / reps
+        result["eval"] = {"metric": "full-frame eval rays/sec (66x1030, staged 4096)", "value": round(66 * 1030 / dt, 1),
+                          "unit": "rays/s", "ms_per_frame": round(1e3 * dt, 3)}
+        model.train()
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
     print(json.dumps(result))
