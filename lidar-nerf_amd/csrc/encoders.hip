@@ -8,6 +8,7 @@
 // SH: the 16 real-SH polynomials of degree <= 4 (shencoder.cu:53-89) evaluated on the RAW direction, plus the
 //   analytic Jacobian (shencoder.cu:281-831 restated by differentiating the same polynomials).
 #include "common.h"
+#include "sh_tables.h"
 
 namespace {
 
@@ -112,6 +113,53 @@ k_sh_forward(const float *__restrict__ inputs, float *__restrict__ outputs, uint
     }
 }
 
+// Degrees 5..8 (shencoder.cu:90-300): the same functions, evaluated from their structure instead of 64 unrolled
+// expressions — Y_l^m = Q_lm(z) * Re/Im (x + iy)^|m| with the polynomial coefficients of sh_tables.h (generated with
+// exact arithmetic by gen_sh_tables.py).  Identical polynomials in (x, y, z) as the reference's, also off the unit sphere.
+template <bool DYDX>
+__global__ void __launch_bounds__(256)
+k_sh_forward_generic(const float *__restrict__ inputs, float *__restrict__ outputs, uint32_t B, uint32_t degree,
+                     float *__restrict__ dy_dx) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t C2 = degree * degree;
+    const float x = inputs[(size_t)b * 3], y = inputs[(size_t)b * 3 + 1], z = inputs[(size_t)b * 3 + 2];
+    float A[kShLMax], Bm[kShLMax], zp[kShLMax];  // Re / Im of (x+iy)^m, z^k
+    A[0] = 1.0f; Bm[0] = 0.0f; zp[0] = 1.0f;
+#pragma unroll
+    for (int m = 1; m < kShLMax; m++) {
+        A[m] = x * A[m - 1] - y * Bm[m - 1];
+        Bm[m] = x * Bm[m - 1] + y * A[m - 1];
+        zp[m] = zp[m - 1] * z;
+    }
+    float *out = outputs + (size_t)b * C2;
+    float *d0 = DYDX ? dy_dx + (size_t)b * 3 * C2 : nullptr;
+    for (uint32_t l = 0; l < degree; l++) {
+        for (uint32_t am = 0; am <= l; am++) {
+            float q = 0.0f, dq = 0.0f;
+            for (uint32_t k = 0; k + am <= l; k++) {
+                const float c = kShQ[l][am][k];
+                q = fmaf(c, zp[k], q);
+                if (k) dq = fmaf(c * (float)k, zp[k - 1], dq);
+            }
+            const float fm = (float)am;
+            if (am == 0) {
+                const uint32_t i = l * l + l;
+                out[i] = q;
+                if constexpr (DYDX) { d0[i] = 0.0f; d0[C2 + i] = 0.0f; d0[2 * C2 + i] = dq; }
+            } else {
+                const uint32_t ip = l * l + l + am, in = l * l + l - am;  // m = +am (cosine-like), m = -am (sine-like)
+                out[ip] = q * A[am];
+                out[in] = q * Bm[am];
+                if constexpr (DYDX) {
+                    d0[ip] = q * fm * A[am - 1];  d0[C2 + ip] = -q * fm * Bm[am - 1]; d0[2 * C2 + ip] = dq * A[am];
+                    d0[in] = q * fm * Bm[am - 1]; d0[C2 + in] = q * fm * A[am - 1];   d0[2 * C2 + in] = dq * Bm[am];
+                }
+            }
+        }
+    }
+}
+
 // shencoder.cu:834-858 (accumulates into grad_inputs, which the caller zero-initialises)
 __global__ void __launch_bounds__(256)
 k_sh_backward(const float *__restrict__ grad, uint32_t B, uint32_t D, uint32_t degree,
@@ -156,11 +204,16 @@ int lnh_sh_encode_forward(const float *inputs, float *outputs, uint32_t B, uint3
                           lnh_stream_t stream) {
     LNH_REQUIRE(inputs && outputs, LNH_ERR_INVALID_ARG, "sh forward: null pointer");
     LNH_REQUIRE(D == 3, LNH_ERR_UNSUPPORTED, "SH encoder only support input dim == 3 (got %u)", D);
-    LNH_REQUIRE(degree >= 1 && degree <= 4, LNH_ERR_UNSUPPORTED,
-                "SH encoder: this build carries degree 1..4 (reference: 1..8), got %u", degree);
+    LNH_REQUIRE(degree >= 1 && degree <= 8, LNH_ERR_UNSUPPORTED, "SH encoder only supports degree in [1, 8] (got %u)",
+                degree);
     if (B == 0) return LNH_OK;
     dim3 grid(div_up(B, 256)), block(256);
-    if (dy_dx)
+    if (degree > 4) {
+        if (dy_dx)
+            LNH_LAUNCH(k_sh_forward_generic<true>, grid, block, 0, (hipStream_t)stream, inputs, outputs, B, degree, dy_dx);
+        else
+            LNH_LAUNCH(k_sh_forward_generic<false>, grid, block, 0, (hipStream_t)stream, inputs, outputs, B, degree, dy_dx);
+    } else if (dy_dx)
         LNH_LAUNCH(k_sh_forward<true>, grid, block, 0, (hipStream_t)stream, inputs, outputs, B, degree, dy_dx);
     else
         LNH_LAUNCH(k_sh_forward<false>, grid, block, 0, (hipStream_t)stream, inputs, outputs, B, degree, dy_dx);
@@ -171,7 +224,7 @@ int lnh_sh_encode_backward(const float *grad, const float *inputs, uint32_t B, u
                            const float *dy_dx, float *grad_inputs, lnh_stream_t stream) {
     (void)inputs;
     LNH_REQUIRE(grad && dy_dx && grad_inputs, LNH_ERR_INVALID_ARG, "sh backward: null pointer");
-    LNH_REQUIRE(D == 3 && degree >= 1 && degree <= 4, LNH_ERR_UNSUPPORTED, "sh backward: D must be 3, degree 1..4");
+    LNH_REQUIRE(D == 3 && degree >= 1 && degree <= 8, LNH_ERR_UNSUPPORTED, "sh backward: D must be 3, degree 1..8");
     if (B == 0) return LNH_OK;
     LNH_LAUNCH(k_sh_backward, dim3(div_up((uint64_t)B * D, 256)), dim3(256), 0, (hipStream_t)stream, grad, B, D,
                        degree, dy_dx, grad_inputs);

@@ -127,3 +127,42 @@ def trunc_exp_backward(g, x):
     """activation.py:17-19: g * exp(clamp(x, -15, 15))."""
     x = np.clip(np.asarray(x, dtype=np.float32), -15, 15)
     return (np.asarray(g, dtype=np.float32) * np.exp(x.astype(np.float64))).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------- SH, degree 1..8
+def sh_forward_any(d, degree):
+    """Real spherical harmonics of shencoder.cu:53-300 for degree 1..8 in float64, from their structure:
+    Y_l^m = N_lm * d^|m|/dz^|m| P_l(z) * {Re, Im}(x + iy)^|m|  (Condon-Shortley sign, index l*l + l + m) — the same
+    polynomials in the RAW (x, y, z) as the reference's unrolled expressions.  Cross-checked against the explicit
+    degree <= 4 table above and against scipy's complex harmonics on the unit sphere (tests/test_oracle_cross.py)."""
+    from math import factorial, pi, sqrt
+    from numpy.polynomial import legendre as npl
+    from numpy.polynomial import polynomial as npp
+    assert 1 <= degree <= 8
+    d = np.asarray(d, dtype=np.float64)
+    x, y, z = d[:, 0], d[:, 1], d[:, 2]
+    w = (x + 1j * y)
+    out = np.empty((d.shape[0], degree * degree))
+    for l in range(degree):
+        p = npl.leg2poly([0] * l + [1])                      # P_l as an ordinary polynomial in z
+        for m in range(0, l + 1):
+            q = npp.polyval(z, npp.polyder(p, m) if m else p)
+            if m == 0:
+                out[:, l * l + l] = sqrt((2 * l + 1) / (4 * pi)) * q
+            else:
+                n = (-1) ** m * sqrt(2.0) * sqrt((2 * l + 1) / (4 * pi) * factorial(l - m) / factorial(l + m))
+                wm = w ** m
+                out[:, l * l + l + m] = n * q * wm.real
+                out[:, l * l + l - m] = n * q * wm.imag
+    return out
+
+
+def sh_jacobian_fd_any(d, degree, eps=1e-4):
+    d = np.asarray(d, dtype=np.float64)
+    J = np.empty((d.shape[0], 3, degree * degree))
+    for k in range(3):
+        dp, dm = d.copy(), d.copy()
+        dp[:, k] += eps
+        dm[:, k] -= eps
+        J[:, k] = (sh_forward_any(dp, degree) - sh_forward_any(dm, degree)) / (2 * eps)
+    return J

@@ -155,3 +155,22 @@ def test_march_rays_train_properties():
         want = 1 - np.exp(-3.0 * deltas[s:s + k, 0].astype(np.float64).sum())
         assert abs(ws[n] - want) < 1e-4
         assert abs(img[n, 0] - 0.5 * want) < 1e-4
+
+
+def test_sh_structure_form_matches_explicit_table_and_scipy():
+    """oracle/encoders_ref.sh_forward_any (degree 1..8, from the structure of the harmonics) vs the explicit degree <= 4
+    restatement of shencoder.cu:53-89 on raw directions, and vs scipy's complex harmonics on the unit sphere."""
+    import numpy as np
+    from scipy.special import sph_harm_y
+    from oracle import encoders_ref as e
+    d = np.random.default_rng(0).normal(size=(300, 3))
+    for deg in (1, 2, 3, 4):
+        np.testing.assert_allclose(e.sh_forward_any(d, deg), e.sh_forward(d.astype(np.float32), deg), rtol=1e-5, atol=3e-6)
+    u = d / np.linalg.norm(d, axis=1, keepdims=True)
+    theta, phi = np.arccos(u[:, 2]), np.arctan2(u[:, 1], u[:, 0])
+    Y = e.sh_forward_any(u, 8)
+    for l in range(8):
+        for m in range(-l, l + 1):
+            c = sph_harm_y(l, abs(m), theta, phi)
+            ref = c.real if m == 0 else np.sqrt(2) * (c.real if m > 0 else c.imag)
+            np.testing.assert_allclose(Y[:, l * l + l + m], ref, rtol=0, atol=1e-12)
