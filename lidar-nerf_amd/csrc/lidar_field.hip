@@ -154,7 +154,7 @@ k_color_forward(ColorArgs a) {
             half8_t bh[HS];
 #pragma unroll
             for (int s = 0; s < HS; s++)
-                bh[s] = pack_pair(acc[2 * s], acc[2 * s + 1], [](float v) { return v > 0.0f ? v : 0.0f; });
+                bh[s] = pack_pair_relu(acc[2 * s], acc[2 * s + 1]);
 #pragma unroll
             for (int t = 0; t < HT; t++) {
                 acc[t] = zero_f4();
@@ -163,7 +163,7 @@ k_color_forward(ColorArgs a) {
             }
 #pragma unroll
             for (int s = 0; s < HS; s++)
-                bh[s] = pack_pair(acc[2 * s], acc[2 * s + 1], [](float v) { return v > 0.0f ? v : 0.0f; });
+                bh[s] = pack_pair_relu(acc[2 * s], acc[2 * s + 1]);
             f32x4 o = zero_f4();
 #pragma unroll
             for (int s = 0; s < HS; s++) o = MFMA16(w2[s], bh[s], o);
@@ -327,7 +327,7 @@ k_color_backward_wi(ColorArgs a) {
                 for (int t = 0; t < HT; t++) acc[t] = MFMA16(WF(F_W0 + t), bx[n], cb[t]);
 #pragma unroll
                 for (int s = 0; s < HS; s++)
-                    bh0[n][s] = pack_pair(acc[2 * s], acc[2 * s + 1], [](float v) { return v > 0.0f ? v : 0.0f; });
+                    bh0[n][s] = pack_pair_relu(acc[2 * s], acc[2 * s + 1]);
 #pragma unroll
                 for (int t = 0; t < HT; t++) {
                     acc[t] = zero_f4();
@@ -336,7 +336,7 @@ k_color_backward_wi(ColorArgs a) {
                 }
 #pragma unroll
                 for (int s = 0; s < HS; s++)
-                    bh1[n][s] = pack_pair(acc[2 * s], acc[2 * s + 1], [](float v) { return v > 0.0f ? v : 0.0f; });
+                    bh1[n][s] = pack_pair_relu(acc[2 * s], acc[2 * s + 1]);
                 f32x4 o = zero_f4();
 #pragma unroll
                 for (int s = 0; s < HS; s++) o = MFMA16(WF(F_W2 + s), bh1[n][s], o);

@@ -94,7 +94,7 @@ k_mlp_forward(MlpArgs a) {
             for (int n = 0; n < NT; n++)
 #pragma unroll
                 for (int s = 0; s < HS; s++)
-                    bh[n][s] = pack_pair(acc[2 * s][n], acc[2 * s + 1][n], [&](float v) { return act_fwd<ACT>(act, v); });
+                    bh[n][s] = pack_pair_act<ACT>(acc[2 * s][n], acc[2 * s + 1][n], act);
         }
         auto save_hidden = [&](int layer) {
             if (!a.fb) return;
@@ -129,7 +129,7 @@ k_mlp_forward(MlpArgs a) {
             for (int n = 0; n < NT; n++)
 #pragma unroll
                 for (int s = 0; s < HS; s++)
-                    bh[n][s] = pack_pair(acc[2 * s][n], acc[2 * s + 1][n], [&](float v) { return act_fwd<ACT>(act, v); });
+                    bh[n][s] = pack_pair_act<ACT>(acc[2 * s][n], acc[2 * s + 1][n], act);
             save_hidden(m + 1);
         }
         // ---- output layer (16 padded outputs)

@@ -147,7 +147,7 @@ k_mlp_backward(MlpBwdArgs a) {
             }
 #pragma unroll
             for (int s = 0; s < HS; s++)
-                bh[0][n][s] = pack_pair(acc[2 * s], acc[2 * s + 1], [&](float v) { return act_fwd<ACT>(act, v); });
+                bh[0][n][s] = pack_pair_act<ACT>(acc[2 * s], acc[2 * s + 1], act);
         }
 #pragma unroll
         for (int m = 0; m < NHM; m++)
@@ -162,7 +162,7 @@ k_mlp_backward(MlpBwdArgs a) {
                 }
 #pragma unroll
                 for (int s = 0; s < HS; s++)
-                    bh[m + 1][n][s] = pack_pair(acc[2 * s], acc[2 * s + 1], [&](float v) { return act_fwd<ACT>(act, v); });
+                    bh[m + 1][n][s] = pack_pair_act<ACT>(acc[2 * s], acc[2 * s + 1], act);
             }
 
         // ---- output matrix: dWo[o][i] += sum_p dY[p][o] h_last[p][i]
