@@ -351,12 +351,7 @@ k_color_backward_wi(ColorArgs a) {
 #pragma unroll
                 for (int t = 0; t < HT; t++) d[t] = MFMA16(WF(F_W2T + t), by[n], zero_f4());
 #pragma unroll
-                for (int s = 0; s < HS; s++)
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        bd1[n][s][j] = (float)bh1[n][s][j] > 0.0f ? (half_t)d[2 * s][j] : (half_t)0.0f;
-                        bd1[n][s][4 + j] = (float)bh1[n][s][4 + j] > 0.0f ? (half_t)d[2 * s + 1][j] : (half_t)0.0f;
-                    }
+                for (int s = 0; s < HS; s++) bd1[n][s] = pack_pair_relu_bwd(d[2 * s], d[2 * s + 1], bh1[n][s]);
 #pragma unroll
                 for (int t = 0; t < HT; t++) {
                     d[t] = zero_f4();
@@ -364,12 +359,7 @@ k_color_backward_wi(ColorArgs a) {
                     for (int s = 0; s < HS; s++) d[t] = MFMA16(WF(F_W1T + 2 * t + s), bd1[n][s], d[t]);
                 }
 #pragma unroll
-                for (int s = 0; s < HS; s++)
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        bd0[n][s][j] = (float)bh0[n][s][j] > 0.0f ? (half_t)d[2 * s][j] : (half_t)0.0f;
-                        bd0[n][s][4 + j] = (float)bh0[n][s][4 + j] > 0.0f ? (half_t)d[2 * s + 1][j] : (half_t)0.0f;
-                    }
+                for (int s = 0; s < HS; s++) bd0[n][s] = pack_pair_relu_bwd(d[2 * s], d[2 * s + 1], bh0[n][s]);
                 // d(sigma-net row) = W0g^T dH0, col 0 <- trunc_exp backward of the compositing gradient
                 f32x4 dx = zero_f4();
 #pragma unroll

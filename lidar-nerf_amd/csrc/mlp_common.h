@@ -134,6 +134,25 @@ __device__ __forceinline__ half8_t pack_pair_relu(const f32x4 &lo, const f32x4 &
     const half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
     return __builtin_elementwise_max(r, z);
 }
+// ReLU backward on packed halves: narrow(d) where the stored (non-negative, never -0) activation h is non-zero, else 0.
+// Three packed integer ops per PAIR of values: nz = min(bits(h), 1) per half, m = 0 - nz (0 / 0xffff), d & m.
+__device__ __forceinline__ half8_t pack_pair_relu_bwd(const f32x4 &lo, const f32x4 &hi, const half8_t &h) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const h4 a = __builtin_convertvector(lo, h4), b = __builtin_convertvector(hi, h4);
+    const half8_t d = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    u4 dw = __builtin_bit_cast(u4, d);
+    const u4 hw = __builtin_bit_cast(u4, h);
+    const uint32_t ones = 0x00010001u;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint32_t nz, m;
+        asm("v_pk_min_u16 %0, %1, %2" : "=v"(nz) : "v"(hw[i]), "v"(ones));
+        asm("v_pk_sub_i16 %0, 0, %1" : "=v"(m) : "v"(nz));
+        dw[i] &= m;
+    }
+    return __builtin_bit_cast(half8_t, dw);
+}
 // activation resolved at compile time: ReLU takes the packed path, everything else the generic one
 template <int ACT>
 __device__ __forceinline__ half8_t pack_pair_act(const f32x4 &lo, const f32x4 &hi, uint32_t act_rt) {
