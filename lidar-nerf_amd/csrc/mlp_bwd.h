@@ -189,12 +189,17 @@ k_mlp_backward(MlpBwdArgs a) {
 #pragma unroll
             for (int t = 0; t < HT; t++) acc[t] = MFMA16(woT[t], by[n], zero_f4());
 #pragma unroll
-            for (int s = 0; s < HS; s++)
+            for (int s = 0; s < HS; s++) {
+                if constexpr (ACT == (int)LNH_ACT_RELU) {
+                    bd[n][s] = pack_pair_relu_bwd(acc[2 * s], acc[2 * s + 1], bh[NHM][n][s]);
+                } else {
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    bd[n][s][j] = (half_t)act_bwd<ACT>(act, acc[2 * s][j], (float)bh[NHM][n][s][j]);
-                    bd[n][s][4 + j] = (half_t)act_bwd<ACT>(act, acc[2 * s + 1][j], (float)bh[NHM][n][s][4 + j]);
+                    for (int j = 0; j < 4; j++) {
+                        bd[n][s][j] = (half_t)act_bwd<ACT>(act, acc[2 * s][j], (float)bh[NHM][n][s][j]);
+                        bd[n][s][4 + j] = (half_t)act_bwd<ACT>(act, acc[2 * s + 1][j], (float)bh[NHM][n][s][4 + j]);
+                    }
                 }
+            }
         }
         // ---- hidden matrices, last to first
 #pragma unroll
@@ -218,12 +223,17 @@ k_mlp_backward(MlpBwdArgs a) {
                     for (int s = 0; s < HS; s++) acc[t] = MFMA16(whT[m][t][s], bd[n][s], acc[t]);
                 }
 #pragma unroll
-                for (int s = 0; s < HS; s++)
+                for (int s = 0; s < HS; s++) {
+                    if constexpr (ACT == (int)LNH_ACT_RELU) {
+                        bd[n][s] = pack_pair_relu_bwd(acc[2 * s], acc[2 * s + 1], bh[m][n][s]);
+                    } else {
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        bd[n][s][j] = (half_t)act_bwd<ACT>(act, acc[2 * s][j], (float)bh[m][n][s][j]);
-                        bd[n][s][4 + j] = (half_t)act_bwd<ACT>(act, acc[2 * s + 1][j], (float)bh[m][n][s][4 + j]);
+                        for (int j = 0; j < 4; j++) {
+                            bd[n][s][j] = (half_t)act_bwd<ACT>(act, acc[2 * s][j], (float)bh[m][n][s][j]);
+                            bd[n][s][4 + j] = (half_t)act_bwd<ACT>(act, acc[2 * s + 1][j], (float)bh[m][n][s][4 + j]);
+                        }
                     }
+                }
             }
         }
         // ---- first matrix: dW0[o][i] += sum_p dH_0[p][o] x[p][i]
@@ -376,14 +386,19 @@ k_mlp_backward_wi(MlpBwdArgs a) {
                 d[t] = MFMA16(woT[t], by[n], zero_f4());
             }
 #pragma unroll
-            for (int s = 0; s < HS; s++)
+            for (int s = 0; s < HS; s++) {
+                if constexpr (ACT == (int)LNH_ACT_RELU) {
+                    bd[n][s] = pack_pair_relu_bwd(d[2 * s], d[2 * s + 1], pack_pair_relu(h[2 * s], h[2 * s + 1]));
+                } else {
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const float p0 = (float)(half_t)act_fwd<ACT>(act, h[2 * s][j]);
-                    const float p1 = (float)(half_t)act_fwd<ACT>(act, h[2 * s + 1][j]);
-                    bd[n][s][j] = (half_t)act_bwd<ACT>(act, d[2 * s][j], p0);
-                    bd[n][s][4 + j] = (half_t)act_bwd<ACT>(act, d[2 * s + 1][j], p1);
+                    for (int j = 0; j < 4; j++) {
+                        const float p0 = (float)(half_t)act_fwd<ACT>(act, h[2 * s][j]);
+                        const float p1 = (float)(half_t)act_fwd<ACT>(act, h[2 * s + 1][j]);
+                        bd[n][s][j] = (half_t)act_bwd<ACT>(act, d[2 * s][j], p0);
+                        bd[n][s][4 + j] = (half_t)act_bwd<ACT>(act, d[2 * s + 1][j], p1);
+                    }
                 }
+            }
             if (want_dx) {
                 const uint64_t p = base + n * 16 + c;
 #pragma unroll
@@ -417,14 +432,23 @@ k_mlp_backward_wi(MlpBwdArgs a) {
 #pragma unroll
                 for (int s = 0; s < IN_KS; s++) h_pm[n] = MFMA16(bx[n][s], w0[t][s], h_pm[n]);  // D[point][channel 16t+c]
                 d_pm[n] = MFMA16(by[n], woT[t], zero_f4());
+                if constexpr (ACT != (int)LNH_ACT_RELU) {
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const float post = (float)(half_t)act_fwd<ACT>(act, h_pm[n][r]);
-                    h_pm[n][r] = post;
-                    d_pm[n][r] = act_bwd<ACT>(act, d_pm[n][r], post);
+                    for (int r = 0; r < 4; r++) {
+                        const float post = (float)(half_t)act_fwd<ACT>(act, h_pm[n][r]);
+                        h_pm[n][r] = post;
+                        d_pm[n][r] = act_bwd<ACT>(act, d_pm[n][r], post);
+                    }
                 }
             }
-            const half8_t fh = pack2(h_pm[0], h_pm[1]), fd = pack2(d_pm[0], d_pm[1]);
+            half8_t fh, fd;
+            if constexpr (ACT == (int)LNH_ACT_RELU) {
+                fh = pack_pair_relu(h_pm[0], h_pm[1]);
+                fd = pack_pair_relu_bwd(d_pm[0], d_pm[1], fh);
+            } else {
+                fh = pack2(h_pm[0], h_pm[1]);
+                fd = pack2(d_pm[0], d_pm[1]);
+            }
             gWo[t] = MFMA16(fa_y, fh, gWo[t]);  // dWo[o][16t + c]
 #pragma unroll
             for (int i = 0; i < IT; i++) gW0[t][i] = MFMA16(fd, fx[i], gW0[t][i]);  // dW0[16t + .][16i + c]
