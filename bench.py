@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--rays", type=int, default=4096, help="rays per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-eval", action="store_true", help="skip the secondary full-frame evaluation measurement")
     ap.add_argument("--kernel-timers", action="store_true", help="HIP-event timing of every C-ABI call (adds ~4 %)")
     args = ap.parse_args()
 
@@ -212,7 +213,7 @@ def main():
     }
     # secondary number of SURVEY §8(d): full-frame evaluation (67 980 rays of a 66 x 1030 range image, staged in
     # chunks of 4096, no perturbation, no gradient) — reported beside the headline metric, never instead of it
-    if world == 1:
+    if world == 1 and not args.no_eval:
         model.eval()
         frame = make_batch(poses, 0, 66 * 1030, rank, device)
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):

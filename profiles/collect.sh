@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerates the files of this directory on a GPU box:  bash profiles/collect.sh r01
-#   <tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of `python bench.py --steps 10 --warmup 3 --no-cpu-baseline`
+#   <tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of `python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-eval`
 #   <tag>_kernel_summary.txt the same, per training step, top kernels
 #   <tag>_pmc.json           FETCH_SIZE / WRITE_SIZE per launch of the grid kernels (separate --pmc passes, no other
 #                            trace domains; FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM": gfx950 tallies 128-B reads at 64 B)
@@ -9,19 +9,19 @@ tag=${1:-r01}
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 out=gpurun_out/profiles; mkdir -p $out
 STEPS=10; WARM=3
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -o r -- python bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -o r -- python bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-eval > /dev/null 2>&1
 find /tmp/prof_kt -name "*kernel_stats.csv" -exec cp {} $out/${tag}_kernel_stats.csv \;
 python - $out/${tag}_kernel_stats.csv $((STEPS+WARM)) > $out/${tag}_kernel_summary.txt <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1]))); n = float(sys.argv[2])
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
-print(f"rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline   ({int(n)} steps incl. warm-up)")
+print(f"rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-eval   ({int(n)} steps incl. warm-up)")
 print(f"total kernel time per training step: {tot/n/1e6:.3f} ms")
 for r in rows[:40]:
     print(f"{float(r['TotalDurationNs'])/n/1e6:8.3f} ms/step {int(r['Calls'])/n:6.1f} calls/step  avg {float(r['AverageNs'])/1e3:9.1f} us  {r['Name'][:110]}")
 PY
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/prof_$c -o r -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/prof_$c -o r -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-eval > /dev/null 2>&1
 done
 python - $out/${tag}_pmc.json <<'PY'
 import csv, glob, json, sys, collections
@@ -45,7 +45,7 @@ for k, d in res.items():
         # 4-12 B/lane loads of the other kernels are calibrated on k_grid_bwd_scatter (raw FETCH_SIZE == known input bytes).
         d["fetch_scale"] = 2.0 if k == "k_grid_bwd_reduce" else 1.0
         d["hbm_bytes_per_launch"] = int((d["fetch_scale"] * f + w) * 1024)
-json.dump({"command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline",
+json.dump({"command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-eval",
            "note": "KB per launch, averaged over all launches. hbm_bytes_per_launch = fetch_scale*FETCH_SIZE + WRITE_SIZE "
                    "(fetch_scale 2 for the 16 B/lane streaming loads of k_grid_bwd_reduce, 1 elsewhere; see profiles/README.md)",
            "kernels": res},
