@@ -140,7 +140,7 @@ def test_backward(dt, kind):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.float16])
-@pytest.mark.parametrize("kind", ["random", "rays", "same_cell"])
+@pytest.mark.parametrize("kind", ["random", "rays", "same_cell", "tiny"])
 def test_backward_bucketed(dt, kind):
     """lnh_grid_encode_backward_ws (no HBM atomics) must give the same table as the oracle's order-free sum."""
     from gpu_util import call, dev, host
@@ -149,6 +149,9 @@ def test_backward_bucketed(dt, kind):
         x = _points(5000, 7)
     elif kind == "rays":
         x = _ray_points(24, 256, 7)
+    elif kind == "tiny":  # fewer points than a wave, one of them outside the grid
+        x = np.random.default_rng(9).random((3, 3), dtype=np.float32)
+        x[1] = [1.5, 0.2, 0.3]
     else:  # adversarial: every point in one cell -> one bucket overflows its pool, excess goes through atomics
         x = (np.random.default_rng(1).random((20000, 3), dtype=np.float32) * 1e-6 + 0.3).astype(np.float32)
         x[::2] += np.float32(0.11)  # break the runs so the wave merge cannot collapse everything
