@@ -1,24 +1,25 @@
 """Fused LiDAR render step: the whole `NeRFRenderer.run` + `NeRFNetwork.density/color` chain of the reference
-(lidarnerf/nerf/renderer.py:99-298, lidarnerf/nerf/network.py:162-237) as ~14 kernel launches forward and ~8
+(lidarnerf/nerf/renderer.py:99-298, lidarnerf/nerf/network.py:162-237) as ~16 kernel launches forward and ~10
 backward, with explicit gradients.
 
-Used by NeRFNetwork.render for the configuration the reference trains (`cal_lidar_color=True`, hash-grid L=16 F=2,
-64-wide sigma net with one hidden layer, 64-wide LiDAR colour net with two, frequency-12 direction encoding) under
-fp16 autocast.  Anything else takes the modular path in renderer.py / network.py, which computes the same values
-from the same kernels' unfused forms.
+Used by NeRFNetwork.render (both flavours: `network` and the tcnn-shaped `network_tcnn`, through `model.fused_spec()`)
+for the configuration the reference trains (`cal_lidar_color=True`, hash-grid L=16 F=2, 64-wide sigma net with one
+hidden layer, 64-wide LiDAR colour net with two) under fp16 autocast.  Anything else takes the modular path in
+renderer.py / network.py, which computes the same values from the same kernels' unfused forms.
 
-Forward                                                     kernels (liblidarnerf_hip.so)
-  z = near + (far-near) linspace + perturb                  torch (3 tiny launches)
-  x = (clip(o + d z) + b) / 2b                              lnh_lidar_sample_points
-  feat = hashgrid(x)            [16,B,2] fp16               lnh_grid_encode_forward
-  h16, sigma = sigma_net(feat)  strided into [N,T+t,*]      lnh_density_mlp_forward
-  new_z, z_all, perm = resample(z, sigma)                   lnh_lidar_resample
-  (same three steps for the t new samples)
-  sigma_m, w = merge + weights                              lnh_lidar_merge_weights
-  cdir = W0[:, :75] freq(d)     per RAY                     lnh_freq_encode_forward + one [N,75]x[75,64] GEMM
-  rgb = colour_net(h16[perm], cdir) * (w > 1e-4)            lnh_lidar_color_forward
-  ws, depth, image = composite(sigma_m, rgb, z_all)         lnh_lidar_composite_forward
-Backward runs the mirror image; the hash-table gradient uses the bucketed scatter-reduce (no HBM atomics).
+Forward                                                       kernels (liblidarnerf_hip.so)
+  z = near + (far-near) linspace + perturb                    one torch.rand + lnh_lidar_coarse_samples
+  x = (clip(o + d z) + b) / 2b                                lnh_lidar_sample_points
+  feat = hashgrid(x)      [16, N(T+t), 2] fp16, row-mapped    lnh_grid_encode_forward_mapped
+  h16, sigma = sigma_net(feat)  strided into [N,T+t,*]        lnh_density_mlp_forward   (weights: lnh_lidar_pack_weights)
+  new_z, z_all, perm = resample(z, sigma)                     lnh_lidar_resample
+  (same three steps for the t new samples, same buffers)
+  sigma_m, w = merge + weights                                lnh_lidar_merge_weights
+  cdir = W0[:, :kd] enc(d)      per RAY                       model's direction features + lnh_lidar_dir_term
+  rgb = colour_net(h16[perm], cdir) * (w > 1e-4)              lnh_lidar_color_forward
+  ws, depth, image = composite(sigma_m, rgb, z_all)           lnh_lidar_composite_forward
+Backward runs the mirror image over all N(T+t) points at once; the hash-table gradient uses the bucketed
+scatter-reduce (no HBM atomics) and, data-parallel, goes on the wire in fp16 window by window.
 """
 import numpy as np
 import torch
