@@ -470,7 +470,7 @@ k_grid_backward(const T *__restrict__ grad, const float *__restrict__ inputs, T 
 //           order-independent (fp16 contributions are multiples of 2^-24, so scale 2^24 loses nothing).
 // A bucket whose pool overflows (adversarial, non-uniform input) falls back to global atomics for the excess in
 // pass 1, which completes before pass 2 starts (kernel boundary), so the result is always the full sum.
-constexpr uint32_t kBucketRowsLog2 = 13;  // (12 -> 128 buckets/level was measured: scatter +0.07 ms, reduce -0.025 ms)
+constexpr uint32_t kBucketRowsLog2 = 13;
 constexpr uint32_t kBucketRows = 1u << kBucketRowsLog2;
 constexpr uint32_t kMaxBucketsPerLevel = 64;
 
@@ -541,6 +541,7 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
     constexpr int C = 2, NCORN = 1 << D;
     __shared__ uint2 lout[kMaxBucketsPerLevel];           // per bucket: {pool slot - staging slot, staging slots that fit}
     __shared__ uint32_t lcnt[kMaxBucketsPerLevel];
+    __shared__ uint32_t lbase[kMaxBucketsPerLevel];       // first reserved pool slot per bucket (global)
     __shared__ uint32_t lstart[kMaxBucketsPerLevel + 1];  // first staging slot per bucket (workgroup-local)
     __shared__ PoolEntry<T> stage[NTHREADS * PPT * NCORN];
     // level-fastest workgroup order: concurrently resident workgroups work on the same points at different levels
@@ -558,7 +559,10 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
     if constexpr (MODE == 1) lv.flags = LV_HASH | LV_POW2;
     if constexpr (MODE == 2) lv.flags = LV_NOWRAP | (uint32_t)D;
     const uint32_t align = MODE ? 0u : align_rt, interp = MODE ? 0u : interp_rt;
-    if (threadIdx.x < kMaxBucketsPerLevel) lcnt[threadIdx.x] = 0;
+    if (threadIdx.x < kMaxBucketsPerLevel) {
+        lcnt[threadIdx.x] = 0;
+        lbase[threadIdx.x] = 0;
+    }
 
     float v0[PPT][NCORN], v1[PPT][NCORN];
     uint32_t row[PPT][NCORN];
@@ -666,35 +670,22 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
         }
     }
     __syncthreads();
-    // global reservation + exclusive scan of the workgroup's bucket counts: the first wave, kCPL consecutive counters
-    // per lane
+    // global reservation + exclusive scan of the workgroup's bucket counts (first wave; 128 counters = 2 per lane)
     if (threadIdx.x < 64) {
-        constexpr uint32_t kCPL = kMaxBucketsPerLevel / 64;
-        static_assert(kMaxBucketsPerLevel % 64 == 0, "whole counters per lane of the first wave");
-        uint32_t n[kCPL], base[kCPL], psum = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < kCPL; k++) {
-            const uint32_t bk = (uint32_t)lane * kCPL + k;
-            n[k] = lcnt[bk];
-            base[k] = (bk < nb && n[k]) ? atomicAdd(&cursor[fb + bk], n[k]) : 0u;
-            psum += n[k];
-        }
-        uint32_t incl = psum;
+        static_assert(kMaxBucketsPerLevel == 64, "one bucket counter per lane of the first wave");
+        const uint32_t n0 = lcnt[lane];
+        if ((uint32_t)lane < nb && n0) lbase[lane] = atomicAdd(&cursor[fb + lane], n0);
+        uint32_t incl = n0;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t up = __shfl_up(incl, o, 64);
             if (lane >= o) incl += up;
         }
-        uint32_t st = incl - psum;
-#pragma unroll
-        for (uint32_t k = 0; k < kCPL; k++) {
-            const uint32_t bk = (uint32_t)lane * kCPL + k;
-            lstart[bk] = st;
-            // staging slot pos of bucket bk goes to pool slot bk*cap + base + (pos - st) while base + (pos - st) < cap
-            lout[bk] = make_uint2(bk * cap + base[k] - st, base[k] < cap ? st + min(cap - base[k], 0x10000u) : st);
-            st += n[k];
-        }
+        const uint32_t st = incl - n0, base = lbase[lane];
+        lstart[lane] = st;
         if (lane == 63) lstart[kMaxBucketsPerLevel] = incl;
+        // staging slot pos of bucket bk goes to pool slot bk*cap + base + (pos - st) while base + (pos - st) < cap
+        lout[lane] = make_uint2((uint32_t)lane * cap + base - st, base < cap ? st + min(cap - base, 0x10000u) : st);
     }
     __syncthreads();
     // ---- stage the entries in LDS grouped by bucket, then stream them out: consecutive lanes write consecutive pool
