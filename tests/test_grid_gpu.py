@@ -233,6 +233,60 @@ def test_backward_full_size_checksum():
         assert torch.allclose(s_tab, s_g, rtol=1e-3, atol=1e-2), (l, s_tab, s_g)
 
 
+def test_forward_full_size_properties():
+    """Full BASELINE size (4096 rays x 832 samples), fp16 table, size-independent properties of the interpolation:
+    (1) a table that is constant per level reproduces that constant (the 8 weights of a cell sum to 1) wherever the
+    point is inside the grid, and 0 outside; (2) the bucketed backward of the same batch is the adjoint of the forward:
+    <forward(table), g> == <table, backward(g)>; (3) the row-mapped variant writes the same values into its slots."""
+    from gpu_util import call
+    from lidarnerf import _hip
+    n_rays, T = 4096, 832
+    x = torch.from_numpy(_ray_points(64, T, 5)).cuda().repeat(n_rays // 64, 1)
+    x = (x + torch.rand_like(x) * 1e-3)
+    x[::1000] = 1.5                                   # some points outside the grid
+    B = x.shape[0]
+    rows = int(OFF[-1])
+    offh = torch.from_numpy(OFF)
+    offs = OFF.astype(np.int64)
+    consts = torch.linspace(0.25, 4.0, L)
+    tab = torch.empty((rows, CH), dtype=torch.half, device="cuda")
+    for l in range(L):
+        tab[offs[l]:offs[l + 1]] = consts[l]
+    out = torch.empty((L, B, CH), dtype=torch.half, device="cuda")
+    call("lnh_grid_encode_forward", x, tab, offh, out, B, 3, CH, L, S, H, None, 0, 0, 0, 1)
+    inside = ((x >= 0) & (x <= 1)).all(1)
+    for l in range(L):
+        v = out[l].float()
+        assert float((v[inside] - consts[l]).abs().max()) <= 4e-3 * float(consts[l])   # 8 fp16 roundings
+        assert float(v[~inside].abs().max()) == 0.0
+    # (2) adjointness on a random table / gradient (fp32 accumulation on both sides, fp16 storage)
+    tab = (torch.randn((rows, CH), device="cuda") * 0.5).half()
+    call("lnh_grid_encode_forward", x, tab, offh, out, B, 3, CH, L, S, H, None, 0, 0, 0, 1)
+    g = (torch.randn((L, B, CH), device="cuda") * 0.01).half()
+    need = _hip.lib().lnh_grid_backward_workspace_size(offh.data_ptr(), B, 3, CH, L, S, H, 0, 0, 1)
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    gt = torch.zeros((rows, CH), dtype=torch.half, device="cuda")
+    call("lnh_grid_encode_backward_ws", g, x, offh, gt, B, 3, CH, L, S, H, 0, 0, 0, 1, ws, need)
+    lhs = float((out.double() * g.double()).sum())
+    rhs = float((tab.double() * gt.double()).sum())
+    assert abs(lhs - rhs) <= 2e-3 * max(abs(lhs), abs(rhs), 1.0), (lhs, rhs)
+    # (3) row map: T_cur = 768 of T_tot = 832 slots per ray, offset 0 -> rows r*832 + j
+    Tc = 768
+    Bc = n_rays * Tc
+    xs = torch.zeros((B, 3), device="cuda")
+    ray = torch.arange(Bc, device="cuda") // Tc
+    dst = ray * T + torch.arange(Bc, device="cuda") % Tc
+    xs[dst] = x[:Bc]
+    mapped = torch.zeros((L, B, CH), dtype=torch.half, device="cuda")
+    call("lnh_grid_encode_forward_mapped", xs, tab, offh, mapped, Bc, Tc, T, 0, B, CH, L, S, H, 1)
+    plain = torch.empty((L, Bc, CH), dtype=torch.half, device="cuda")
+    call("lnh_grid_encode_forward", x[:Bc].contiguous(), tab, offh, plain, Bc, 3, CH, L, S, H, None, 0, 0, 0, 1)
+    assert torch.equal(mapped[:, dst], plain)
+    untouched = torch.ones(B, dtype=torch.bool, device="cuda")
+    untouched[dst] = False
+    assert float(mapped[:, untouched].abs().max()) == 0.0
+
+
 def test_error_paths():
     from lidarnerf import _hip
     x = torch.rand((8, 3), device="cuda")

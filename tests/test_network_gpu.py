@@ -305,3 +305,37 @@ def test_fused_table_optimizer_matches_torch_adam_and_gradscaler():
     both(41)
     compare("after recovery")
     assert float(tr_b.t_steps[tr_b.t_flip]) == 4.0
+
+
+def test_fused_render_full_size_properties():
+    """BASELINE size (4096 rays x (768 + 64) samples) through the fused chain: compositing invariants that do not
+    depend on the size — weights of a ray sum to at most 1, depth is a convex combination of sample depths
+    (0 <= depth <= far * weights_sum), ray-drop / intensity are sigmoids weighted the same way — determinism of the
+    evaluation path, and finite gradients for every parameter in training mode."""
+    net, _ = _pair(seed=21, table_scale=0.5)
+    o, d = _rays(4096, 31)
+    o, d = o.cuda()[None], d.cuda()[None]
+    far = 81.0 * SCALE
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        a = net.render(o, d, cal_lidar_color=True, staged=False, perturb=False, num_steps=768, upsample_steps=64)
+        b = net.render(o, d, cal_lidar_color=True, staged=True, max_ray_batch=1000, perturb=False, num_steps=768,
+                       upsample_steps=64)
+    ws, depth, img = a["weights_sum_lidar"].float(), a["depth_lidar"].float()[0], a["image_lidar"].float()[0]
+    assert torch.isfinite(ws).all() and torch.isfinite(depth).all() and torch.isfinite(img).all()
+    assert float(ws.min()) >= 0.0 and float(ws.max()) <= 1.0 + 1e-4
+    assert float(depth.min()) >= 0.0 and bool((depth <= far * ws.view(-1) * (1 + 1e-4) + 1e-7).all())
+    assert float(img.min()) >= 0.0 and bool((img <= ws.view(-1, 1) * (1 + 1e-4) + 1e-7).all())
+    # rays are independent: chunked evaluation gives the same image
+    torch.testing.assert_close(b["depth_lidar"].float()[0], depth, rtol=0, atol=0)
+    torch.testing.assert_close(b["image_lidar"].float()[0], img, rtol=0, atol=0)
+    net.train()
+    net.zero_grad(set_to_none=True)
+    torch.manual_seed(5)
+    with torch.autocast("cuda", dtype=torch.float16):
+        out = net.render(o, d, cal_lidar_color=True, staged=False, perturb=True, num_steps=768, upsample_steps=64)
+        loss = out["depth_lidar"].mean() * 100 + out["image_lidar"].mean()
+    (loss * 1024.0).backward()
+    for name, p in net.named_parameters():
+        if name.startswith(("encoder.", "sigma_net.", "lidar_color_net.")):
+            assert p.grad is not None and torch.isfinite(p.grad).all(), name
+            assert float(p.grad.abs().max()) > 0.0, name
