@@ -11,6 +11,7 @@
 // one atomic per element per wave at the end of the kernel.
 #include "mlp_bwd.h"
 
+int lnh_mlp_backward_h32(uint32_t in_ks, uint32_t nhm, const MlpBwdArgs &a, hipStream_t s);
 int lnh_mlp_backward_nhm0(uint32_t in_ks, const MlpBwdArgs &a, hipStream_t s);
 int lnh_mlp_backward_nhm1(uint32_t in_ks, const MlpBwdArgs &a, hipStream_t s);
 int lnh_mlp_backward_nhm2(uint32_t in_ks, const MlpBwdArgs &a, hipStream_t s);
@@ -173,35 +174,37 @@ int check_shape(uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, ui
     LNH_REQUIRE(input_dim <= 128, LNH_ERR_UNSUPPORTED, "fused MLP: input_dim <= 128 in this build (got %u)", input_dim);
     LNH_REQUIRE(output_dim == 16, LNH_ERR_UNSUPPORTED,
                 "FFMLP current only supports (padded) output dim == 16, but got %u", output_dim);
-    LNH_REQUIRE(hidden_dim == 64, LNH_ERR_UNSUPPORTED,
-                "fused MLP: hidden_dim must be 64 in this build (reference: 16..256), got %u", hidden_dim);
+    LNH_REQUIRE(hidden_dim == 64 || hidden_dim == 32, LNH_ERR_UNSUPPORTED,
+                "fused MLP: hidden_dim must be 32 or 64 in this build (reference: 16..256), got %u", hidden_dim);
     LNH_REQUIRE(n_hidden_mats <= 2, LNH_ERR_UNSUPPORTED,
                 "fused MLP: at most 2 hidden->hidden matrices in this build (got %u)", n_hidden_mats);
     return LNH_OK;
 }
 
-#define LNH_MLP_FWD_DISPATCH(ARGS)                                                                       \
-    {                                                                                                     \
-        const uint32_t iks = (input_dim + 31) / 32;                                                       \
-        const uint32_t key = iks * 10 + n_hidden_mats;                                                    \
+#define LNH_MLP_FWD_CASES(HT, ARGS)                                                                      \
         switch (key) {                                                                                    \
-            case 10: rc = launch_fwd<1, 4, 0>(ARGS, s); break;                                            \
-            case 11: rc = launch_fwd<1, 4, 1>(ARGS, s); break;                                            \
-            case 12: rc = launch_fwd<1, 4, 2>(ARGS, s); break;                                            \
-            case 20: rc = launch_fwd<2, 4, 0>(ARGS, s); break;                                            \
-            case 21: rc = launch_fwd<2, 4, 1>(ARGS, s); break;                                            \
-            case 22: rc = launch_fwd<2, 4, 2>(ARGS, s); break;                                            \
-            case 30: rc = launch_fwd<3, 4, 0>(ARGS, s); break;                                            \
-            case 31: rc = launch_fwd<3, 4, 1>(ARGS, s); break;                                            \
-            case 32: rc = launch_fwd<3, 4, 2>(ARGS, s); break;                                            \
-            case 40: rc = launch_fwd<4, 4, 0>(ARGS, s); break;                                            \
-            case 41: rc = launch_fwd<4, 4, 1>(ARGS, s); break;                                            \
-            case 42: rc = launch_fwd<4, 4, 2>(ARGS, s); break;                                            \
+            case 10: rc = launch_fwd<1, HT, 0>(ARGS, s); break;                                           \
+            case 11: rc = launch_fwd<1, HT, 1>(ARGS, s); break;                                           \
+            case 12: rc = launch_fwd<1, HT, 2>(ARGS, s); break;                                           \
+            case 20: rc = launch_fwd<2, HT, 0>(ARGS, s); break;                                           \
+            case 21: rc = launch_fwd<2, HT, 1>(ARGS, s); break;                                           \
+            case 22: rc = launch_fwd<2, HT, 2>(ARGS, s); break;                                           \
+            case 30: rc = launch_fwd<3, HT, 0>(ARGS, s); break;                                           \
+            case 31: rc = launch_fwd<3, HT, 1>(ARGS, s); break;                                           \
+            case 32: rc = launch_fwd<3, HT, 2>(ARGS, s); break;                                           \
+            case 40: rc = launch_fwd<4, HT, 0>(ARGS, s); break;                                           \
+            case 41: rc = launch_fwd<4, HT, 1>(ARGS, s); break;                                           \
+            case 42: rc = launch_fwd<4, HT, 2>(ARGS, s); break;                                           \
             default:                                                                                      \
                 lnh_set_error("fused MLP: no kernel instance for input_dim=%u hidden=%u hidden_mats=%u",  \
                               input_dim, hidden_dim, n_hidden_mats);                                      \
                 rc = LNH_ERR_UNSUPPORTED;                                                                 \
-        }                                                                                                 \
+        }
+#define LNH_MLP_FWD_DISPATCH(ARGS)                                                                       \
+    {                                                                                                     \
+        const uint32_t iks = (input_dim + 31) / 32;                                                       \
+        const uint32_t key = iks * 10 + n_hidden_mats;                                                    \
+        if (hidden_dim == 32) { LNH_MLP_FWD_CASES(2, ARGS) } else { LNH_MLP_FWD_CASES(4, ARGS) }          \
     }
 
 }  // namespace
@@ -239,6 +242,7 @@ int lnh_mlp_backward(const void *grad, const void *inputs, const void *weights, 
                  grad_weights, B, input_dim, hidden_dim, activation, output_activation, IoDims{1, 1, 0, 0}};
     hipStream_t s = (hipStream_t)stream;
     const uint32_t iks = (input_dim + 31) / 32;
+    if (hidden_dim == 32) return lnh_mlp_backward_h32(iks, n_hidden_mats, a, s);
     switch (n_hidden_mats) {
         case 0: rc = lnh_mlp_backward_nhm0(iks, a, s); break;
         case 1: rc = lnh_mlp_backward_nhm1(iks, a, s); break;

@@ -63,7 +63,7 @@ class _FusedMLP(Function):
 
 
 def fused_mlp(x, mats, activation=0, inference=False):
-    """Bias-free Linear stack as one kernel.  mats: list of weight tensors [out_k, in_k] (>= 2); hidden width 64;
+    """Bias-free Linear stack as one kernel.  mats: list of weight tensors [out_k, in_k] (>= 2); hidden width 32 or 64;
     last out <= 16; first in <= 128.  Returns [B, out_last] fp16."""
     hidden = mats[0].shape[0]
     in_dim = mats[0].shape[1]

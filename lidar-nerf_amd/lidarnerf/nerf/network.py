@@ -55,8 +55,8 @@ class NeRFNetwork(NeRFRenderer):
     # -- one bias-free Linear/ReLU stack ----------------------------------------------------------------------
     def _mlp(self, net, h):
         mats = [lin.weight for lin in net]
-        fusable = (h.is_cuda and torch.is_autocast_enabled() and len(mats) >= 2 and mats[0].shape[0] == 64
-                   and all(m.shape == (64, 64) for m in mats[1:-1]) and mats[-1].shape[0] <= 16
+        fusable = (h.is_cuda and torch.is_autocast_enabled() and len(mats) >= 2 and mats[0].shape[0] in (32, 64)
+                   and all(m.shape == (mats[0].shape[0],) * 2 for m in mats[1:-1]) and mats[-1].shape[0] <= 16
                    and mats[0].shape[1] <= 128 and len(mats) <= 4)
         if fusable:
             return fused_mlp(h, mats, activation=0, inference=not torch.is_grad_enabled())

@@ -171,7 +171,7 @@ class Network(nn.Module):
         lead = x.shape[:-1]
         x = x.reshape(-1, self.n_input_dims)
         mats = self.matrices()
-        if self.n_neurons == 64 and self.out_pad == 16 and self.in_pad <= 128 and len(mats) <= 4:
+        if self.n_neurons in (32, 64) and self.out_pad == 16 and self.in_pad <= 128 and len(mats) <= 4:
             xp = torch.nn.functional.pad(x, (0, self.in_pad - self.n_input_dims)) if self.in_pad != self.n_input_dims else x
             y = fused_mlp(xp, mats, activation=self.activation, inference=not torch.is_grad_enabled())
         else:

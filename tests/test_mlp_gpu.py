@@ -102,6 +102,39 @@ def test_backward(in_dim, nhm, B):
     np.testing.assert_allclose(host(dw2), host(dw), rtol=1e-4, atol=1e-4 * scale)
 
 
+@pytest.mark.parametrize("in_dim,nhm", [(32, 0), (16, 1), (96, 2), (128, 1)])
+def test_hidden_32_forward_backward(in_dim, nhm):
+    """hidden = 32 (two 16-row tiles per layer) — same kernels, HT = 2."""
+    from gpu_util import call, dev, host
+    B, H = 777, 32
+    r = np.random.default_rng(in_dim * 5 + nhm)
+    x = r.standard_normal((B, in_dim)).astype(np.float16)
+    n = mlp_ref.ffmlp_num_params(in_dim, 16, H, nhm + 1)
+    w = (r.uniform(-1, 1, n) * np.sqrt(3 / H)).astype(np.float16)
+    mats = mlp_ref.ffmlp_split_weights(w, in_dim, 16, H, nhm + 1)
+    want, _ = mlp_ref.mlp_forward(x, mats)
+    got = _run_fwd(x, w, in_dim, H, nhm, mlp_ref.ACT_RELU)
+    np.testing.assert_allclose(got.astype(np.float64), want, rtol=2e-3, atol=4e-3)
+    gy = (r.standard_normal((B, 16)) * 0.1).astype(np.float16)
+    gx_want, dws = mlp_ref.mlp_backward(x, mats, gy)
+    dw_want = np.concatenate([d.ravel() for d in dws])
+    gx = torch.zeros((B, in_dim), dtype=torch.float16, device="cuda")
+    dw = torch.zeros(n, dtype=torch.float32, device="cuda")
+    call("lnh_mlp_backward", dev(gy), dev(x), dev(w), B, in_dim, 16, H, nhm, 0, 6, gx, dw)
+    np.testing.assert_allclose(host(gx).astype(np.float64), gx_want, rtol=5e-3, atol=2e-3)
+    np.testing.assert_allclose(host(dw).astype(np.float64), dw_want, rtol=5e-3, atol=2e-3 * np.abs(dw_want).max())
+
+
+def test_ffmlp_module_hidden_32():
+    from lidarnerf.ffmlp import FFMLP
+    m = FFMLP(32, 3, 32, 3).cuda()
+    x = torch.randn(500, 32, device="cuda", requires_grad=True)
+    with torch.autocast("cuda", dtype=torch.float16):
+        y = m(x)
+    y.float().square().sum().backward()
+    assert y.shape == (500, 3) and torch.isfinite(m.weights.grad).all() and float(m.weights.grad.abs().max()) > 0
+
+
 def test_unsupported_shapes_fail_loudly():
     from lidarnerf import _hip
     t = torch.zeros(16, device="cuda")
