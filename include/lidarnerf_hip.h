@@ -180,6 +180,19 @@ LNH_API int lnh_composite_rays_train_backward(const float *grad_weights_sum, con
                                               const int32_t *rays, const float *weights_sum, const float *image,
                                               uint32_t M, uint32_t N, float T_thresh, float *grad_sigmas,
                                               float *grad_rgbs, lnh_stream_t stream);
+/*
+ * Inference variants (raymarching.h:55-69 march_rays / composite_rays; raymarching.cu:808-928, 966-1053): march the
+ * first n_alive rays listed in rays_alive for at most n_step occupied samples from their current rays_t (outputs
+ * [n_alive*n_step, 3|3|2], caller-zeroed: delta == 0 ends a ray), then accumulate sigmas / rgbs [n_alive*n_step, 1|3]
+ * into weights_sum / depth / image [N, 1|1|3] in place; finished rays get rays_alive[n] = -1, the others their new t.
+ */
+LNH_API int lnh_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, const float *rays_t,
+                           const float *rays_o, const float *rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                           uint32_t C, uint32_t H, const uint8_t *grid, const float *nears, const float *fars,
+                           float *xyzs, float *dirs, float *deltas, const float *noises, lnh_stream_t stream);
+LNH_API int lnh_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive, float *rays_t,
+                               const float *sigmas, const float *rgbs, const float *deltas, float *weights_sum,
+                               float *depth, float *image, lnh_stream_t stream);
 
 /* ------------------------------------------------------------------ LiDAR renderer kernels ------------------ */
 /*

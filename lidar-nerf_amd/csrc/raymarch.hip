@@ -315,6 +315,84 @@ k_composite_train_bwd(const float *__restrict__ grad_ws, const float *__restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------ inference
+// raymarching.cu:808-928: march the ALIVE rays for at most n_step occupied samples starting at their current t;
+// slots a ray does not fill stay as the caller initialised them (zeros: delta == 0 marks the end of a ray).
+__global__ void __launch_bounds__(64)
+k_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *__restrict__ rays_alive,
+             const float *__restrict__ rays_t, const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+             const uint8_t *__restrict__ grid, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
+             const float *__restrict__ nears, const float *__restrict__ fars, float *__restrict__ xyzs,
+             float *__restrict__ dirs, float *__restrict__ deltas, const float *__restrict__ noises) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_alive) return;
+    const uint32_t index = (uint32_t)rays_alive[n];
+    MarchRay r;
+    r.ox = rays_o[index * 3]; r.oy = rays_o[index * 3 + 1]; r.oz = rays_o[index * 3 + 2];
+    r.dx = rays_d[index * 3]; r.dy = rays_d[index * 3 + 1]; r.dz = rays_d[index * 3 + 2];
+    r.rdx = 1 / r.dx; r.rdy = 1 / r.dy; r.rdz = 1 / r.dz;
+    const float rH = 1 / (float)H, H3 = (float)(H * H * H);
+    const float far = fars[index];
+    const float SQRT3 = 1.7320508075688772f;
+    const float dt_min = 2 * SQRT3 / max_steps;
+    const float dt_max = 2 * SQRT3 * (float)(1 << (C - 1)) / H;
+    float t = rays_t[index];
+    t += clampf(t * dt_gamma, dt_min, dt_max) * noises[n];
+    float *px = xyzs + (size_t)n * n_step * 3, *pd = dirs + (size_t)n * n_step * 3,
+          *pl = deltas + (size_t)n * n_step * 2;
+    float last_t = t;
+    uint32_t step = 0;
+    while (t < far && step < n_step) {
+        const Probe p = probe(r, t, grid, bound, dt_gamma, dt_min, dt_max, C, H, rH, H3);
+        if (p.occ) {
+            px[0] = p.x; px[1] = p.y; px[2] = p.z;
+            pd[0] = r.dx; pd[1] = r.dy; pd[2] = r.dz;
+            t += p.dt;
+            pl[0] = p.dt;
+            pl[1] = t - last_t;
+            last_t = t;
+            px += 3; pd += 3; pl += 2;
+            step++;
+        } else {
+            t = p.t_next;
+        }
+    }
+}
+
+// raymarching.cu:966-1053: accumulate n_step samples into the per-ray running sums (T_i = 1 - sum of earlier weights);
+// a ray that ends (delta == 0) or saturates (T < T_thresh) is marked dead (rays_alive[n] = -1), others save their t.
+__global__ void __launch_bounds__(64)
+k_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *__restrict__ rays_alive,
+                 float *__restrict__ rays_t, const float *__restrict__ sigmas, const float *__restrict__ rgbs,
+                 const float *__restrict__ deltas, float *__restrict__ weights_sum, float *__restrict__ depth,
+                 float *__restrict__ image) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_alive) return;
+    const uint32_t index = (uint32_t)rays_alive[n];
+    const float *s = sigmas + (size_t)n * n_step, *c = rgbs + (size_t)n * n_step * 3,
+                *dl = deltas + (size_t)n * n_step * 2;
+    float t = rays_t[index], ws = weights_sum[index], d = depth[index];
+    float r = image[index * 3], g = image[index * 3 + 1], b = image[index * 3 + 2];
+    uint32_t step = 0;
+    while (step < n_step) {
+        if (dl[0] == 0) break;
+        const float alpha = 1.0f - expf(-s[0] * dl[0]);
+        const float T = 1 - ws;
+        const float weight = alpha * T;
+        ws += weight;
+        t += dl[1];
+        d += weight * t;
+        r += weight * c[0]; g += weight * c[1]; b += weight * c[2];
+        if (T < T_thresh) break;
+        s++; c += 3; dl += 2;
+        step++;
+    }
+    if (step < n_step) rays_alive[n] = -1;
+    else rays_t[index] = t;
+    weights_sum[index] = ws; depth[index] = d;
+    image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
+}
+
 }  // namespace
 
 extern "C" {
@@ -407,6 +485,31 @@ int lnh_composite_rays_train_backward(const float *grad_weights_sum, const float
                        grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, T_thresh, grad_sigmas,
                        grad_rgbs);
     return lnh_check_launch("lnh_composite_rays_train_backward");
+}
+
+int lnh_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, const float *rays_t,
+                   const float *rays_o, const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C,
+                   uint32_t H, const uint8_t *grid, const float *nears, const float *fars, float *xyzs, float *dirs,
+                   float *deltas, const float *noises, lnh_stream_t stream) {
+    LNH_REQUIRE(rays_alive && rays_t && rays_o && rays_d && grid && nears && fars && xyzs && dirs && deltas && noises,
+                LNH_ERR_INVALID_ARG, "march_rays: null pointer");
+    LNH_REQUIRE(C >= 1 && C <= 16 && H >= 1 && H <= 1024 && max_steps >= 1, LNH_ERR_INVALID_ARG,
+                "march_rays: bad cascade / grid size / max_steps");
+    if (n_alive == 0 || n_step == 0) return LNH_OK;
+    LNH_LAUNCH(k_march_rays, dim3(div_up(n_alive, 64)), dim3(64), 0, (hipStream_t)stream, n_alive, n_step, rays_alive,
+               rays_t, rays_o, rays_d, grid, bound, dt_gamma, max_steps, C, H, nears, fars, xyzs, dirs, deltas, noises);
+    return lnh_check_launch("lnh_march_rays");
+}
+
+int lnh_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive, float *rays_t,
+                       const float *sigmas, const float *rgbs, const float *deltas, float *weights_sum, float *depth,
+                       float *image, lnh_stream_t stream) {
+    LNH_REQUIRE(rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image, LNH_ERR_INVALID_ARG,
+                "composite_rays: null pointer");
+    if (n_alive == 0) return LNH_OK;
+    LNH_LAUNCH(k_composite_rays, dim3(div_up(n_alive, 64)), dim3(64), 0, (hipStream_t)stream, n_alive, n_step, T_thresh,
+               rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image);
+    return lnh_check_launch("lnh_composite_rays");
 }
 
 }  // extern "C"

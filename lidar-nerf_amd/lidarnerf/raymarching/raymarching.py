@@ -121,3 +121,44 @@ class _CompositeRaysTrain(Function):
 
 
 composite_rays_train = _CompositeRaysTrain.apply
+
+
+# ----------------------------------------
+# infer functions (raymarching.py:362-512)
+# ----------------------------------------
+def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, density_bitfield, C, H, near, far, align=-1,
+               perturb=False, dt_gamma=0, max_steps=1024):
+    """March the first n_alive rays of rays_alive for at most n_step occupied samples from their current rays_t.
+    Returns xyzs [M,3], dirs [M,3], deltas [M,2] with M = n_alive*n_step (padded to a multiple of `align`); unused
+    slots are zero (delta == 0 ends a ray in composite_rays)."""
+    rays_o = rays_o.contiguous().float().view(-1, 3)
+    rays_d = rays_d.contiguous().float().view(-1, 3)
+    _hip.require_cuda(rays_o, rays_d, density_bitfield, near, far, rays_alive, rays_t)
+    M = n_alive * n_step
+    if align > 0:
+        M += align - (M % align)
+    dev = rays_o.device
+    xyzs = torch.zeros((M, 3), dtype=torch.float32, device=dev)
+    dirs = torch.zeros((M, 3), dtype=torch.float32, device=dev)
+    deltas = torch.zeros((M, 2), dtype=torch.float32, device=dev)
+    noises = torch.rand(n_alive, dtype=torch.float32, device=dev) if perturb \
+        else torch.zeros(n_alive, dtype=torch.float32, device=dev)
+    _hip.call("lnh_march_rays", int(n_alive), int(n_step), rays_alive.data_ptr(), rays_t.data_ptr(), rays_o.data_ptr(),
+              rays_d.data_ptr(), float(bound), float(dt_gamma), int(max_steps), int(C), int(H),
+              density_bitfield.contiguous().data_ptr(), near.contiguous().data_ptr(), far.contiguous().data_ptr(),
+              xyzs.data_ptr(), dirs.data_ptr(), deltas.data_ptr(), noises.data_ptr())
+    return xyzs, dirs, deltas
+
+
+def composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, T_thresh=1e-2):
+    """In-place accumulation of one marching round into weights_sum [N], depth [N], image [N,3]; rays that ended get
+    rays_alive[n] = -1, the others their advanced rays_t."""
+    sigmas, rgbs, deltas = sigmas.contiguous().float(), rgbs.contiguous().float(), deltas.contiguous().float()
+    _hip.require_cuda(sigmas, rgbs, deltas, rays_alive, rays_t, weights_sum, depth, image)
+    for t in (weights_sum, depth, image, rays_t):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise RuntimeError("composite_rays: in-place outputs must be contiguous float32 tensors")
+    _hip.call("lnh_composite_rays", int(n_alive), int(n_step), float(T_thresh), rays_alive.data_ptr(), rays_t.data_ptr(),
+              sigmas.data_ptr(), rgbs.data_ptr(), deltas.data_ptr(), weights_sum.data_ptr(), depth.data_ptr(),
+              image.data_ptr())
+    return tuple()

@@ -197,3 +197,28 @@ def chamfer_nn(xyz1, xyz2):
     dist, idx = np.zeros(n, np.float32), np.zeros(n, np.int32)
     lib().lnh_oracle_chamfer_nn(_p(a), C.c_uint32(n), _p(b), C.c_uint32(m), _p(dist), _p(idx))
     return dist, idx
+
+
+def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, cascade, H, bitfield,
+               nears, fars, noises):
+    """raymarching.cu:808-928.  Returns xyzs, dirs, deltas [n_alive*n_step, 3|3|2] (unused slots zero)."""
+    ra, rt = _i32(rays_alive), _f32(rays_t)
+    o, d = _f32(rays_o), _f32(rays_d)
+    bf = np.ascontiguousarray(bitfield, dtype=np.uint8)
+    nears, fars, noises = _f32(nears), _f32(fars), _f32(noises)
+    M = n_alive * n_step
+    xyzs, dirs, deltas = np.zeros((M, 3), np.float32), np.zeros((M, 3), np.float32), np.zeros((M, 2), np.float32)
+    lib().lnh_oracle_march_rays(C.c_uint32(n_alive), C.c_uint32(n_step), _p(ra), _p(rt), _p(o), _p(d), C.c_float(bound),
+                                C.c_float(dt_gamma), C.c_uint32(max_steps), C.c_uint32(cascade), C.c_uint32(H), _p(bf),
+                                _p(nears), _p(fars), _p(xyzs), _p(dirs), _p(deltas), _p(noises))
+    return xyzs, dirs, deltas
+
+
+def composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, T_thresh=1e-2):
+    """raymarching.cu:966-1053.  Returns updated COPIES (rays_alive, rays_t, weights_sum, depth, image)."""
+    ra, rt = _i32(rays_alive).copy(), _f32(rays_t).copy()
+    s, c, dl = _f32(sigmas), _f32(rgbs), _f32(deltas)
+    ws, dep, img = _f32(weights_sum).copy(), _f32(depth).copy(), _f32(image).copy()
+    lib().lnh_oracle_composite_rays(C.c_uint32(n_alive), C.c_uint32(n_step), C.c_float(T_thresh), _p(ra), _p(rt), _p(s),
+                                    _p(c), _p(dl), _p(ws), _p(dep), _p(img))
+    return ra, rt, ws, dep, img

@@ -641,3 +641,74 @@ ORACLE_API void lnh_oracle_chamfer_nn(const float *xyz1, uint32_t n, const float
         idx[j] = best_i;
     }
 }
+
+/* ---- inference marching / compositing: raymarching.cu:808-928, 966-1053 */
+ORACLE_API void lnh_oracle_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, const float *rays_t,
+                                      const float *rays_o, const float *rays_d, float bound, float dt_gamma,
+                                      uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *grid,
+                                      const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas,
+                                      const float *noises) {
+    const float SQRT3 = 1.7320508075688772f;
+    for (uint32_t n = 0; n < n_alive; n++) {
+        const uint32_t index = (uint32_t)rays_alive[n];
+        march_ctx m;
+        m.ox = rays_o[index * 3]; m.oy = rays_o[index * 3 + 1]; m.oz = rays_o[index * 3 + 2];
+        m.dx = rays_d[index * 3]; m.dy = rays_d[index * 3 + 1]; m.dz = rays_d[index * 3 + 2];
+        m.rdx = 1 / m.dx; m.rdy = 1 / m.dy; m.rdz = 1 / m.dz;
+        m.rH = 1 / (float)H; m.H3 = (float)(H * H * H);
+        m.near = nears[index]; m.far = fars[index];
+        m.dt_min = 2 * SQRT3 / max_steps;
+        m.dt_max = 2 * SQRT3 * (float)(1 << (C - 1)) / H;
+        m.bound = bound; m.dt_gamma = dt_gamma; m.C = C; m.H = H; m.grid = grid;
+        float t = rays_t[index];
+        t += clampf(t * dt_gamma, m.dt_min, m.dt_max) * noises[n];
+        float *px = xyzs + (size_t)n * n_step * 3, *pd = dirs + (size_t)n * n_step * 3,
+              *pl = deltas + (size_t)n * n_step * 2;
+        float last_t = t, x, y, z, dt, ts;
+        uint32_t step = 0;
+        while (t < m.far && step < n_step) {
+            if (march_probe(&m, t, &x, &y, &z, &dt, &ts, 0)) {
+                px[0] = x; px[1] = y; px[2] = z;
+                pd[0] = m.dx; pd[1] = m.dy; pd[2] = m.dz;
+                t += dt;
+                pl[0] = dt;
+                pl[1] = t - last_t;
+                last_t = t;
+                px += 3; pd += 3; pl += 2;
+                step++;
+            } else {
+                t = ts;
+            }
+        }
+    }
+}
+
+ORACLE_API void lnh_oracle_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive,
+                                          float *rays_t, const float *sigmas, const float *rgbs, const float *deltas,
+                                          float *weights_sum, float *depth, float *image) {
+    for (uint32_t n = 0; n < n_alive; n++) {
+        const uint32_t index = (uint32_t)rays_alive[n];
+        const float *s = sigmas + (size_t)n * n_step, *c = rgbs + (size_t)n * n_step * 3,
+                    *dl = deltas + (size_t)n * n_step * 2;
+        float t = rays_t[index], ws = weights_sum[index], d = depth[index];
+        float r = image[index * 3], g = image[index * 3 + 1], b = image[index * 3 + 2];
+        uint32_t step = 0;
+        while (step < n_step) {
+            if (dl[0] == 0) break;
+            const float alpha = 1.0f - expf(-s[0] * dl[0]);
+            const float T = 1 - ws;
+            const float weight = alpha * T;
+            ws += weight;
+            t += dl[1];
+            d += weight * t;
+            r += weight * c[0]; g += weight * c[1]; b += weight * c[2];
+            if (T < T_thresh) break;
+            s++; c += 3; dl += 2;
+            step++;
+        }
+        if (step < n_step) rays_alive[n] = -1;
+        else rays_t[index] = t;
+        weights_sum[index] = ws; depth[index] = d;
+        image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
+    }
+}

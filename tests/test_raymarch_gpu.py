@@ -129,3 +129,60 @@ def test_march_rays_train(cascade, bound, dt_gamma):
     np.testing.assert_allclose(host(gs), w_gs, rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(host(gc), w_gc, rtol=1e-5, atol=1e-6)
     assert P > 0
+
+
+@pytest.mark.parametrize("cascade,bound,dt_gamma", [(1, 1.0, 0.0), (2, 2.0, 1 / 128)])
+def test_march_and_composite_rays_inference(cascade, bound, dt_gamma):
+    """Inference loop of torch-ngp's run_cuda (raymarching.cu:808-928, 966-1053; raymarching.py:362-512): rounds of
+    march_rays -> composite_rays over a shrinking set of alive rays, every round checked against the C restatement —
+    sample positions / deltas and the alive table bit-exact, the accumulated sums to float rounding (expf)."""
+    from lidarnerf import raymarching
+    bits, Hh = _scene(cascade)
+    r = np.random.default_rng(11)
+    N, n_step = 700, 8
+    o = (r.standard_normal((N, 3)) * 0.05 + np.array([-0.8 * bound, 0.1, 0.0])).astype(np.float32)
+    d = r.standard_normal((N, 3)).astype(np.float32)
+    d[:, 0] = np.abs(d[:, 0]) + 0.7
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)
+    wn, wf = c_oracle.near_far_from_aabb(o, d, aabb, 0.05)
+    t_o, t_d, t_bits = torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda(), torch.from_numpy(bits).cuda()
+    near, far = torch.from_numpy(wn).cuda(), torch.from_numpy(wf).cuda()
+    alive = torch.arange(N, dtype=torch.int32, device="cuda")
+    rays_t = near.clone()
+    ws = torch.zeros(N, device="cuda")
+    dep = torch.zeros(N, device="cuda")
+    img = torch.zeros((N, 3), device="cuda")
+    # host mirrors
+    h_alive, h_t = np.arange(N, dtype=np.int32), wn.copy()
+    h_ws, h_dep, h_img = np.zeros(N, np.float32), np.zeros(N, np.float32), np.zeros((N, 3), np.float32)
+    n_alive, rounds = N, 0
+    while n_alive > 0 and rounds < 40:
+        xyzs, dirs, deltas = raymarching.march_rays(n_alive, n_step, alive, rays_t, t_o, t_d, bound, t_bits, cascade, Hh,
+                                                    near, far, -1, False, dt_gamma, 1024)
+        wx, wd, wdl = c_oracle.march_rays(n_alive, n_step, h_alive, h_t, o, d, bound, dt_gamma, 1024, cascade, Hh, bits,
+                                          wn, wf, np.zeros(n_alive, np.float32))
+        np.testing.assert_array_equal(xyzs.cpu().numpy(), wx)
+        np.testing.assert_array_equal(dirs.cpu().numpy(), wd)
+        np.testing.assert_array_equal(deltas.cpu().numpy(), wdl)
+        sig = (r.random(n_alive * n_step, dtype=np.float32) * 4).astype(np.float32)
+        rgb = r.random((n_alive * n_step, 3), dtype=np.float32)
+        raymarching.composite_rays(n_alive, n_step, alive, rays_t, torch.from_numpy(sig).cuda(),
+                                   torch.from_numpy(rgb).cuda(), deltas, ws, dep, img, 1e-2)
+        h_alive2, h_t, h_ws, h_dep, h_img = c_oracle.composite_rays(n_alive, n_step, h_alive, h_t, sig, rgb, wdl, h_ws,
+                                                                    h_dep, h_img, 1e-2)
+        g_alive = alive.cpu().numpy()
+        np.testing.assert_array_equal(g_alive[:n_alive], h_alive2[:n_alive])
+        np.testing.assert_allclose(ws.cpu().numpy(), h_ws, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(dep.cpu().numpy(), h_dep, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(img.cpu().numpy(), h_img, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(rays_t.cpu().numpy(), h_t, rtol=0, atol=0)
+        # compaction of the survivors (the caller's job: renderer of torch-ngp does rays_alive[rays_alive >= 0])
+        keep = g_alive[:n_alive] >= 0
+        h_alive = g_alive[:n_alive][keep].astype(np.int32)
+        n_alive = int(keep.sum())
+        alive = torch.from_numpy(np.concatenate([h_alive, np.zeros(N - n_alive, np.int32)])).cuda()
+        h_alive = alive.cpu().numpy()
+        rounds += 1
+    assert rounds >= 3 and n_alive == 0          # every ray left the grid or saturated
+    assert float(ws.max()) <= 1.0 + 1e-5 and float(ws.max()) > 0.5
