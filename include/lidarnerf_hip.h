@@ -72,14 +72,23 @@ LNH_API int lnh_grid_encode_backward(const void *grad, const float *inputs, cons
                                      lnh_stream_t stream);
 /*
  * Same result as lnh_grid_encode_backward for the hot configuration (D == 3, C == 2) without a single atomic add to
- * HBM: contributions are binned per 8192-row table bucket in a caller-provided workspace and reduced in LDS
- * (grid.hip, "bucketed backward").  `workspace` is scratch device memory of at least
+ * HBM: contributions are binned per 8192-row table bucket in a caller-provided workspace and reduced in LDS in 64-bit
+ * fixed point (grid.hip, "bucketed backward"): the result is one integer sum per table row, independent of execution
+ * order (bit-reproducible run to run), rounded once to the table type.  `workspace` is scratch device memory of at least
  * lnh_grid_backward_workspace_size(...) bytes (0 = configuration not supported by this path); its content is
  * irrelevant before and after the call.  No dy_dx / grad_inputs (LiDAR sample positions carry no gradient).
  */
 LNH_API uint64_t lnh_grid_backward_workspace_size(const int32_t *offsets_host, uint32_t B, uint32_t D, uint32_t C,
                                                   uint32_t L, float S, uint32_t H, uint32_t gridtype,
                                                   int align_corners, int dtype);
+/* Host-side description of that workspace's bucket plan for `level` (no device work): out[0] = table buckets of the
+ * level, out[1] = pool slots per bucket (what exceeds them goes to the level's spill list), out[2] = rows per bucket,
+ * out[3] = entries per reduce slice (a bucket with more is reduced by several workgroups).  The sum the call produces
+ * never depends on these numbers — integer accumulation (see grid.hip) — the tests use them to build inputs that
+ * overflow a bucket by a few entries or split one.  Returns LNH_ERR_UNSUPPORTED where workspace_size returns 0. */
+LNH_API int lnh_grid_backward_plan_info(const int32_t *offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                                        float S, uint32_t H, uint32_t gridtype, int align_corners, int dtype,
+                                        uint32_t level, uint32_t *out4);
 LNH_API int lnh_grid_encode_backward_ws(const void *grad, const float *inputs, const int32_t *offsets_host,
                                         void *grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
                                         uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, int dtype,

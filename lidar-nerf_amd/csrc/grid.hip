@@ -20,9 +20,6 @@
 
 namespace {
 
-// experiment knobs (scratch/ micro-benchmarks only): level window + kernel flags
-static uint32_t g_dbg_l0 = 0, g_dbg_ln = 0, g_dbg_flags = 0;
-
 struct LevelParams {
     float scale;
     uint32_t resolution;
@@ -373,20 +370,11 @@ __device__ __forceinline__ void atomic_add_one(float *p, float a) { unsafeAtomic
 template <typename T, int D, int C, int NC, bool MERGE>
 __global__ void __launch_bounds__(256)
 k_grid_backward(const T *__restrict__ grad, const float *__restrict__ inputs, T *__restrict__ grad_table, uint32_t B,
-                GridMeta meta, uint32_t align, uint32_t interp, uint32_t xflags) {
+                GridMeta meta, uint32_t align, uint32_t interp) {
     constexpr int NP = C / NC;  // channel groups per point
-    uint32_t level = blockIdx.y + (xflags >> 8);
-    uint32_t bx = blockIdx.x;
-    if (xflags & 4) {  // experiment: XCD-affine — block's XCD (bid % 8) picks one of 8 consecutive levels
-        level = (xflags >> 8) + (blockIdx.x & 7);
-        bx = blockIdx.x >> 3;
-    } else if (xflags & 1) {  // experiment: only blocks that land on XCD 0 (bid % 8 == 0) work
-        const uint32_t lin = blockIdx.y * gridDim.x + blockIdx.x;
-        if (lin & 7) return;
-        bx = blockIdx.x >> 3;
-    }
+    const uint32_t level = blockIdx.y;
     const LevelParams lv = meta.lv[level];
-    const uint32_t t = bx * blockDim.x + threadIdx.x;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t b = t / NP;
     const uint32_t ch = (t % NP) * NC;
     const bool in_range = b < B;
@@ -400,7 +388,7 @@ k_grid_backward(const T *__restrict__ grad, const float *__restrict__ inputs, T 
     for (int c = 0; c < NC; c++) g[c] = ok ? (float)grad[((size_t)level * B + b) * C + ch + c] : 0.0f;
     T *gt = grad_table + (size_t)lv.offset * C + ch;
 
-    if (MERGE && NP == 1 && !(xflags & 2)) {
+    if (MERGE && NP == 1) {
         // Lanes are consecutive samples.  If this lane's base cell equals the previous lane's, both touch the same
         // 2^D table rows: pre-reduce w*g over such runs with a segmented inclusive scan; the LAST lane of each run
         // issues the atomics.  Cell identity = all per-dimension base terms equal (exact, hash or dense).
@@ -468,8 +456,12 @@ k_grid_backward(const T *__restrict__ grad, const float *__restrict__ inputs, T 
 //           FIXED POINT: measured on MI355X, ds_add_f32 sustains ~100 G adds/s chip-wide while ds_add_u64 keeps up
 //           with the 6 TB/s pool stream (scratch/ldsbench), and integer accumulation makes the sum exact and
 //           order-independent (fp16 contributions are multiples of 2^-24, so scale 2^24 loses nothing).
-// A bucket whose pool overflows (adversarial, non-uniform input) falls back to global atomics for the excess in
-// pass 1, which completes before pass 2 starts (kernel boundary), so the result is always the full sum.
+// A bucket whose pool overflows (non-uniform input) sends the excess to the level's SPILL list (full row + value, sized
+// for the worst case); pass 2's workgroups of exactly those buckets (cursor > cap) scan the list and add their entries
+// into the same fixed-point image.  Buckets with many entries are cut into slices (blockIdx.y of pass 2); the slices'
+// integer images are written out and summed by pass 3 (k_grid_bwd_finalize).  Every contribution therefore enters ONE
+// integer sum per table row, whichever pool / spill slot it landed in: the result does not depend on workgroup arrival
+// order, for fp32 tables too (each contribution is truncated to 2^-40 on its own before the sum).
 constexpr uint32_t kBucketRowsLog2 = 13;
 constexpr uint32_t kBucketRows = 1u << kBucketRowsLog2;
 constexpr uint32_t kMaxBucketsPerLevel = 64;
@@ -479,6 +471,10 @@ struct BucketPlan {
     uint32_t cap[LNH_MAX_LEVELS];               // pool slots per bucket of that level
     uint64_t pool_off[LNH_MAX_LEVELS];          // byte offset of that level's pool region (16-byte aligned)
     uint64_t rows_off[LNH_MAX_LEVELS];          // fp16 tables: byte offset of the level's row-index array (SoA pool)
+    uint64_t spill_off[LNH_MAX_LEVELS];         // byte offset of the level's spill list (PoolEntry<T> with level-local rows)
+    uint64_t partial_off;                       // byte offset of the slice images (kBucketRows * 2 int64 each)
+    uint32_t spill_cap;                         // entries per spill list (= worst case of a level: B * 2^D)
+    uint32_t partial_slots;
 };
 
 template <typename T>
@@ -536,10 +532,11 @@ template <typename T, int D, int PPT, int NTHREADS>
 __global__ void __launch_bounds__(NTHREADS)
 k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs, T *__restrict__ grad_table,
                    uint32_t B, GridMeta meta, BucketPlan plan, PoolEntry<T> *__restrict__ pool,
-                   uint32_t *__restrict__ cursor, uint32_t align_rt, uint32_t interp_rt, uint32_t dbg, uint32_t n_levels,
-                   uint32_t level0) {
+                   uint32_t *__restrict__ cursor, uint32_t *__restrict__ spill_cursor, uint32_t align_rt,
+                   uint32_t interp_rt, uint32_t n_levels, uint32_t level0) {
     constexpr int C = 2, NCORN = 1 << D;
     __shared__ uint2 lout[kMaxBucketsPerLevel];           // per bucket: {pool slot - staging slot, staging slots that fit}
+    __shared__ uint32_t lsp[kMaxBucketsPerLevel];         // per bucket: spill slot - staging slot of the entries that do not
     __shared__ uint32_t lcnt[kMaxBucketsPerLevel];
     __shared__ uint32_t lbase[kMaxBucketsPerLevel];       // first reserved pool slot per bucket (global)
     __shared__ uint32_t lstart[kMaxBucketsPerLevel + 1];  // first staging slot per bucket (workgroup-local)
@@ -605,7 +602,7 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
             same_prev &= (up == key[d]);
         }
         unsigned long long heads = __ballot(!same_prev);
-        const bool any_merge = !(dbg & 2) && __builtin_popcountll(~heads) >= kMinMerges;  // wave-uniform
+        const bool any_merge = __builtin_popcountll(~heads) >= kMinMerges;  // wave-uniform
         if (!any_merge) heads = ~0ull;
         const unsigned long long below = heads & ((2ull << lane) - 1ull);
         const int run_start = 63 - __builtin_clzll(below);
@@ -684,8 +681,21 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
         const uint32_t st = incl - n0, base = lbase[lane];
         lstart[lane] = st;
         if (lane == 63) lstart[kMaxBucketsPerLevel] = incl;
-        // staging slot pos of bucket bk goes to pool slot bk*cap + base + (pos - st) while base + (pos - st) < cap
-        lout[lane] = make_uint2((uint32_t)lane * cap + base - st, base < cap ? st + min(cap - base, 0x10000u) : st);
+        // staging slot pos of bucket bk goes to pool slot bk*cap + base + (pos - st) while base + (pos - st) < cap;
+        // the `over` entries behind those go to consecutive slots of the level's spill list, reserved with ONE atomic
+        // per workgroup (and none at all in the usual case of no overflow)
+        const uint32_t fit = base < cap ? min(cap - base, n0) : 0u, over = n0 - fit;
+        uint32_t oincl = over;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(oincl, o, 64);
+            if (lane >= o) oincl += up;
+        }
+        uint32_t sp0 = 0;
+        if (lane == 63 && oincl) sp0 = atomicAdd(&spill_cursor[level], oincl);
+        sp0 = __shfl(sp0, 63, 64);
+        lout[lane] = make_uint2((uint32_t)lane * cap + base - st, st + fit);
+        lsp[lane] = sp0 + (oincl - over) - (st + fit);
     }
     __syncthreads();
     // ---- stage the entries in LDS grouped by bucket, then stream them out: consecutive lanes write consecutive pool
@@ -707,26 +717,26 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
     PoolEntry<T> *lp = reinterpret_cast<PoolEntry<T> *>(pool_bytes + plan.pool_off[level]);
     half2_t *lvals = reinterpret_cast<half2_t *>(pool_bytes + plan.pool_off[level]);
     unsigned short *lrows = reinterpret_cast<unsigned short *>(pool_bytes + plan.rows_off[level]);
-    T *gt = grad_table + (size_t)lv.offset * C;
+    PoolEntry<T> *spill = reinterpret_cast<PoolEntry<T> *>(pool_bytes + plan.spill_off[level]);
     const uint32_t total = lstart[kMaxBucketsPerLevel];
     for (uint32_t pos = threadIdx.x; pos < total; pos += blockDim.x) {
         PoolEntry<T> e = stage[pos];
         const uint32_t bk = e.row >> kBucketRowsLog2;
         const uint2 o = lout[bk];
-        e.row &= kBucketRows - 1;
         if (pos < o.y) {
+            e.row &= kBucketRows - 1;
             if constexpr (sizeof(T) == 2) {
                 lvals[o.x + pos] = pool_value(e);
                 lrows[o.x + pos] = (unsigned short)e.row;
             } else {
                 lp[o.x + pos] = e;
             }
-        } else {  // pool overflow: exact but slow
-            float a, b2;
-            entry_get(e, a, b2);
-            atomic_add_pair(gt + ((size_t)bk * kBucketRows + e.row) * C, a, b2);
+        } else {  // the bucket's pool is full: level-local row + value go to the spill list (consumed by pass 2)
+            const uint32_t sp = lsp[bk] + pos;
+            if (sp < plan.spill_cap) spill[sp] = e;  // (always true: a level emits at most B * 2^D entries)
         }
     }
+    (void)grad_table;
     };
     const bool plain = align_rt == 0 && interp_rt == 0;
     if (plain && (lv_rt.flags & (LV_HASH | LV_POW2)) == (LV_HASH | LV_POW2)) body(std::integral_constant<int, 1>{});
@@ -735,18 +745,40 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
     else body(std::integral_constant<int, 0>{});
 }
 
-// A bucket with many entries (coarse dense levels: every ray passes the same few cells) is split over up to
-// kMaxSlices workgroups (blockIdx.y); slices of a split bucket add their partial sums with (few) global atomics, an
-// unsplit bucket owns its rows and uses plain stores.
-constexpr uint32_t kSliceEntries = 384 * 1024;  // measured: 96 K -> 445 us, 192 K -> 425, 384 K -> 415, unsliced 418
+// A bucket with many entries (coarse dense levels: every ray passes the same few cells; very large batches) is split
+// over up to kMaxSlices workgroups (blockIdx.y).  An unsplit bucket owns its rows and adds its image into the table with
+// plain stores; the slices of a split bucket write their 64-bit integer images to the workspace and pass 3
+// (k_grid_bwd_finalize) adds them up — integers, so the sum does not depend on the order.
+constexpr uint32_t kSliceEntries = 512 * 1024;  // measured: 96 K -> 445 us, 192 K -> 425, 384 K -> 415, unsliced 418
 constexpr uint32_t kMaxSlices = 16;
+
+__device__ __forceinline__ uint32_t slices_of(uint32_t n_tot) {
+    const uint32_t s = (n_tot + kSliceEntries - 1) / kSliceEntries;
+    return s > kMaxSlices ? kMaxSlices : s;
+}
+// First image slot of split bucket `bid`: the slices of the split buckets before it in this launch's window
+// [bucket0, ...), in bucket order.  Called by every thread of a 1024-thread workgroup (at most 1024 buckets exist).
+__device__ __forceinline__ uint32_t partial_base(const uint32_t *__restrict__ cursor, uint32_t bucket0, uint32_t bid,
+                                                 uint32_t *sh_sum) {
+    if (threadIdx.x == 0) *sh_sum = 0;
+    __syncthreads();
+    const uint32_t b = bucket0 + threadIdx.x;
+    if (b < bid) {
+        const uint32_t s = slices_of(cursor[b]);
+        if (s > 1) atomicAdd(sh_sum, s);
+    }
+    __syncthreads();
+    return *sh_sum;
+}
 
 template <typename T>
 __global__ void __launch_bounds__(1024)
 k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, const PoolEntry<T> *__restrict__ pool,
-                  const uint32_t *__restrict__ cursor, uint32_t L, uint32_t dbg, uint32_t bucket0) {
+                  const uint32_t *__restrict__ cursor, const uint32_t *__restrict__ spill_cursor, uint32_t L,
+                  uint32_t bucket0) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     unsigned long long *acc = reinterpret_cast<unsigned long long *>(smem_raw);  // [kBucketRows][2] fixed point
+    __shared__ uint32_t sh_sum;
     // fp16 contributions are exact multiples of 2^-24; fp32 ones get 2^-40 resolution and +-8e6 of range
     constexpr int K = sizeof(T) == 2 ? 24 : 40;
     const uint32_t bid = bucket0 + blockIdx.x;
@@ -755,10 +787,10 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
         if (bid >= plan.first_bucket[l]) level = l;
     const LevelParams lv = meta.lv[level];
     const uint32_t bk = bid - plan.first_bucket[level], cap = plan.cap[level];
-    const uint32_t n_all = min(cursor[bid], cap);
-    uint32_t slices = (n_all + kSliceEntries - 1) / kSliceEntries;
-    slices = slices > kMaxSlices ? kMaxSlices : slices;
-    if (blockIdx.y >= slices) return;  // workgroup-uniform (also covers n_all == 0)
+    const uint32_t n_tot = cursor[bid];          // every entry reserved for this bucket, pool + spill
+    const uint32_t n_all = min(n_tot, cap);      // ... of which in the pool
+    const uint32_t slices = slices_of(n_tot);
+    if (blockIdx.y >= slices) return;  // workgroup-uniform (also covers n_tot == 0)
     const uint32_t i_begin = (uint32_t)((uint64_t)n_all * blockIdx.y / slices);
     const uint32_t i_end = (uint32_t)((uint64_t)n_all * (blockIdx.y + 1) / slices);
     const uint32_t n = i_end - i_begin;
@@ -780,7 +812,7 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
         const uint2 *rows4 = reinterpret_cast<const uint2 *>(pool_bytes + plan.rows_off[level]);
         const uint32_t a_begin = bk * cap + i_begin, a_end = a_begin + n;  // level-relative slots (< 2^32, checked)
         const uint32_t q_begin = a_begin >> 2, q_end = (a_end + 3) >> 2;
-        const uint32_t nquads = q_end - q_begin, stride = blockDim.x * UNROLL;
+        const uint32_t nquads = n ? q_end - q_begin : 0u, stride = blockDim.x * UNROLL;
         // double-buffered: the loads of batch i+1 are in flight while the LDS adds of batch i execute
         uint4 rv[2][UNROLL];
         uint2 rr[2][UNROLL];
@@ -849,25 +881,104 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
             }
         }
     }
+    // ---- this bucket overflowed its pool: its remaining entries sit somewhere in the level's spill list (among those
+    //      of the level's other overflowing buckets).  Each slice filters its share of the list.
+    if (n_tot > cap) {  // workgroup-uniform
+        const PoolEntry<T> *spill = reinterpret_cast<const PoolEntry<T> *>(reinterpret_cast<const char *>(pool) +
+                                                                           plan.spill_off[level]);
+        const uint32_t s_all = min(spill_cursor[level], plan.spill_cap);
+        const uint32_t s_begin = (uint32_t)((uint64_t)s_all * blockIdx.y / slices);
+        const uint32_t s_end = (uint32_t)((uint64_t)s_all * (blockIdx.y + 1) / slices);
+        constexpr uint32_t UNROLL = 4;
+        for (uint32_t i0 = s_begin + threadIdx.x; i0 < s_end; i0 += blockDim.x * UNROLL) {
+            PoolEntry<T> e[UNROLL];
+#pragma unroll
+            for (uint32_t u = 0; u < UNROLL; u++) {
+                const uint32_t i = i0 + u * blockDim.x;
+                e[u] = spill[i < s_end ? i : s_end - 1];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < UNROLL; u++) {
+                const uint32_t i = i0 + u * blockDim.x;
+                if (i < s_end && (e[u].row >> kBucketRowsLog2) == bk) {
+                    const uint32_t row = e[u].row & (kBucketRows - 1);
+                    long long qa, qb;
+                    entry_fixed(e[u], K, qa, qb);
+                    atomicAdd(&acc[row], (unsigned long long)qa);
+                    atomicAdd(&acc[kBucketRows + row], (unsigned long long)qb);
+                }
+            }
+        }
+    }
     __syncthreads();
-    T *gt = grad_table + ((size_t)lv.offset + (size_t)bk * kBucketRows) * 2;
-    for (uint32_t r = threadIdx.x; r < rows; r += blockDim.x) {
-        const long long qa = (long long)acc[r], qb = (long long)acc[kBucketRows + r];
-        if (qa != 0 || qb != 0) {
-            const float a = (float)ldexp((double)qa, -K), b = (float)ldexp((double)qb, -K);
-            if (slices == 1) {
+    if (slices == 1) {
+        T *gt = grad_table + ((size_t)lv.offset + (size_t)bk * kBucketRows) * 2;
+        for (uint32_t r = threadIdx.x; r < rows; r += blockDim.x) {
+            const long long qa = (long long)acc[r], qb = (long long)acc[kBucketRows + r];
+            if (qa != 0 || qb != 0) {
+                const float a = (float)ldexp((double)qa, -K), b = (float)ldexp((double)qb, -K);
                 Vec<T, 2> cur = load_vec<T, 2>(gt + 2 * r);
                 cur.v[0] = (T)((float)cur.v[0] + a);
                 cur.v[1] = (T)((float)cur.v[1] + b);
                 store_vec<T, 2>(gt + 2 * r, cur);
-            } else {
-                atomic_add_pair(gt + 2 * r, a, b);
             }
+        }
+    } else {
+        // slice image -> workspace (coalesced 16-byte stores of the whole image); k_grid_bwd_finalize sums the slices
+        const uint32_t slot = partial_base(cursor, bucket0, bid, &sh_sum) + blockIdx.y;
+        if (slot < plan.partial_slots) {  // (always true: plan_buckets sizes the region for the worst case)
+            uint4 *dst = reinterpret_cast<uint4 *>(const_cast<char *>(reinterpret_cast<const char *>(pool)) +
+                                                   plan.partial_off) + (size_t)slot * kBucketRows;
+            const uint4 *src = reinterpret_cast<const uint4 *>(acc);
+            for (uint32_t i = threadIdx.x; i < kBucketRows; i += blockDim.x) dst[i] = src[i];
         }
     }
 }
 
-// Host: bucket layout + pool sizing.  Returns the number of bytes of workspace needed (cursor array + pool).
+// Pass 3: one workgroup per bucket of the window; buckets that were not split return at once.
+template <typename T>
+__global__ void __launch_bounds__(1024)
+k_grid_bwd_finalize(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, const char *__restrict__ pool_bytes,
+                    const uint32_t *__restrict__ cursor, uint32_t L, uint32_t bucket0) {
+    __shared__ uint32_t sh_sum;
+    constexpr int K = sizeof(T) == 2 ? 24 : 40;
+    const uint32_t bid = bucket0 + blockIdx.x;
+    const uint32_t slices = slices_of(cursor[bid]);
+    if (slices <= 1) return;  // workgroup-uniform
+    uint32_t level = 0;
+    for (uint32_t l = 0; l < L; l++)
+        if (bid >= plan.first_bucket[l]) level = l;
+    const LevelParams lv = meta.lv[level];
+    const uint32_t bk = bid - plan.first_bucket[level];
+    const uint32_t rows = min(kBucketRows, lv.hashmap_size - bk * kBucketRows);
+    const uint32_t slot0 = partial_base(cursor, bucket0, bid, &sh_sum);
+    if (slot0 + slices > plan.partial_slots) return;
+    const unsigned long long *img = reinterpret_cast<const unsigned long long *>(pool_bytes + plan.partial_off) +
+                                    (size_t)slot0 * kBucketRows * 2;
+    T *gt = grad_table + ((size_t)lv.offset + (size_t)bk * kBucketRows) * 2;
+    for (uint32_t r = threadIdx.x; r < rows; r += blockDim.x) {
+        long long qa = 0, qb = 0;
+        for (uint32_t sl = 0; sl < slices; sl++) {
+            qa += (long long)img[(size_t)sl * kBucketRows * 2 + r];
+            qb += (long long)img[(size_t)sl * kBucketRows * 2 + kBucketRows + r];
+        }
+        if (qa != 0 || qb != 0) {
+            const float a = (float)ldexp((double)qa, -K), b = (float)ldexp((double)qb, -K);
+            Vec<T, 2> cur = load_vec<T, 2>(gt + 2 * r);
+            cur.v[0] = (T)((float)cur.v[0] + a);
+            cur.v[1] = (T)((float)cur.v[1] + b);
+            store_vec<T, 2>(gt + 2 * r, cur);
+        }
+    }
+}
+
+// Host: bucket layout + pool sizing.  Returns the number of bytes of workspace needed:
+//   [cursor: one u32 per bucket | spill cursor: one u32 per level]  (zeroed by every launch)
+//   [pool of every level] [spill list of every level] [slice images]
+// Pool slots per bucket = even split of the level's worst case (B * 2^D entries) + 12.5 % + 12 sigma of a Poisson
+// count (hashed levels are statistically even; correlated corners of neighbouring samples widen the spread, so the
+// margin is generous) — whatever does not fit goes to the spill list, which holds the level's worst case.
+constexpr uint32_t kCursorAlign = 256;
 template <typename T>
 uint64_t plan_buckets(BucketPlan &plan, const GridMeta &m, uint32_t L, uint32_t B, uint32_t D, uint32_t &total_buckets) {
     const uint64_t per_level = (uint64_t)B << D;  // worst-case entries of one level
@@ -876,9 +987,8 @@ uint64_t plan_buckets(BucketPlan &plan, const GridMeta &m, uint32_t L, uint32_t 
     for (uint32_t l = 0; l < L; l++) {
         const uint32_t nb = (m.lv[l].hashmap_size + kBucketRows - 1) / kBucketRows;
         plan.first_bucket[l] = nbt;
-        // even split of the worst case plus 12.5 % head-room for the statistical imbalance of hashed levels
-        uint64_t cap = (per_level + nb - 1) / nb;
-        cap += cap / 8 + 64;
+        const uint64_t mean = (per_level + nb - 1) / nb;
+        uint64_t cap = mean + mean / 8 + (uint64_t)(12.0 * sqrt((double)mean)) + 64;
         if (cap > per_level) cap = per_level;
         if (cap > 0xffffffffull) cap = 0xffffffffull;
         plan.cap[l] = (uint32_t)cap;
@@ -896,8 +1006,33 @@ uint64_t plan_buckets(BucketPlan &plan, const GridMeta &m, uint32_t L, uint32_t 
     }
     plan.first_bucket[L] = nbt;
     total_buckets = nbt;
-    const uint64_t cursor_bytes = ((uint64_t)nbt * 4 + 255) / 256 * 256;
+    plan.spill_cap = per_level > 0xffffffffull ? 0xffffffffu : (uint32_t)per_level;
+    for (uint32_t l = 0; l < L; l++) {
+        plan.spill_off[l] = bytes;
+        bytes += ((uint64_t)plan.spill_cap * sizeof(PoolEntry<T>) + 15) / 16 * 16;
+    }
+    // slice images: a split bucket has n > kSliceEntries entries and ceil(n / kSliceEntries) < 2 n / kSliceEntries
+    // slices, so all split buckets together have fewer than 2 * (entries of all levels) / kSliceEntries of them
+    uint64_t slots = 2 * (per_level * L) / kSliceEntries + 1;
+    if (slots > (uint64_t)nbt * kMaxSlices) slots = (uint64_t)nbt * kMaxSlices;
+    plan.partial_slots = (uint32_t)slots;
+    plan.partial_off = bytes;
+    bytes += slots * kBucketRows * 2 * sizeof(unsigned long long);
+    const uint64_t cursor_bytes = ((uint64_t)(nbt + L) * 4 + kCursorAlign - 1) / kCursorAlign * kCursorAlign;
     return cursor_bytes + bytes;
+}
+
+// 128 KiB of dynamic LDS needs an opt-in per kernel and DEVICE (a process may drive several devices)
+template <typename K>
+void allow_big_lds(K kernel, size_t lds) {
+    static unsigned long long done = 0;  // bit per device ordinal; the attribute call is idempotent, so a race is harmless
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(__atomic_load_n(&done, __ATOMIC_RELAXED) & bit)) {
+        (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        __atomic_fetch_or(&done, bit, __ATOMIC_RELAXED);
+    }
 }
 
 template <typename T>
@@ -914,6 +1049,10 @@ int launch_backward_bucketed(const T *grad, const float *inputs, T *ge, uint32_t
                       (unsigned long long)need);
         return LNH_ERR_INVALID_ARG;
     }
+    if (((uint64_t)B << 3) > 0xffffffffull) {
+        lnh_set_error("grid backward (bucketed): B = %u is too large for 32-bit pool slots", B);
+        return LNH_ERR_UNSUPPORTED;
+    }
     for (uint32_t l = 0; l < L; l++)
         if ((uint64_t)plan.cap[l] * (plan.first_bucket[l + 1] - plan.first_bucket[l]) > 0xffffffffull) {
             lnh_set_error("grid backward (bucketed): B = %u is too large for 32-bit pool slots", B);
@@ -924,8 +1063,9 @@ int launch_backward_bucketed(const T *grad, const float *inputs, T *ge, uint32_t
             lnh_set_error("grid backward (bucketed): level %u has more than %u buckets", l, kMaxBucketsPerLevel);
             return LNH_ERR_UNSUPPORTED;
         }
-    const uint64_t cursor_bytes = ((uint64_t)nbt * 4 + 255) / 256 * 256;
+    const uint64_t cursor_bytes = ((uint64_t)(nbt + L) * 4 + kCursorAlign - 1) / kCursorAlign * kCursorAlign;
     uint32_t *cursor = reinterpret_cast<uint32_t *>(workspace);
+    uint32_t *spill_cursor = cursor + nbt;
     PoolEntry<T> *pool = reinterpret_cast<PoolEntry<T> *>(reinterpret_cast<char *>(workspace) + cursor_bytes);
     (void)hipGetLastError();
     if (hipMemsetAsync(cursor, 0, cursor_bytes, s) != hipSuccess) {
@@ -937,19 +1077,19 @@ int launch_backward_bucketed(const T *grad, const float *inputs, T *ge, uint32_t
     // staging buffer at 64 KiB (two workgroups per CU)
     const uint32_t n_win = level_end - level_begin;
     LNH_LAUNCH((k_grid_bwd_scatter<T, 3, 1, 1024>), dim3(div_up(B, 1024) * n_win), dim3(1024), 0, s, grad, inputs, ge, B,
-               m, plan, pool, cursor, align, interp, g_dbg_flags, n_win, level_begin);
+               m, plan, pool, cursor, spill_cursor, align, interp, n_win, level_begin);
     int rc = lnh_check_launch("lnh_grid_encode_backward_ws(scatter)");
     if (rc) return rc;
     auto k = k_grid_bwd_reduce<T>;
     const size_t lds = (size_t)kBucketRows * 2 * sizeof(unsigned long long);
-    static bool attr_set = false;  // 128 KiB of dynamic LDS needs the opt-in once per process
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    allow_big_lds(k, lds);
     const uint32_t b0 = plan.first_bucket[level_begin], b1 = plan.first_bucket[level_end];
-    LNH_LAUNCH(k, dim3(b1 - b0, kMaxSlices), dim3(1024), lds, s, ge, m, plan, pool, cursor, L, g_dbg_flags, b0);
-    return lnh_check_launch("lnh_grid_encode_backward_ws(reduce)");
+    LNH_LAUNCH(k, dim3(b1 - b0, kMaxSlices), dim3(1024), lds, s, ge, m, plan, pool, cursor, spill_cursor, L, b0);
+    rc = lnh_check_launch("lnh_grid_encode_backward_ws(reduce)");
+    if (rc) return rc;
+    LNH_LAUNCH((k_grid_bwd_finalize<T>), dim3(b1 - b0), dim3(1024), 0, s, ge, m, plan,
+               reinterpret_cast<const char *>(pool), cursor, L, b0);
+    return lnh_check_launch("lnh_grid_encode_backward_ws(finalize)");
 }
 
 // gridencoder.cu:364-390
@@ -1078,9 +1218,6 @@ template <typename T, int D>
 int launch_backward_c(const T *grad, const float *inputs, T *ge, uint32_t B, uint32_t C, uint32_t L,
                       const GridMeta &m, uint32_t align, uint32_t interp, hipStream_t s) {
     dim3 block(256);
-    const uint32_t xflags = (g_dbg_flags & 0xff) | (g_dbg_l0 << 8);
-    const uint32_t xm = (g_dbg_flags & 5) ? 8 : 1;
-    if (g_dbg_ln) L = g_dbg_ln;
     switch (C) {
         case 1:
             if constexpr (sizeof(T) == 2) {
@@ -1088,21 +1225,21 @@ int launch_backward_c(const T *grad, const float *inputs, T *ge, uint32_t B, uin
                               "grid.py:54-57)");
                 return LNH_ERR_UNSUPPORTED;
             } else {
-                LNH_LAUNCH((k_grid_backward<T, D, 1, 1, true>), dim3(div_up(B, 256) * xm, L), block, 0, s, grad,
-                                   inputs, ge, B, m, align, interp, xflags);
+                LNH_LAUNCH((k_grid_backward<T, D, 1, 1, true>), dim3(div_up(B, 256), L), block, 0, s, grad,
+                                   inputs, ge, B, m, align, interp);
             }
             break;
         case 2:
-            LNH_LAUNCH((k_grid_backward<T, D, 2, 2, true>), dim3(div_up(B, 256) * xm, L), block, 0, s, grad, inputs,
-                               ge, B, m, align, interp, xflags);
+            LNH_LAUNCH((k_grid_backward<T, D, 2, 2, true>), dim3(div_up(B, 256), L), block, 0, s, grad, inputs,
+                               ge, B, m, align, interp);
             break;
         case 4:
             LNH_LAUNCH((k_grid_backward<T, D, 4, 2, false>), dim3(div_up((uint64_t)B * 2, 256), L), block, 0, s,
-                               grad, inputs, ge, B, m, align, interp, xflags);
+                               grad, inputs, ge, B, m, align, interp);
             break;
         case 8:
             LNH_LAUNCH((k_grid_backward<T, D, 8, 2, false>), dim3(div_up((uint64_t)B * 4, 256), L), block, 0, s,
-                               grad, inputs, ge, B, m, align, interp, xflags);
+                               grad, inputs, ge, B, m, align, interp);
             break;
         default: lnh_set_error("GridEncoding: C must be 1, 2, 4, or 8 (got %u)", C); return LNH_ERR_UNSUPPORTED;
     }
@@ -1166,13 +1303,6 @@ int check_common(const void *inputs, const int32_t *offsets_host, uint32_t B, ui
     }
 
 extern "C" {
-
-// not part of the public ABI (not declared in lidarnerf_hip.h): experiment knobs for scratch/ micro-benchmarks
-__attribute__((visibility("default"))) void lnh_debug_grid_bwd(uint32_t l0, uint32_t ln, uint32_t flags) {
-    g_dbg_l0 = l0;
-    g_dbg_ln = ln;
-    g_dbg_flags = flags;
-}
 
 int lnh_grid_encode_forward(const float *inputs, const void *embeddings, const int32_t *offsets_host, void *outputs,
                             uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void *dy_dx,
@@ -1258,6 +1388,25 @@ uint64_t lnh_grid_backward_workspace_size(const int32_t *offsets_host, uint32_t 
     for (uint32_t l = 0; l < L; l++)
         if ((m.lv[l].hashmap_size + kBucketRows - 1) / kBucketRows > kMaxBucketsPerLevel) return 0;
     return dtype == LNH_F16 ? plan_buckets<half_t>(plan, m, L, B, D, nbt) : plan_buckets<float>(plan, m, L, B, D, nbt);
+}
+
+int lnh_grid_backward_plan_info(const int32_t *offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                uint32_t H, uint32_t gridtype, int align_corners, int dtype, uint32_t level,
+                                uint32_t *out4) {
+    LNH_REQUIRE(out4 && offsets_host, LNH_ERR_INVALID_ARG, "grid backward plan: null argument");
+    LNH_REQUIRE(lnh_grid_backward_workspace_size(offsets_host, B, D, C, L, S, H, gridtype, align_corners, dtype) != 0 &&
+                    level < L, LNH_ERR_UNSUPPORTED, "grid backward plan: configuration not served by the bucketed path");
+    GridMeta m;
+    (void)build_meta(m, offsets_host, D, L, S, H, gridtype, align_corners != 0);
+    BucketPlan plan;
+    uint32_t nbt = 0;
+    if (dtype == LNH_F16) (void)plan_buckets<half_t>(plan, m, L, B, D, nbt);
+    else (void)plan_buckets<float>(plan, m, L, B, D, nbt);
+    out4[0] = plan.first_bucket[level + 1] - plan.first_bucket[level];
+    out4[1] = plan.cap[level];
+    out4[2] = kBucketRows;
+    out4[3] = kSliceEntries;
+    return LNH_OK;
 }
 
 int lnh_grid_encode_backward_ws(const void *grad, const float *inputs, const int32_t *offsets_host,

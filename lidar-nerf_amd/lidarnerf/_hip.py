@@ -61,7 +61,8 @@ _SIGS = {
     "lnh_lidar_loss": [P, P, P, U32, F32, F32, F32, P, P, P],
     "lnh_lidar_color_backward": [P, P, P, P, P, P, P, U32, U32, P, P, P],
 }
-EXPORTS = sorted(list(_SIGS) + ["lnh_version", "lnh_last_error", "lnh_arch", "lnh_grid_backward_workspace_size"])
+EXPORTS = sorted(list(_SIGS) + ["lnh_version", "lnh_last_error", "lnh_arch", "lnh_grid_backward_workspace_size",
+                                 "lnh_grid_backward_plan_info"])
 
 LNH_F32, LNH_F16 = 0, 1
 
@@ -87,6 +88,8 @@ def lib():
             fn.restype = C.c_int
         L.lnh_grid_backward_workspace_size.argtypes = [P, U32, U32, U32, U32, F32, U32, U32, I32, I32]
         L.lnh_grid_backward_workspace_size.restype = C.c_uint64
+        L.lnh_grid_backward_plan_info.argtypes = [P, U32, U32, U32, U32, F32, U32, U32, I32, I32, U32, P]
+        L.lnh_grid_backward_plan_info.restype = C.c_int
         L.lnh_last_error.restype = C.c_char_p
         L.lnh_arch.restype = C.c_char_p
         L.lnh_version.restype = C.c_int

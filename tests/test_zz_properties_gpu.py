@@ -1,0 +1,130 @@
+"""Self-consistency and size-independent property tests (no oracle on the other side).  The file name sorts after every
+oracle-parity file on purpose: under `pytest -x` a failure here cannot hide a parity test."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import grid_ref
+
+pytestmark = pytest.mark.gpu
+
+H, L, CH = 16, 16, 2
+PLS = grid_ref.per_level_scale(32768, H, L)
+S = float(np.log2(PLS))
+OFF = grid_ref.make_offsets(3, L, PLS, H, 19)
+
+
+def _ray_points(n_rays, T, seed):
+    """Consecutive samples along rays (exercises the wave run-merge in backward)."""
+    r = np.random.default_rng(seed)
+    o = r.random((n_rays, 1, 3), dtype=np.float32) * 0.2 + 0.4
+    d = r.standard_normal((n_rays, 1, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    t = np.linspace(0.005, 0.45, T, dtype=np.float32)[None, :, None]
+    return np.clip(o + d * t, 0, 1).reshape(-1, 3).astype(np.float32)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16])
+def test_backward_bucketed_level_windows(dt):
+    """lnh_grid_encode_backward_ws_levels over consecutive windows == the one-shot call, bit for bit (the bucketed sum
+    is order-independent), and a window leaves the rows of the other levels alone."""
+    from gpu_util import call, dev
+    from lidarnerf import _hip
+    x = _ray_points(40, 256, 3)
+    B = x.shape[0]
+    nd = np.float32 if dt == torch.float32 else np.float16
+    g = (np.random.default_rng(4).standard_normal((L, B, CH)) * 0.1).astype(nd)
+    rows = int(OFF[-1])
+    code = 0 if dt == torch.float32 else 1
+    offh = torch.from_numpy(OFF)
+    need = _hip.lib().lnh_grid_backward_workspace_size(offh.data_ptr(), B, 3, CH, L, S, H, 0, 0, code)
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    full = torch.zeros((rows, CH), dtype=dt, device="cuda")
+    call("lnh_grid_encode_backward_ws", dev(g), dev(x), offh, full, B, 3, CH, L, S, H, 0, 0, 0, code, ws, need)
+    part = torch.zeros((rows, CH), dtype=dt, device="cuda")
+    gd, xd = dev(g), dev(x)
+    windows = [(0, 7), (7, 10), (10, 13), (13, L)] if L == 16 else [(0, L // 2), (L // 2, L)]
+    for k, (l0, l1) in enumerate(windows):
+        call("lnh_grid_encode_backward_ws_levels", gd, xd, offh, part, B, 3, CH, L, S, H, 0, 0, 0, code, ws, need, l0, l1)
+        done = int(OFF[l1])
+        assert torch.equal(part[:done], full[:done])
+        assert float(part[done:].abs().max()) == 0.0 if done < rows else True
+    assert torch.equal(part, full)
+    call("lnh_grid_encode_backward_ws_levels", gd, xd, offh, part, B, 3, CH, L, S, H, 0, 0, 0, code, ws, need, 5, 5)  # empty
+    assert torch.equal(part, full)
+    with pytest.raises(RuntimeError, match="level_begin"):
+        call("lnh_grid_encode_backward_ws_levels", gd, xd, offh, part, B, 3, CH, L, S, H, 0, 0, 0, code, ws, need, 3, L + 1)
+
+
+def test_backward_full_size_checksum():
+    """Full BASELINE size: sum of the gradient table == sum of upstream grads (weights of a cell sum to 1)."""
+    from gpu_util import call
+    n_rays, T = 4096, 832
+    x = torch.from_numpy(_ray_points(64, T, 3)).cuda().repeat(n_rays // 64, 1)
+    x = (x + torch.rand_like(x) * 1e-3).clamp(0, 1)
+    B = x.shape[0]
+    g = torch.randn((L, B, CH), device="cuda") * 0.01
+    rows = int(OFF[-1])
+    ge = torch.zeros((rows, CH), device="cuda")
+    call("lnh_grid_encode_backward", g, x, None, torch.from_numpy(OFF), ge, B, 3, CH, L, S, H, None, None, 0, 0, 0, 0)
+    torch.cuda.synchronize()
+    offs = torch.from_numpy(OFF.astype(np.int64))
+    for l in range(L):
+        s_tab = ge[offs[l]:offs[l + 1]].double().sum(0)
+        s_g = g[l].double().sum(0)
+        assert torch.allclose(s_tab, s_g, rtol=1e-3, atol=1e-2), (l, s_tab, s_g)
+
+
+def test_forward_full_size_properties():
+    """Full BASELINE size (4096 rays x 832 samples), fp16 table, size-independent properties of the interpolation:
+    (1) a table that is constant per level reproduces that constant (the 8 weights of a cell sum to 1) wherever the
+    point is inside the grid, and 0 outside; (2) the bucketed backward of the same batch is the adjoint of the forward:
+    <forward(table), g> == <table, backward(g)>; (3) the row-mapped variant writes the same values into its slots."""
+    from gpu_util import call
+    from lidarnerf import _hip
+    n_rays, T = 4096, 832
+    x = torch.from_numpy(_ray_points(64, T, 5)).cuda().repeat(n_rays // 64, 1)
+    x = (x + torch.rand_like(x) * 1e-3)
+    x[::1000] = 1.5                                   # some points outside the grid
+    B = x.shape[0]
+    rows = int(OFF[-1])
+    offh = torch.from_numpy(OFF)
+    offs = OFF.astype(np.int64)
+    consts = torch.linspace(0.25, 4.0, L)
+    tab = torch.empty((rows, CH), dtype=torch.half, device="cuda")
+    for l in range(L):
+        tab[offs[l]:offs[l + 1]] = consts[l]
+    out = torch.empty((L, B, CH), dtype=torch.half, device="cuda")
+    call("lnh_grid_encode_forward", x, tab, offh, out, B, 3, CH, L, S, H, None, 0, 0, 0, 1)
+    inside = ((x >= 0) & (x <= 1)).all(1)
+    for l in range(L):
+        v = out[l].float()
+        assert float((v[inside] - consts[l]).abs().max()) <= 4e-3 * float(consts[l])   # 8 fp16 roundings
+        assert float(v[~inside].abs().max()) == 0.0
+    # (2) adjointness on a random POSITIVE table / gradient (so that the two inner products are large sums without
+    #     cancellation and a relative tolerance means something; fp32 accumulation on both sides, fp16 storage)
+    tab = (torch.rand((rows, CH), device="cuda") * 0.5 + 0.1).half()
+    call("lnh_grid_encode_forward", x, tab, offh, out, B, 3, CH, L, S, H, None, 0, 0, 0, 1)
+    g = (torch.rand((L, B, CH), device="cuda") * 1e-3 + 1e-4).half()  # row sums of ~50 of these stay far below 65504
+    need = _hip.lib().lnh_grid_backward_workspace_size(offh.data_ptr(), B, 3, CH, L, S, H, 0, 0, 1)
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    gt = torch.zeros((rows, CH), dtype=torch.half, device="cuda")
+    call("lnh_grid_encode_backward_ws", g, x, offh, gt, B, 3, CH, L, S, H, 0, 0, 0, 1, ws, need)
+    lhs = float((out.double() * g.double()).sum())
+    rhs = float((tab.double() * gt.double()).sum())
+    assert lhs > 1e3 and abs(lhs - rhs) <= 2e-3 * abs(lhs), (lhs, rhs)
+    # (3) row map: T_cur = 768 of T_tot = 832 slots per ray, offset 0 -> rows r*832 + j
+    Tc = 768
+    Bc = n_rays * Tc
+    xs = torch.zeros((B, 3), device="cuda")
+    ray = torch.arange(Bc, device="cuda") // Tc
+    dst = ray * T + torch.arange(Bc, device="cuda") % Tc
+    xs[dst] = x[:Bc]
+    mapped = torch.zeros((L, B, CH), dtype=torch.half, device="cuda")
+    call("lnh_grid_encode_forward_mapped", xs, tab, offh, mapped, Bc, Tc, T, 0, B, CH, L, S, H, 1)
+    plain = torch.empty((L, Bc, CH), dtype=torch.half, device="cuda")
+    call("lnh_grid_encode_forward", x[:Bc].contiguous(), tab, offh, plain, Bc, 3, CH, L, S, H, None, 0, 0, 0, 1)
+    assert torch.equal(mapped[:, dst], plain)
+    untouched = torch.ones(B, dtype=torch.bool, device="cuda")
+    untouched[dst] = False
+    assert float(mapped[:, untouched].abs().max()) == 0.0
