@@ -15,8 +15,11 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "lib", "obj")
-LIB = os.path.join(HERE, "lib", "liblidarnerf_hip.so")
+# Developer hook for A/B experiments (tools/): LNH_VARIANT=name builds lib/liblidarnerf_hip_<name>.so from objects in
+# lib/obj_<name>/ with LNH_EXTRA_FLAGS appended; the product library and its objects are not touched.
+_VARIANT = os.environ.get("LNH_VARIANT", "")
+OBJ = os.path.join(HERE, "lib", "obj" + ("_" + _VARIANT if _VARIANT else ""))
+LIB = os.path.join(HERE, "lib", "liblidarnerf_hip" + ("_" + _VARIANT if _VARIANT else "") + ".so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 # -ffp-contract=off: fused multiply-adds are written explicitly (fmaf) where the reference's compiler fuses them, so
@@ -42,11 +45,13 @@ def _newer(src, deps, out):
 
 def _compile(src, force):
     out = os.path.join(OBJ, os.path.basename(src).replace(".hip", ".o"))
+    if _VARIANT and os.path.basename(src) not in os.environ.get("LNH_VARIANT_FILES", "grid.hip").split():
+        return os.path.join(HERE, "lib", "obj", os.path.basename(out)), False  # unchanged files: the product's objects
     deps = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
     if not force and not _newer(src, deps, out):
         return out, False
     extra = [] if os.path.basename(src) in NO_VGPR_FORM else MFMA_VGPR_FORM
-    cmd = [HIPCC] + FLAGS + extra + ["-c", src, "-o", out]
+    cmd = [HIPCC] + FLAGS + extra + os.environ.get("LNH_EXTRA_FLAGS", "").split() + ["-c", src, "-o", out]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")

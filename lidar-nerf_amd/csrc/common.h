@@ -72,6 +72,17 @@ __device__ __forceinline__ float wave_scan_mul(float v, int lane) {
     return v;
 }
 
+// inclusive scan (sum) of a 32-bit integer across the 64 lanes on the DPP network (row_shr x4, row_bcast:15, :31)
+__device__ __forceinline__ uint32_t wave_scan_add_u32(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
 // ---- segmented inclusive add-scan over the 64 lanes on the DPP network (6 VALU ops, no LDS/bpermute traffic).
 // `run_start` = first lane of the run this lane belongs to (runs are contiguous lane ranges).  After the four
 // row_shr steps a lane holds the sum over [max(run_start, row_start) .. lane]; row_bcast:15 / :31 carry the partial

@@ -14,8 +14,11 @@
 //     coarse levels, where one cell spans many consecutive samples of a ray) are summed with a segmented shuffle
 //     scan and only the run tail issues the atomic.
 #include "common.h"
+typedef uint32_t uint4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t uint2_t __attribute__((ext_vector_type(2)));
 #include <type_traits>
 
+#include <algorithm>
 #include <cmath>
 
 namespace {
@@ -459,7 +462,7 @@ k_grid_backward(const T *__restrict__ grad, const float *__restrict__ inputs, T 
 // A bucket whose pool overflows (non-uniform input) sends the excess to the level's SPILL list (full row + value, sized
 // for the worst case); pass 2's workgroups of exactly those buckets (cursor > cap) scan the list and add their entries
 // into the same fixed-point image.  Buckets with many entries are cut into slices (blockIdx.y of pass 2); the slices'
-// integer images are written out and summed by pass 3 (k_grid_bwd_finalize).  Every contribution therefore enters ONE
+// integer images are written out and summed by the slice that finishes last.  Every contribution therefore enters ONE
 // integer sum per table row, whichever pool / spill slot it landed in: the result does not depend on workgroup arrival
 // order, for fp32 tables too (each contribution is truncated to 2^-40 on its own before the sum).
 constexpr uint32_t kBucketRowsLog2 = 13;
@@ -498,13 +501,15 @@ __device__ __forceinline__ void entry_set(PoolEntry<float> &e, uint32_t row, flo
     e.v0 = a;
     e.v1 = b;
 }
-// value * 2^24 of an fp16 number as an exact 64-bit integer, from its bits (no double-precision round trip):
-// normal: (1024 | m) << (e - 1), subnormal: m
+// value * 2^24 of an fp16 number as an exact 64-bit integer in 5 VALU operations: x = h * 2^24 is an integer with
+// |x| < 2^40, so the double 1.5 * 2^52 + x is exact and its 52 mantissa bits hold 2^51 + x — low word = x mod 2^32, the 20
+// bits above = 2^19 + floor(x / 2^32).  (The bit-twiddling form — (1024 | m) << (e - 1), negate — cost 12 per value and
+// made the reduce pass VALU-bound: 34 VALU operations per pool entry against two ds_add_u64.)
 __device__ __forceinline__ long long half_to_fixed24(half_t h) {
-    const uint32_t bits = __builtin_bit_cast(unsigned short, h);
-    const uint32_t e = (bits >> 10) & 31u, mant = bits & 1023u;
-    const unsigned long long mag = e ? ((unsigned long long)(1024u | mant) << (e - 1u)) : (unsigned long long)mant;
-    return (bits & 0x8000u) ? -(long long)mag : (long long)mag;
+    const double d = __builtin_fma((double)(float)h, 16777216.0, 6755399441055744.0);
+    const unsigned long long bits = __builtin_bit_cast(unsigned long long, d);
+    const int hi = (int)((uint32_t)(bits >> 32) & 0xFFFFFu) - 0x80000;
+    return (long long)(((unsigned long long)(uint32_t)hi << 32) | (bits & 0xFFFFFFFFull));
 }
 __device__ __forceinline__ void entry_fixed(const PoolEntry<half_t> &e, int, long long &qa, long long &qb) {
     qa = half_to_fixed24(e.v[0]);
@@ -538,7 +543,6 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
     __shared__ uint2 lout[kMaxBucketsPerLevel];           // per bucket: {pool slot - staging slot, staging slots that fit}
     __shared__ uint32_t lsp[kMaxBucketsPerLevel];         // per bucket: spill slot - staging slot of the entries that do not
     __shared__ uint32_t lcnt[kMaxBucketsPerLevel];
-    __shared__ uint32_t lbase[kMaxBucketsPerLevel];       // first reserved pool slot per bucket (global)
     __shared__ uint32_t lstart[kMaxBucketsPerLevel + 1];  // first staging slot per bucket (workgroup-local)
     __shared__ PoolEntry<T> stage[NTHREADS * PPT * NCORN];
     // level-fastest workgroup order: concurrently resident workgroups work on the same points at different levels
@@ -556,10 +560,7 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
     if constexpr (MODE == 1) lv.flags = LV_HASH | LV_POW2;
     if constexpr (MODE == 2) lv.flags = LV_NOWRAP | (uint32_t)D;
     const uint32_t align = MODE ? 0u : align_rt, interp = MODE ? 0u : interp_rt;
-    if (threadIdx.x < kMaxBucketsPerLevel) {
-        lcnt[threadIdx.x] = 0;
-        lbase[threadIdx.x] = 0;
-    }
+    if (threadIdx.x < kMaxBucketsPerLevel) lcnt[threadIdx.x] = 0;
 
     float v0[PPT][NCORN], v1[PPT][NCORN];
     uint32_t row[PPT][NCORN];
@@ -577,11 +578,18 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
         }
         const Vec<T, 2> gv = load_vec<T, 2>(grad + ((size_t)level * B + bc) * C);
         Cell<D> cell;
-        bool ok = in_range && locate<D>(x, lv, align != 0, interp, cell);
+        bool ok = in_range;
+#pragma unroll
+        for (int d = 0; d < D; d++) ok = ok && !(x[d] < 0.0f || x[d] > 1.0f);
+        // Lanes that are not `ok` never emit and never merge with a neighbour (unique key below): instead of zeroing
+        // their 8 weights and 8 rows afterwards, they are located at the cube centre (3 selects) with a zero gradient
+        // (every value stays finite — the scan multiplies foreign lanes by 0, and 0 * inf would poison a neighbour).
+#pragma unroll
+        for (int d = 0; d < D; d++) x[d] = ok ? x[d] : 0.5f;
+        (void)locate<D>(x, lv, align != 0, interp, cell);
         const float g0 = ok ? (float)gv.v[0] : 0.0f, g1 = ok ? (float)gv.v[1] : 0.0f;
         // a sample whose upstream gradient is exactly zero (fp16 underflow behind an opaque surface, masked-out
         // rays) contributes nothing: drop it here instead of moving 8 zero entries through the pool
-        (void)0;
         ok = ok && (g0 != 0.0f || g1 != 0.0f);
         // ---- run-merge inside 16-lane rows: consecutive lanes are consecutive samples of a ray, which share their cell
         //      on the coarser levels.  Runs are cut at DPP row starts (pure-VALU row_shr scan, no cross-row traffic), and
@@ -610,14 +618,14 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
         emit[q] = ok && ((lane == 63) || (heads_above & 1ull));
 #pragma unroll
         for (uint32_t c = 0; c < (uint32_t)NCORN; c++) {
-            const float w = ok ? corner_weight<D>(cell, c) : 0.0f;
+            const float w = corner_weight<D>(cell, c);
             v0[q][c] = w * g0;
             v1[q][c] = w * g1;
             if constexpr (sizeof(T) == 2) {  // per-contribution rounding of the reference (gridencoder.cu:350)
                 v0[q][c] = (float)(half_t)v0[q][c];
                 v1[q][c] = (float)(half_t)v1[q][c];
             }
-            row[q][c] = ok ? corner_row<D>(cell, lv, c) : 0u;
+            row[q][c] = corner_row<D>(cell, lv, c);
         }
         if (any_merge) {  // wave-uniform
             const SegScanMask sm = wave_segscan_mask(lane, run_start);
@@ -671,26 +679,17 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
     if (threadIdx.x < 64) {
         static_assert(kMaxBucketsPerLevel == 64, "one bucket counter per lane of the first wave");
         const uint32_t n0 = lcnt[lane];
-        if ((uint32_t)lane < nb && n0) lbase[lane] = atomicAdd(&cursor[fb + lane], n0);
-        uint32_t incl = n0;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t up = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += up;
-        }
-        const uint32_t st = incl - n0, base = lbase[lane];
+        uint32_t base = 0;
+        if ((uint32_t)lane < nb && n0) base = atomicAdd(&cursor[fb + lane], n0);
+        const uint32_t incl = wave_scan_add_u32(n0);  // DPP network: no LDS round trips while the atomics are in flight
+        const uint32_t st = incl - n0;
         lstart[lane] = st;
         if (lane == 63) lstart[kMaxBucketsPerLevel] = incl;
         // staging slot pos of bucket bk goes to pool slot bk*cap + base + (pos - st) while base + (pos - st) < cap;
         // the `over` entries behind those go to consecutive slots of the level's spill list, reserved with ONE atomic
         // per workgroup (and none at all in the usual case of no overflow)
         const uint32_t fit = base < cap ? min(cap - base, n0) : 0u, over = n0 - fit;
-        uint32_t oincl = over;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t up = __shfl_up(oincl, o, 64);
-            if (lane >= o) oincl += up;
-        }
+        const uint32_t oincl = wave_scan_add_u32(over);
         uint32_t sp0 = 0;
         if (lane == 63 && oincl) sp0 = atomicAdd(&spill_cursor[level], oincl);
         sp0 = __shfl(sp0, 63, 64);
@@ -719,14 +718,29 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
     unsigned short *lrows = reinterpret_cast<unsigned short *>(pool_bytes + plan.rows_off[level]);
     PoolEntry<T> *spill = reinterpret_cast<PoolEntry<T> *>(pool_bytes + plan.spill_off[level]);
     const uint32_t total = lstart[kMaxBucketsPerLevel];
-    for (uint32_t pos = threadIdx.x; pos < total; pos += blockDim.x) {
-        PoolEntry<T> e = stage[pos];
+    // every thread moves up to PPT * 2^D entries: all their LDS reads (entry, then the bucket's slot map) are issued
+    // before the first use — one round trip for the batch instead of two dependent ones per entry
+    constexpr int NW = PPT * NCORN;
+    PoolEntry<T> es[NW];
+    uint2 os[NW];
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+        const uint32_t pos = threadIdx.x + (uint32_t)i * NTHREADS;
+        es[i] = stage[pos < total ? pos : 0u];
+    }
+#pragma unroll
+    for (int i = 0; i < NW; i++) os[i] = lout[(es[i].row >> kBucketRowsLog2) & (kMaxBucketsPerLevel - 1)];
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+        const uint32_t pos = threadIdx.x + (uint32_t)i * NTHREADS;
+        if (pos >= total) break;
+        PoolEntry<T> e = es[i];
         const uint32_t bk = e.row >> kBucketRowsLog2;
-        const uint2 o = lout[bk];
+        const uint2 o = os[i];
         if (pos < o.y) {
             e.row &= kBucketRows - 1;
             if constexpr (sizeof(T) == 2) {
-                lvals[o.x + pos] = pool_value(e);
+                lvals[o.x + pos] = pool_value(e);  // (non-temporal stores here: scatter +40 us, reduce -8 us)
                 lrows[o.x + pos] = (unsigned short)e.row;
             } else {
                 lp[o.x + pos] = e;
@@ -747,8 +761,8 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
 
 // A bucket with many entries (coarse dense levels: every ray passes the same few cells; very large batches) is split
 // over up to kMaxSlices workgroups (blockIdx.y).  An unsplit bucket owns its rows and adds its image into the table with
-// plain stores; the slices of a split bucket write their 64-bit integer images to the workspace and pass 3
-// (k_grid_bwd_finalize) adds them up — integers, so the sum does not depend on the order.
+// plain stores; the slices of a split bucket write their 64-bit integer images to the workspace and the slice that
+// arrives last adds them up — integers, so the sum does not depend on the order.
 constexpr uint32_t kSliceEntries = 512 * 1024;  // measured: 96 K -> 445 us, 192 K -> 425, 384 K -> 415, unsliced 418
 constexpr uint32_t kMaxSlices = 16;
 
@@ -756,32 +770,70 @@ __device__ __forceinline__ uint32_t slices_of(uint32_t n_tot) {
     const uint32_t s = (n_tot + kSliceEntries - 1) / kSliceEntries;
     return s > kMaxSlices ? kMaxSlices : s;
 }
-// First image slot of split bucket `bid`: the slices of the split buckets before it in this launch's window
-// [bucket0, ...), in bucket order.  Called by every thread of a 1024-thread workgroup (at most 1024 buckets exist).
-__device__ __forceinline__ uint32_t partial_base(const uint32_t *__restrict__ cursor, uint32_t bucket0, uint32_t bid,
-                                                 uint32_t *sh_sum) {
-    if (threadIdx.x == 0) *sh_sum = 0;
-    __syncthreads();
-    const uint32_t b = bucket0 + threadIdx.x;
-    if (b < bid) {
-        const uint32_t s = slices_of(cursor[b]);
-        if (s > 1) atomicAdd(sh_sum, s);
-    }
-    __syncthreads();
-    return *sh_sum;
-}
+// Work items of pass 2 in dispatch order (blockIdx.x): first the EXTRA slices (slice 1.. of every split bucket — known
+// only on the device, so the launch carries the host-side upper bound `n_extra` of them and the surplus workgroups
+// exit after one look at the cursors), then slice 0 of every bucket of the window, longest first: buckets of the dense
+// levels (few rows near the sensor take most entries -> same-address LDS adds), then the hashed levels from the finest
+// (no run-merge, most entries) to the coarsest.  The dispatcher hands a free CU the next workgroup in that order, i.e.
+// longest-processing-time-first list scheduling; with the plain (bucket, slice) grid the slices of the split buckets
+// were dispatched behind everything else and 15 of 16 workgroups were empty, each waiting for a CU with 128 KiB of
+// free LDS only to exit.
+struct ReduceOrder {
+    uint32_t level[LNH_MAX_LEVELS];      // levels of the window in processing order
+    uint32_t first[LNH_MAX_LEVELS + 1];  // prefix sum of their bucket counts
+    uint32_t n_levels, n_extra, bucket0, n_buckets;  // window: buckets [bucket0, bucket0 + n_buckets)
+};
 
 template <typename T>
 __global__ void __launch_bounds__(1024)
 k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, const PoolEntry<T> *__restrict__ pool,
-                  const uint32_t *__restrict__ cursor, const uint32_t *__restrict__ spill_cursor, uint32_t L,
-                  uint32_t bucket0) {
+                  const uint32_t *__restrict__ cursor, const uint32_t *__restrict__ spill_cursor,
+                  uint32_t *__restrict__ done, uint32_t L, ReduceOrder ord) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     unsigned long long *acc = reinterpret_cast<unsigned long long *>(smem_raw);  // [kBucketRows][2] fixed point
-    __shared__ uint32_t sh_sum;
+    __shared__ uint32_t sh_sum, sh_item[4], sh_wave[2][16];
     // fp16 contributions are exact multiples of 2^-24; fp32 ones get 2^-40 resolution and +-8e6 of range
     constexpr int K = sizeof(T) == 2 ? 24 : 40;
-    const uint32_t bid = bucket0 + blockIdx.x;
+    // ---- which (bucket, slice) is this workgroup?
+    const bool is_extra = blockIdx.x < ord.n_extra;
+    uint32_t bid = ord.bucket0, slice = 0, slot0 = 0;
+    if (!is_extra) {
+        const uint32_t j = blockIdx.x - ord.n_extra;
+        uint32_t k = 0;
+        for (uint32_t q = 1; q < ord.n_levels; q++)
+            if (j >= ord.first[q]) k = q;
+        bid = plan.first_bucket[ord.level[k]] + (j - ord.first[k]);
+    }
+    if (is_extra || slices_of(cursor[bid]) > 1) {  // workgroup-uniform
+        // block-wide exclusive scan over the window's buckets: extra slices before a bucket (-> which bucket an extra
+        // workgroup serves) and image slots before it (-> where a split bucket keeps its slice images)
+        const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
+        const uint32_t sl = t < ord.n_buckets ? slices_of(cursor[ord.bucket0 + t]) : 0u;
+        const uint32_t ex = sl > 1 ? sl - 1 : 0u, im = sl > 1 ? sl : 0u;
+        const uint32_t in_ex = wave_scan_add_u32(ex), in_im = wave_scan_add_u32(im);
+        if (lane == 63) {
+            sh_wave[0][wv] = in_ex;
+            sh_wave[1][wv] = in_im;
+        }
+        if (t == 0) sh_item[0] = 0;
+        __syncthreads();
+        uint32_t ex0 = in_ex - ex, im0 = in_im - im;
+        for (uint32_t w = 0; w < wv; w++) {
+            ex0 += sh_wave[0][w];
+            im0 += sh_wave[1][w];
+        }
+        if (is_extra ? (ex && blockIdx.x >= ex0 && blockIdx.x < ex0 + ex) : (ord.bucket0 + t == bid)) {
+            sh_item[0] = 1;
+            sh_item[1] = ord.bucket0 + t;
+            sh_item[2] = is_extra ? blockIdx.x - ex0 + 1 : 0u;
+            sh_item[3] = im0;
+        }
+        __syncthreads();
+        if (!sh_item[0]) return;  // surplus extra workgroup
+        bid = sh_item[1];
+        slice = sh_item[2];
+        slot0 = sh_item[3];
+    }
     uint32_t level = 0;
     for (uint32_t l = 0; l < L; l++)
         if (bid >= plan.first_bucket[l]) level = l;
@@ -790,9 +842,9 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
     const uint32_t n_tot = cursor[bid];          // every entry reserved for this bucket, pool + spill
     const uint32_t n_all = min(n_tot, cap);      // ... of which in the pool
     const uint32_t slices = slices_of(n_tot);
-    if (blockIdx.y >= slices) return;  // workgroup-uniform (also covers n_tot == 0)
-    const uint32_t i_begin = (uint32_t)((uint64_t)n_all * blockIdx.y / slices);
-    const uint32_t i_end = (uint32_t)((uint64_t)n_all * (blockIdx.y + 1) / slices);
+    if (slice >= slices) return;  // workgroup-uniform (n_tot == 0: nothing to add)
+    const uint32_t i_begin = (uint32_t)((uint64_t)n_all * slice / slices);
+    const uint32_t i_end = (uint32_t)((uint64_t)n_all * (slice + 1) / slices);
     const uint32_t n = i_end - i_begin;
     const uint32_t rows = min(kBucketRows, lv.hashmap_size - bk * kBucketRows);
     // channel-planar image: acc[row] | acc[kBucketRows + row].  With the two channels of a row interleaved, each
@@ -806,7 +858,7 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
     if constexpr (sizeof(T) == 2) {
         // fp16 tables: two streams, read as aligned QUADS of entries (16 bytes of values + 8 bytes of rows per load
         // pair); slots outside [a_begin, a_end) are masked
-        constexpr uint32_t UNROLL = 4;
+        constexpr uint32_t UNROLL = 4;  // (2 and 8 measured within noise of 4)
         const char *pool_bytes = reinterpret_cast<const char *>(pool);
         const uint4 *vals4 = reinterpret_cast<const uint4 *>(pool_bytes + plan.pool_off[level]);
         const uint2 *rows4 = reinterpret_cast<const uint2 *>(pool_bytes + plan.rows_off[level]);
@@ -820,8 +872,11 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
 #pragma unroll
             for (uint32_t u = 0; u < UNROLL; u++) {
                 const uint32_t j = j0 + u * blockDim.x, q = q_begin + (j < nquads ? j : nquads - 1);
-                v[u] = vals4[q];
-                r[u] = rows4[q];
+                // the pool is written once and read once: non-temporal loads (measured: reduce 415 -> 375 us)
+                const uint4_t tv = __builtin_nontemporal_load(reinterpret_cast<const uint4_t *>(vals4) + q);
+                const uint2_t tr = __builtin_nontemporal_load(reinterpret_cast<const uint2_t *>(rows4) + q);
+                v[u] = make_uint4(tv.x, tv.y, tv.z, tv.w);
+                r[u] = make_uint2(tr.x, tr.y);
             }
         };
         auto consume = [&](uint32_t j0, const uint4 (&v)[UNROLL], const uint2 (&r)[UNROLL]) {
@@ -857,6 +912,7 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
             consume(j1, rv[1], rr[1]);
             j0 = j2;
         }
+
     } else {
         constexpr uint32_t UNROLL = 8;
         const PoolEntry<T> *src = reinterpret_cast<const PoolEntry<T> *>(reinterpret_cast<const char *>(pool) +
@@ -887,8 +943,8 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
         const PoolEntry<T> *spill = reinterpret_cast<const PoolEntry<T> *>(reinterpret_cast<const char *>(pool) +
                                                                            plan.spill_off[level]);
         const uint32_t s_all = min(spill_cursor[level], plan.spill_cap);
-        const uint32_t s_begin = (uint32_t)((uint64_t)s_all * blockIdx.y / slices);
-        const uint32_t s_end = (uint32_t)((uint64_t)s_all * (blockIdx.y + 1) / slices);
+        const uint32_t s_begin = (uint32_t)((uint64_t)s_all * slice / slices);
+        const uint32_t s_end = (uint32_t)((uint64_t)s_all * (slice + 1) / slices);
         constexpr uint32_t UNROLL = 4;
         for (uint32_t i0 = s_begin + threadIdx.x; i0 < s_end; i0 += blockDim.x * UNROLL) {
             PoolEntry<T> e[UNROLL];
@@ -912,9 +968,50 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
     }
     __syncthreads();
     if (slices == 1) {
+        // this workgroup owns the bucket's rows: table += image.  All row loads of a thread are issued before the first
+        // use (a load -> add -> store chain per row would cost a memory round trip per row: 8 in a row per thread)
+        T *gt = grad_table + ((size_t)lv.offset + (size_t)bk * kBucketRows) * 2;
+        constexpr uint32_t RPT = kBucketRows / 1024;
+        Vec<T, 2> cur[RPT];
+#pragma unroll
+        for (uint32_t i = 0; i < RPT; i++) {
+            const uint32_t r = threadIdx.x + i * 1024u;
+            cur[i] = load_vec<T, 2>(gt + 2 * (r < rows ? r : 0u));
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < RPT; i++) {
+            const uint32_t r = threadIdx.x + i * 1024u;
+            const long long qa = (long long)acc[r], qb = (long long)acc[kBucketRows + r];
+            if (r < rows && (qa != 0 || qb != 0)) {
+                const float a = (float)ldexp((double)qa, -K), b = (float)ldexp((double)qb, -K);
+                cur[i].v[0] = (T)((float)cur[i].v[0] + a);
+                cur[i].v[1] = (T)((float)cur[i].v[1] + b);
+                store_vec<T, 2>(gt + 2 * r, cur[i]);
+            }
+        }
+    } else {
+        // slice image -> workspace (coalesced 16-byte stores of the whole image); the slice that finishes LAST adds the
+        // images up (integers: the sum does not depend on which slice that is) and adds the rows into the table
+        if (slot0 + slices > plan.partial_slots) return;  // (never: plan_buckets sizes the region for the worst case)
+        char *images = const_cast<char *>(reinterpret_cast<const char *>(pool)) + plan.partial_off;
+        uint4 *dst = reinterpret_cast<uint4 *>(images) + (size_t)(slot0 + slice) * kBucketRows;
+        const uint4 *src = reinterpret_cast<const uint4 *>(acc);
+        for (uint32_t i = threadIdx.x; i < kBucketRows; i += blockDim.x) dst[i] = src[i];
+        __threadfence();  // release (agent scope): this slice's image is visible before its arrival is
+        __syncthreads();
+        if (threadIdx.x == 0) sh_sum = atomicAdd(&done[bid], 1u);
+        __syncthreads();
+        if (sh_sum != slices - 1) return;  // workgroup-uniform
+        __threadfence();  // acquire: the other slices' images (written by other CUs / XCDs) are read from memory
+        const unsigned long long *img = reinterpret_cast<const unsigned long long *>(images) +
+                                        (size_t)slot0 * kBucketRows * 2;
         T *gt = grad_table + ((size_t)lv.offset + (size_t)bk * kBucketRows) * 2;
         for (uint32_t r = threadIdx.x; r < rows; r += blockDim.x) {
-            const long long qa = (long long)acc[r], qb = (long long)acc[kBucketRows + r];
+            long long qa = 0, qb = 0;
+            for (uint32_t sl = 0; sl < slices; sl++) {
+                qa += (long long)img[(size_t)sl * kBucketRows * 2 + r];
+                qb += (long long)img[(size_t)sl * kBucketRows * 2 + kBucketRows + r];
+            }
             if (qa != 0 || qb != 0) {
                 const float a = (float)ldexp((double)qa, -K), b = (float)ldexp((double)qb, -K);
                 Vec<T, 2> cur = load_vec<T, 2>(gt + 2 * r);
@@ -923,57 +1020,12 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
                 store_vec<T, 2>(gt + 2 * r, cur);
             }
         }
-    } else {
-        // slice image -> workspace (coalesced 16-byte stores of the whole image); k_grid_bwd_finalize sums the slices
-        const uint32_t slot = partial_base(cursor, bucket0, bid, &sh_sum) + blockIdx.y;
-        if (slot < plan.partial_slots) {  // (always true: plan_buckets sizes the region for the worst case)
-            uint4 *dst = reinterpret_cast<uint4 *>(const_cast<char *>(reinterpret_cast<const char *>(pool)) +
-                                                   plan.partial_off) + (size_t)slot * kBucketRows;
-            const uint4 *src = reinterpret_cast<const uint4 *>(acc);
-            for (uint32_t i = threadIdx.x; i < kBucketRows; i += blockDim.x) dst[i] = src[i];
-        }
-    }
-}
-
-// Pass 3: one workgroup per bucket of the window; buckets that were not split return at once.
-template <typename T>
-__global__ void __launch_bounds__(1024)
-k_grid_bwd_finalize(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, const char *__restrict__ pool_bytes,
-                    const uint32_t *__restrict__ cursor, uint32_t L, uint32_t bucket0) {
-    __shared__ uint32_t sh_sum;
-    constexpr int K = sizeof(T) == 2 ? 24 : 40;
-    const uint32_t bid = bucket0 + blockIdx.x;
-    const uint32_t slices = slices_of(cursor[bid]);
-    if (slices <= 1) return;  // workgroup-uniform
-    uint32_t level = 0;
-    for (uint32_t l = 0; l < L; l++)
-        if (bid >= plan.first_bucket[l]) level = l;
-    const LevelParams lv = meta.lv[level];
-    const uint32_t bk = bid - plan.first_bucket[level];
-    const uint32_t rows = min(kBucketRows, lv.hashmap_size - bk * kBucketRows);
-    const uint32_t slot0 = partial_base(cursor, bucket0, bid, &sh_sum);
-    if (slot0 + slices > plan.partial_slots) return;
-    const unsigned long long *img = reinterpret_cast<const unsigned long long *>(pool_bytes + plan.partial_off) +
-                                    (size_t)slot0 * kBucketRows * 2;
-    T *gt = grad_table + ((size_t)lv.offset + (size_t)bk * kBucketRows) * 2;
-    for (uint32_t r = threadIdx.x; r < rows; r += blockDim.x) {
-        long long qa = 0, qb = 0;
-        for (uint32_t sl = 0; sl < slices; sl++) {
-            qa += (long long)img[(size_t)sl * kBucketRows * 2 + r];
-            qb += (long long)img[(size_t)sl * kBucketRows * 2 + kBucketRows + r];
-        }
-        if (qa != 0 || qb != 0) {
-            const float a = (float)ldexp((double)qa, -K), b = (float)ldexp((double)qb, -K);
-            Vec<T, 2> cur = load_vec<T, 2>(gt + 2 * r);
-            cur.v[0] = (T)((float)cur.v[0] + a);
-            cur.v[1] = (T)((float)cur.v[1] + b);
-            store_vec<T, 2>(gt + 2 * r, cur);
-        }
     }
 }
 
 // Host: bucket layout + pool sizing.  Returns the number of bytes of workspace needed:
-//   [cursor: one u32 per bucket | spill cursor: one u32 per level]  (zeroed by every launch)
+//   [cursor: one u32 per bucket | spill cursor: one u32 per level | slice arrival counter: one u32 per bucket]
+//                                                                      (zeroed by every launch)
 //   [pool of every level] [spill list of every level] [slice images]
 // Pool slots per bucket = even split of the level's worst case (B * 2^D entries) + 12.5 % + 12 sigma of a Poisson
 // count (hashed levels are statistically even; correlated corners of neighbouring samples widen the spread, so the
@@ -1018,7 +1070,7 @@ uint64_t plan_buckets(BucketPlan &plan, const GridMeta &m, uint32_t L, uint32_t 
     plan.partial_slots = (uint32_t)slots;
     plan.partial_off = bytes;
     bytes += slots * kBucketRows * 2 * sizeof(unsigned long long);
-    const uint64_t cursor_bytes = ((uint64_t)(nbt + L) * 4 + kCursorAlign - 1) / kCursorAlign * kCursorAlign;
+    const uint64_t cursor_bytes = ((uint64_t)(2 * nbt + L) * 4 + kCursorAlign - 1) / kCursorAlign * kCursorAlign;
     return cursor_bytes + bytes;
 }
 
@@ -1063,9 +1115,9 @@ int launch_backward_bucketed(const T *grad, const float *inputs, T *ge, uint32_t
             lnh_set_error("grid backward (bucketed): level %u has more than %u buckets", l, kMaxBucketsPerLevel);
             return LNH_ERR_UNSUPPORTED;
         }
-    const uint64_t cursor_bytes = ((uint64_t)(nbt + L) * 4 + kCursorAlign - 1) / kCursorAlign * kCursorAlign;
+    const uint64_t cursor_bytes = ((uint64_t)(2 * nbt + L) * 4 + kCursorAlign - 1) / kCursorAlign * kCursorAlign;
     uint32_t *cursor = reinterpret_cast<uint32_t *>(workspace);
-    uint32_t *spill_cursor = cursor + nbt;
+    uint32_t *spill_cursor = cursor + nbt, *done = spill_cursor + L;
     PoolEntry<T> *pool = reinterpret_cast<PoolEntry<T> *>(reinterpret_cast<char *>(workspace) + cursor_bytes);
     (void)hipGetLastError();
     if (hipMemsetAsync(cursor, 0, cursor_bytes, s) != hipSuccess) {
@@ -1083,13 +1135,27 @@ int launch_backward_bucketed(const T *grad, const float *inputs, T *ge, uint32_t
     auto k = k_grid_bwd_reduce<T>;
     const size_t lds = (size_t)kBucketRows * 2 * sizeof(unsigned long long);
     allow_big_lds(k, lds);
-    const uint32_t b0 = plan.first_bucket[level_begin], b1 = plan.first_bucket[level_end];
-    LNH_LAUNCH(k, dim3(b1 - b0, kMaxSlices), dim3(1024), lds, s, ge, m, plan, pool, cursor, spill_cursor, L, b0);
-    rc = lnh_check_launch("lnh_grid_encode_backward_ws(reduce)");
-    if (rc) return rc;
-    LNH_LAUNCH((k_grid_bwd_finalize<T>), dim3(b1 - b0), dim3(1024), 0, s, ge, m, plan,
-               reinterpret_cast<const char *>(pool), cursor, L, b0);
-    return lnh_check_launch("lnh_grid_encode_backward_ws(finalize)");
+    ReduceOrder ord;
+    ord.bucket0 = plan.first_bucket[level_begin];
+    ord.n_buckets = plan.first_bucket[level_end] - ord.bucket0;
+    ord.n_levels = 0;
+    ord.first[0] = 0;
+    auto push = [&](uint32_t l) {
+        ord.level[ord.n_levels] = l;
+        ord.first[ord.n_levels + 1] = ord.first[ord.n_levels] + plan.first_bucket[l + 1] - plan.first_bucket[l];
+        ord.n_levels++;
+    };
+    for (uint32_t l = level_begin; l < level_end; l++)
+        if (!(m.lv[l].flags & LV_HASH)) push(l);
+    for (uint32_t l = level_end; l-- > level_begin;)
+        if (m.lv[l].flags & LV_HASH) push(l);
+    // slices beyond the first: sum over buckets of ceil(n / kSliceEntries) - 1 <= (entries of the window) / kSliceEntries
+    const uint64_t extra = std::min<uint64_t>((uint64_t)ord.n_buckets * (kMaxSlices - 1),
+                                              (((uint64_t)B << 3) * n_win) / kSliceEntries);
+    ord.n_extra = (uint32_t)extra;
+    LNH_LAUNCH(k, dim3(ord.n_extra + ord.n_buckets), dim3(1024), lds, s, ge, m, plan, pool, cursor, spill_cursor, done, L,
+               ord);
+    return lnh_check_launch("lnh_grid_encode_backward_ws(reduce)");
 }
 
 // gridencoder.cu:364-390

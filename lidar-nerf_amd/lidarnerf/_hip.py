@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "liblidarnerf_hip.so")
+# LNH_LIB_PATH: developer override (A/B builds of the same library, tools/); still no fallback if it is missing
+_LIB_PATH = os.environ.get("LNH_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "liblidarnerf_hip.so")
 
 P, U32, I32, F32 = C.c_void_p, C.c_uint32, C.c_int, C.c_float
 
