@@ -11,8 +11,10 @@ accumulation (the reference's documented `--fp16` mode), Adam + GradScaler.  One
 one batch of rays: render forward, LiDAR loss, backward, (DP: gradient all-reduce), optimizer step.
 
 Prints ONE JSON line on rank 0 (see the contract in the task description): metric/value/unit, roofline of the
-dominant kernel (algorithmic bytes / HIP-event duration measured inside the timed region), and a CPU baseline (the
-oracle restatement of the same pipeline, timed on the host cores, N=1 only).
+dominant kernel (algorithmic bytes / HIP-event duration measured inside the timed region) with the forward encode and
+the MFMA utilisation of the MLP kernels beside it, and a CPU baseline (BASELINE config 1 — the reference's CPU-runnable
+path: pure-torch frequency encoder + nn.Linear stacks — restated in oracle/render_ref.py, timed on the host cores, N=1
+only).  `--gpus N` without torchrun's environment re-launches itself under torch.distributed.run with N ranks.
 """
 import argparse
 import json
@@ -31,6 +33,13 @@ SCALE = 0.010784853507573345  # configs/kitti360_1908.txt:12
 H_IMG, W_IMG, INTRINSICS = 66, 1030, (2.0, 26.9)
 NUM_STEPS, UPSAMPLE = 768, 64  # configs/kitti360_1908.txt:9-10
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA peak
+# SURVEY.md §8(d) / BASELINE.md §4: MLP flops per sample point, forward; backward (dgrad + wgrad) counts twice that
+SIGMA_FLOPS = 2 * (32 * 64 + 64 * 16)                 # 6 144
+COLOR_FLOPS = 2 * (96 * 64 + 64 * 64 + 64 * 16)       # 22 528 (90 -> 64 -> 64 -> 2 padded to MFMA tiles), masked points
+# what the colour kernels execute per masked point: the 75 direction columns of layer 0 are folded into a per-ray
+# term, leaving K = 16 per sample
+COLOR_FLOPS_EXECUTED = 2 * (16 * 64 + 64 * 64 + 64 * 16)
 
 # algorithmic bytes per sample point, fp16 tables, L=16, F=2, D=3
 GRID_FWD_BYTES = 12 + 16 * 8 * 2 * 2 + 16 * 2 * 2  # 588
@@ -70,39 +79,89 @@ def build_model(device):
     return model.to(device).train()
 
 
-def cpu_baseline(budget_s=12.0):
-    """Oracle restatement of the same pipeline (hash grid via the scalar C oracle, MLPs/compositing in torch fp32)
-    on the host cores; bounded sample: batches of 64 rays x 832 samples until ~budget_s of CPU work."""
+def _cpu_config1(n_rays, threads, budget_s, max_steps=10):
+    """Median step time of BASELINE config 1 on `threads` host threads: RefFreqField (pure-torch positional encoder +
+    bias-free nn.Linear stacks, fp32) through run_lidar (NeRFRenderer.run restated), forward + LiDAR loss + backward,
+    n_rays x 832 samples of KITTI-360-shaped synthetic rays.  Returns (seconds per step, timed steps, warmed_up)."""
     from oracle import render_ref
-    threads = torch.get_num_threads()
+    torch.set_num_threads(threads)
     torch.manual_seed(0)
-    ref = render_ref.RefLidarField(desired_resolution=32768).train()
-    n = 64
-    g = torch.Generator().manual_seed(1)
-    o = (torch.rand(n, 3, generator=g) - 0.5) * 0.02
-    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)
-    gt = torch.rand(n, 3, generator=g)
+    ref = render_ref.RefFreqField().train()
+    poses = synthetic_frames(60, "cpu")
+    o, d, gt = make_batch(poses, 0, n_rays, 0, "cpu")
+    o, d, gt = o[0], d[0], gt[0]
     aabb = torch.tensor([-1.0, -1, -1, 1, 1, 1])
-    steps, t0 = 0, time.perf_counter()
-    first = None
-    while True:
+    times, t_begin = [], time.perf_counter()
+    for it in range(max_steps + 1):
+        t0 = time.perf_counter()
         ref.zero_grad(set_to_none=True)
         res = render_ref.run_lidar(o, d, ref.density, ref.color, aabb, SCALE, NUM_STEPS, UPSAMPLE, perturb=True,
                                    training=True)
-        loss = render_ref.lidar_loss(res["depth_lidar"], res["image_lidar"], gt)
-        loss.backward()
-        steps += 1
-        if first is None:  # first step = warm-up (page-in of the 55 MB table, thread pools)
-            first = time.perf_counter()
-            steps = 0
-            t0 = first
-        if steps >= 2 and time.perf_counter() - t0 > budget_s:
+        render_ref.lidar_loss(res["depth_lidar"], res["image_lidar"], gt).backward()
+        dt = time.perf_counter() - t0
+        if it == 0 and dt > budget_s:  # one step already blows the budget: it is the sample, warm-up included
+            return dt, 1, False
+        if it:  # first step = warm-up (thread pools, allocator)
+            times.append(dt)
+        if times and time.perf_counter() - t_begin > budget_s:
             break
-    dt = time.perf_counter() - t0
-    return {"value": round(n * steps / dt, 2), "unit": "rays/s", "cores": threads, "kind": "port",
-            "sample": f"{steps} steps x {n} rays x {NUM_STEPS + UPSAMPLE} samples, fwd+bwd, fp32, oracle/render_ref.py "
-                      f"(hash grid in scalar C, MLP/compositing torch CPU with {threads} threads); "
-                      f"{os.cpu_count()} host cores present"}
+    return float(np.median(times)), len(times), True
+
+
+def cpu_baseline():
+    """config 1, N = 1024 rays x 832 samples, forward + loss + backward, fp32, on k host threads for
+    k = 1, k = 16 and k = all (`os.cpu_count()`), each leg bounded to ~10 s of wall time (median of up to 10 steps).
+    `value` / `cores` = the fastest leg (on a 256-thread host torch's CPU ops are far slower with k = all than with a
+    handful of threads — every leg is listed).  Validated against the imported reference in the build container
+    (tests/test_config1_cpu.py) and pinned on the GPU box by golden vectors G2 / G4."""
+    import platform
+    cores = os.cpu_count() or 1
+    saved = torch.get_num_threads()
+    legs = []
+    try:
+        for k in sorted({1, min(16, cores), cores}):
+            t, n, warm = _cpu_config1(1024, k, budget_s=10.0)
+            legs.append({"cores": k, "value": round(1024 / t, 2), "unit": "rays/s", "steps": n,
+                         "sample": f"median of {n} step(s) x 1024 rays" + ("" if warm else " (single cold step: over budget)")})
+    finally:
+        torch.set_num_threads(saved)
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        model = platform.processor()
+    best = max(legs, key=lambda l: l["value"])
+    return {"value": best["value"], "unit": "rays/s", "cores": best["cores"], "kind": "port",
+            "sample": f"BASELINE config 1 (pure-torch freq encoder + nn.Linear 39->64->16 / 90->64->64->2, fp32), "
+                      f"{best['sample']} x {NUM_STEPS + UPSAMPLE} samples, fwd+loss+bwd, "
+                      f"torch.set_num_threads({best['cores']}); oracle/render_ref.py RefFreqField",
+            "legs": legs, "host": {"cpu": model, "os_cpu_count": cores, "torch": torch.__version__}}
+
+
+def _relaunch_distributed(n):
+    """`python bench.py --gpus N` outside torchrun: start N ranks (one per GPU) and hand them the same command line."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def _latest_pmc():
+    """HBM bytes per launch of the grid kernels from the newest committed PMC pass (profiles/r*_pmc.json, written by
+    profiles/collect.sh from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
+        try:
+            return os.path.relpath(path, ROOT), json.load(open(path)).get("kernels", {})
+        except Exception:
+            continue
+    return None, {}
 
 
 def main():
@@ -119,12 +178,17 @@ def main():
     from lidarnerf import _hip, parallel
     from lidarnerf.nerf.train_step import LidarTrainer
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _relaunch_distributed(args.gpus)
     rank, local, world = parallel.init_from_env()
-    if world != args.gpus and rank == 0:
-        print(f"[bench] WORLD_SIZE={world} differs from --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} ranks were launched")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP extension is the product path (no CPU fallback)")
-    local = local % torch.cuda.device_count()  # (functional tests run several ranks on one GPU)
+    if world > torch.cuda.device_count() and os.environ.get("LNH_DIST_BACKEND") != "gloo":
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible (one rank per GPU; "
+                         "LNH_DIST_BACKEND=gloo allows functional runs with several ranks on one GPU)")
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     _hip.lib()  # fail loudly now if the extension is missing
@@ -149,12 +213,13 @@ def main():
     # HIP events around the encoder entry points only (the roofline candidates): every timed call costs two event
     # records on the stream, and timing all ~25 calls of a step inflates the step by ~4 % (--kernel-timers for all)
     grid_calls = ["lnh_grid_encode_forward", "lnh_grid_encode_forward_mapped", "lnh_grid_encode_backward",
-                  "lnh_grid_encode_backward_ws"]
-    all_calls = grid_calls + ["lnh_mlp_forward", "lnh_mlp_backward", "lnh_lidar_composite_forward",
-                              "lnh_lidar_composite_backward", "lnh_lidar_resample", "lnh_lidar_weights",
-                              "lnh_freq_encode_forward", "lnh_density_mlp_forward", "lnh_density_mlp_backward",
-                              "lnh_lidar_color_forward", "lnh_lidar_color_backward", "lnh_lidar_merge_weights",
-                              "lnh_lidar_sample_points", "lnh_adam_table_step"]
+                  "lnh_grid_encode_backward_ws", "lnh_grid_encode_backward_ws_levels"]
+    mlp_calls = ["lnh_density_mlp_forward", "lnh_density_mlp_backward", "lnh_lidar_color_forward",
+                 "lnh_lidar_color_backward"]
+    all_calls = grid_calls + mlp_calls + ["lnh_mlp_forward", "lnh_mlp_backward", "lnh_lidar_composite_forward",
+                                          "lnh_lidar_composite_backward", "lnh_lidar_resample", "lnh_lidar_weights",
+                                          "lnh_freq_encode_forward", "lnh_lidar_merge_weights",
+                                          "lnh_lidar_sample_points", "lnh_adam_table_step"]
     _hip.enable_timers(all_calls if args.kernel_timers else grid_calls)
     t0 = time.perf_counter()
     for s in range(args.steps):
@@ -165,35 +230,102 @@ def main():
     elapsed = parallel.max_over_ranks(elapsed, device)
     loss_val = float(loss.detach().float().item())
 
+    def event_table(tm):
+        out = {}
+        for name, evs in tm.items():
+            ms = [a.elapsed_time(b) for a, b, _ in evs]
+            units = [t for _, _, t in evs if t]
+            out[name] = {"calls": len(ms), "total_ms": round(sum(ms), 3), "avg_us": round(1e3 * sum(ms) / len(ms), 2),
+                         "points": int(sum(units)) if units else None}
+        return out
+
+    # ---- MFMA pass (outside the timed region, every rank): a few more steps with HIP events on the four MLP entry
+    #      points and the fraction of samples the colour head really evaluates (weights > 1e-4) recorded per step
+    from lidarnerf.nerf import fused
+    n_prof = min(args.steps, 5)
+    fused.MASK_STATS = []
+    _hip.enable_timers(mlp_calls)
+    for s in range(n_prof):
+        trainer.step(*batches[(args.warmup + args.steps + s) % len(batches)])
+    sync()
+    mlp_timers = event_table(_hip.disable_timers())
+    mask_frac = float(torch.stack(fused.MASK_STATS).mean().item()) if fused.MASK_STATS else 1.0
+    fused.MASK_STATS = None
+
+    # ---- data parallel: the same step with the gradient exchange switched off (every rank keeps its own gradient;
+    #      timing only, the replicas are not used afterwards) -> all-reduce cost = inclusive - exclusive
+    comm = None
+    if world > 1:
+        saved_ws, trainer.world = parallel.world_size, 1
+        parallel.world_size = lambda: 1
+        n_nc = min(args.steps, 10)
+        for s in range(2):
+            trainer.step(*batches[s % len(batches)])
+        sync()
+        t0 = time.perf_counter()
+        for s in range(n_nc):
+            trainer.step(*batches[(2 + s) % len(batches)])
+        sync()
+        t_nc = parallel_max = time.perf_counter() - t0
+        parallel.world_size, trainer.world = saved_ws, world
+        t_nc = parallel.max_over_ranks(parallel_max, device) / n_nc
+        comm = {"ms_per_step_inclusive": round(1e3 * elapsed / args.steps, 3),
+                "ms_per_step_without_allreduce": round(1e3 * t_nc, 3),
+                "allreduce_exposed_ms": round(1e3 * (elapsed / args.steps - t_nc), 3),
+                "payload": "hash-table gradient 27.4 MB fp16 (4 level windows, overlapped with the backward kernels) + "
+                           "21.5 k MLP gradients fp32 (one flat buffer), sum over ranks, RCCL"}
+
     if rank != 0:
         return
     rays_total = args.rays * world * args.steps
-    # ---- per-kernel HIP-event durations inside the timed region
-    kernels = {}
-    for name, evs in timers.items():
-        ms = [a.elapsed_time(b) for a, b, _ in evs]
-        units = [t for _, _, t in evs if t]
-        kernels[name] = {"calls": len(ms), "total_ms": round(sum(ms), 3), "avg_us": round(1e3 * sum(ms) / len(ms), 2),
-                         "points": int(sum(units)) if units else None}
-    dom = max(("lnh_grid_encode_forward", "lnh_grid_encode_forward_mapped", "lnh_grid_encode_backward",
-               "lnh_grid_encode_backward_ws"),
-              key=lambda k: kernels.get(k, {}).get("total_ms", 0))
-    per_pt = GRID_FWD_BYTES if "forward" in dom else GRID_BWD_BYTES
-    k = kernels[dom]
-    avg_points = k["points"] / k["calls"]
-    achieved = per_pt * k["points"] / (k["total_ms"] * 1e-3) / 1e9  # GB/s over all launches of that kernel
-    # HBM bytes per launch from the committed PMC pass of this same command (profiles/collect.sh); bench.py itself
-    # cannot run rocprofv3, so the number is only reported when that file exists and names the dominant kernels
-    traffic, traffic_src = None, None
-    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc.json")
-    if os.path.exists(pmc_path) and args.rays == 4096:
-        pk = json.load(open(pmc_path)).get("kernels", {})
-        names = {"lnh_grid_encode_backward_ws": ("k_grid_bwd_scatter", "k_grid_bwd_reduce"),
+    kernels = event_table(timers)
+    if "lnh_grid_encode_backward_ws_levels" in kernels:  # DP: the backward runs as 4 level windows -> one logical launch
+        kw = kernels.pop("lnh_grid_encode_backward_ws_levels")
+        kernels["lnh_grid_encode_backward_ws"] = {"calls": args.steps, "total_ms": kw["total_ms"],
+                                                  "avg_us": round(1e3 * kw["total_ms"] / args.steps, 2),
+                                                  "points": args.rays * (NUM_STEPS + UPSAMPLE) * args.steps,
+                                                  "note": "sum of 4 level-window calls per step"}
+    fwd_names = ("lnh_grid_encode_forward", "lnh_grid_encode_forward_mapped")
+    bwd_names = ("lnh_grid_encode_backward", "lnh_grid_encode_backward_ws")
+    dom = max(fwd_names + bwd_names, key=lambda k: kernels.get(k, {}).get("total_ms", 0))
+    pmc_file, pmc = _latest_pmc()
+    pmc_names = {"lnh_grid_encode_backward_ws": ("k_grid_bwd_scatter", "k_grid_bwd_reduce"),
                  "lnh_grid_encode_forward_mapped": ("k_grid_forward",), "lnh_grid_encode_forward": ("k_grid_forward",)}
-        parts = [pk.get(n, {}).get("hbm_bytes_per_launch") for n in names.get(dom, ())]
-        if parts and all(p is not None for p in parts):
-            traffic = int(sum(parts))
-            traffic_src = "profiles/r01_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, " + " + ".join(names[dom]) + ")"
+
+    def hbm_roofline(name):
+        k = kernels[name]
+        per_pt = GRID_FWD_BYTES if "forward" in name else GRID_BWD_BYTES
+        avg_points = k["points"] / k["calls"]
+        achieved = per_pt * k["points"] / (k["total_ms"] * 1e-3) / 1e9  # GB/s over all launches of that entry point
+        # HBM bytes per launch from the newest committed PMC pass of this same command (profiles/collect.sh);
+        # bench.py itself cannot run rocprofv3.  Scaled to this call's points (the PMC pass profiles whole launches).
+        traffic, src = None, None
+        parts = [pmc.get(n, {}).get("hbm_bytes_per_launch") for n in pmc_names.get(name, ())]
+        if pmc_file and parts and all(p is not None for p in parts) and args.rays == 4096:
+            traffic, src = int(sum(parts)), f"{pmc_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes: " + \
+                " + ".join(pmc_names[name]) + ")"
+        return {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
+                "algorithmic_bytes_per_launch": int(per_pt * avg_points), "bytes_per_point": per_pt,
+                "points_per_launch": int(avg_points), "avg_launch_us": k["avg_us"]}
+
+    # MFMA utilisation of the MLP kernels: BASELINE.md §4 flops (6 144 sigma + 22 528 * mask fraction colour per sample
+    # forward, backward = 2x) over the summed HIP-event time of the four MLP entry points, against the dense fp16 peak
+    pts = args.rays * (NUM_STEPS + UPSAMPLE)
+    mlp_ms = sum(v["total_ms"] for v in mlp_timers.values()) / max(n_prof, 1)
+    flops_step = 3 * pts * (SIGMA_FLOPS + COLOR_FLOPS * mask_frac)
+    flops_exec = 3 * pts * (SIGMA_FLOPS + COLOR_FLOPS_EXECUTED * mask_frac)
+    tf = flops_step / (mlp_ms * 1e-3) / 1e12 if mlp_ms else 0.0
+    roofline_mfma = {"bound": "mfma", "kernel": "+".join(sorted(mlp_timers)), "achieved": round(tf, 1),
+                     "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
+                     "flops_per_step": int(flops_step), "mask_fraction": round(mask_frac, 4),
+                     "mlp_kernel_ms_per_step": round(mlp_ms, 4),
+                     "executed_tflops": round(flops_exec / (mlp_ms * 1e-3) / 1e12, 1) if mlp_ms else 0.0,
+                     "note": "flops per SURVEY 8(d): 3 x points x (6144 + 22528 x mask fraction); 'executed' counts the "
+                             "colour head at K = 16 per sample (direction columns folded into a per-ray term); the MLP "
+                             "kernels also read the encoder output and write activations: at 61 flop/B the sigma net is "
+                             "HBM-bound by construction (DESIGN.md)",
+                     "per_kernel_us": {k: v["avg_us"] for k, v in mlp_timers.items()}}
     result = {
         "metric": "train rays/sec (encode+MLP+composite+bwd), KITTI-360 66x1030",
         "value": round(rays_total / elapsed, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps,
@@ -204,13 +336,13 @@ def main():
                                "fused MLPs, 66x1030 range image", "rays_per_gpu_per_step": args.rays,
                    "samples_per_ray": NUM_STEPS + UPSAMPLE, "parallelism": f"dp{world}",
                    "optimizer": "Adam + dynamic loss scaling, in the timed region (hash table: fused lnh_adam_table_step; MLPs: torch fused Adam)", "final_loss": round(loss_val, 5)},
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(per_pt * avg_points),
-                     "bytes_per_point": per_pt, "points_per_launch": int(avg_points),
-                     "avg_launch_us": k["avg_us"]},
+        "roofline": hbm_roofline(dom),
+        "roofline_fwd": hbm_roofline(max(fwd_names, key=lambda k: kernels.get(k, {}).get("total_ms", 0))),
+        "roofline_mfma": roofline_mfma,
         "kernels": kernels,
     }
+    if comm is not None:
+        result["comm"] = comm
     # secondary number of SURVEY §8(d): full-frame evaluation (67 980 rays of a 66 x 1030 range image, staged in
     # chunks of 4096, no perturbation, no gradient) — reported beside the headline metric, never instead of it
     if world == 1 and not args.no_eval:

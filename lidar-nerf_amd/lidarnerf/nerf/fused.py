@@ -102,6 +102,24 @@ def _grid_bwd_overlapped(g_feat, x01, g_table16, enc, B, table_param):
     return handles
 
 
+def table16_of(param, embeddings=None, training=True):
+    """fp16 compute copy of the hash table.  With the fused table optimizer (train_step.LidarTrainer) the copy is a
+    persistent shadow that the optimizer kernel rewrites together with the fp32 master; it is tied to the master's
+    torch version counter, so a write to the parameter through torch (load_state_dict, parallel.broadcast_parameters, a
+    manual re-initialisation under no_grad) is noticed here and the shadow is re-cast.  Writes through `.data` (torch_ema's
+    copy_to / restore) do not move the version counter: evaluation (`training=False`) therefore never trusts the shadow
+    and casts the parameter as it is — 82 MB of traffic per render call, noise next to the render itself.  Without a
+    shadow the table is cast per call (the autocast rule of grid.py:54-57)."""
+    src = param if embeddings is None else embeddings
+    shadow = getattr(param, "_lnh_table16", None)
+    if shadow is None or not training:
+        return src.detach().to(torch.half).contiguous()
+    if getattr(param, "_lnh_table16_version", None) != param._version:
+        shadow.copy_(param.detach().reshape(shadow.shape))
+        param._lnh_table16_version = param._version
+    return shadow
+
+
 def _no_autocast(fn):
     """The kernel chain manages precision itself: run the glue ops (casts, the tiny per-ray GEMMs) with autocast off,
     otherwise fp32 operands of a matmul silently become fp16 tensors handed to kernels that expect fp32."""
@@ -130,9 +148,7 @@ class FusedLidarRender(Function):
 
         # fp16 copy of the table: maintained by the fused table optimizer when there is one (train_step.LidarTrainer),
         # otherwise cast here (the autocast rule of grid.py:54-57)
-        table16 = getattr(spec.table_param, "_lnh_table16", None)
-        if table16 is None:
-            table16 = embeddings.detach().to(torch.half).contiguous()
+        table16 = table16_of(spec.table_param, embeddings, model.training)
         # fp32 master matrices (possibly strided views of flat parameter vectors) -> the flat fp16 vectors of the
         # kernels, one launch: wsig16 = [ws0 | ws1]; wcol16 = [(0 | wc0[:, kd:kd+15]) | wc1 | wc2 padded to 16 rows]
         wsig16 = torch.empty(64 * 32 + 16 * 64, dtype=torch.half, device=dev)
@@ -245,15 +261,23 @@ class FusedLidarRender(Function):
         else:
             _grid_bwd(g_feat, x01, g_table16, enc, B_all)
         dts = ctx.param_dtypes
+        world = parallel.world_size()
         if getattr(ctx.table_param, "_lnh_keep_grad16", False):
             # the fused table optimizer consumes the fp16 gradient directly: no fp32 copy, no .grad on the table
+            # (data parallel: the gradient is the SUM over ranks; the optimizer divides by `_lnh_grad16_div` in fp32)
             ctx.table_param._lnh_grad16 = g_table16
+            ctx.table_param._lnh_grad16_div = world
             g_table = None
         else:
             g_table = g_table16.to(dts[0])
+            if world > 1:
+                g_table.div_(world)  # sum over ranks -> mean, after the widening
         return (None, None, None, None, g_table, g_wsig[:64 * 32].view(64, 32).to(dts[1]),
                 g_wsig[64 * 32:].view(16, 64).to(dts[2]), g_wc0.to(dts[3]), g_wc1.to(dts[4]), g_wc2.to(dts[5]),
                 None, None, None)
+
+
+MASK_STATS = None  # bench.py: set to a list to collect, per render call, the fraction of samples with weight > 1e-4
 
 
 def render_lidar(model, rays_o, rays_d, num_steps, upsample_steps, perturb):
@@ -280,6 +304,8 @@ def render_lidar(model, rays_o, rays_d, num_steps, upsample_steps, perturb):
         u = torch.linspace(0.5 / upsample_steps, 1.0 - 0.5 / upsample_steps, upsample_steps,
                            device=dev).expand(N, upsample_steps).contiguous()
     sp = model.fused_spec()
-    ws, depth, image, _, _ = FusedLidarRender.apply(rays_o, rays_d, z, u, sp.table, sp.ws0, sp.ws1, sp.wc0, sp.wc1,
-                                                    sp.wc2, model, model.density_scale, sp)
+    ws, depth, image, weights, _ = FusedLidarRender.apply(rays_o, rays_d, z, u, sp.table, sp.ws0, sp.ws1, sp.wc0,
+                                                          sp.wc1, sp.wc2, model, model.density_scale, sp)
+    if MASK_STATS is not None:
+        MASK_STATS.append((weights > 1e-4).float().mean())
     return {"depth_lidar": depth.view(*prefix), "image_lidar": image.view(*prefix, 2), "weights_sum_lidar": ws}

@@ -95,6 +95,7 @@ class LidarTrainer:
                 self.t_flip = 0
                 tp._lnh_keep_grad16 = True
                 tp._lnh_table16 = tp.detach().to(torch.half).reshape(-1, 2).contiguous()
+                tp._lnh_table16_version = tp._version  # fused.table16_of re-casts when the parameter is written elsewhere
                 self.loss_scale = torch.full((), 65536.0, dtype=torch.float32, device=tp.device)
                 self.growth_tracker = torch.zeros((), dtype=torch.int32, device=tp.device)
         params = [g for g in params if len(g["params"])]
@@ -117,9 +118,11 @@ class LidarTrainer:
 
     def _step_fused_table(self, rays_o, rays_d, images_lidar, patch):
         from .. import _hip
+        from .fused import table16_of
         tp = self.table
         self.optimizer.zero_grad(set_to_none=True)
         tp._lnh_grad16 = None
+        tp._lnh_grad_reduced = False
         with torch.autocast("cuda", dtype=torch.float16):
             loss = self.loss(rays_o, rays_d, images_lidar, patch)
         (loss * self.loss_scale).backward()
@@ -128,6 +131,8 @@ class LidarTrainer:
         # --- GradScaler.step / update, with the table handled by the fused kernels
         found_inf = torch.zeros((), dtype=torch.float32, device=tp.device)
         inv_scale = self.loss_scale.reciprocal()
+        # data parallel: the fp16 table gradient arrives as the sum over ranks; its mean is taken here, in fp32
+        inv_scale_table = inv_scale / float(getattr(tp, "_lnh_grad16_div", 1))
         grads = [p.grad for p in self.params if p.grad is not None]
         if grads:
             torch._amp_foreach_non_finite_check_and_unscale_(grads, found_inf, inv_scale)
@@ -143,13 +148,49 @@ class LidarTrainer:
             del self.optimizer.grad_scale, self.optimizer.found_inf
         lr = float(self.optimizer.param_groups[0]["lr"])
         s_in, s_out = self.t_steps[self.t_flip], self.t_steps[1 - self.t_flip]
+        shadow = table16_of(tp)  # (re-cast first if somebody wrote the parameter since the last step)
         _hip.call("lnh_adam_table_step", tp.data_ptr(), self.t_m.data_ptr(), self.t_v.data_ptr(), g16.data_ptr(),
-                  tp._lnh_table16.data_ptr(), tp.numel(), lr, 0.9, 0.99, 1e-15, inv_scale.data_ptr(),
+                  shadow.data_ptr(), tp.numel(), lr, 0.9, 0.99, 1e-15, inv_scale_table.data_ptr(),
                   found_inf.data_ptr(), s_in.data_ptr(), s_out.data_ptr())
         self.t_flip = 1 - self.t_flip
         torch._amp_update_scale_(self.loss_scale, self.growth_tracker, found_inf, 2.0, 0.5, 2000)
         self.scheduler.step()
         return loss
+
+    # ---- what lives outside torch.optim / GradScaler when the table is stepped by the fused kernel
+    def table_grad(self):
+        """fp32, unscaled gradient of the hash table of the LAST step (the fused path keeps it in fp16 and never sets
+        `.grad` on the parameter: code that wants `embeddings.grad` — gradient clipping, `grad_total_variation` — asks
+        here).  None before the first step or without the fused table optimizer."""
+        g16 = getattr(self.table, "_lnh_grad16", None) if self.table is not None else None
+        if g16 is None:
+            return None
+        div = float(getattr(self.table, "_lnh_grad16_div", 1))
+        return g16.float().reshape(self.table.shape) / (self.loss_scale * div)
+
+    def state_dict(self):
+        """Everything a resume needs: torch optimizer / scheduler / scaler state plus — fused table optimizer — the
+        table's Adam moments, its device-side step counter and the dynamic loss scale (99.8 % of the optimizer state)."""
+        sd = {"optimizer": self.optimizer.state_dict(), "scheduler": self.scheduler.state_dict(),
+              "scaler": self.scaler.state_dict(), "fused_table": None}
+        if self.table is not None:
+            sd["fused_table"] = {"exp_avg": self.t_m, "exp_avg_sq": self.t_v, "step": self.t_steps[self.t_flip].clone(),
+                                 "loss_scale": self.loss_scale.clone(), "growth_tracker": self.growth_tracker.clone()}
+        return sd
+
+    def load_state_dict(self, sd):
+        self.optimizer.load_state_dict(sd["optimizer"])
+        self.scheduler.load_state_dict(sd["scheduler"])
+        self.scaler.load_state_dict(sd["scaler"])
+        ft = sd.get("fused_table")
+        if (ft is None) != (self.table is None):
+            raise RuntimeError("LidarTrainer.load_state_dict: checkpoint and trainer disagree on the fused table optimizer")
+        if ft is not None:
+            self.t_m.copy_(ft["exp_avg"])
+            self.t_v.copy_(ft["exp_avg_sq"])
+            self.t_steps[self.t_flip].copy_(ft["step"])
+            self.loss_scale.copy_(ft["loss_scale"])
+            self.growth_tracker.copy_(ft["growth_tracker"])
 
     def step(self, rays_o, rays_d, images_lidar, patch=(1, 1)):
         if self.table is not None:

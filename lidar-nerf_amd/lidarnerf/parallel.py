@@ -6,8 +6,9 @@ replicated, and the only collective is ONE gradient all-reduce per step:
   * the hash-table gradient (13.7 M fp32 = 54.7 MB) goes out as a single large message — on the fully connected
     xGMI mesh a few big collectives beat many small buckets (per-link bound, no NVSwitch);
   * all small MLP gradients are flattened into one coalesced buffer (one launch instead of ~8).
-Sum-then-divide keeps the DP mean equal to the single-GPU mean over the concatenated batch when every rank draws
-the same number of rays (lidarnerf/nerf/utils.py:746 uses .mean() over rays).
+Sum-then-divide (never divide-then-sum: the fp16 table gradient would lose its low bits) keeps the DP mean equal to
+the single-GPU mean over the concatenated batch when every rank draws the same number of rays
+(lidarnerf/nerf/utils.py:746 uses .mean() over rays).
 """
 import os
 
@@ -73,14 +74,16 @@ def world_size():
 
 
 def allreduce_half_table(g_table16, param):
-    """Average the hash-table gradient over ranks WHILE IT IS STILL fp16 (27 MB instead of 55 MB on the wire; the
-    kernels produce it in fp16 anyway).  Returns a handle to wait on; marks `param` so allreduce_gradients skips it.
-    An fp16 overflow of the sum surfaces as inf, which GradScaler turns into a skipped step + smaller scale, exactly
-    as it does for a single-rank overflow."""
+    """SUM the hash-table gradient over ranks WHILE IT IS STILL fp16 (27 MB instead of 55 MB on the wire; the kernels
+    produce it in fp16 anyway).  Returns a handle to wait on; marks `param` so allreduce_gradients skips it.
+    The division by the world size happens AFTER the sum, in fp32, by the consumer (the fused table optimizer folds it
+    into its inverse loss scale; the autograd path divides the fp32 copy): dividing the fp16 values first would drop
+    log2(world) bits at the bottom of the fp16 range and flush small scaled gradients to zero.  An fp16 overflow of the
+    sum surfaces as inf, which GradScaler turns into a skipped step + smaller scale, exactly as it does for a
+    single-rank overflow."""
     w = world_size()
     if w <= 1:
         return None
-    g_table16.div_(w)  # pre-divide: keeps the sum inside fp16 range whenever the per-rank values are
     param._lnh_grad_reduced = True
     return dist.all_reduce(g_table16, op=dist.ReduceOp.SUM, async_op=True)
 
@@ -89,8 +92,9 @@ def broadcast_parameters(module, src=0):
     """Make every replica start from rank `src`'s weights."""
     if not dist.is_initialized() or dist.get_world_size() <= 1:
         return
-    for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src)
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.detach(), src=src)  # (detach shares the version counter: fused.table16_of sees the write)
 
 
 def max_over_ranks(value, device):

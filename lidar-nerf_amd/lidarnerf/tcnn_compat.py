@@ -4,6 +4,11 @@ tinycudann.  Only the two entry points that file uses exist: `Encoding(n_input_d
 `Network(n_input_dims, n_output_dims, network_config)`, with tcnn's conventions: inputs in [0,1], a flat fp32 `params`
 Parameter per module (state-dict key `<name>.params`), `n_output_dims`, fp16 outputs under autocast.
 
+NOT CHECKPOINT-COMPATIBLE with real tiny-cuda-nn: `_HashGrid` keeps torch-ngp's level geometry ((res+1)^D rows and
+stride res+1 on the dense levels, row counts rounded up to 8) whereas tiny-cuda-nn uses res^D rows / stride res there, so
+the flat `params` vector of a tcnn-trained HashGrid has a different length and index function (strict load fails with a
+size mismatch).  The modules train, render and resume their OWN checkpoints; see INTEGRATION.md §A.
+
 PARITY UNPINNED: tiny-cuda-nn is an external, unversioned dependency of the reference (readme.md:74-76) whose source is
 not in the tree.  HashGrid / SphericalHarmonics reuse the in-tree encoders' arithmetic (torch-ngp's gridencoder and
 shencoder are restatements of tcnn's); Frequency follows tcnn's published layout (72 = 3 * 12 * 2 outputs,

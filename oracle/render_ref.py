@@ -190,6 +190,30 @@ class RefLidarField(torch.nn.Module):
         return rgbs
 
 
+class RefFreqField(torch.nn.Module):
+    """BASELINE config 1 (the reference's CPU-runnable path): NeRFNetwork with the PURE-TORCH positional encoder of
+    encoding.py:6-47 in place of the hash grid — [x | sin(2^f x) | cos(2^f x)]_{f<6} on the raw position (FreqEncoder's
+    forward ignores `bound`; degree = get_encoder's default multires, encoding.py:53) -> bias-free Linear 39->64->16
+    (network.py:45-59), LiDAR colour head as in RefLidarField (network.py:83-99, 199-237), fp32, CPU."""
+
+    def __init__(self, pos_degree=6, hidden_dim=64, geo_feat_dim=15, hidden_dim_color=64, num_layers_color=3,
+                 freq_degree=12, bound=1.0, out_dim=2):
+        super().__init__()
+        self.bound, self.pos_degree, self.freq_degree, self.out_dim = bound, pos_degree, freq_degree, out_dim
+        self.sigma_net = torch.nn.ModuleList([torch.nn.Linear(3 + 6 * pos_degree, hidden_dim, bias=False),
+                                              torch.nn.Linear(hidden_dim, 1 + geo_feat_dim, bias=False)])
+        dims = [3 + 6 * freq_degree + geo_feat_dim] + [hidden_dim_color] * (num_layers_color - 1) + [out_dim]
+        self.lidar_color_net = torch.nn.ModuleList(
+            [torch.nn.Linear(dims[i], dims[i + 1], bias=False) for i in range(num_layers_color)])
+
+    def density(self, x):
+        h = torch.relu(self.sigma_net[0](freq_encode_torch(x, self.pos_degree)))
+        h = self.sigma_net[1](h)
+        return trunc_exp(h[..., 0]), h[..., 1:]
+
+    color = RefLidarField.color
+
+
 # ----------------------------------------------------------------------------- loss
 def lidar_loss(depth, image, gt, alpha_d=1000.0, alpha_r=1.0, alpha_i=10.0):
     """utils.py:712-746 with L1 depth, MSE raydrop, MSE intensity (main_lidarnerf.py:330-342 defaults)."""

@@ -40,12 +40,16 @@ def _worker(rank, world, port, out):
     # fp16 table-gradient path used by the fused backward
     tbl = torch.nn.Parameter(torch.zeros(8, 2))
     g16 = torch.full((8, 2), float(rank + 1) * 2.0, dtype=torch.float16)
+    g16[0, 0] = 2.0 ** -24                                    # smallest fp16 subnormal: must survive the exchange
     h = parallel.allreduce_half_table(g16, tbl)
     h.wait()
-    torch.testing.assert_close(g16, torch.full((8, 2), 3.0, dtype=torch.float16))
-    tbl.grad = g16.float()
+    want = torch.full((8, 2), 6.0, dtype=torch.float16)       # the SUM over ranks; the consumer divides in fp32
+    want[0, 0] = 2.0 ** -23
+    torch.testing.assert_close(g16, want, rtol=0, atol=0)
+    tbl.grad = g16.float() / world                            # what fused.backward does on the autograd path
     parallel.allreduce_gradients([tbl], world)  # must NOT reduce it a second time
-    torch.testing.assert_close(tbl.grad, torch.full((8, 2), 3.0))
+    torch.testing.assert_close(tbl.grad, want.float() / 2)
+    assert float(tbl.grad[0, 0]) == 2.0 ** -24                # (dividing the fp16 values first would have flushed it)
     assert tbl._lnh_grad_reduced is False
     a, b = parallel.shard_rays(67980, rank, world)
     assert (a, b) == ((0, 33990) if rank == 0 else (33990, 67980))
