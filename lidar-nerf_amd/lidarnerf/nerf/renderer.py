@@ -103,7 +103,10 @@ class NeRFRenderer(nn.Module):
         return raymarching.near_far_from_aabb(rays_o, rays_d, aabb, self.min_near)
 
     def run(self, rays_o, rays_d, cal_lidar_color=False, num_steps=128, upsample_steps=128, bg_color=None,
-            perturb=False, **kwargs):
+            perturb=False, noise=None, u=None, **kwargs):
+        """renderer.py:99-298.  `noise` [N, num_steps] / `u` [N, upsample_steps] in [0,1) replace the two torch.rand
+        draws of the reference (perturbation, sample_pdf) — parity tests replay the reference's own draws through them;
+        the reference's **kwargs swallows both names, so passing them there is harmless."""
         self.out_dim = self.out_lidar_color_dim if cal_lidar_color else self.out_color_dim
         prefix = rays_o.shape[:-1]
         rays_o = rays_o.contiguous().view(-1, 3).float()
@@ -116,7 +119,7 @@ class NeRFRenderer(nn.Module):
         z = nears + (fars - nears) * torch.linspace(0.0, 1.0, num_steps, device=dev).unsqueeze(0)
         sample_dist = (fars - nears) / num_steps
         if perturb:
-            z = z + (torch.rand(z.shape, device=dev) - 0.5) * sample_dist
+            z = z + ((torch.rand(z.shape, device=dev) if noise is None else noise.to(dev).view(z.shape)) - 0.5) * sample_dist
         z = z.contiguous()
         sd = sample_dist.reshape(-1).contiguous()
 
@@ -131,7 +134,9 @@ class NeRFRenderer(nn.Module):
 
         if upsample_steps > 0:
             with torch.no_grad():
-                if self.training:
+                if u is not None:
+                    u = u.to(dev).view(N, upsample_steps).float().contiguous()
+                elif self.training:
                     u = torch.rand((N, upsample_steps), device=dev)
                 else:
                     u = torch.linspace(0.5 / upsample_steps, 1.0 - 0.5 / upsample_steps, upsample_steps,
