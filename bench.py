@@ -170,6 +170,8 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--rays", type=int, default=4096, help="rays per step per GPU")
+    ap.add_argument("--mlp-dtype", choices=("fp16", "bf16"), default="fp16",
+                    help="MFMA operand type of the MLP kernels (bf16 = BASELINE config 5; hash features stay fp16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eval", action="store_true", help="skip the secondary full-frame evaluation measurement")
     ap.add_argument("--kernel-timers", action="store_true", help="HIP-event timing of every C-ABI call (adds ~4 %)")
@@ -196,7 +198,8 @@ def main():
     model = build_model(device)
     parallel.broadcast_parameters(model)
     trainer = LidarTrainer(model, lr=1e-2, iters=30000, fp16=True, scale=SCALE, world_size=world,
-                           render_kwargs=dict(num_steps=NUM_STEPS, upsample_steps=UPSAMPLE))
+                           render_kwargs=dict(num_steps=NUM_STEPS, upsample_steps=UPSAMPLE),
+                           mlp_dtype=torch.bfloat16 if args.mlp_dtype == "bf16" else torch.float16)
     poses = synthetic_frames(60, device)
     n_steps_total = args.warmup + args.steps
     batches = [make_batch(poses, s, args.rays, rank, device) for s in range(min(n_steps_total, 60))]
@@ -330,7 +333,8 @@ def main():
         "metric": "train rays/sec (encode+MLP+composite+bwd), KITTI-360 66x1030",
         "value": round(rays_total / elapsed, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f16 (fp16 hash tables + fp16 MFMA MLP, fp32 accumulate)",
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": f"{'bf16' if args.mlp_dtype == 'bf16' else 'f16'} (fp16 hash tables + {args.mlp_dtype} MFMA MLP, fp32 accumulate)",
         "data": "synthetic",
         "config": {"workload": "KITTI-360 seq 1908 shaped: hash-grid L=16 F=2 (2^19 rows, res 16..32768) + 64-wide "
                                "fused MLPs, 66x1030 range image", "rays_per_gpu_per_step": args.rays,
@@ -348,7 +352,7 @@ def main():
     if world == 1 and not args.no_eval:
         model.eval()
         frame = make_batch(poses, 0, 66 * 1030, rank, device)
-        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        with torch.no_grad(), torch.autocast("cuda", dtype=trainer.amp_dtype):
             for _ in range(2):
                 model.render(frame[0], frame[1], cal_lidar_color=True, staged=True, max_ray_batch=4096, perturb=False,
                              num_steps=NUM_STEPS, upsample_steps=UPSAMPLE)

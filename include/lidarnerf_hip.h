@@ -366,6 +366,42 @@ LNH_API int lnh_adam_table_step(float *param, float *exp_avg, float *exp_avg_sq,
                                 const float *inv_scale, const float *found_inf, const float *step_in,
                                 float *step_out, lnh_stream_t stream);
 
+
+/* ------------------------------------------------------------------ bf16 MLP operands (BASELINE config 5) ---- */
+/*
+ * The same eight entry points with v_mfma_f32_16x16x32_bf16 operands ("fp16 hash features + bf16 MFMA MLP"; the
+ * reference reaches the MLPs through torch.autocast, lidarnerf/nerf/utils.py:626,1212 — under
+ * autocast(dtype=torch.bfloat16) its Linear stacks run in bf16 while the grid encoder keeps casting its table to half,
+ * gridencoder/grid.py:54-57).  Every buffer that holds MLP-side 16-bit data is bf16 here — inputs / outputs /
+ * forward_buffer / grad / grad_inputs of lnh_mlp_*_bf16, the packed weights, h16 and grad_h16 — while the hash-grid
+ * `features` entering lnh_density_mlp_forward_bf16 and the `grad_features` leaving lnh_density_mlp_backward_bf16 stay
+ * fp16 (the grid kernels' type).  Accumulation is fp32, weight gradients are fp32, as in the fp16 build.
+ */
+LNH_API int lnh_mlp_forward_bf16(const void *inputs, const void *weights, uint32_t B, uint32_t input_dim,
+                            uint32_t output_dim, uint32_t hidden_dim, uint32_t n_hidden_mats, uint32_t activation,
+                            uint32_t output_activation, void *forward_buffer, void *outputs, lnh_stream_t stream);
+LNH_API int lnh_mlp_backward_bf16(const void *grad, const void *inputs, const void *weights, uint32_t B,
+                             uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t n_hidden_mats,
+                             uint32_t activation, uint32_t output_activation, void *grad_inputs, float *grad_weights,
+                             lnh_stream_t stream);
+LNH_API int lnh_density_mlp_forward_bf16(const void *features, const void *weights, uint32_t B, uint32_t T_cur,
+                                    uint32_t T_tot, uint32_t slot_off, uint32_t feat_rows, void *h16, float *sigma,
+                                    lnh_stream_t stream);
+LNH_API int lnh_density_mlp_backward_bf16(const void *grad_h16, const void *features, const void *weights, uint32_t B,
+                                     uint32_t T_cur, uint32_t T_tot, uint32_t slot_off, void *grad_features,
+                                     float *grad_weights, lnh_stream_t stream);
+LNH_API int lnh_lidar_dir_term_bf16(const float *dir_features, const float *w0, uint32_t ldw, uint32_t N, uint32_t K,
+                               float *features16, float *cdir, lnh_stream_t stream);
+LNH_API int lnh_lidar_pack_weights_bf16(const float *ws0, uint32_t ld_s0, const float *ws1, uint32_t ld_s1,
+                                   const float *wc0, uint32_t ld_c0, uint32_t n_dir, const float *wc1, uint32_t ld_c1,
+                                   const float *wc2, uint32_t ld_c2, void *wsig16, void *wcol16, lnh_stream_t stream);
+LNH_API int lnh_lidar_color_forward_bf16(const void *h16, const int32_t *perm, const float *weights, const float *cdir,
+                                    const void *w16, uint32_t N, uint32_t T, float *rgb, lnh_stream_t stream);
+LNH_API int lnh_lidar_color_backward_bf16(const float *grad_rgb, const float *grad_sigma, const void *h16,
+                                     const int32_t *perm, const float *weights, const float *cdir, const void *w16,
+                                     uint32_t N, uint32_t T, void *grad_h16, float *grad_w, float *ray_sum,
+                                     lnh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,7 +33,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-ato
 
 MFMA_VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 # hipcc (ROCm 7.2) crashes on the 2-hidden-matrix backward instantiations with that option: they keep the default
-NO_VGPR_FORM = {"mlp_bwd_nhm2.hip"}
+NO_VGPR_FORM = {"mlp_bwd_nhm2.hip", "mlp_bwd_nhm2_bf16.hip"}
 
 
 def _newer(src, deps, out):

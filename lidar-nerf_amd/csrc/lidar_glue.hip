@@ -22,8 +22,9 @@ k_coarse_samples(const float *__restrict__ u, uint32_t N, uint32_t T, float near
 }
 
 // ------------------------------------------------------------------------------------------------ direction term
-// enc16[n,k] = fp16-rounded direction feature; cdir[n,o] = sum_k enc16[n,k] * fp16(W0[o,k])  (fp32 accumulate).
-// One workgroup = 4 rays x 64 outputs; the feature row of a ray is broadcast through LDS.
+// enc16[n,k] = direction feature rounded to the MLP element type E (fp16 / bf16); cdir[n,o] = sum_k enc16[n,k] *
+// E(W0[o,k])  (fp32 accumulate).  One workgroup = 4 rays x 64 outputs; the feature row of a ray is broadcast through LDS.
+template <typename E>
 __global__ void __launch_bounds__(256)
 k_dir_term(const float *__restrict__ enc, const float *__restrict__ W0, uint32_t ldw, uint32_t N, uint32_t K,
            float *__restrict__ enc16, float *__restrict__ cdir) {
@@ -32,14 +33,14 @@ k_dir_term(const float *__restrict__ enc, const float *__restrict__ W0, uint32_t
     const uint32_t n = blockIdx.x * 4 + r;
     const bool valid = n < N;
     for (uint32_t k = o; k < K; k += 64) {
-        const float v = (float)(half_t)enc[(size_t)(valid ? n : 0) * K + k];
+        const float v = (float)(E)enc[(size_t)(valid ? n : 0) * K + k];
         row[r][k] = v;
         if (valid) enc16[(size_t)n * K + k] = v;
     }
     __syncthreads();
     float acc = 0.0f;
     const float *w = W0 + (size_t)o * ldw;
-    for (uint32_t k = 0; k < K; k++) acc = fmaf(row[r][k], (float)(half_t)w[k], acc);
+    for (uint32_t k = 0; k < K; k++) acc = fmaf(row[r][k], (float)(E)w[k], acc);
     if (valid) cdir[(size_t)n * 64 + o] = acc;
 }
 
@@ -92,30 +93,32 @@ k_dir_term_backward_sum(const float *__restrict__ partial, uint32_t chunks, uint
 // ------------------------------------------------------------------------------------------------ weight packing
 // fp32 master weights (possibly strided views) -> the flat fp16 vectors the fused kernels read:
 //   wsig = [ws0 (64x32) | ws1 (16x64)],  wcol = [W0g (64x16: col 0 zero, cols 1..15 = wc0[:, kd:kd+15]) | wc1 | wc2 padded to 16 rows]
+template <typename E>
 struct PackArgs {
     const float *ws0, *ws1, *wc0, *wc1, *wc2;
     uint32_t ld_s0, ld_s1, ld_c0, ld_c1, ld_c2, kd;
-    half_t *wsig, *wcol;
+    E *wsig, *wcol;
 };
+template <typename E>
 __global__ void __launch_bounds__(256)
-k_pack_weights(PackArgs a) {
+k_pack_weights(PackArgs<E> a) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     constexpr uint32_t nS0 = 64 * 32, nS1 = 16 * 64, nC0 = 64 * 16, nC1 = 64 * 64, nC2 = 16 * 64;
     if (i < nS0) {
-        a.wsig[i] = (half_t)a.ws0[(i / 32) * a.ld_s0 + i % 32];
+        a.wsig[i] = (E)a.ws0[(i / 32) * a.ld_s0 + i % 32];
     } else if (i < nS0 + nS1) {
         const uint32_t j = i - nS0;
-        a.wsig[i] = (half_t)a.ws1[(j / 64) * a.ld_s1 + j % 64];
+        a.wsig[i] = (E)a.ws1[(j / 64) * a.ld_s1 + j % 64];
     }
     if (i < nC0) {
         const uint32_t o = i / 16, c = i % 16;
-        a.wcol[i] = c == 0 ? (half_t)0.0f : (half_t)a.wc0[o * a.ld_c0 + a.kd + c - 1];
+        a.wcol[i] = c == 0 ? (E)0.0f : (E)a.wc0[o * a.ld_c0 + a.kd + c - 1];
     } else if (i < nC0 + nC1) {
         const uint32_t j = i - nC0;
-        a.wcol[i] = (half_t)a.wc1[(j / 64) * a.ld_c1 + j % 64];
+        a.wcol[i] = (E)a.wc1[(j / 64) * a.ld_c1 + j % 64];
     } else if (i < nC0 + nC1 + nC2) {
         const uint32_t j = i - nC0 - nC1, o = j / 64;
-        a.wcol[i] = o < 2 ? (half_t)a.wc2[o * a.ld_c2 + j % 64] : (half_t)0.0f;
+        a.wcol[i] = o < 2 ? (E)a.wc2[o * a.ld_c2 + j % 64] : (E)0.0f;
     }
 }
 
@@ -150,6 +153,28 @@ k_lidar_loss(const float *__restrict__ depth, const float *__restrict__ image, c
 
 }  // namespace
 
+template <typename E>
+static int dir_term(const float *dir_features, const float *w0, uint32_t ldw, uint32_t N, uint32_t K, float *features16,
+                    float *cdir, lnh_stream_t stream) {
+    LNH_REQUIRE(dir_features && w0 && features16 && cdir, LNH_ERR_INVALID_ARG, "lidar_dir_term: null pointer");
+    LNH_REQUIRE(K >= 1 && K <= 128 && ldw >= K, LNH_ERR_INVALID_ARG, "lidar_dir_term: need 1 <= K <= 128 and ldw >= K");
+    if (N == 0) return LNH_OK;
+    LNH_LAUNCH(k_dir_term<E>, dim3(div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, dir_features, w0, ldw, N, K,
+               features16, cdir);
+    return lnh_check_launch("lnh_lidar_dir_term");
+}
+template <typename E>
+static int pack_weights(const float *ws0, uint32_t ld_s0, const float *ws1, uint32_t ld_s1, const float *wc0,
+                        uint32_t ld_c0, uint32_t n_dir, const float *wc1, uint32_t ld_c1, const float *wc2, uint32_t ld_c2,
+                        void *wsig16, void *wcol16, lnh_stream_t stream) {
+    LNH_REQUIRE(ws0 && ws1 && wc0 && wc1 && wc2 && wsig16 && wcol16, LNH_ERR_INVALID_ARG,
+                "lidar_pack_weights: null pointer");
+    LNH_REQUIRE(ld_s0 >= 32 && ld_s1 >= 64 && ld_c0 >= n_dir + 15 && ld_c1 >= 64 && ld_c2 >= 64, LNH_ERR_INVALID_ARG,
+                "lidar_pack_weights: leading dimension smaller than the row");
+    PackArgs<E> a{ws0, ws1, wc0, wc1, wc2, ld_s0, ld_s1, ld_c0, ld_c1, ld_c2, n_dir, (E *)wsig16, (E *)wcol16};
+    LNH_LAUNCH(k_pack_weights<E>, dim3(div_up(64 * 16 + 64 * 64 + 16 * 64, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return lnh_check_launch("lnh_lidar_pack_weights");
+}
 extern "C" {
 
 int lnh_lidar_coarse_samples(const float *u, uint32_t N, uint32_t T, float near, float far, float *z,
@@ -164,12 +189,11 @@ int lnh_lidar_coarse_samples(const float *u, uint32_t N, uint32_t T, float near,
 
 int lnh_lidar_dir_term(const float *dir_features, const float *w0, uint32_t ldw, uint32_t N, uint32_t K,
                        float *features16, float *cdir, lnh_stream_t stream) {
-    LNH_REQUIRE(dir_features && w0 && features16 && cdir, LNH_ERR_INVALID_ARG, "lidar_dir_term: null pointer");
-    LNH_REQUIRE(K >= 1 && K <= 128 && ldw >= K, LNH_ERR_INVALID_ARG, "lidar_dir_term: need 1 <= K <= 128 and ldw >= K");
-    if (N == 0) return LNH_OK;
-    LNH_LAUNCH(k_dir_term, dim3(div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, dir_features, w0, ldw, N, K,
-               features16, cdir);
-    return lnh_check_launch("lnh_lidar_dir_term");
+    return dir_term<half_t>(dir_features, w0, ldw, N, K, features16, cdir, stream);
+}
+int lnh_lidar_dir_term_bf16(const float *dir_features, const float *w0, uint32_t ldw, uint32_t N, uint32_t K,
+                            float *features16, float *cdir, lnh_stream_t stream) {
+    return dir_term<__bf16>(dir_features, w0, ldw, N, K, features16, cdir, stream);
 }
 
 int lnh_lidar_dir_term_backward(const float *ray_sum, const float *features16, uint32_t N, uint32_t K, float *scratch,
@@ -191,13 +215,12 @@ int lnh_lidar_dir_term_backward(const float *ray_sum, const float *features16, u
 int lnh_lidar_pack_weights(const float *ws0, uint32_t ld_s0, const float *ws1, uint32_t ld_s1, const float *wc0,
                            uint32_t ld_c0, uint32_t n_dir, const float *wc1, uint32_t ld_c1, const float *wc2,
                            uint32_t ld_c2, void *wsig16, void *wcol16, lnh_stream_t stream) {
-    LNH_REQUIRE(ws0 && ws1 && wc0 && wc1 && wc2 && wsig16 && wcol16, LNH_ERR_INVALID_ARG,
-                "lidar_pack_weights: null pointer");
-    LNH_REQUIRE(ld_s0 >= 32 && ld_s1 >= 64 && ld_c0 >= n_dir + 15 && ld_c1 >= 64 && ld_c2 >= 64, LNH_ERR_INVALID_ARG,
-                "lidar_pack_weights: leading dimension smaller than the row");
-    PackArgs a{ws0, ws1, wc0, wc1, wc2, ld_s0, ld_s1, ld_c0, ld_c1, ld_c2, n_dir, (half_t *)wsig16, (half_t *)wcol16};
-    LNH_LAUNCH(k_pack_weights, dim3(div_up(64 * 16 + 64 * 64 + 16 * 64, 256)), dim3(256), 0, (hipStream_t)stream, a);
-    return lnh_check_launch("lnh_lidar_pack_weights");
+    return pack_weights<half_t>(ws0, ld_s0, ws1, ld_s1, wc0, ld_c0, n_dir, wc1, ld_c1, wc2, ld_c2, wsig16, wcol16, stream);
+}
+int lnh_lidar_pack_weights_bf16(const float *ws0, uint32_t ld_s0, const float *ws1, uint32_t ld_s1, const float *wc0,
+                                uint32_t ld_c0, uint32_t n_dir, const float *wc1, uint32_t ld_c1, const float *wc2,
+                                uint32_t ld_c2, void *wsig16, void *wcol16, lnh_stream_t stream) {
+    return pack_weights<__bf16>(ws0, ld_s0, ws1, ld_s1, wc0, ld_c0, n_dir, wc1, ld_c1, wc2, ld_c2, wsig16, wcol16, stream);
 }
 
 int lnh_lidar_loss(const float *depth, const float *image, const float *gt, uint32_t N, float alpha_d, float alpha_r,

@@ -11,6 +11,8 @@
 // one atomic per element per wave at the end of the kernel.
 #include "mlp_bwd.h"
 
+namespace LNH_MLP_NS {
+
 int lnh_mlp_backward_h32(uint32_t in_ks, uint32_t nhm, const MlpBwdArgs &a, hipStream_t s);
 int lnh_mlp_backward_nhm0(uint32_t in_ks, const MlpBwdArgs &a, hipStream_t s);
 int lnh_mlp_backward_nhm1(uint32_t in_ks, const MlpBwdArgs &a, hipStream_t s);
@@ -20,7 +22,7 @@ int lnh_density_mlp_backward_launch(const MlpBwdArgs &a, hipStream_t s);
 namespace {
 
 struct MlpArgs {
-    const half_t *X;      // [B, in_dim]
+    const void *X;        // [B, in_dim] (IO::in_t: MLP element type, or level-major fp16 features for DensityIO)
     const half_t *W;      // flat weights
     half_t *Y;            // [B, 16]
     half_t *fb;           // NULL or [NHM+1, B, hidden]
@@ -75,7 +77,7 @@ k_mlp_forward(MlpArgs a) {
                 // unconditional load from a clamped address + register select (a predicated load would make hipcc
                 // branch around every load and drain vmcnt per element)
                 const bool ok = p < a.B && k0 < a.in_dim;
-                const half8_t v = IO::load_x(a.X, ok ? p : 0, ok ? k0 : 0, a.B, a.in_dim, a.io);
+                const half8_t v = IO::load_x((const typename IO::in_t *)a.X, ok ? p : 0, ok ? k0 : 0, a.B, a.in_dim, a.io);
                 bx[n][s] = ok ? v : zero_h8();
             }
         }
@@ -211,7 +213,7 @@ int check_shape(uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, ui
 
 extern "C" {
 
-int lnh_mlp_forward(const void *inputs, const void *weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
+int LNH_MLP_FN(lnh_mlp_forward)(const void *inputs, const void *weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
                     uint32_t hidden_dim, uint32_t n_hidden_mats, uint32_t activation, uint32_t output_activation,
                     void *forward_buffer, void *outputs, lnh_stream_t stream) {
     LNH_REQUIRE(inputs && weights && outputs, LNH_ERR_INVALID_ARG, "mlp forward: null pointer");
@@ -220,14 +222,14 @@ int lnh_mlp_forward(const void *inputs, const void *weights, uint32_t B, uint32_
     int rc = check_shape(input_dim, output_dim, hidden_dim, n_hidden_mats);
     if (rc) return rc;
     if (B == 0) return LNH_OK;
-    MlpArgs a{(const half_t *)inputs, (const half_t *)weights, (half_t *)outputs, (half_t *)forward_buffer,
+    MlpArgs a{inputs, (const half_t *)weights, (half_t *)outputs, (half_t *)forward_buffer,
               B, input_dim, hidden_dim, activation, output_activation, nullptr, IoDims{1, 1, 0, 0}};
     hipStream_t s = (hipStream_t)stream;
     LNH_MLP_FWD_DISPATCH(a)
     return rc;
 }
 
-int lnh_mlp_backward(const void *grad, const void *inputs, const void *weights, uint32_t B, uint32_t input_dim,
+int LNH_MLP_FN(lnh_mlp_backward)(const void *grad, const void *inputs, const void *weights, uint32_t B, uint32_t input_dim,
                      uint32_t output_dim, uint32_t hidden_dim, uint32_t n_hidden_mats, uint32_t activation,
                      uint32_t output_activation, void *grad_inputs, float *grad_weights, lnh_stream_t stream) {
     LNH_REQUIRE(grad && inputs && weights && grad_weights, LNH_ERR_INVALID_ARG, "mlp backward: null pointer");
@@ -238,7 +240,7 @@ int lnh_mlp_backward(const void *grad, const void *inputs, const void *weights, 
     int rc = check_shape(input_dim, output_dim, hidden_dim, n_hidden_mats);
     if (rc) return rc;
     if (B == 0) return LNH_OK;
-    MlpBwdArgs a{(const half_t *)grad, (const half_t *)inputs, (const half_t *)weights, (half_t *)grad_inputs,
+    MlpBwdArgs a{(const half_t *)grad, inputs, (const half_t *)weights, grad_inputs,
                  grad_weights, B, input_dim, hidden_dim, activation, output_activation, IoDims{1, 1, 0, 0}};
     hipStream_t s = (hipStream_t)stream;
     const uint32_t iks = (input_dim + 31) / 32;
@@ -252,18 +254,18 @@ int lnh_mlp_backward(const void *grad, const void *inputs, const void *weights, 
 }
 
 
-int lnh_density_mlp_forward(const void *features, const void *weights, uint32_t B, uint32_t T_cur, uint32_t T_tot,
+int LNH_MLP_FN(lnh_density_mlp_forward)(const void *features, const void *weights, uint32_t B, uint32_t T_cur, uint32_t T_tot,
                             uint32_t slot_off, uint32_t feat_rows, void *h16, float *sigma, lnh_stream_t stream) {
     LNH_REQUIRE(features && weights && h16 && sigma, LNH_ERR_INVALID_ARG, "density mlp forward: null pointer");
     LNH_REQUIRE(T_cur >= 1 && slot_off + T_cur <= T_tot && B % T_cur == 0, LNH_ERR_INVALID_ARG,
                 "density mlp forward: need B %% T_cur == 0 and slot_off + T_cur <= T_tot");
     if (B == 0) return LNH_OK;
-    MlpArgs a{(const half_t *)features, (const half_t *)weights, (half_t *)h16, nullptr, B, 32, 64, LNH_ACT_RELU,
+    MlpArgs a{features, (const half_t *)weights, (half_t *)h16, nullptr, B, 32, 64, LNH_ACT_RELU,
               LNH_ACT_NONE, sigma, IoDims{T_cur, T_tot, slot_off, feat_rows}};
     return launch_fwd<1, 4, 0, DensityIO, 2>(a, (hipStream_t)stream);
 }
 
-int lnh_density_mlp_backward(const void *grad_h16, const void *features, const void *weights, uint32_t B,
+int LNH_MLP_FN(lnh_density_mlp_backward)(const void *grad_h16, const void *features, const void *weights, uint32_t B,
                              uint32_t T_cur, uint32_t T_tot, uint32_t slot_off, void *grad_features,
                              float *grad_weights, lnh_stream_t stream) {
     const uint32_t feat_rows = 0;
@@ -272,9 +274,11 @@ int lnh_density_mlp_backward(const void *grad_h16, const void *features, const v
     LNH_REQUIRE(T_cur >= 1 && slot_off + T_cur <= T_tot && B % T_cur == 0, LNH_ERR_INVALID_ARG,
                 "density mlp backward: need B %% T_cur == 0 and slot_off + T_cur <= T_tot");
     if (B == 0) return LNH_OK;
-    MlpBwdArgs a{(const half_t *)grad_h16, (const half_t *)features, (const half_t *)weights, (half_t *)grad_features,
+    MlpBwdArgs a{(const half_t *)grad_h16, features, (const half_t *)weights, grad_features,
                  grad_weights, B, 32, 64, LNH_ACT_RELU, LNH_ACT_NONE, IoDims{T_cur, T_tot, slot_off, feat_rows}};
     return lnh_density_mlp_backward_launch(a, (hipStream_t)stream);
 }
 
 }  // extern "C"
+
+}  // namespace LNH_MLP_NS

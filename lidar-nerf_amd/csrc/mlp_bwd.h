@@ -13,11 +13,13 @@
 #pragma once
 #include "mlp_common.h"
 
+namespace LNH_MLP_NS {
+
 struct MlpBwdArgs {
     const half_t *dY;  // [B,16]
-    const half_t *X;   // [B,in_dim]
-    const half_t *W;   // flat fp16 weights
-    half_t *dX;        // NULL or [B,in_dim]
+    const void *X;     // [B,in_dim] MLP element type (RowMajorIO) / level-major fp16 features (DensityIO): IO::in_t
+    const half_t *W;   // flat weights (MLP element type)
+    void *dX;          // NULL or the gradient of X, same layout and type as X
     float *dW;         // flat fp32, atomically accumulated
     uint32_t B, in_dim, hidden, act, out_act;
     IoDims io;
@@ -128,7 +130,7 @@ k_mlp_backward(MlpBwdArgs a) {
                 const uint32_t k0 = 32 * s + 8 * g;
                 // unconditional loads from clamped addresses + register selects (see mlp.hip)
                 const bool ok = p < a.B && k0 < in_dim;
-                const half8_t v = IO::load_x(a.X, ok ? p : 0, ok ? k0 : 0, a.B, in_dim, a.io);
+                const half8_t v = IO::load_x((const typename IO::in_t *)a.X, ok ? p : 0, ok ? k0 : 0, a.B, in_dim, a.io);
                 bx[n][s] = ok ? v : zero_h8();
             }
             const bool oky = p < a.B && g < 2;
@@ -261,7 +263,7 @@ k_mlp_backward(MlpBwdArgs a) {
                     f32x4 acc = zero_f4();
 #pragma unroll
                     for (int s = 0; s < HS; s++) acc = MFMA16(w0T[t][s], bd[n][s], acc);
-                    if (p < a.B && (uint32_t)t < in_tiles) IO::store_dx(a.dX, p, t, g, a.B, in_dim, acc);
+                    if (p < a.B && (uint32_t)t < in_tiles) IO::store_dx((typename IO::in_t *)a.dX, p, t, g, a.B, in_dim, acc);
                 }
             }
         }
@@ -366,7 +368,7 @@ k_mlp_backward_wi(MlpBwdArgs a) {
                 const uint32_t k0 = 32 * s + 8 * g;
                 // unconditional loads from clamped addresses + register selects (see mlp.hip)
                 const bool ok = p < a.B && k0 < in_dim;
-                const half8_t v = IO::load_x(a.X, ok ? p : 0, ok ? k0 : 0, a.B, in_dim, a.io);
+                const half8_t v = IO::load_x((const typename IO::in_t *)a.X, ok ? p : 0, ok ? k0 : 0, a.B, in_dim, a.io);
                 bx[n][s] = ok ? v : zero_h8();
             }
             const bool oky = p < a.B && g < 2;
@@ -406,7 +408,7 @@ k_mlp_backward_wi(MlpBwdArgs a) {
                     f32x4 acc = zero_f4();
 #pragma unroll
                     for (int s = 0; s < HS; s++) acc = MFMA16(w0T[t][s], bd[n][s], acc);
-                    if (p < a.B && (uint32_t)t < in_tiles) IO::store_dx(a.dX, p, t, g, a.B, in_dim, acc);
+                    if (p < a.B && (uint32_t)t < in_tiles) IO::store_dx((typename IO::in_t *)a.dX, p, t, g, a.B, in_dim, acc);
                 }
             }
         }
@@ -518,5 +520,4 @@ int launch_mlp_backward(const MlpBwdArgs &a, hipStream_t s) {
     return lnh_check_launch("lnh_mlp_backward");
 }
 
-
-
+}  // namespace LNH_MLP_NS

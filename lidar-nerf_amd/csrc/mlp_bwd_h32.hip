@@ -1,6 +1,8 @@
 // mlp_bwd_h32.hip — instantiations of the fused-MLP backward kernel for hidden = 32 (HT = 2), all depths.
 #include "mlp_bwd.h"
 
+namespace LNH_MLP_NS {
+
 int lnh_mlp_backward_h32(uint32_t in_ks, uint32_t nhm, const MlpBwdArgs &a, hipStream_t s) {
     switch (in_ks * 10 + nhm) {
         case 10: return launch_mlp_backward<1, 2, 0>(a, s);
@@ -19,3 +21,5 @@ int lnh_mlp_backward_h32(uint32_t in_ks, uint32_t nhm, const MlpBwdArgs &a, hipS
     lnh_set_error("fused MLP backward: input_dim > 128 is not instantiated");
     return LNH_ERR_UNSUPPORTED;
 }
+
+}  // namespace LNH_MLP_NS

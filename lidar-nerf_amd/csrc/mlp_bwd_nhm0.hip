@@ -1,6 +1,8 @@
 // mlp_bwd_nhm0.hip — instantiations of the fused-MLP backward kernel with 0 hidden->hidden matrices (hidden = 64).
 #include "mlp_bwd.h"
 
+namespace LNH_MLP_NS {
+
 // One-hidden-layer nets up to 64 inputs take the wave-independent kernel (measured 166 us vs 196 us for the
 // workgroup-cooperative one on the sigma net); wider inputs would not fit its register budget.
 int lnh_mlp_backward_nhm0(uint32_t in_ks, const MlpBwdArgs &a, hipStream_t s) {
@@ -18,3 +20,5 @@ int lnh_mlp_backward_nhm0(uint32_t in_ks, const MlpBwdArgs &a, hipStream_t s) {
 int lnh_density_mlp_backward_launch(const MlpBwdArgs &a, hipStream_t s) {
     return launch_mlp_backward_wi<1, 4, DensityIO>(a, s);
 }
+
+}  // namespace LNH_MLP_NS

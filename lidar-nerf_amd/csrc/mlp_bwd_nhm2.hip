@@ -1,6 +1,8 @@
 // mlp_bwd_nhm2.hip — instantiations of the fused-MLP backward kernel with 2 hidden->hidden matrices (hidden = 64).
 #include "mlp_bwd.h"
 
+namespace LNH_MLP_NS {
+
 int lnh_mlp_backward_nhm2(uint32_t in_ks, const MlpBwdArgs &a, hipStream_t s) {
     switch (in_ks) {
         case 1: return launch_mlp_backward<1, 4, 2>(a, s);
@@ -11,3 +13,5 @@ int lnh_mlp_backward_nhm2(uint32_t in_ks, const MlpBwdArgs &a, hipStream_t s) {
     lnh_set_error("fused MLP backward: input_dim > 128 is not instantiated");
     return LNH_ERR_UNSUPPORTED;
 }
+
+}  // namespace LNH_MLP_NS

@@ -12,12 +12,41 @@
 // round trip between layers.  The weight fragments are gathered once per wave with the same enumeration.
 //
 // Replaces the shared-memory/WMMA chain of lidarnerf/ffmlp/src/ffmlp.cu:54-180,460-576 (semantics only).
+//
+// Element type: the whole MLP code base (this header, mlp_bwd.h, mlp.hip, mlp_bwd_*.hip, lidar_color.hip) is compiled
+// TWICE into one library — fp16 operands (v_mfma_f32_16x16x32_f16; entry points lnh_*) and, from the *_bf16.hip
+// wrapper translation units that define LNH_MLP_BF16, bf16 operands (v_mfma_f32_16x16x32_bf16; entry points
+// lnh_*_bf16: BASELINE config 5, "fp16 hash features + bf16 MFMA MLP").  Each build lives in its own namespace, in
+// which `half_t` / `half8_t` / ... name the MLP element type (so the kernels read the same either way); accumulation
+// is fp32 in both.  The hash-grid features entering the sigma net and the feature gradients leaving it stay fp16
+// (`feat_t`, the grid kernels' type) in both builds — DensityIO converts at that boundary.
 #pragma once
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 feat_t;                                         // hash-grid features / their gradients: always fp16
+typedef _Float16 feat2_t __attribute__((ext_vector_type(2)));
 
+#ifdef LNH_MLP_BF16
+#define LNH_MLP_NS lnh_mlp_bf16
+#define LNH_MLP_FN(name) name##_bf16
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#else
+#define LNH_MLP_NS lnh_mlp_f16
+#define LNH_MLP_FN(name) name
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#endif
+
+namespace LNH_MLP_NS {
+#ifdef LNH_MLP_BF16
+typedef __bf16 half_t;  // (shadows the global fp16 typedefs inside this namespace)
+typedef __bf16 half2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 half4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 half8_t __attribute__((ext_vector_type(8)));
+constexpr bool kMlpBf16 = true;
+#else
+constexpr bool kMlpBf16 = false;
+#endif
 
 constexpr float kActK = 10.0f;  // utils.h squareplus / softplus sharpness
 
@@ -66,7 +95,8 @@ __device__ __forceinline__ float act_bwd(uint32_t rt, float g, float post) {
 }
 
 __device__ __forceinline__ half8_t zero_h8() {
-    half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+    const half_t o = (half_t)0.0f;
+    half8_t z = {o, o, o, o, o, o, o, o};
     return z;
 }
 __device__ __forceinline__ f32x4 zero_f4() {
@@ -124,22 +154,29 @@ __device__ __forceinline__ half8_t pack_pair(const f32x4 &lo, const f32x4 &hi, F
     return r;
 }
 
-// ReLU variant on packed halves: narrow first (v_cvt_pk_f16_f32), then one v_pk_max_f16 per PAIR of values —
-// relu(narrow(x)) == narrow(relu(x)) exactly (rounding is monotonic and keeps the sign), at half the VALU instructions
-// of the fp32 form.  These kernels are VALU-issue bound, so this is wall time.
+// ReLU variant on packed 16-bit floats: narrow first (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32), then ONE packed op per
+// PAIR of values — relu(narrow(x)) == narrow(relu(x)) exactly (rounding is monotonic and keeps the sign), at half the
+// VALU instructions of the fp32 form.  These kernels are VALU-issue bound, so this is wall time.  fp16: v_pk_max_f16;
+// bf16 (no packed bf16 max on gfx950): v_pk_max_i16 against 0 on the bit patterns — a negative float (sign bit set,
+// -0 included) is a negative int16, a positive one keeps its bits.
 __device__ __forceinline__ half8_t pack_pair_relu(const f32x4 &lo, const f32x4 &hi) {
-    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-    const h4 a = __builtin_convertvector(lo, h4), b = __builtin_convertvector(hi, h4);
+    const half4_t a = __builtin_convertvector(lo, half4_t), b = __builtin_convertvector(hi, half4_t);
     const half8_t r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-    const half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
-    return __builtin_elementwise_max(r, z);
+#ifdef LNH_MLP_BF16
+    // (as a compiler-visible vector op, NOT inline asm: the result feeds the next MFMA directly, and the hazard
+    //  recogniser inserts the VALU-write -> MFMA-read wait states only for instructions it can see)
+    typedef short s8 __attribute__((ext_vector_type(8)));
+    const s8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    return __builtin_bit_cast(half8_t, __builtin_elementwise_max(__builtin_bit_cast(s8, r), zero));
+#else
+    return __builtin_elementwise_max(r, zero_h8());
+#endif
 }
 // ReLU backward on packed halves: narrow(d) where the stored (non-negative, never -0) activation h is non-zero, else 0.
 // Three packed integer ops per PAIR of values: nz = min(bits(h), 1) per half, m = 0 - nz (0 / 0xffff), d & m.
 __device__ __forceinline__ half8_t pack_pair_relu_bwd(const f32x4 &lo, const f32x4 &hi, const half8_t &h) {
-    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-    const h4 a = __builtin_convertvector(lo, h4), b = __builtin_convertvector(hi, h4);
+    const half4_t a = __builtin_convertvector(lo, half4_t), b = __builtin_convertvector(hi, half4_t);
     const half8_t d = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
     u4 dw = __builtin_bit_cast(u4, d);
     const u4 hw = __builtin_bit_cast(u4, h);
@@ -176,12 +213,13 @@ struct IoDims {
 
 struct RowMajorIO {
     static constexpr bool kDensity = false;
-    __device__ static __forceinline__ half8_t load_x(const half_t *X, uint64_t p, uint32_t k0, uint32_t B, uint32_t in_dim,
+    typedef half_t in_t;  // inputs / input gradients have the MLP element type
+    __device__ static __forceinline__ half8_t load_x(const in_t *X, uint64_t p, uint32_t k0, uint32_t B, uint32_t in_dim,
                                                      const IoDims &) {
         return *reinterpret_cast<const half8_t *>(X + p * in_dim + k0);
     }
     __device__ static __forceinline__ uint64_t out_row(uint64_t p, const IoDims &) { return p; }
-    __device__ static __forceinline__ void store_dx(half_t *dX, uint64_t p, uint32_t t, uint32_t g, uint32_t B,
+    __device__ static __forceinline__ void store_dx(in_t *dX, uint64_t p, uint32_t t, uint32_t g, uint32_t B,
                                                     uint32_t in_dim, const f32x4 &acc) {
         half4_t v = {(half_t)acc[0], (half_t)acc[1], (half_t)acc[2], (half_t)acc[3]};
         *reinterpret_cast<half4_t *>(dX + p * in_dim + 16 * t + 4 * g) = v;
@@ -190,12 +228,13 @@ struct RowMajorIO {
 
 struct DensityIO {
     static constexpr bool kDensity = true;
+    typedef feat_t in_t;  // hash-grid features / feature gradients: fp16 whatever the MLP element type
     __device__ static __forceinline__ uint64_t out_row(uint64_t p, const IoDims &d) {
         const uint32_t p32 = (uint32_t)p, r = p32 / d.T_cur;  // B is 32-bit: no 64-bit software division
         return (uint64_t)r * d.T_tot + d.slot_off + (p32 - r * d.T_cur);
     }
     // features k0..k0+7 = levels k0/2 .. k0/2+3, two channels each: four 4-byte loads from [L,B,2]
-    __device__ static __forceinline__ half8_t load_x(const half_t *X, uint64_t p0, uint32_t k0, uint32_t B0, uint32_t in_dim,
+    __device__ static __forceinline__ half8_t load_x(const in_t *X, uint64_t p0, uint32_t k0, uint32_t B0, uint32_t in_dim,
                                                      const IoDims &d) {
         half8_t r;
         const uint32_t l0 = k0 >> 1;
@@ -203,18 +242,25 @@ struct DensityIO {
         const uint64_t B = d.feat_rows ? d.feat_rows : B0;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const half2_t v = *reinterpret_cast<const half2_t *>(X + ((uint64_t)(l0 + i) * B + p) * 2);
+            const feat2_t v = *reinterpret_cast<const feat2_t *>(X + ((uint64_t)(l0 + i) * B + p) * 2);
+#ifdef LNH_MLP_BF16  // fp16 feature -> fp32 (exact) -> bf16 (round to nearest even)
+            r[2 * i] = (half_t)(float)v[0];
+            r[2 * i + 1] = (half_t)(float)v[1];
+#else
             r[2 * i] = v[0];
             r[2 * i + 1] = v[1];
+#endif
         }
         return r;
     }
     // features 16t+4g+r -> levels 8t+2g, 8t+2g+1
-    __device__ static __forceinline__ void store_dx(half_t *dX, uint64_t p, uint32_t t, uint32_t g, uint32_t B,
+    __device__ static __forceinline__ void store_dx(in_t *dX, uint64_t p, uint32_t t, uint32_t g, uint32_t B,
                                                     uint32_t in_dim, const f32x4 &acc) {
         const uint32_t l0 = 8 * t + 2 * g;
-        half2_t a = {(half_t)acc[0], (half_t)acc[1]}, b = {(half_t)acc[2], (half_t)acc[3]};
-        *reinterpret_cast<half2_t *>(dX + ((uint64_t)l0 * B + p) * 2) = a;
-        *reinterpret_cast<half2_t *>(dX + ((uint64_t)(l0 + 1) * B + p) * 2) = b;
+        feat2_t a = {(feat_t)acc[0], (feat_t)acc[1]}, b = {(feat_t)acc[2], (feat_t)acc[3]};
+        *reinterpret_cast<feat2_t *>(dX + ((uint64_t)l0 * B + p) * 2) = a;
+        *reinterpret_cast<feat2_t *>(dX + ((uint64_t)(l0 + 1) * B + p) * 2) = b;
     }
 };
+
+}  // namespace LNH_MLP_NS

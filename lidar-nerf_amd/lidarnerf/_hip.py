@@ -62,6 +62,9 @@ _SIGS = {
     "lnh_lidar_loss": [P, P, P, U32, F32, F32, F32, P, P, P],
     "lnh_lidar_color_backward": [P, P, P, P, P, P, P, U32, U32, P, P, P],
 }
+for _n in ("lnh_mlp_forward", "lnh_mlp_backward", "lnh_density_mlp_forward", "lnh_density_mlp_backward",
+           "lnh_lidar_dir_term", "lnh_lidar_pack_weights", "lnh_lidar_color_forward", "lnh_lidar_color_backward"):
+    _SIGS[_n + "_bf16"] = _SIGS[_n]  # bf16-operand build of the MLP kernels (include/lidarnerf_hip.h, last section)
 EXPORTS = sorted(list(_SIGS) + ["lnh_version", "lnh_last_error", "lnh_arch", "lnh_grid_backward_workspace_size",
                                  "lnh_grid_backward_plan_info"])
 
@@ -142,6 +145,15 @@ def call(name, *args, tag=None):
         TIMERS.setdefault(name, []).append((e0, e1, tag))
     if rc != 0:
         raise RuntimeError(f"{name} failed ({rc}): {L.lnh_last_error().decode()}")
+
+
+def mlp_suffix(dt):
+    """Entry-point suffix of the MLP kernels for a torch element type (fp16 build: '', bf16 build: '_bf16')."""
+    if dt == torch.float16:
+        return ""
+    if dt == torch.bfloat16:
+        return "_bf16"
+    raise RuntimeError(f"lidarnerf_hip: unsupported MLP element type {dt} (float16 / bfloat16)")
 
 
 def dtype_code(dt):

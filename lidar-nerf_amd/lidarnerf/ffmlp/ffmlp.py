@@ -20,31 +20,40 @@ def convert_activation(act):
     return _ACT.get(act, 6)
 
 
+def mlp_dtype():
+    """Element type of the fused MLP kernels: bf16 under torch.autocast(dtype=torch.bfloat16) (BASELINE config 5: "fp16
+    hash features + bf16 MFMA MLP"), fp16 otherwise (the reference's ffmlp is fp16 only, ffmlp.py:14-60)."""
+    if torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+        return torch.bfloat16
+    return torch.half
+
+
 def _forward_raw(x16, w16, in_dim, hidden, nhm, act, out_act, save_hidden=False):
     B = x16.shape[0]
-    y = torch.empty((B, 16), dtype=torch.half, device=x16.device)
-    fb = torch.empty((nhm + 1, B, hidden), dtype=torch.half, device=x16.device) if save_hidden else None
-    _hip.call("lnh_mlp_forward", x16.data_ptr(), w16.data_ptr(), B, in_dim, 16, hidden, nhm, act, out_act,
+    y = torch.empty((B, 16), dtype=x16.dtype, device=x16.device)
+    fb = torch.empty((nhm + 1, B, hidden), dtype=x16.dtype, device=x16.device) if save_hidden else None
+    _hip.call("lnh_mlp_forward" + _hip.mlp_suffix(x16.dtype), x16.data_ptr(), w16.data_ptr(), B, in_dim, 16, hidden, nhm, act, out_act,
               _hip.ptr(fb), y.data_ptr())
     return y, fb
 
 
 def _backward_raw(gy16, x16, w16, in_dim, hidden, nhm, act, need_dx):
     B = x16.shape[0]
-    gx = torch.empty((B, in_dim), dtype=torch.half, device=x16.device) if need_dx else None
+    gx = torch.empty((B, in_dim), dtype=x16.dtype, device=x16.device) if need_dx else None
     gw = torch.zeros(w16.numel(), dtype=torch.float32, device=x16.device)
-    _hip.call("lnh_mlp_backward", gy16.data_ptr(), x16.data_ptr(), w16.data_ptr(), B, in_dim, 16, hidden, nhm, act, 6,
+    _hip.call("lnh_mlp_backward" + _hip.mlp_suffix(x16.dtype), gy16.data_ptr(), x16.data_ptr(), w16.data_ptr(), B, in_dim, 16, hidden, nhm, act, 6,
               _hip.ptr(gx), gw.data_ptr())
     return gx, gw
 
 
 class _FusedMLP(Function):
-    """x [B,in_pad] (any float dtype), flat weights (any float dtype) -> y [B,16] fp16."""
+    """x [B,in_pad] (any float dtype), flat weights (any float dtype) -> y [B,16] fp16 (bf16 under bf16 autocast)."""
 
     @staticmethod
     def forward(ctx, x, w, in_dim, hidden, nhm, act, out_act, inference):
-        x16 = x.contiguous().to(torch.half)
-        w16 = w.contiguous().to(torch.half)
+        dt = mlp_dtype()
+        x16 = x.contiguous().to(dt)
+        w16 = w.contiguous().to(dt)
         _hip.require_cuda(x16, w16)
         y, _ = _forward_raw(x16, w16, in_dim, hidden, nhm, act, out_act)
         if not inference:
@@ -58,7 +67,7 @@ class _FusedMLP(Function):
         in_dim, hidden, nhm, act, out_act, xdt, wdt, need_dx = ctx.meta
         if out_act != 6:
             raise RuntimeError("fused MLP: backward through an output activation is not supported (ffmlp.py:196)")
-        gx, gw = _backward_raw(gy.contiguous().to(torch.half), x16, w16, in_dim, hidden, nhm, act, need_dx)
+        gx, gw = _backward_raw(gy.contiguous().to(x16.dtype), x16, w16, in_dim, hidden, nhm, act, need_dx)
         return (gx.to(xdt) if gx is not None else None), gw.to(wdt), None, None, None, None, None, None
 
 

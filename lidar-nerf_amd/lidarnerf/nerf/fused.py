@@ -132,7 +132,10 @@ def _no_autocast(fn):
 class FusedLidarRender(Function):
     @staticmethod
     @_no_autocast
-    def forward(ctx, rays_o, rays_d, z, u, embeddings, ws0, ws1, wc0, wc1, wc2, model, density_scale, spec):
+    def forward(ctx, rays_o, rays_d, z, u, embeddings, ws0, ws1, wc0, wc1, wc2, model, density_scale, spec, mdt):
+        # mdt: element type of everything MLP-side (packed weights, sigma-net rows, their gradients): torch.half, or
+        # torch.bfloat16 for the bf16-operand build of the kernels (config 5); hash features stay fp16 either way
+        sfx = _hip.mlp_suffix(mdt)
         enc = spec.grid
         kd = spec.n_dir
         dev = rays_o.device
@@ -151,15 +154,15 @@ class FusedLidarRender(Function):
         table16 = table16_of(spec.table_param, embeddings, model.training)
         # fp32 master matrices (possibly strided views of flat parameter vectors) -> the flat fp16 vectors of the
         # kernels, one launch: wsig16 = [ws0 | ws1]; wcol16 = [(0 | wc0[:, kd:kd+15]) | wc1 | wc2 padded to 16 rows]
-        wsig16 = torch.empty(64 * 32 + 16 * 64, dtype=torch.half, device=dev)
-        wcol16 = torch.empty(64 * 16 + 64 * 64 + 16 * 64, dtype=torch.half, device=dev)
+        wsig16 = torch.empty(64 * 32 + 16 * 64, dtype=mdt, device=dev)
+        wcol16 = torch.empty(64 * 16 + 64 * 64 + 16 * 64, dtype=mdt, device=dev)
         mats = [m.detach() if m.dtype == torch.float32 and m.stride(-1) == 1 else m.detach().float().contiguous()
                 for m in (ws0, ws1, wc0, wc1, wc2)]
-        _hip.call("lnh_lidar_pack_weights", mats[0].data_ptr(), mats[0].stride(0), mats[1].data_ptr(),
+        _hip.call("lnh_lidar_pack_weights" + sfx, mats[0].data_ptr(), mats[0].stride(0), mats[1].data_ptr(),
                   mats[1].stride(0), mats[2].data_ptr(), mats[2].stride(0), kd, mats[3].data_ptr(), mats[3].stride(0),
                   mats[4].data_ptr(), mats[4].stride(0), wsig16.data_ptr(), wcol16.data_ptr())
 
-        h16 = torch.empty((N * Ttot, 16), dtype=torch.half, device=dev)
+        h16 = torch.empty((N * Ttot, 16), dtype=mdt, device=dev)
         sigma_pt = torch.empty((N, Ttot), dtype=torch.float32, device=dev)
         # coarse and importance samples of a ray live side by side (slots 0..T-1 | T..T+t-1) in ONE set of buffers, so
         # the backward pass is a single launch chain over all N*(T+t) points
@@ -175,7 +178,7 @@ class FusedLidarRender(Function):
             _hip.call("lnh_grid_encode_forward_mapped", x01.data_ptr(), table16.data_ptr(),
                       enc._offsets_host.data_ptr(), feat.data_ptr(), B, Tc, Ttot, off, B_all, 2, L, enc.log2_scale,
                       enc.base_resolution, _hip.LNH_F16, tag=B)
-            _hip.call("lnh_density_mlp_forward", feat.data_ptr(), wsig16.data_ptr(), B, Tc, Ttot, off, B_all,
+            _hip.call("lnh_density_mlp_forward" + sfx, feat.data_ptr(), wsig16.data_ptr(), B, Tc, Ttot, off, B_all,
                       h16.data_ptr(), sigma_pt.data_ptr())
 
         density(z, T, 0)
@@ -195,11 +198,11 @@ class FusedLidarRender(Function):
         enc_d = spec.dir_features(rays_d).contiguous()  # [N, kd] fp32, constant along a ray
         enc_d16 = torch.empty_like(enc_d)                # the same, rounded to fp16 (what the MLP would see)
         cdir = torch.empty((N, 64), dtype=torch.float32, device=dev)
-        _hip.call("lnh_lidar_dir_term", enc_d.data_ptr(), mats[2].data_ptr(), mats[2].stride(0), N, kd,
+        _hip.call("lnh_lidar_dir_term" + sfx, enc_d.data_ptr(), mats[2].data_ptr(), mats[2].stride(0), N, kd,
                   enc_d16.data_ptr(), cdir.data_ptr())
 
         rgb = torch.empty((N, Ttot, 2), dtype=torch.float32, device=dev)
-        _hip.call("lnh_lidar_color_forward", h16.data_ptr(), perm.data_ptr(), weights.data_ptr(), cdir.data_ptr(),
+        _hip.call("lnh_lidar_color_forward" + sfx, h16.data_ptr(), perm.data_ptr(), weights.data_ptr(), cdir.data_ptr(),
                   wcol16.data_ptr(), N, Ttot, rgb.data_ptr())
         ws = torch.empty(N, dtype=torch.float32, device=dev)
         depth = torch.empty(N, dtype=torch.float32, device=dev)
@@ -209,7 +212,7 @@ class FusedLidarRender(Function):
 
         ctx.save_for_backward(x01, feat, h16, perm, weights, z_all, sigma_m, rgb, sd, cdir, enc_d16, wsig16, wcol16)
         ctx.model, ctx.dims, ctx.density_scale, ctx.enc = model, (N, T, t_new), density_scale, enc
-        ctx.table_param = spec.table_param
+        ctx.table_param, ctx.mdt = spec.table_param, mdt
         ctx.param_dtypes = (embeddings.dtype, ws0.dtype, ws1.dtype, wc0.dtype, wc1.dtype, wc2.dtype)
         ctx.mark_non_differentiable(weights, z_all)
         return ws, depth, image, weights, z_all
@@ -221,6 +224,7 @@ class FusedLidarRender(Function):
         model, (N, T, t_new), ds = ctx.model, ctx.dims, ctx.density_scale
         enc = ctx.enc
         dev = h16.device
+        mdt, sfx = ctx.mdt, _hip.mlp_suffix(ctx.mdt)
         Ttot = T + t_new
         g_ws, g_depth, g_image = g_ws.contiguous().float(), g_depth.contiguous().float(), g_image.contiguous().float()
 
@@ -230,13 +234,13 @@ class FusedLidarRender(Function):
                   z_all.data_ptr(), sigma_m.data_ptr(), rgb.data_ptr(), sd.data_ptr(), N, Ttot, 2, float(ds),
                   g_sigma.data_ptr(), g_rgb.data_ptr())
 
-        g_h16 = torch.empty((N * Ttot, 16), dtype=torch.half, device=dev)
+        g_h16 = torch.empty((N * Ttot, 16), dtype=mdt, device=dev)
         kd = enc_d16.shape[1]
         n_col, n_sig, n_c0 = wcol16.numel(), wsig16.numel(), 64 * (kd + 15)
         zeros = torch.zeros(n_col + n_sig + n_c0, dtype=torch.float32, device=dev)  # one fill for all small gradients
         g_wcol, g_wsig = zeros[:n_col], zeros[n_col:n_col + n_sig]
         ray_sum = torch.empty((N, 64), dtype=torch.float32, device=dev)
-        _hip.call("lnh_lidar_color_backward", g_rgb.data_ptr(), g_sigma.data_ptr(), h16.data_ptr(), perm.data_ptr(),
+        _hip.call("lnh_lidar_color_backward" + sfx, g_rgb.data_ptr(), g_sigma.data_ptr(), h16.data_ptr(), perm.data_ptr(),
                   weights.data_ptr(), cdir.data_ptr(), wcol16.data_ptr(), N, Ttot, g_h16.data_ptr(), g_wcol.data_ptr(),
                   ray_sum.data_ptr())
         g_w0g = g_wcol[:64 * 16].view(64, 16)
@@ -251,7 +255,7 @@ class FusedLidarRender(Function):
         g_table16 = torch.zeros((int(enc._offsets_host[-1]), 2), dtype=torch.half, device=dev)
         B_all = N * Ttot
         g_feat = torch.empty((enc.num_levels, B_all, 2), dtype=torch.half, device=dev)
-        _hip.call("lnh_density_mlp_backward", g_h16.data_ptr(), feat.data_ptr(), wsig16.data_ptr(), B_all, Ttot, Ttot, 0,
+        _hip.call("lnh_density_mlp_backward" + sfx, g_h16.data_ptr(), feat.data_ptr(), wsig16.data_ptr(), B_all, Ttot, Ttot, 0,
                   g_feat.data_ptr(), g_wsig.data_ptr())
         if parallel.world_size() > 1:
             # data parallel: the table gradient goes on the wire as fp16, window by window, behind the kernels of the
@@ -274,7 +278,7 @@ class FusedLidarRender(Function):
                 g_table.div_(world)  # sum over ranks -> mean, after the widening
         return (None, None, None, None, g_table, g_wsig[:64 * 32].view(64, 32).to(dts[1]),
                 g_wsig[64 * 32:].view(16, 64).to(dts[2]), g_wc0.to(dts[3]), g_wc1.to(dts[4]), g_wc2.to(dts[5]),
-                None, None, None)
+                None, None, None, None)
 
 
 MASK_STATS = None  # bench.py: set to a list to collect, per render call, the fraction of samples with weight > 1e-4
@@ -304,8 +308,9 @@ def render_lidar(model, rays_o, rays_d, num_steps, upsample_steps, perturb):
         u = torch.linspace(0.5 / upsample_steps, 1.0 - 0.5 / upsample_steps, upsample_steps,
                            device=dev).expand(N, upsample_steps).contiguous()
     sp = model.fused_spec()
+    from ..ffmlp.ffmlp import mlp_dtype
     ws, depth, image, weights, _ = FusedLidarRender.apply(rays_o, rays_d, z, u, sp.table, sp.ws0, sp.ws1, sp.wc0,
-                                                          sp.wc1, sp.wc2, model, model.density_scale, sp)
+                                                          sp.wc1, sp.wc2, model, model.density_scale, sp, mlp_dtype())
     if MASK_STATS is not None:
         MASK_STATS.append((weights > 1e-4).float().mean())
     return {"depth_lidar": depth.view(*prefix), "image_lidar": image.view(*prefix, 2), "weights_sum_lidar": ws}

@@ -72,8 +72,11 @@ class LidarTrainer:
     => the step is skipped for EVERY parameter and the scale backs off); the MLP parameters stay on torch's Adam."""
 
     def __init__(self, model, lr=1e-2, iters=30000, fp16=True, alpha_d=1000.0, alpha_r=1.0, alpha_i=10.0,
-                 alpha_grad=100.0, scale=1.0, world_size=1, render_kwargs=None, fused_table_optimizer=True):
-        self.model, self.fp16, self.world = model, fp16, world_size
+                 alpha_grad=100.0, scale=1.0, world_size=1, render_kwargs=None, fused_table_optimizer=True,
+                 mlp_dtype=torch.float16):
+        # mlp_dtype: the autocast dtype — torch.float16 (the reference's --fp16) or torch.bfloat16 (BASELINE config 5:
+        # bf16 MFMA MLPs; the hash table and its gradient stay fp16, so the dynamic loss scale is kept either way)
+        self.model, self.fp16, self.world, self.amp_dtype = model, fp16, world_size, mlp_dtype
         self.alpha = (alpha_d, alpha_r, alpha_i, alpha_grad)
         self.scale = scale
         self.render_kwargs = render_kwargs or {}
@@ -123,7 +126,7 @@ class LidarTrainer:
         self.optimizer.zero_grad(set_to_none=True)
         tp._lnh_grad16 = None
         tp._lnh_grad_reduced = False
-        with torch.autocast("cuda", dtype=torch.float16):
+        with torch.autocast("cuda", dtype=self.amp_dtype):
             loss = self.loss(rays_o, rays_d, images_lidar, patch)
         (loss * self.loss_scale).backward()
         if self.world > 1:
@@ -196,7 +199,7 @@ class LidarTrainer:
         if self.table is not None:
             return self._step_fused_table(rays_o, rays_d, images_lidar, patch)
         self.optimizer.zero_grad(set_to_none=True)
-        with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):
+        with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.fp16):
             loss = self.loss(rays_o, rays_d, images_lidar, patch)
         self.scaler.scale(loss).backward()
         if self.world > 1:

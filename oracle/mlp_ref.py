@@ -8,7 +8,8 @@ TEST INFRASTRUCTURE ONLY.  Follows /root/reference:
   lidarnerf/ffmlp/src/utils.h:479-664         activations (ReLU/Exponential/Sine/Sigmoid/Squareplus/Softplus/None)
   lidarnerf/nerf/network.py:45-59,83-99       bias-free Linear stacks (same algebra, n matrices >= 2)
 
-Numerics model: inputs, weights and inter-layer activations are fp16 values (as in the reference, which stores them
+Numerics model (`half=True`; `half="bf16"` models the bf16-operand build the same way with bfloat16 roundings):
+inputs, weights and inter-layer activations are fp16 values (as in the reference, which stores them
 as __half); every dot product is evaluated exactly (float64) and rounded ONCE to fp16 when it is stored as an
 activation.  The reference accumulates in fp16 WMMA fragments, the HIP kernel in fp32 MFMA accumulators; both are
 approximations of this value (tolerance stated in tests/test_mlp_gpu.py and DESIGN.md).
@@ -72,7 +73,18 @@ def act_backward_from_post(a, g, post):
     return g
 
 
+def round_bf16(x):
+    """float -> nearest bfloat16 (ties to even), returned as float32.  bf16 = the upper 16 bits of an IEEE float32."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32)
+
+
 def _h(x, half):
+    """Storage rounding of the MLP element type: True / "f16" -> fp16 (the reference), "bf16" -> bfloat16 (the bf16-operand
+    build of the kernels, BASELINE config 5), False -> none (float64 throughout)."""
+    if half == "bf16":
+        return round_bf16(x).astype(np.float64)
     return x.astype(np.float16).astype(np.float64) if half else x.astype(np.float64)
 
 

@@ -125,6 +125,52 @@ def test_hidden_32_forward_backward(in_dim, nhm):
     np.testing.assert_allclose(host(dw).astype(np.float64), dw_want, rtol=5e-3, atol=2e-3 * np.abs(dw_want).max())
 
 
+# ------------------------------------------------------------------------------------------------ bf16 operands
+def _bf(a):
+    """numpy float array -> CUDA bfloat16 tensor (values are rounded to bf16 by the oracle's own model first)."""
+    return torch.from_numpy(mlp_ref.round_bf16(a)).cuda().to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("in_dim,nhm,H", [(32, 0, 64), (96, 1, 64), (48, 2, 64), (32, 1, 32)])
+def test_bf16_forward_backward(in_dim, nhm, H):
+    """lnh_mlp_forward_bf16 / lnh_mlp_backward_bf16 (v_mfma_f32_16x16x32_bf16 operands, BASELINE config 5) vs the
+    oracle with bfloat16 storage roundings.  bf16 keeps 8 significant bits: one rounding is <= 2^-9 relative, so the
+    bounds are 8x those of the fp16 tests (2^-8 vs 2^-11)."""
+    from gpu_util import call, host
+    B = 1000
+    r = np.random.default_rng(in_dim * 7 + nhm)
+    x = mlp_ref.round_bf16(r.standard_normal((B, in_dim)))
+    n = mlp_ref.ffmlp_num_params(in_dim, 16, H, nhm + 1)
+    w = mlp_ref.round_bf16(r.uniform(-1, 1, n) * np.sqrt(3 / H))
+    gy = mlp_ref.round_bf16(r.standard_normal((B, 16)) * 0.1)
+    mats = mlp_ref.ffmlp_split_weights(w, in_dim, 16, H, nhm + 1)
+    want, _ = mlp_ref.mlp_forward(x, mats, half="bf16")
+    y = torch.empty((B, 16), dtype=torch.bfloat16, device="cuda")
+    call("lnh_mlp_forward_bf16", _bf(x), _bf(w), B, in_dim, 16, H, nhm, 0, 6, None, y)
+    np.testing.assert_allclose(host(y.float()).astype(np.float64), want, rtol=1.6e-2, atol=3e-2)
+    gx_want, dws = mlp_ref.mlp_backward(x, mats, gy, half="bf16")
+    dw_want = np.concatenate([d.ravel() for d in dws])
+    gx = torch.zeros((B, in_dim), dtype=torch.bfloat16, device="cuda")
+    dw = torch.zeros(n, dtype=torch.float32, device="cuda")
+    call("lnh_mlp_backward_bf16", _bf(gy), _bf(x), _bf(w), B, in_dim, 16, H, nhm, 0, 6, gx, dw)
+    np.testing.assert_allclose(host(gx.float()).astype(np.float64), gx_want, rtol=4e-2, atol=1.6e-2)
+    np.testing.assert_allclose(host(dw).astype(np.float64), dw_want, rtol=4e-2, atol=1.6e-2 * np.abs(dw_want).max())
+
+
+def test_bf16_ffmlp_module_under_bf16_autocast():
+    from lidarnerf.ffmlp import FFMLP
+    m = FFMLP(32, 3, 64, 2).cuda()
+    x = torch.randn(500, 32, device="cuda", requires_grad=True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = m(x)
+    assert y.dtype == torch.bfloat16 and y.shape == (500, 3)
+    with torch.autocast("cuda", dtype=torch.float16):
+        y16 = m(x)
+    torch.testing.assert_close(y.float(), y16.float(), rtol=3e-2, atol=3e-2)  # same function, 8 vs 11 significant bits
+    y.float().square().sum().backward()
+    assert torch.isfinite(m.weights.grad).all() and float(m.weights.grad.abs().max()) > 0
+
+
 def test_ffmlp_module_hidden_32():
     from lidarnerf.ffmlp import FFMLP
     m = FFMLP(32, 3, 32, 3).cuda()
