@@ -217,8 +217,9 @@ def main():
     # records on the stream, and timing all ~25 calls of a step inflates the step by ~4 % (--kernel-timers for all)
     grid_calls = ["lnh_grid_encode_forward", "lnh_grid_encode_forward_mapped", "lnh_grid_encode_backward",
                   "lnh_grid_encode_backward_ws", "lnh_grid_encode_backward_ws_levels"]
-    mlp_calls = ["lnh_density_mlp_forward", "lnh_density_mlp_backward", "lnh_lidar_color_forward",
-                 "lnh_lidar_color_backward"]
+    sfx = "_bf16" if args.mlp_dtype == "bf16" else ""
+    mlp_calls = [n + sfx for n in ("lnh_density_mlp_forward", "lnh_density_mlp_backward", "lnh_lidar_color_forward",
+                                   "lnh_lidar_color_backward")]
     all_calls = grid_calls + mlp_calls + ["lnh_mlp_forward", "lnh_mlp_backward", "lnh_lidar_composite_forward",
                                           "lnh_lidar_composite_backward", "lnh_lidar_resample", "lnh_lidar_weights",
                                           "lnh_freq_encode_forward", "lnh_lidar_merge_weights",

@@ -538,7 +538,8 @@ __global__ void __launch_bounds__(NTHREADS)
 k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs, T *__restrict__ grad_table,
                    uint32_t B, GridMeta meta, BucketPlan plan, PoolEntry<T> *__restrict__ pool,
                    uint32_t *__restrict__ cursor, uint32_t *__restrict__ spill_cursor, uint32_t align_rt,
-                   uint32_t interp_rt, uint32_t n_levels, uint32_t level0) {
+                   uint32_t interp_rt, uint32_t n_levels, uint32_t level0, uint32_t b_begin, uint32_t B_all) {
+    // this launch handles the points [b_begin, b_begin + B) of a batch of B_all (large batches are walked in chunks)
     constexpr int C = 2, NCORN = 1 << D;
     __shared__ uint2 lout[kMaxBucketsPerLevel];           // per bucket: {pool slot - staging slot, staging slots that fit}
     __shared__ uint32_t lsp[kMaxBucketsPerLevel];         // per bucket: spill slot - staging slot of the entries that do not
@@ -567,16 +568,16 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
     bool emit[PPT];
 #pragma unroll
     for (int q = 0; q < PPT; q++) {
-        const uint32_t b = (chunk * PPT + q) * blockDim.x + threadIdx.x;
-        const bool in_range = b < B;
-        const uint32_t bc = in_range ? b : 0;  // unconditional loads from a clamped index + selects
+        const uint32_t bl = (chunk * PPT + q) * blockDim.x + threadIdx.x;
+        const bool in_range = bl < B;
+        const uint32_t bc = b_begin + (in_range ? bl : 0);  // unconditional loads from a clamped index + selects
         float x[D];
 #pragma unroll
         for (int d = 0; d < D; d++) {
             const float xv = inputs[(size_t)bc * D + d];
             x[d] = in_range ? xv : -1.0f;
         }
-        const Vec<T, 2> gv = load_vec<T, 2>(grad + ((size_t)level * B + bc) * C);
+        const Vec<T, 2> gv = load_vec<T, 2>(grad + ((size_t)level * B_all + bc) * C);
         Cell<D> cell;
         bool ok = in_range;
 #pragma unroll
@@ -1087,15 +1088,47 @@ void allow_big_lds(K kernel, size_t lds) {
     }
 }
 
+// Large batches are walked in chunks of at most kChunkPoints points (scatter + reduce per chunk, the table accumulates):
+// up to 4 M points a bucket of a hashed level stays within one reduce slice (4 M * 8 / 64 buckets = 512 K entries);
+// beyond that every bucket would be cut into slices whose images travel through HBM (measured at 16 384 rays x 832:
+// 6.5 ms in one piece vs 4 x 1.2 ms in chunks), and the workspace would grow with the batch.  The sum stays a
+// fixed-order, bit-reproducible one: integer per chunk, chunks added to the table in order.
+constexpr uint32_t kChunkPoints = 4u << 20;
+__host__ inline uint32_t chunk_points(uint32_t B) {
+    const uint32_t n = div_up(B, kChunkPoints);
+    return n <= 1 ? B : div_up(div_up(B, n), 1024) * 1024;
+}
+
+template <typename T>
+int launch_backward_bucketed_chunk(const T *grad, const float *inputs, T *ge, uint32_t B, uint32_t L, const GridMeta &m,
+                                   uint32_t align, uint32_t interp, void *workspace, uint64_t workspace_bytes,
+                                   hipStream_t s, uint32_t level_begin, uint32_t level_end, uint32_t b_begin,
+                                   uint32_t B_all, uint32_t B_plan);
+
 template <typename T>
 int launch_backward_bucketed(const T *grad, const float *inputs, T *ge, uint32_t B, uint32_t L, const GridMeta &m,
                              uint32_t align, uint32_t interp, void *workspace, uint64_t workspace_bytes,
                              hipStream_t s, uint32_t level_begin = 0, uint32_t level_end = 0xffffffffu) {
     if (level_end > L) level_end = L;
     if (level_begin >= level_end) return LNH_OK;
+    const uint32_t step = chunk_points(B);
+    for (uint32_t b0 = 0; b0 < B; b0 += step) {
+        const int rc = launch_backward_bucketed_chunk<T>(grad, inputs, ge, std::min(step, B - b0), L, m, align, interp,
+                                                         workspace, workspace_bytes, s, level_begin, level_end, b0, B,
+                                                         step);
+        if (rc) return rc;
+    }
+    return LNH_OK;
+}
+
+template <typename T>
+int launch_backward_bucketed_chunk(const T *grad, const float *inputs, T *ge, uint32_t B, uint32_t L, const GridMeta &m,
+                                   uint32_t align, uint32_t interp, void *workspace, uint64_t workspace_bytes,
+                                   hipStream_t s, uint32_t level_begin, uint32_t level_end, uint32_t b_begin,
+                                   uint32_t B_all, uint32_t B_plan) {
     BucketPlan plan;
     uint32_t nbt = 0;
-    const uint64_t need = plan_buckets<T>(plan, m, L, B, 3, nbt);
+    const uint64_t need = plan_buckets<T>(plan, m, L, B_plan, 3, nbt);  // (the plan of a full chunk serves the last, shorter one)
     if (workspace == nullptr || workspace_bytes < need) {
         lnh_set_error("grid backward: workspace too small (%llu < %llu bytes)", (unsigned long long)workspace_bytes,
                       (unsigned long long)need);
@@ -1129,7 +1162,7 @@ int launch_backward_bucketed(const T *grad, const float *inputs, T *ge, uint32_t
     // staging buffer at 64 KiB (two workgroups per CU)
     const uint32_t n_win = level_end - level_begin;
     LNH_LAUNCH((k_grid_bwd_scatter<T, 3, 1, 1024>), dim3(div_up(B, 1024) * n_win), dim3(1024), 0, s, grad, inputs, ge, B,
-               m, plan, pool, cursor, spill_cursor, align, interp, n_win, level_begin);
+               m, plan, pool, cursor, spill_cursor, align, interp, n_win, level_begin, b_begin, B_all);
     int rc = lnh_check_launch("lnh_grid_encode_backward_ws(scatter)");
     if (rc) return rc;
     auto k = k_grid_bwd_reduce<T>;
@@ -1453,7 +1486,8 @@ uint64_t lnh_grid_backward_workspace_size(const int32_t *offsets_host, uint32_t 
     uint32_t nbt = 0;
     for (uint32_t l = 0; l < L; l++)
         if ((m.lv[l].hashmap_size + kBucketRows - 1) / kBucketRows > kMaxBucketsPerLevel) return 0;
-    return dtype == LNH_F16 ? plan_buckets<half_t>(plan, m, L, B, D, nbt) : plan_buckets<float>(plan, m, L, B, D, nbt);
+    const uint32_t Bc = chunk_points(B);  // the workspace serves one chunk at a time
+    return dtype == LNH_F16 ? plan_buckets<half_t>(plan, m, L, Bc, D, nbt) : plan_buckets<float>(plan, m, L, Bc, D, nbt);
 }
 
 int lnh_grid_backward_plan_info(const int32_t *offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
@@ -1466,8 +1500,8 @@ int lnh_grid_backward_plan_info(const int32_t *offsets_host, uint32_t B, uint32_
     (void)build_meta(m, offsets_host, D, L, S, H, gridtype, align_corners != 0);
     BucketPlan plan;
     uint32_t nbt = 0;
-    if (dtype == LNH_F16) (void)plan_buckets<half_t>(plan, m, L, B, D, nbt);
-    else (void)plan_buckets<float>(plan, m, L, B, D, nbt);
+    if (dtype == LNH_F16) (void)plan_buckets<half_t>(plan, m, L, chunk_points(B), D, nbt);
+    else (void)plan_buckets<float>(plan, m, L, chunk_points(B), D, nbt);
     out4[0] = plan.first_bucket[level + 1] - plan.first_bucket[level];
     out4[1] = plan.cap[level];
     out4[2] = kBucketRows;

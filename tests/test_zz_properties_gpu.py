@@ -128,3 +128,38 @@ def test_forward_full_size_properties():
     untouched = torch.ones(B, dtype=torch.bool, device="cuda")
     untouched[dst] = False
     assert float(mapped[:, untouched].abs().max()) == 0.0
+
+
+def test_backward_bucketed_chunked_matches_atomic_path():
+    """5 M points (> 4 M: the bucketed backward walks the batch in two chunks) — fp32 table gradient of the bucketed path
+    vs the independent atomic kernel (lnh_grid_encode_backward), plus the per-level checksum sum(table) == sum(grad)
+    (the 8 weights of a cell sum to 1): a point dropped or counted twice at the chunk boundary would show in both."""
+    from gpu_util import call
+    from lidarnerf import _hip
+    n_rays, T = 6016, 832
+    x = torch.from_numpy(_ray_points(64, T, 11)).cuda().repeat(n_rays // 64, 1)
+    x = (x + torch.rand_like(x) * 1e-3).clamp(0, 1).contiguous()
+    B = x.shape[0]
+    assert B > 4 * 1024 * 1024
+    g = torch.randn((L, B, CH), device="cuda") * 0.01
+    rows = int(OFF[-1])
+    offh = torch.from_numpy(OFF)
+    need = _hip.lib().lnh_grid_backward_workspace_size(offh.data_ptr(), B, 3, CH, L, S, H, 0, 0, 0)
+    need_small = _hip.lib().lnh_grid_backward_workspace_size(offh.data_ptr(), (B + 1) // 2, 3, CH, L, S, H, 0, 0, 0)
+    assert need <= need_small * 1.01                          # the workspace serves one chunk, not the whole batch
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    a = torch.zeros((rows, CH), device="cuda")
+    call("lnh_grid_encode_backward_ws", g, x, offh, a, B, 3, CH, L, S, H, 0, 0, 0, 0, ws, need)
+    b = torch.zeros((rows, CH), device="cuda")
+    call("lnh_grid_encode_backward", g, x, None, offh, b, B, 3, CH, L, S, H, None, None, 0, 0, 0, 0)
+    torch.cuda.synchronize()
+    scale = float(b.abs().max())
+    assert float((a - b).abs().max()) <= 2e-4 * scale
+    offs = torch.from_numpy(OFF.astype(np.int64))
+    for l in range(L):
+        s_tab = a[offs[l]:offs[l + 1]].double().sum(0)
+        s_g = g[l].double().sum(0)
+        assert torch.allclose(s_tab, s_g, rtol=1e-3, atol=1e-2), (l, s_tab, s_g)
+    a2 = torch.zeros((rows, CH), device="cuda")
+    call("lnh_grid_encode_backward_ws", g, x, offh, a2, B, 3, CH, L, S, H, 0, 0, 0, 0, ws, need)
+    assert torch.equal(a, a2)                                 # chunked sums are bit-reproducible too
