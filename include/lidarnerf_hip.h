@@ -190,6 +190,26 @@ LNH_API int lnh_composite_rays_train_backward(const float *grad_weights_sum, con
                                               uint32_t M, uint32_t N, float T_thresh, float *grad_sigmas,
                                               float *grad_rgbs, lnh_stream_t stream);
 /*
+ * LiDAR variant of the ragged compositing (no reference counterpart: the reference composites LiDAR rays with PyTorch
+ * ops on dense [N,T] tensors, renderer.py:233-271, and its CUDA template above has 3 colour channels and no depth
+ * gradient, raymarching.py:330).  feats [M,K] (K <= 3; K = 2: ray-drop, intensity), deltas [M,2] and xyzs [M,3] as
+ * written by lnh_march_rays_train; depth = sum w * z with z = (xyz - o) . d the ABSOLUTE distance along the unit ray.
+ * Backward: grad_sigmas [M] / grad_feats [M,K] ZERO-INITIALISED by the caller, includes the depth term.
+ */
+LNH_API int lnh_lidar_composite_rays_train_forward(const float *sigmas, const float *feats, const float *deltas,
+                                                   const float *xyzs, const float *rays_o, const float *rays_d,
+                                                   const int32_t *rays, uint32_t M, uint32_t N, uint32_t K,
+                                                   float T_thresh, float *weights_sum, float *depth, float *image,
+                                                   lnh_stream_t stream);
+LNH_API int lnh_lidar_composite_rays_train_backward(const float *grad_weights_sum, const float *grad_depth,
+                                                    const float *grad_image, const float *sigmas, const float *feats,
+                                                    const float *deltas, const float *xyzs, const float *rays_o,
+                                                    const float *rays_d, const int32_t *rays,
+                                                    const float *weights_sum, const float *depth, const float *image,
+                                                    uint32_t M, uint32_t N, uint32_t K, float T_thresh,
+                                                    float *grad_sigmas, float *grad_feats, lnh_stream_t stream);
+
+/*
  * Inference variants (raymarching.h:55-69 march_rays / composite_rays; raymarching.cu:808-928, 966-1053): march the
  * first n_alive rays listed in rays_alive for at most n_step occupied samples from their current rays_t (outputs
  * [n_alive*n_step, 3|3|2], caller-zeroed: delta == 0 ends a ray), then accumulate sigmas / rgbs [n_alive*n_step, 1|3]

@@ -315,6 +315,96 @@ k_composite_train_bwd(const float *__restrict__ grad_ws, const float *__restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------ LiDAR ragged composite
+// The reference's ragged compositing (above) is the RGB template: 3 channels, relative depth, NO depth gradient
+// (raymarching.py:330).  The LiDAR path composites K channels (ray-drop, intensity: K = 2) and needs the ABSOLUTE
+// depth sum(w * z) WITH its gradient (renderer.py:233-271 semantics on the marcher's ragged samples):
+//   z_i = (xyz_i - o) . d  (distance of the sample along its unit ray),  alpha_i = 1 - exp(-sigma_i dt_i),
+//   w_i = alpha_i T_i,  T_{i+1} = T_i (1 - alpha_i),  stop after the sample that takes T below T_thresh.
+// Backward, for any composited quantity O = sum w_i c_i:  dO/dsigma_i = dt_i (T_{i+1} c_i - (O - O_{<=i})).
+template <int K>
+__global__ void __launch_bounds__(64)
+k_lidar_composite_ragged_fwd(const float *__restrict__ sigmas, const float *__restrict__ feats,
+                             const float *__restrict__ deltas, const float *__restrict__ xyzs,
+                             const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                             const int32_t *__restrict__ rays, uint32_t M, uint32_t N, float T_thresh,
+                             float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1],
+                   num_steps = (uint32_t)rays[n * 3 + 2];
+    float acc[K], ws = 0, d = 0, T = 1.0f;
+#pragma unroll
+    for (int k = 0; k < K; k++) acc[k] = 0;
+    if (num_steps != 0 && offset + num_steps <= M) {
+        const float ox = rays_o[index * 3], oy = rays_o[index * 3 + 1], oz = rays_o[index * 3 + 2];
+        const float dx = rays_d[index * 3], dy = rays_d[index * 3 + 1], dz = rays_d[index * 3 + 2];
+        for (uint32_t step = 0; step < num_steps; step++) {
+            const size_t i = (size_t)offset + step;
+            const float alpha = 1.0f - expf(-sigmas[i] * deltas[i * 2]);
+            const float w = alpha * T;
+            const float z = (xyzs[i * 3] - ox) * dx + (xyzs[i * 3 + 1] - oy) * dy + (xyzs[i * 3 + 2] - oz) * dz;
+#pragma unroll
+            for (int k = 0; k < K; k++) acc[k] += w * feats[i * K + k];
+            d += w * z;
+            ws += w;
+            T *= 1.0f - alpha;
+            if (T < T_thresh) break;
+        }
+    }
+    weights_sum[index] = ws;
+    depth[index] = d;
+#pragma unroll
+    for (int k = 0; k < K; k++) image[index * K + k] = acc[k];
+}
+
+template <int K>
+__global__ void __launch_bounds__(64)
+k_lidar_composite_ragged_bwd(const float *__restrict__ grad_ws, const float *__restrict__ grad_depth,
+                             const float *__restrict__ grad_image, const float *__restrict__ sigmas,
+                             const float *__restrict__ feats, const float *__restrict__ deltas,
+                             const float *__restrict__ xyzs, const float *__restrict__ rays_o,
+                             const float *__restrict__ rays_d, const int32_t *__restrict__ rays,
+                             const float *__restrict__ weights_sum, const float *__restrict__ depth,
+                             const float *__restrict__ image, uint32_t M, uint32_t N, float T_thresh,
+                             float *__restrict__ grad_sigmas, float *__restrict__ grad_feats) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1],
+                   num_steps = (uint32_t)rays[n * 3 + 2];
+    if (num_steps == 0 || offset + num_steps > M) return;  // (grad buffers are zero-initialised by the caller)
+    const float ox = rays_o[index * 3], oy = rays_o[index * 3 + 1], oz = rays_o[index * 3 + 2];
+    const float dx = rays_d[index * 3], dy = rays_d[index * 3 + 1], dz = rays_d[index * 3 + 2];
+    const float gws = grad_ws[index], gd = grad_depth[index], ws_final = weights_sum[index], d_final = depth[index];
+    float gi[K], fin[K], acc[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        gi[k] = grad_image[index * K + k];
+        fin[k] = image[index * K + k];
+        acc[k] = 0;
+    }
+    float T = 1.0f, d = 0;
+    for (uint32_t step = 0; step < num_steps; step++) {
+        const size_t i = (size_t)offset + step;
+        const float dt = deltas[i * 2];
+        const float alpha = 1.0f - expf(-sigmas[i] * dt);
+        const float w = alpha * T;
+        const float z = (xyzs[i * 3] - ox) * dx + (xyzs[i * 3 + 1] - oy) * dy + (xyzs[i * 3 + 2] - oz) * dz;
+        d += w * z;
+        T *= 1.0f - alpha;  // T_{i+1}
+        float g = gws * (1.0f - ws_final) + gd * (T * z - (d_final - d));
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const float c = feats[i * K + k];
+            acc[k] += w * c;
+            g += gi[k] * (T * c - (fin[k] - acc[k]));
+            grad_feats[i * K + k] = gi[k] * w;
+        }
+        grad_sigmas[i] = dt * g;
+        if (T < T_thresh) break;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ inference
 // raymarching.cu:808-928: march the ALIVE rays for at most n_step occupied samples starting at their current t;
 // slots a ray does not fill stay as the caller initialised them (zeros: delta == 0 marks the end of a ray).
@@ -485,6 +575,44 @@ int lnh_composite_rays_train_backward(const float *grad_weights_sum, const float
                        grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, T_thresh, grad_sigmas,
                        grad_rgbs);
     return lnh_check_launch("lnh_composite_rays_train_backward");
+}
+
+int lnh_lidar_composite_rays_train_forward(const float *sigmas, const float *feats, const float *deltas,
+                                           const float *xyzs, const float *rays_o, const float *rays_d,
+                                           const int32_t *rays, uint32_t M, uint32_t N, uint32_t K, float T_thresh,
+                                           float *weights_sum, float *depth, float *image, lnh_stream_t stream) {
+    LNH_REQUIRE(sigmas && feats && deltas && xyzs && rays_o && rays_d && rays && weights_sum && depth && image,
+                LNH_ERR_INVALID_ARG, "lidar_composite_rays_train_forward: null pointer");
+    LNH_REQUIRE(K >= 1 && K <= 3, LNH_ERR_UNSUPPORTED, "lidar_composite_rays_train: K must be 1, 2 or 3 (got %u)", K);
+    if (N == 0) return LNH_OK;
+    hipStream_t s = (hipStream_t)stream;
+#define LNH_RAGGED_FWD(KK)                                                                                          \
+    LNH_LAUNCH(k_lidar_composite_ragged_fwd<KK>, dim3(div_up(N, 64)), dim3(64), 0, s, sigmas, feats, deltas, xyzs, \
+               rays_o, rays_d, rays, M, N, T_thresh, weights_sum, depth, image)
+    if (K == 1) LNH_RAGGED_FWD(1); else if (K == 2) LNH_RAGGED_FWD(2); else LNH_RAGGED_FWD(3);
+#undef LNH_RAGGED_FWD
+    return lnh_check_launch("lnh_lidar_composite_rays_train_forward");
+}
+
+int lnh_lidar_composite_rays_train_backward(const float *grad_weights_sum, const float *grad_depth,
+                                            const float *grad_image, const float *sigmas, const float *feats,
+                                            const float *deltas, const float *xyzs, const float *rays_o,
+                                            const float *rays_d, const int32_t *rays, const float *weights_sum,
+                                            const float *depth, const float *image, uint32_t M, uint32_t N, uint32_t K,
+                                            float T_thresh, float *grad_sigmas, float *grad_feats, lnh_stream_t stream) {
+    LNH_REQUIRE(grad_weights_sum && grad_depth && grad_image && sigmas && feats && deltas && xyzs && rays_o && rays_d &&
+                    rays && weights_sum && depth && image && grad_sigmas && grad_feats,
+                LNH_ERR_INVALID_ARG, "lidar_composite_rays_train_backward: null pointer");
+    LNH_REQUIRE(K >= 1 && K <= 3, LNH_ERR_UNSUPPORTED, "lidar_composite_rays_train: K must be 1, 2 or 3 (got %u)", K);
+    if (N == 0) return LNH_OK;
+    hipStream_t s = (hipStream_t)stream;
+#define LNH_RAGGED_BWD(KK)                                                                                          \
+    LNH_LAUNCH(k_lidar_composite_ragged_bwd<KK>, dim3(div_up(N, 64)), dim3(64), 0, s, grad_weights_sum, grad_depth, \
+               grad_image, sigmas, feats, deltas, xyzs, rays_o, rays_d, rays, weights_sum, depth, image, M, N,     \
+               T_thresh, grad_sigmas, grad_feats)
+    if (K == 1) LNH_RAGGED_BWD(1); else if (K == 2) LNH_RAGGED_BWD(2); else LNH_RAGGED_BWD(3);
+#undef LNH_RAGGED_BWD
+    return lnh_check_launch("lnh_lidar_composite_rays_train_backward");
 }
 
 int lnh_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, const float *rays_t,

@@ -38,6 +38,8 @@ _SIGS = {
     "lnh_march_rays_train": [P, P, P, F32, F32, U32, U32, U32, U32, U32, P, P, P, P, P, P, P, P],
     "lnh_composite_rays_train_forward": [P, P, P, P, U32, U32, F32, P, P, P],
     "lnh_composite_rays_train_backward": [P, P, P, P, P, P, P, P, U32, U32, F32, P, P],
+    "lnh_lidar_composite_rays_train_forward": [P, P, P, P, P, P, P, U32, U32, U32, F32, P, P, P],
+    "lnh_lidar_composite_rays_train_backward": [P, P, P, P, P, P, P, P, P, P, P, P, P, U32, U32, U32, F32, P, P],
     "lnh_march_rays": [U32, U32, P, P, P, P, F32, F32, U32, U32, U32, P, P, P, P, P, P, P],
     "lnh_composite_rays": [U32, U32, F32, P, P, P, P, P, P, P, P],
     "lnh_lidar_weights": [P, P, P, U32, U32, F32, P],

@@ -71,6 +71,46 @@ class _FusedMLP(Function):
         return (gx.to(xdt) if gx is not None else None), gw.to(wdt), None, None, None, None, None, None
 
 
+def _act_torch(a, x):
+    """lidarnerf/ffmlp/src/utils.h:479-531 on tensors (K = 10 for squareplus / softplus)."""
+    if a == 0:
+        return torch.relu(x)
+    if a == 1:
+        return torch.exp(x)
+    if a == 2:
+        return torch.sin(x)
+    if a == 3:
+        return torch.sigmoid(x)
+    if a == 4:
+        y = x * 10.0
+        return 0.5 * (y + torch.sqrt(y * y + 4.0)) / 10.0
+    if a == 5:
+        return torch.log(torch.exp(x * 10.0) + 1.0) / 10.0
+    return x
+
+
+def kernel_supported(in_dim, hidden, nhm):
+    """Shapes the register-resident MFMA kernels (csrc/mlp.hip) are instantiated for."""
+    return hidden in (32, 64) and nhm <= 2 and in_dim <= 128 and in_dim % 16 == 0
+
+
+def gemm_mlp(x, w, in_dim, hidden, nhm, act, out_act):
+    """The reference's remaining hidden widths (16, 128, 256: ffmlp.py:202-209) as a chain of plain library GEMMs
+    (rocBLAS / hipBLASLt through torch.matmul, fp32 accumulation) with the same storage model as the fused kernels: every
+    layer's activations are stored in the 16-bit element type.  At 128 / 256 the layers ARE library-sized GEMMs (weights
+    no longer fit a wave's registers, the point of the fused kernel); autograd differentiates the chain."""
+    dt = mlp_dtype()
+    with torch.autocast("cuda", enabled=False):
+        h = x.to(dt)
+        w = w.to(dt)
+        o = hidden * in_dim
+        h = _act_torch(act, h @ w[:o].view(hidden, in_dim).t())
+        for _ in range(nhm):
+            h = _act_torch(act, h @ w[o:o + hidden * hidden].view(hidden, hidden).t())
+            o += hidden * hidden
+        return _act_torch(out_act, h @ w[o:o + 16 * hidden].view(16, hidden).t())
+
+
 def fused_mlp(x, mats, activation=0, inference=False):
     """Bias-free Linear stack as one kernel.  mats: list of weight tensors [out_k, in_k] (>= 2); hidden width 32 or 64;
     last out <= 16; first in <= 128.  Returns [B, out_last] fp16."""
@@ -117,6 +157,12 @@ class FFMLP(nn.Module):
         self.weights.data.uniform_(-std, std)
 
     def forward(self, inputs):
-        y = _FusedMLP.apply(inputs, self.weights, self.input_dim, self.hidden_dim, self.num_layers - 1,
-                            self.activation, self.output_activation, not self.training)
+        if kernel_supported(self.input_dim, self.hidden_dim, self.num_layers - 1):
+            y = _FusedMLP.apply(inputs, self.weights, self.input_dim, self.hidden_dim, self.num_layers - 1,
+                                self.activation, self.output_activation, not self.training)
+        else:  # hidden 16 / 128 / 256, deeper or wider-input nets: library GEMM chain, same semantics
+            if not inputs.is_cuda:
+                raise RuntimeError("lidarnerf_hip: tensor must live on the GPU (no CPU path in this library)")
+            y = gemm_mlp(inputs, self.weights, self.input_dim, self.hidden_dim, self.num_layers - 1, self.activation,
+                         self.output_activation)
         return y[:, :self.output_dim] if self.output_dim != self.padded_output_dim else y

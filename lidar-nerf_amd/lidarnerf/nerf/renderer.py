@@ -71,7 +71,8 @@ lidar_composite = _LidarComposite.apply
 
 
 class NeRFRenderer(nn.Module):
-    def __init__(self, bound=1, density_scale=1, min_near=0.2, min_near_lidar=0.2, density_thresh=0.01, bg_radius=-1):
+    def __init__(self, bound=1, density_scale=1, min_near=0.2, min_near_lidar=0.2, density_thresh=0.01, bg_radius=-1,
+                 cuda_ray=False):
         super().__init__()
         self.bound = bound
         self.cascade = 1 + math.ceil(math.log2(bound))
@@ -84,6 +85,15 @@ class NeRFRenderer(nn.Module):
         box = torch.FloatTensor([-bound, -bound, -bound, bound, bound, bound])
         self.register_buffer("aabb_train", box)
         self.register_buffer("aabb_infer", box.clone())
+        # Occupancy-grid sampling (BASELINE config 4).  The reference kept the constructor arguments (`density_thresh`,
+        # cascade / grid_size above) and the raymarching kernels of torch-ngp but dropped the caller (SURVEY.md §0.6:
+        # no density_grid / run_cuda / update_extra_state in renderer.py); this is that caller, for the LiDAR outputs.
+        self.cuda_ray = cuda_ray
+        if cuda_ray:
+            self.register_buffer("density_grid", torch.zeros(self.cascade, self.grid_size ** 3))
+            self.register_buffer("density_bitfield", torch.zeros(self.cascade * self.grid_size ** 3 // 8, dtype=torch.uint8))
+            self.register_buffer("step_counter", torch.zeros(16, 2, dtype=torch.int32))  # 16 most recent marches
+            self.mean_density, self.iter_density, self.mean_count, self.local_step = 0.0, 0, 0, 0
 
     def forward(self, x, d):
         raise NotImplementedError()
@@ -175,9 +185,110 @@ class NeRFRenderer(nn.Module):
         return {"depth_lidar": depth.view(*prefix), "image_lidar": image.view(*prefix, self.out_dim),
                 "weights_sum_lidar": weights_sum}
 
+    # -- occupancy-grid sampling ------------------------------------------------------------------------------
+    def reset_extra_state(self):
+        if not self.cuda_ray:
+            return
+        self.density_grid.zero_()
+        self.step_counter.zero_()
+        self.mean_density, self.iter_density, self.mean_count, self.local_step = 0.0, 0, 0, 0
+
+    @torch.no_grad()
+    def update_extra_state(self, decay=0.95, S=128):
+        """Refresh the occupancy grid from the current density field (call every ~16 training steps): sample one
+        jittered point per grid cell (every cell for the first 16 updates, then a random quarter of the cells plus a
+        quarter's worth of currently occupied ones), grid = max(grid * decay, density), threshold at
+        min(mean density, density_thresh) and pack to the bitfield the marcher reads.  Cell <-> flat index is the Morton
+        code of raymarching.cu:71-95 (lnh_morton3D / lnh_morton3D_invert, bit-exact)."""
+        if not self.cuda_ray:
+            return
+        dev, G = self.density_grid.device, self.grid_size
+        tmp = -torch.ones_like(self.density_grid)
+
+        def splat(cas, coords, indices):
+            bound = min(2 ** cas, self.bound)
+            half = bound / G
+            xyzs = (2 * coords.float() / (G - 1) - 1) * (bound - half)
+            xyzs = xyzs + (torch.rand_like(xyzs) * 2 - 1) * half
+            sig = self.density(xyzs)["sigma"].reshape(-1).detach().float() * self.density_scale
+            tmp[cas, indices] = sig
+
+        if self.iter_density < 16:  # full sweep, S^3 cells at a time
+            ar = torch.arange(G, dtype=torch.int32, device=dev)
+            for xs in ar.split(S):
+                for ys in ar.split(S):
+                    for zs in ar.split(S):
+                        xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing="ij")
+                        coords = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], -1).contiguous()
+                        indices = raymarching.morton3D(coords).long()
+                        for cas in range(self.cascade):
+                            splat(cas, coords, indices)
+        else:
+            n = G ** 3 // 4
+            for cas in range(self.cascade):
+                coords = torch.randint(0, G, (n, 3), dtype=torch.int32, device=dev)
+                indices = raymarching.morton3D(coords).long()
+                occ = torch.nonzero(self.density_grid[cas] > 0).squeeze(-1)
+                if occ.numel() > 0:
+                    occ = occ[torch.randint(0, occ.shape[0], (n,), device=dev)]
+                    coords = torch.cat([coords, raymarching.morton3D_invert(occ.int())], 0)
+                    indices = torch.cat([indices, occ], 0)
+                splat(cas, coords.contiguous(), indices)
+        valid = (self.density_grid >= 0) & (tmp >= 0)
+        self.density_grid[valid] = torch.maximum(self.density_grid[valid] * decay, tmp[valid])
+        self.mean_density = float(self.density_grid.clamp(min=0).mean())
+        self.iter_density += 1
+        raymarching.packbits(self.density_grid, min(self.mean_density, self.density_thresh), self.density_bitfield)
+        steps = min(16, self.local_step)
+        if steps > 0:  # average number of samples of the recent marches -> size of the next sample buffers
+            self.mean_count = int(self.step_counter[:steps, 0].sum().item() / steps)
+        self.local_step = 0
+
+    def run_cuda(self, rays_o, rays_d, cal_lidar_color=True, dt_gamma=0, perturb=False, force_all_rays=False,
+                 max_steps=1024, T_thresh=1e-4, **kwargs):
+        """Occupancy-grid render of LiDAR rays: march through the occupied cells between 1 m and 81 m (scene units,
+        renderer.py:129-138) with lnh_march_rays_train, evaluate density + LiDAR colour on the ragged samples, composite
+        with the K = 2 / absolute-depth kernel.  Training mode keeps autograd; evaluation marches the same way (all rays)
+        under no_grad.  Same result keys as run()."""
+        if not cal_lidar_color:
+            raise NotImplementedError("occupancy-grid rendering is built for the LiDAR outputs (cal_lidar_color=True)")
+        self.out_dim = self.out_lidar_color_dim
+        prefix = rays_o.shape[:-1]
+        rays_o = rays_o.contiguous().view(-1, 3).float()
+        rays_d = rays_d.contiguous().view(-1, 3).float()
+        N = rays_o.shape[0]
+        nears = torch.full((N,), float(self.min_near_lidar), dtype=torch.float32, device=rays_o.device)
+        fars = nears * 81.0
+        if self.training:
+            counter = self.step_counter[self.local_step % 16]
+            counter.zero_()
+            self.local_step += 1
+            mean_count = self.mean_count
+        else:
+            counter, mean_count, force_all_rays = None, -1, True
+        xyzs, dirs, deltas, rays = raymarching.march_rays_train(
+            rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size, nears, fars, counter,
+            mean_count, perturb, 128, force_all_rays, dt_gamma, max_steps)
+        if xyzs.shape[0] == 0:
+            z = torch.zeros(N, device=rays_o.device)
+            return {"depth_lidar": z.view(*prefix), "image_lidar": torch.zeros(*prefix, self.out_dim, device=z.device),
+                    "weights_sum_lidar": z}
+        dens = self.density(xyzs)
+        sigmas = dens["sigma"].float() * self.density_scale
+        # every marched sample lies in an occupied cell: the colour head runs on all of them (no weight mask)
+        feats = self.color(xyzs, dirs, cal_lidar_color=True, mask=None, geo_feat=dens["geo_feat"]).float()
+        ws, depth, image = raymarching.composite_rays_train_lidar(sigmas, feats, deltas, xyzs, rays_o, rays_d, rays,
+                                                                 T_thresh)
+        return {"depth_lidar": depth.view(*prefix), "image_lidar": image.view(*prefix, self.out_dim),
+                "weights_sum_lidar": ws}
+
     def render(self, rays_o, rays_d, cal_lidar_color=False, staged=False, max_ray_batch=4096, **kwargs):
+        if self.cuda_ray and cal_lidar_color:
+            run = self.run_cuda
+        else:
+            run = self.run
         if not staged:
-            return self.run(rays_o, rays_d, cal_lidar_color=cal_lidar_color, **kwargs)
+            return run(rays_o, rays_d, cal_lidar_color=cal_lidar_color, **kwargs)
         B, N = rays_o.shape[:2]
         out_dim = self.out_lidar_color_dim if cal_lidar_color else self.out_color_dim
         depth = torch.empty((B, N), device=rays_o.device)
@@ -185,8 +296,8 @@ class NeRFRenderer(nn.Module):
         for b in range(B):
             for head in range(0, N, max_ray_batch):
                 tail = min(head + max_ray_batch, N)
-                part = self.run(rays_o[b:b + 1, head:tail], rays_d[b:b + 1, head:tail],
-                                cal_lidar_color=cal_lidar_color, **kwargs)
+                part = run(rays_o[b:b + 1, head:tail], rays_d[b:b + 1, head:tail],
+                           cal_lidar_color=cal_lidar_color, **kwargs)
                 depth[b:b + 1, head:tail] = part["depth_lidar"]
                 image[b:b + 1, head:tail] = part["image_lidar"]
         return {"depth_lidar": depth, "image_lidar": image}

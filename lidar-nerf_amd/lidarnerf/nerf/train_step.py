@@ -85,7 +85,10 @@ class LidarTrainer:
         params = [dict(g, params=list(g["params"])) for g in model.get_params(lr)]
         on_gpu = all(p.is_cuda for g in params for p in g["params"])
         self.table = None
-        if fused_table_optimizer and fp16 and on_gpu and hasattr(model, "fused_spec"):
+        # occupancy-grid sampling renders through the modular density()/color() path: the table gradient is a normal .grad
+        self.occupancy = bool(getattr(model, "cuda_ray", False))
+        self.update_extra_interval, self.global_step = 16, 0
+        if fused_table_optimizer and fp16 and on_gpu and hasattr(model, "fused_spec") and not self.occupancy:
             try:
                 tp = model.fused_spec().table_param
             except AttributeError:
@@ -196,6 +199,10 @@ class LidarTrainer:
             self.growth_tracker.copy_(ft["growth_tracker"])
 
     def step(self, rays_o, rays_d, images_lidar, patch=(1, 1)):
+        if self.occupancy and self.global_step % self.update_extra_interval == 0:
+            with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.fp16):
+                self.model.update_extra_state()  # refresh the occupancy grid the marcher reads (every 16 steps)
+        self.global_step += 1
         if self.table is not None:
             return self._step_fused_table(rays_o, rays_d, images_lidar, patch)
         self.optimizer.zero_grad(set_to_none=True)

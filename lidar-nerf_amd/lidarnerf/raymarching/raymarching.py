@@ -123,6 +123,45 @@ class _CompositeRaysTrain(Function):
 composite_rays_train = _CompositeRaysTrain.apply
 
 
+class _CompositeRaysTrainLidar(Function):
+    """LiDAR variant of composite_rays_train: K channels (ray-drop, intensity) and the ABSOLUTE depth sum(w * z) with
+    its gradient — what renderer.py:233-271 computes on dense [N,T] tensors, on the marcher's ragged samples.
+    (sigmas [M], feats [M,K], deltas [M,2], xyzs [M,3], rays_o/rays_d [N,3], rays [N,3]) -> (ws [N], depth [N], image [N,K])."""
+
+    @staticmethod
+    def forward(ctx, sigmas, feats, deltas, xyzs, rays_o, rays_d, rays, T_thresh=1e-4):
+        sigmas, feats = sigmas.contiguous().float(), feats.contiguous().float()
+        deltas, xyzs = deltas.contiguous().float(), xyzs.contiguous().float()
+        rays_o, rays_d, rays = rays_o.contiguous().float(), rays_d.contiguous().float(), rays.contiguous().int()
+        _hip.require_cuda(sigmas, feats, deltas, xyzs, rays_o, rays_d, rays)
+        M, N, K = sigmas.shape[0], rays.shape[0], feats.shape[-1]
+        ws = torch.empty(N, dtype=torch.float32, device=sigmas.device)
+        depth = torch.empty(N, dtype=torch.float32, device=sigmas.device)
+        image = torch.empty((N, K), dtype=torch.float32, device=sigmas.device)
+        _hip.call("lnh_lidar_composite_rays_train_forward", sigmas.data_ptr(), feats.data_ptr(), deltas.data_ptr(),
+                  xyzs.data_ptr(), rays_o.data_ptr(), rays_d.data_ptr(), rays.data_ptr(), M, N, K, float(T_thresh),
+                  ws.data_ptr(), depth.data_ptr(), image.data_ptr())
+        ctx.save_for_backward(sigmas, feats, deltas, xyzs, rays_o, rays_d, rays, ws, depth, image)
+        ctx.dims = (M, N, K, T_thresh)
+        return ws, depth, image
+
+    @staticmethod
+    def backward(ctx, g_ws, g_depth, g_image):
+        sigmas, feats, deltas, xyzs, rays_o, rays_d, rays, ws, depth, image = ctx.saved_tensors
+        M, N, K, T_thresh = ctx.dims
+        gs = torch.zeros_like(sigmas)
+        gf = torch.zeros_like(feats)
+        _hip.call("lnh_lidar_composite_rays_train_backward", g_ws.contiguous().float().data_ptr(),
+                  g_depth.contiguous().float().data_ptr(), g_image.contiguous().float().data_ptr(), sigmas.data_ptr(),
+                  feats.data_ptr(), deltas.data_ptr(), xyzs.data_ptr(), rays_o.data_ptr(), rays_d.data_ptr(),
+                  rays.data_ptr(), ws.data_ptr(), depth.data_ptr(), image.data_ptr(), M, N, K, float(T_thresh),
+                  gs.data_ptr(), gf.data_ptr())
+        return gs, gf, None, None, None, None, None, None
+
+
+composite_rays_train_lidar = _CompositeRaysTrainLidar.apply
+
+
 # ----------------------------------------
 # infer functions (raymarching.py:362-512)
 # ----------------------------------------

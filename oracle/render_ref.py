@@ -98,6 +98,38 @@ def run_lidar(rays_o, rays_d, density_fn, color_fn, aabb, min_near_lidar, num_st
             "weights": weights, "z_vals": z_vals, "mask": mask}
 
 
+def composite_ragged(sigmas, feats, deltas, xyzs, rays_o, rays_d, rays, T_thresh=1e-4):
+    """Ragged LiDAR compositing over the marcher's samples (the product's lnh_lidar_composite_rays_train_*): the weight
+    arithmetic of raymarching.cu:577-655 (alpha = 1 - exp(-sigma dt), w = alpha T, T *= 1 - alpha, stop once T < T_thresh)
+    with the LiDAR outputs of renderer.py:268-271 — absolute depth sum(w z), z = (xyz - o) . d, and K feature channels.
+    Differentiable torch code (autograd supplies the reference gradients); small inputs only (Python loop over rays)."""
+    N, K = rays.shape[0], feats.shape[-1]
+    ws = torch.zeros(N, dtype=sigmas.dtype)
+    depth = torch.zeros(N, dtype=sigmas.dtype)
+    image = torch.zeros(N, K, dtype=sigmas.dtype)
+    ws_l, d_l, im_l = [None] * N, [None] * N, [None] * N
+    for n in range(N):
+        idx, off, cnt = (int(v) for v in rays[n])
+        zero = sigmas.sum() * 0
+        if cnt == 0 or off + cnt > sigmas.shape[0]:
+            ws_l[idx], d_l[idx], im_l[idx] = zero, zero, zero.expand(K)
+            continue
+        sl = slice(off, off + cnt)
+        alpha = 1 - torch.exp(-sigmas[sl] * deltas[sl, 0])
+        T = torch.cumprod(torch.cat([torch.ones(1, dtype=sigmas.dtype), 1 - alpha]), 0)  # T[i] before sample i
+        below = (T[1:] < T_thresh).nonzero()
+        last = int(below[0]) if below.numel() else cnt - 1                                # last sample that counts
+        keep = (torch.arange(cnt) <= last).to(sigmas.dtype)
+        w = alpha * T[:-1] * keep
+        z = ((xyzs[sl] - rays_o[idx]) * rays_d[idx]).sum(-1)
+        ws_l[idx], d_l[idx], im_l[idx] = w.sum(), (w * z).sum(), (w[:, None] * feats[sl]).sum(0)
+    for i in range(N):
+        if ws_l[i] is None:
+            z0 = sigmas.sum() * 0
+            ws_l[i], d_l[i], im_l[i] = z0, z0, z0.expand(K)
+    return torch.stack(ws_l), torch.stack(d_l), torch.stack(im_l)
+
+
 # ----------------------------------------------------------------------------- network pieces
 class _TruncExp(torch.autograd.Function):
     """activation.py:6-20"""

@@ -171,6 +171,32 @@ def test_bf16_ffmlp_module_under_bf16_autocast():
     assert torch.isfinite(m.weights.grad).all() and float(m.weights.grad.abs().max()) > 0
 
 
+@pytest.mark.parametrize("hidden,layers,in_dim", [(16, 2, 32), (128, 3, 48), (256, 2, 64), (64, 5, 32)])
+def test_ffmlp_module_all_reference_widths(hidden, layers, in_dim):
+    """FFMLP accepts every width the reference does (ffmlp.py:202-209: 16 .. 256); the ones outside the fused kernels'
+    register budget run as library GEMMs with the same fp16 storage model — forward and gradients vs the oracle."""
+    from lidarnerf.ffmlp import FFMLP
+    m = FFMLP(in_dim, 5, hidden, layers).cuda()
+    with torch.no_grad():
+        m.weights.copy_(m.weights.half().float())
+    r = np.random.default_rng(hidden)
+    x = r.standard_normal((300, in_dim)).astype(np.float16)
+    xt = torch.from_numpy(x.astype(np.float32)).cuda().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.float16):
+        y = m(xt)
+    assert y.shape == (300, 5) and y.dtype == torch.float16
+    mats = mlp_ref.ffmlp_split_weights(m.weights.detach().cpu().numpy(), in_dim, 5, hidden, layers)
+    want, _ = mlp_ref.mlp_forward(x, mats)
+    np.testing.assert_allclose(y.detach().float().cpu().numpy(), want[:, :5], rtol=4e-3, atol=6e-3)
+    gy = np.zeros((300, 16), np.float16)
+    gy[:, :5] = (r.standard_normal((300, 5)) * 0.1).astype(np.float16)
+    y.backward(torch.from_numpy(gy[:, :5]).cuda())
+    gx_want, dws = mlp_ref.mlp_backward(x, mats, gy)
+    dw_want = np.concatenate([d.ravel() for d in dws])
+    np.testing.assert_allclose(xt.grad.cpu().numpy(), gx_want, rtol=1e-2, atol=4e-3)
+    np.testing.assert_allclose(m.weights.grad.cpu().numpy(), dw_want, rtol=1e-2, atol=4e-3 * np.abs(dw_want).max())
+
+
 def test_ffmlp_module_hidden_32():
     from lidarnerf.ffmlp import FFMLP
     m = FFMLP(32, 3, 32, 3).cuda()

@@ -1,0 +1,147 @@
+"""Occupancy-grid training path (BASELINE config 4): ragged LiDAR compositing (K = 2, absolute depth with gradient) vs
+the oracle, the occupancy render vs a recomposition of its own marched samples, the grid update, and a short training
+run on an object-centric synthetic scene.  The indexing underneath (Morton codes, packbits, cell lookup, march_rays_train)
+is pinned bit-exactly in tests/test_raymarch_gpu.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle, render_ref
+
+pytestmark = pytest.mark.gpu
+SCALE = 0.005  # configs/nerf_mvl.txt
+
+
+def _ragged(N, seed, K=2):
+    r = np.random.default_rng(seed)
+    counts = r.integers(0, 40, N)
+    counts[0] = 0                       # a ray without samples
+    counts[1] = 1
+    order = r.permutation(N)            # (id, offset, count) rows come in allocation order, not ray order
+    offs = np.zeros(N, np.int64)
+    off = 0
+    rays = np.zeros((N, 3), np.int32)
+    for row, ray in enumerate(order):
+        rays[row] = (ray, off, counts[ray])
+        off += counts[ray]
+    M = int(off) + 5                    # a few unused tail slots
+    sig = (r.random(M) * 30).astype(np.float32)
+    sig[r.random(M) < 0.1] = 2000.0     # opaque samples: early termination inside a ray
+    feats = r.random((M, K)).astype(np.float32)
+    deltas = np.stack([r.random(M) * 0.02 + 0.002, r.random(M) * 0.03], -1).astype(np.float32)
+    o = (r.random((N, 3)) - 0.5).astype(np.float32) * 0.2
+    d = r.standard_normal((N, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    xyz = np.zeros((M, 3), np.float32)
+    for row in range(N):
+        ray, o0, c = rays[row]
+        t = 0.05 + np.cumsum(r.random(c) * 0.03)
+        xyz[o0:o0 + c] = o[ray] + d[ray] * t[:, None]
+    return sig, feats, deltas, xyz, o, d, rays
+
+
+@pytest.mark.parametrize("K", [1, 2, 3])
+def test_ragged_lidar_composite_vs_oracle(K):
+    from lidarnerf.raymarching import composite_rays_train_lidar
+    sig, feats, deltas, xyz, o, d, rays = _ragged(57, 3 + K, K)
+    t = lambda a: torch.from_numpy(a)
+    sg, ft = t(sig).double().requires_grad_(True), t(feats).double().requires_grad_(True)
+    ws, dep, img = render_ref.composite_ragged(sg, ft, t(deltas).double(), t(xyz).double(), t(o).double(), t(d).double(),
+                                               t(rays))
+    g = torch.Generator().manual_seed(1)
+    gws, gdp, gim = torch.randn(57, generator=g), torch.randn(57, generator=g) * 5, torch.randn(57, K, generator=g)
+    ((ws * gws.double()).sum() + (dep * gdp.double()).sum() + (img * gim.double()).sum()).backward()
+    sc, fc = t(sig).cuda().requires_grad_(True), t(feats).cuda().requires_grad_(True)
+    ws2, dep2, img2 = composite_rays_train_lidar(sc, fc, t(deltas).cuda(), t(xyz).cuda(), t(o).cuda(), t(d).cuda(),
+                                                 t(rays).cuda(), 1e-4)
+    torch.testing.assert_close(ws2.cpu().double(), ws, rtol=2e-5, atol=1e-6)
+    torch.testing.assert_close(dep2.cpu().double(), dep, rtol=2e-5, atol=1e-6)
+    torch.testing.assert_close(img2.cpu().double(), img, rtol=2e-5, atol=1e-6)
+    ((ws2 * gws.cuda()).sum() + (dep2 * gdp.cuda()).sum() + (img2 * gim.cuda()).sum()).backward()
+    scale = sg.grad.abs().max().item()
+    torch.testing.assert_close(sc.grad.cpu().double(), sg.grad, rtol=1e-3, atol=2e-5 * scale)
+    torch.testing.assert_close(fc.grad.cpu().double(), ft.grad, rtol=1e-4, atol=1e-7)
+    # samples behind the termination point and the unused tail receive exactly zero gradient
+    assert float(sc.grad[-5:].abs().max()) == 0.0
+
+
+def _net(cuda_ray=True, seed=0):
+    from lidarnerf.nerf.network import NeRFNetwork
+    torch.manual_seed(seed)
+    net = NeRFNetwork(encoding="hashgrid", desired_resolution=2048, bound=1, min_near=SCALE, min_near_lidar=SCALE,
+                      density_thresh=10, cuda_ray=cuda_ray)
+    with torch.no_grad():
+        net.encoder.embeddings.uniform_(-0.5, 0.5)
+    return net.cuda()
+
+
+def _object_rays(n, seed):
+    """Sensor on a circle of radius 0.6 around an object at the origin, rays towards a jittered point of the object."""
+    g = torch.Generator().manual_seed(seed)
+    ang = torch.rand(n, generator=g) * 2 * np.pi
+    o = torch.stack([0.6 * torch.cos(ang), 0.6 * torch.sin(ang), torch.zeros(n)], -1)
+    target = (torch.rand(n, 3, generator=g) - 0.5) * 0.3
+    d = torch.nn.functional.normalize(target - o, dim=-1)
+    return o, d
+
+
+def test_run_cuda_matches_recomposition_of_its_samples():
+    from lidarnerf import raymarching
+    net = _net().eval()
+    net.density_bitfield.fill_(255)                      # everything occupied: the marcher walks the whole ray
+    o, d = _object_rays(64, 2)
+    with torch.no_grad():
+        out = net.render(o.cuda()[None], d.cuda()[None], cal_lidar_color=True, staged=False, perturb=False)
+        nears = torch.full((64,), SCALE, device="cuda")
+        xyzs, dirs, deltas, rays = raymarching.march_rays_train(o.cuda(), d.cuda(), 1, net.density_bitfield, 1, 128,
+                                                                nears, nears * 81.0, None, -1, False, 128, True, 0, 1024)
+        dens = net.density(xyzs)
+        feats = net.color(xyzs, dirs, cal_lidar_color=True, mask=None, geo_feat=dens["geo_feat"])
+    ws, dep, img = render_ref.composite_ragged(dens["sigma"].cpu().double(), feats.cpu().double(), deltas.cpu().double(),
+                                               xyzs.cpu().double(), o.double(), d.double(), rays.cpu())
+    torch.testing.assert_close(out["depth_lidar"][0].cpu().double(), dep, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(out["image_lidar"][0].cpu().double(), img, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(out["weights_sum_lidar"].cpu().double(), ws, rtol=1e-4, atol=1e-6)
+    # far beyond the box nothing is sampled: 81 * scale = 0.405 < 0.6 + box, rays end inside; count is plausible
+    assert 0 < xyzs.shape[0] <= 64 * 1024
+
+
+def test_update_extra_state_grid_and_bitfield():
+    net = _net().train()
+    net.update_extra_state()
+    grid = net.density_grid.clone()
+    assert net.iter_density == 1 and float(grid.min()) >= 0 and float(grid.max()) > 0
+    thresh = min(net.mean_density, net.density_thresh)
+    want = c_oracle.packbits(grid.cpu().numpy().reshape(-1), thresh)
+    np.testing.assert_array_equal(net.density_bitfield.cpu().numpy(), want)
+    net.update_extra_state()                              # EMA: never below decay * previous
+    assert bool((net.density_grid >= grid * 0.95 - 1e-6).all())
+    net.reset_extra_state()
+    assert float(net.density_grid.abs().max()) == 0.0 and net.iter_density == 0
+
+
+def test_occupancy_training_prunes_empty_space():
+    """Object-centric scene (a sphere of radius 0.15 seen from a ring of sensor positions): 96 training steps with the
+    occupancy path must bring the loss down while marching far fewer samples per ray than the 768 + 64 of the dense path
+    (at scale 0.005 the 1 m .. 81 m ray segment is 0.4 scene units = at most 118 marcher steps of 2 sqrt(3) / 1024)."""
+    from lidarnerf.nerf.train_step import LidarTrainer
+    net = _net(seed=1).train()
+    with torch.no_grad():
+        net.encoder.embeddings.uniform_(-1e-4, 1e-4)
+    tr = LidarTrainer(net, lr=1e-2, fp16=True, scale=SCALE, render_kwargs={})
+    assert tr.occupancy and tr.table is None
+    R = 0.15
+    losses, counts = [], []
+    for step in range(96):
+        o, d = _object_rays(2048, 100 + step)
+        b = (o * d).sum(-1)
+        disc = b * b - ((o * o).sum(-1) - R * R)
+        hit = disc > 0
+        depth = torch.where(hit, -b - torch.sqrt(disc.clamp(min=0)), torch.zeros_like(b))
+        gt = torch.stack([hit.float(), torch.full_like(b, 0.5), depth], -1)[None].cuda()
+        loss = tr.step(o.cuda()[None], d.cuda()[None], gt)
+        losses.append(float(loss.detach()))
+        counts.append(int(net.step_counter[(net.local_step - 1) % 16, 0]) / 2048)
+    assert np.mean(losses[-8:]) < 0.35 * np.mean(losses[:8]), (losses[:8], losses[-8:])
+    assert 0 < np.mean(counts[-8:]) < 0.25 * 832, (counts[:8], counts[-8:])
+    assert all(np.isfinite(losses))
