@@ -83,6 +83,10 @@ class LidarTrainer:
         # Adam(betas .9/.99, eps 1e-15) and lr * 0.1^(it/iters) (main_lidarnerf.py:389-391, 408-410)
         # get_params returns generators: materialise them; one fused kernel for all parameter groups on the GPU
         params = [dict(g, params=list(g["params"])) for g in model.get_params(lr)]
+        # layout of the reference's optimizer (Adam over model.get_params(lr), main_lidarnerf.py:389-391): the order in
+        # which its state_dict numbers the parameters — checkpoints are written / read in that layout
+        self._ref_layout = [[p for p in g["params"]] for g in params]
+        self.epoch, self.stats = 0, {"loss": [], "valid_loss": [], "results": [], "checkpoints": [], "best_result": None}
         on_gpu = all(p.is_cuda for g in params for p in g["params"])
         self.table = None
         # occupancy-grid sampling renders through the modular density()/color() path: the table gradient is a normal .grad
@@ -197,6 +201,90 @@ class LidarTrainer:
             self.t_steps[self.t_flip].copy_(ft["step"])
             self.loss_scale.copy_(ft["loss_scale"])
             self.growth_tracker.copy_(ft["growth_tracker"])
+
+    # ---- checkpoints in the reference Trainer's format (lidarnerf/nerf/utils.py:1449-1568)
+    def _optimizer_state_ref_layout(self):
+        """torch.optim.Adam.state_dict() as the reference's optimizer would write it: one entry per parameter of
+        model.get_params(lr) in order, the fused table optimizer's moments / step count included."""
+        own = self.optimizer.state_dict()
+        own_ids = {id(p): i for i, p in enumerate(p for g in self.optimizer.param_groups for p in g["params"])}
+        template = {k: v for k, v in own["param_groups"][0].items() if k != "params"} if own["param_groups"] else {}
+        state, groups, idx = {}, [], 0
+        for gi, group in enumerate(self._ref_layout):
+            ids = []
+            for p in group:
+                if self.table is not None and p is self.table:
+                    state[idx] = {"step": self.t_steps[self.t_flip].detach().clone().float().cpu(),
+                                  "exp_avg": self.t_m.detach().clone(), "exp_avg_sq": self.t_v.detach().clone()}
+                elif id(p) in own_ids and own_ids[id(p)] in own["state"]:
+                    state[idx] = own["state"][own_ids[id(p)]]
+                ids.append(idx)
+                idx += 1
+            g = dict(template)
+            g["params"] = ids
+            groups.append(g)
+        return {"state": state, "param_groups": groups}
+
+    def _load_optimizer_state_ref_layout(self, sd):
+        own_ids = {id(p): i for i, p in enumerate(p for g in self.optimizer.param_groups for p in g["params"])}
+        own = self.optimizer.state_dict()
+        idx = 0
+        for group in self._ref_layout:
+            for p in group:
+                st = sd["state"].get(idx)
+                if st is not None:
+                    if self.table is not None and p is self.table:
+                        self.t_m.copy_(st["exp_avg"].to(self.t_m.device))
+                        self.t_v.copy_(st["exp_avg_sq"].to(self.t_v.device))
+                        self.t_steps[self.t_flip].fill_(float(st["step"]))
+                    elif id(p) in own_ids:
+                        own["state"][own_ids[id(p)]] = st
+                idx += 1
+        lr_by_pos = [g.get("lr") for g in sd["param_groups"]]
+        for g, lr in zip(own["param_groups"], [l for l, grp in zip(lr_by_pos, self._ref_layout)
+                                               if any(id(p) in own_ids for p in grp)]):
+            if lr is not None:
+                g["lr"] = lr
+        self.optimizer.load_state_dict(own)
+
+    def save_checkpoint(self, path, full=True):
+        """Same dictionary as Trainer.save_checkpoint (utils.py:1449-1480): epoch, global_step, stats, model and — `full`
+        — optimizer / lr_scheduler / scaler in the layout the reference's Trainer.load_checkpoint restores (a reference
+        run can resume from it and vice versa: the state dict keys of the model are the reference's, see network.py)."""
+        state = {"epoch": self.epoch, "global_step": self.global_step, "stats": self.stats}
+        if full:
+            state["optimizer"] = self._optimizer_state_ref_layout()
+            state["lr_scheduler"] = self.scheduler.state_dict()
+            if self.table is not None:  # the dynamic loss scale lives with the fused table optimizer
+                state["scaler"] = {"scale": float(self.loss_scale), "growth_factor": 2.0, "backoff_factor": 0.5,
+                                   "growth_interval": 2000, "_growth_tracker": int(self.growth_tracker)}
+            else:
+                state["scaler"] = self.scaler.state_dict()
+        state["model"] = self.model.state_dict()
+        torch.save(state, path)
+        return path
+
+    def load_checkpoint(self, path, model_only=False):
+        """Trainer.load_checkpoint (utils.py:1511-1568): a bare state dict or the dictionary above; strict=False."""
+        ck = torch.load(path, map_location=next(self.model.parameters()).device, weights_only=False)
+        if "model" not in ck:
+            self.model.load_state_dict(ck)
+            return [], []
+        missing, unexpected = self.model.load_state_dict(ck["model"], strict=False)
+        if model_only:
+            return missing, unexpected
+        self.stats, self.epoch, self.global_step = ck["stats"], ck["epoch"], ck["global_step"]
+        if "optimizer" in ck:
+            self._load_optimizer_state_ref_layout(ck["optimizer"])
+        if "lr_scheduler" in ck:
+            self.scheduler.load_state_dict(ck["lr_scheduler"])
+        if "scaler" in ck and ck["scaler"]:
+            if self.table is not None:
+                self.loss_scale.fill_(float(ck["scaler"]["scale"]))
+                self.growth_tracker.fill_(int(ck["scaler"].get("_growth_tracker", 0)))
+            else:
+                self.scaler.load_state_dict(ck["scaler"])
+        return missing, unexpected
 
     def step(self, rays_o, rays_d, images_lidar, patch=(1, 1)):
         if self.occupancy and self.global_step % self.update_extra_interval == 0:

@@ -163,3 +163,41 @@ def test_backward_bucketed_chunked_matches_atomic_path():
     a2 = torch.zeros((rows, CH), device="cuda")
     call("lnh_grid_encode_backward_ws", g, x, offh, a2, B, 3, CH, L, S, H, 0, 0, 0, 0, ws, need)
     assert torch.equal(a, a2)                                 # chunked sums are bit-reproducible too
+
+
+def test_fused_table_trainer_checkpoint_resume(tmp_path):
+    """Fused table optimizer: save after 3 steps, load into a fresh trainer, and the 4th step of both leaves bit-identical
+    tables (moments, device-side step count, loss scale and the fp16 shadow all survive the reference-format checkpoint);
+    the optimizer entry is loadable by the reference's stock Adam over model.get_params()."""
+    import os
+    import bench
+    from lidarnerf.nerf.train_step import LidarTrainer
+    dev = torch.device("cuda")
+    kw = dict(num_steps=128, upsample_steps=32)
+
+    def fresh():
+        torch.manual_seed(0)
+        from lidarnerf.nerf.network import NeRFNetwork
+        m = NeRFNetwork(encoding="hashgrid", desired_resolution=32768, bound=1, min_near=bench.SCALE,
+                        min_near_lidar=bench.SCALE).to(dev).train()
+        return m, LidarTrainer(m, fp16=True, scale=bench.SCALE, render_kwargs=kw)
+    poses = bench.synthetic_frames(4, dev)
+    batches = [bench.make_batch(poses, s, 256, 0, dev) for s in range(4)]
+    m1, t1 = fresh()
+    assert t1.table is not None
+    for s in range(3):
+        torch.manual_seed(100 + s)
+        t1.step(*batches[s])
+    path = t1.save_checkpoint(os.path.join(tmp_path, "ck.pth"))
+    m2, t2 = fresh()
+    with torch.no_grad():
+        m2.encoder.embeddings.add_(0.25)       # make sure the load really overwrites (and refreshes the fp16 shadow)
+    t2.load_checkpoint(path)
+    for t in (t1, t2):
+        torch.manual_seed(103)
+        t.step(*batches[3])
+    assert torch.equal(m1.encoder.embeddings, m2.encoder.embeddings)
+    assert torch.equal(t1.t_m, t2.t_m) and torch.equal(t1.t_v, t2.t_v) and float(t1.loss_scale) == float(t2.loss_scale)
+    ref_opt = torch.optim.Adam(m1.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+    ref_opt.load_state_dict(torch.load(path, weights_only=False)["optimizer"])
+    assert float(ref_opt.state[m1.encoder.embeddings]["step"]) == 3
