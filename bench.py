@@ -164,6 +164,83 @@ def _latest_pmc():
     return None, {}
 
 
+def run_nerfmvl(args):
+    """BASELINE config 4 (secondary workload, `--workload nerfmvl`): NeRF-MVL-shaped object scene — 256 x 1800 range image,
+    intrinsics (fov_up, fov) = (15, 40), scale 0.005 (configs/nerf_mvl.txt; preprocess/generate_train_rangeview.py:166-168),
+    rays of a frame restricted to the object's bounding box and thinned to <= 4096 per step as the reference's collate
+    does (nerfmvl_dataset.py:116-168) — trained with OCCUPANCY-GRID ray sampling: density-grid update every 16 steps,
+    lnh_march_rays_train, ragged LiDAR compositing.  Synthetic object: a sphere of 2 m radius seen from a 6 m ring."""
+    from lidarnerf import _hip
+    from lidarnerf.dataset.rays import get_lidar_rays
+    from lidarnerf.nerf.network import NeRFNetwork
+    from lidarnerf.nerf.train_step import LidarTrainer
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP extension is the product path (no CPU fallback)")
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    _hip.lib()
+    scale, Himg, Wimg, intr = 0.005, 256, 1800, (15.0, 40.0)
+    R, ring = 2.0 * scale, 6.0 * scale
+    torch.manual_seed(0)
+    model = NeRFNetwork(encoding="hashgrid", desired_resolution=32768, log2_hashmap_size=19, num_layers=2, hidden_dim=64,
+                        geo_feat_dim=15, bound=1, density_scale=1, min_near=scale, min_near_lidar=scale,
+                        density_thresh=10, bg_radius=-1, cuda_ray=True).to(device).train()
+    trainer = LidarTrainer(model, lr=1e-2, iters=30000, fp16=True, scale=scale)
+
+    def frame(k):
+        th = 2 * np.pi * k / 60
+        pose = torch.eye(4)
+        # sensor x axis points at the object (beta = 0 is +x in the sensor frame: base_dataset.py:72-87)
+        pose[:3, :3] = torch.tensor([[-np.cos(th), np.sin(th), 0], [-np.sin(th), -np.cos(th), 0], [0, 0, 1.0]])
+        pose[:3, 3] = torch.tensor([ring * np.cos(th), ring * np.sin(th), 0.0])
+        r = get_lidar_rays(pose[None].to(device), intr, Himg, Wimg, -1)
+        o, d = r["rays_o"][0], r["rays_d"][0]
+        b = (o * d).sum(-1)
+        disc = b * b - ((o * o).sum(-1) - (1.2 * R) ** 2)          # inside the object's bounding sphere (bbox mask)
+        keep = (disc > 0) & (b < 0)
+        o, d, b = o[keep], d[keep], b[keep]
+        disc_s = b * b - ((o * o).sum(-1) - R * R)
+        hit = disc_s > 0
+        depth = torch.where(hit, -b - torch.sqrt(disc_s.clamp(min=0)), torch.zeros_like(b))
+        gt = torch.stack([hit.float(), torch.full_like(b, 0.5), depth], -1)
+        return o, d, gt
+
+    frames = [frame(k) for k in range(60)]
+
+    def batch(step):
+        o, d, gt = frames[step % 60]
+        g = torch.Generator(device="cpu").manual_seed(99 + step)
+        sel = torch.randperm(o.shape[0], generator=g)[:args.rays].to(device)
+        return o[sel][None].contiguous(), d[sel][None].contiguous(), gt[sel][None].contiguous()
+
+    n_pre = 192  # let the occupancy grid settle (12 grid updates) before anything is timed
+    batches = [batch(s) for s in range(n_pre + args.warmup + args.steps)]
+    for s in range(n_pre + args.warmup):
+        trainer.step(*batches[s])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    counts = []
+    for s in range(args.steps):
+        loss = trainer.step(*batches[n_pre + args.warmup + s])
+        counts.append(model.step_counter[(model.local_step - 1) % 16, 0])
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    n_rays = sum(b[0].shape[1] for b in batches[n_pre + args.warmup:])
+    samples = float(torch.stack(counts).float().mean()) / (n_rays / args.steps)
+    occ = float((model.density_grid > min(model.mean_density, model.density_thresh)).float().mean())
+    print(json.dumps({
+        "metric": "train rays/sec (occupancy-grid sampling + encode + MLP + ragged composite + bwd), NeRF-MVL-shaped 256x1800",
+        "value": round(n_rays / elapsed, 1), "unit": "rays/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f16 (fp16 hash tables + fp16 MFMA MLP, fp32 accumulate)", "data": "synthetic",
+        "config": {"workload": "NeRF-MVL shaped (BASELINE configs[3]): 256x1800 range image, intrinsics (15, 40), scale "
+                               "0.005, hash-grid L=16 F=2 + 64-wide MLPs, occupancy-grid ray sampling (128^3, update every "
+                               "16 steps), synthetic 2 m sphere seen from a 6 m ring",
+                   "rays_per_gpu_per_step": int(n_rays / args.steps), "mean_samples_per_ray": round(samples, 2),
+                   "dense_samples_per_ray": NUM_STEPS + UPSAMPLE, "occupied_cell_fraction": round(occ, 5),
+                   "pretrain_steps": n_pre, "final_loss": round(float(loss.detach()), 5)}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,6 +249,8 @@ def main():
     ap.add_argument("--rays", type=int, default=4096, help="rays per step per GPU")
     ap.add_argument("--mlp-dtype", choices=("fp16", "bf16"), default="fp16",
                     help="MFMA operand type of the MLP kernels (bf16 = BASELINE config 5; hash features stay fp16)")
+    ap.add_argument("--workload", choices=("kitti360", "nerfmvl"), default="kitti360",
+                    help="kitti360 = the headline benchmark (BASELINE configs[1]); nerfmvl = configs[3], occupancy-grid path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eval", action="store_true", help="skip the secondary full-frame evaluation measurement")
     ap.add_argument("--kernel-timers", action="store_true", help="HIP-event timing of every C-ABI call (adds ~4 %)")
@@ -180,6 +259,8 @@ def main():
     from lidarnerf import _hip, parallel
     from lidarnerf.nerf.train_step import LidarTrainer
 
+    if args.workload == "nerfmvl":
+        return run_nerfmvl(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         _relaunch_distributed(args.gpus)
     rank, local, world = parallel.init_from_env()
