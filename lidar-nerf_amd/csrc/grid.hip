@@ -473,34 +473,46 @@ struct BucketPlan {
     uint32_t first_bucket[LNH_MAX_LEVELS + 1];  // prefix sum of buckets per level
     uint32_t cap[LNH_MAX_LEVELS];               // pool slots per bucket of that level
     uint64_t pool_off[LNH_MAX_LEVELS];          // byte offset of that level's pool region (16-byte aligned)
-    uint64_t rows_off[LNH_MAX_LEVELS];          // fp16 tables: byte offset of the level's row-index array (SoA pool)
-    uint64_t spill_off[LNH_MAX_LEVELS];         // byte offset of the level's spill list (PoolEntry<T> with level-local rows)
+    uint64_t rows_off[LNH_MAX_LEVELS];          // byte offset of the level's 2-byte (row | code << 13) stream
+    uint64_t spill_off[LNH_MAX_LEVELS];         // byte offset of the level's spill list (SpillEntry<T>, level-local rows)
     uint64_t partial_off;                       // byte offset of the slice images (kBucketRows * 2 int64 each)
     uint32_t spill_cap;                         // entries per spill list (= worst case of a level: B * 2^D)
     uint32_t partial_slots;
 };
 
+// ---- pool entries.  One entry carries the contributions of an x-NEIGHBOUR PAIR of corners (c0 = even corner index,
+// c1 = c0 | 1): their rows differ in a way a 3-bit code describes, so the pair shares ONE 13-bit row field:
+//   hashed power-of-two level:  r1 = r0 ^ ((2 << code) - 1)   (the x term of the hash is the x coordinate itself, so
+//                               r0 ^ r1 = x ^ (x + 1) = 2^(t+1) - 1 with t = trailing ones of x; code = t <= 6)
+//   every other level:          r1 = r0 + 1                    (dense x stride; code = 0)
+//   code 7:                     single — only the first value applies (pairs the code cannot describe: t >= 7, one in
+//                               128; a dense pair straddling a bucket boundary; every corner of the generic level
+//                               classes: tiled grids, align_corners, smoothstep, non-power-of-two hash tables)
+// Pool streams per level: values (two channel pairs: 8 bytes for fp16 tables, 16 for fp32) | 2-byte (row | code << 13):
+// 10 bytes per PAIR of corners through HBM instead of 12, and half the LDS rank / stage / row-decode work per corner.
+constexpr uint32_t kCodeSingle = 7;
+
 template <typename T>
-struct PoolEntry;
+struct V2Of;
 template <>
-struct PoolEntry<half_t> {
-    uint32_t row;
-    half2_t v;
+struct V2Of<half_t> {
+    typedef half2_t type;
 };
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 template <>
-struct PoolEntry<float> {
-    uint32_t row;
-    float v0, v1;
+struct V2Of<float> {
+    typedef f32x2_t type;
 };
-__device__ __forceinline__ void entry_set(PoolEntry<half_t> &e, uint32_t row, float a, float b) {
-    e.row = row;
-    e.v = half2_t{(half_t)a, (half_t)b};
-}
-__device__ __forceinline__ void entry_set(PoolEntry<float> &e, uint32_t row, float a, float b) {
-    e.row = row;
-    e.v0 = a;
-    e.v1 = b;
-}
+template <typename T>
+using v2_t = typename V2Of<T>::type;
+
+// spill-list entry: level-local row (19 bits) | code << 29, then the two channel pairs
+template <typename T>
+struct SpillEntry {
+    uint32_t key;
+    v2_t<T> a, b;
+};
+
 // value * 2^24 of an fp16 number as an exact 64-bit integer in 5 VALU operations: x = h * 2^24 is an integer with
 // |x| < 2^40, so the double 1.5 * 2^52 + x is exact and its 52 mantissa bits hold 2^51 + x — low word = x mod 2^32, the 20
 // bits above = 2^19 + floor(x / 2^32).  (The bit-twiddling form — (1024 | m) << (e - 1), negate — cost 12 per value and
@@ -511,41 +523,48 @@ __device__ __forceinline__ long long half_to_fixed24(half_t h) {
     const int hi = (int)((uint32_t)(bits >> 32) & 0xFFFFFu) - 0x80000;
     return (long long)(((unsigned long long)(uint32_t)hi << 32) | (bits & 0xFFFFFFFFull));
 }
-__device__ __forceinline__ void entry_fixed(const PoolEntry<half_t> &e, int, long long &qa, long long &qb) {
-    qa = half_to_fixed24(e.v[0]);
-    qb = half_to_fixed24(e.v[1]);
+// fixed-point images: fp16 contributions are exact multiples of 2^-24; fp32 ones get 2^-40 resolution, +-8e6 of range
+template <typename T>
+__device__ __forceinline__ void to_fixed(const v2_t<T> &v, long long &qa, long long &qb) {
+    if constexpr (sizeof(T) == 2) {
+        qa = half_to_fixed24(v[0]);
+        qb = half_to_fixed24(v[1]);
+    } else {
+        qa = (long long)ldexp((double)v[0], 40);
+        qb = (long long)ldexp((double)v[1], 40);
+    }
 }
-__device__ __forceinline__ void entry_fixed(const PoolEntry<float> &e, int K, long long &qa, long long &qb) {
-    qa = (long long)ldexp((double)e.v0, K);
-    qb = (long long)ldexp((double)e.v1, K);
+template <typename T>
+__device__ __forceinline__ v2_t<T> make_v2(float a, float b) {
+    v2_t<T> r = {(T)a, (T)b};
+    return r;
 }
-__device__ __forceinline__ half2_t pool_value(const PoolEntry<half_t> &e) { return e.v; }
-__device__ __forceinline__ half2_t pool_value(const PoolEntry<float> &) { return half2_t{0, 0}; }  // (unused)
-__device__ __forceinline__ void entry_get(const PoolEntry<half_t> &e, float &a, float &b) {
-    a = (float)e.v[0];
-    b = (float)e.v[1];
-}
-__device__ __forceinline__ void entry_get(const PoolEntry<float> &e, float &a, float &b) {
-    a = e.v0;
-    b = e.v1;
+// second row of a pair (see above); `hashed` is workgroup-uniform
+__device__ __forceinline__ uint32_t pair_row(uint32_t r0, uint32_t code, bool hashed) {
+    return hashed ? r0 ^ ((2u << code) - 1u) : r0 + 1u;
 }
 
-// PPT points per thread (same level, 1024 points apart so that lanes stay consecutive samples): every workgroup
-// reserves its pool slots with ONE global atomic per touched bucket for 1024*PPT points — the cursor atomics are
-// device atomics too (~20 G/s), so fewer, larger reservations matter.
-template <typename T, int D, int PPT, int NTHREADS>
-__global__ void __launch_bounds__(NTHREADS)
-k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs, T *__restrict__ grad_table,
-                   uint32_t B, GridMeta meta, BucketPlan plan, PoolEntry<T> *__restrict__ pool,
-                   uint32_t *__restrict__ cursor, uint32_t *__restrict__ spill_cursor, uint32_t align_rt,
-                   uint32_t interp_rt, uint32_t n_levels, uint32_t level0, uint32_t b_begin, uint32_t B_all) {
+// One thread = one (point, level): every workgroup reserves its pool slots with ONE global atomic per touched bucket
+// for its 1024 points — the cursor atomics are device atomics too (~20 G/s), so fewer, larger reservations matter.
+// CAP = LDS staging slots of a workgroup: 5 * 1024 serves the pair format (4 entries per point + the rare singles) with
+// two workgroups per CU; 8 * 1024 is the worst case (launched when a level of the window is of a generic class: 8
+// singles per point).  Entries beyond CAP (adversarial inputs: every x coordinate = 127 mod 128) bypass the staging and
+// are written to their global slot by the thread that holds them.
+template <typename T, int D, int CAP>
+__global__ void __launch_bounds__(1024)
+k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs, uint32_t B, GridMeta meta,
+                   BucketPlan plan, char *__restrict__ pool_bytes, uint32_t *__restrict__ cursor,
+                   uint32_t *__restrict__ spill_cursor, uint32_t align_rt, uint32_t interp_rt, uint32_t n_levels,
+                   uint32_t level0, uint32_t b_begin, uint32_t B_all) {
     // this launch handles the points [b_begin, b_begin + B) of a batch of B_all (large batches are walked in chunks)
-    constexpr int C = 2, NCORN = 1 << D;
+    constexpr int C = 2, NCORN = 1 << D, NP = NCORN / 2, NTHREADS = 1024;
+    typedef v2_t<T> V2;
     __shared__ uint2 lout[kMaxBucketsPerLevel];           // per bucket: {pool slot - staging slot, staging slots that fit}
     __shared__ uint32_t lsp[kMaxBucketsPerLevel];         // per bucket: spill slot - staging slot of the entries that do not
     __shared__ uint32_t lcnt[kMaxBucketsPerLevel];
     __shared__ uint32_t lstart[kMaxBucketsPerLevel + 1];  // first staging slot per bucket (workgroup-local)
-    __shared__ PoolEntry<T> stage[NTHREADS * PPT * NCORN];
+    __shared__ uint32_t skey[CAP];                        // staged entries, bucket-sorted: row | code << 29
+    __shared__ V2 sa[CAP], sb[CAP];
     // level-fastest workgroup order: concurrently resident workgroups work on the same points at different levels
     // (the coordinates stay in L2, the cursor atomics spread over all levels' counters instead of 64 hot words).
     // (A persistent-workgroup variant of this kernel was measured 1.5x SLOWER: the hardware dispatcher overlaps the
@@ -563,12 +582,11 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
     const uint32_t align = MODE ? 0u : align_rt, interp = MODE ? 0u : interp_rt;
     if (threadIdx.x < kMaxBucketsPerLevel) lcnt[threadIdx.x] = 0;
 
-    float v0[PPT][NCORN], v1[PPT][NCORN];
-    uint32_t row[PPT][NCORN];
-    bool emit[PPT];
-#pragma unroll
-    for (int q = 0; q < PPT; q++) {
-        const uint32_t bl = (chunk * PPT + q) * blockDim.x + threadIdx.x;
+    float v0[NCORN], v1[NCORN];
+    uint32_t row[NCORN];
+    bool emit;
+    {
+        const uint32_t bl = chunk * blockDim.x + threadIdx.x;
         const bool in_range = bl < B;
         const uint32_t bc = b_begin + (in_range ? bl : 0);  // unconditional loads from a clamped index + selects
         float x[D];
@@ -590,7 +608,7 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
         (void)locate<D>(x, lv, align != 0, interp, cell);
         const float g0 = ok ? (float)gv.v[0] : 0.0f, g1 = ok ? (float)gv.v[1] : 0.0f;
         // a sample whose upstream gradient is exactly zero (fp16 underflow behind an opaque surface, masked-out
-        // rays) contributes nothing: drop it here instead of moving 8 zero entries through the pool
+        // rays) contributes nothing: drop it here instead of moving zero entries through the pool
         ok = ok && (g0 != 0.0f || g1 != 0.0f);
         // ---- run-merge inside 16-lane rows: consecutive lanes are consecutive samples of a ray, which share their cell
         //      on the coarser levels.  Runs are cut at DPP row starts (pure-VALU row_shr scan, no cross-row traffic), and
@@ -616,67 +634,92 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
         const unsigned long long below = heads & ((2ull << lane) - 1ull);
         const int run_start = 63 - __builtin_clzll(below);
         const unsigned long long heads_above = (lane == 63) ? 0ull : (heads >> (lane + 1));
-        emit[q] = ok && ((lane == 63) || (heads_above & 1ull));
+        emit = ok && ((lane == 63) || (heads_above & 1ull));
 #pragma unroll
         for (uint32_t c = 0; c < (uint32_t)NCORN; c++) {
             const float w = corner_weight<D>(cell, c);
-            v0[q][c] = w * g0;
-            v1[q][c] = w * g1;
+            v0[c] = w * g0;
+            v1[c] = w * g1;
             if constexpr (sizeof(T) == 2) {  // per-contribution rounding of the reference (gridencoder.cu:350)
-                v0[q][c] = (float)(half_t)v0[q][c];
-                v1[q][c] = (float)(half_t)v1[q][c];
+                v0[c] = (float)(half_t)v0[c];
+                v1[c] = (float)(half_t)v1[c];
             }
-            row[q][c] = corner_row<D>(cell, lv, c);
+            row[c] = corner_row<D>(cell, lv, c);
         }
         if (any_merge) {  // wave-uniform
             const SegScanMask sm = wave_segscan_mask(lane, run_start);
             float vv[2 * NCORN];
 #pragma unroll
             for (uint32_t c = 0; c < (uint32_t)NCORN; c++) {
-                vv[2 * c] = v0[q][c];
-                vv[2 * c + 1] = v1[q][c];
+                vv[2 * c] = v0[c];
+                vv[2 * c + 1] = v1[c];
             }
             row_segscan_add_n(vv, sm);
             if (!row_local) cross_segscan_add_n(vv, sm);
 #pragma unroll
             for (uint32_t c = 0; c < (uint32_t)NCORN; c++) {
-                v0[q][c] = vv[2 * c];
-                v1[q][c] = vv[2 * c + 1];
+                v0[c] = vv[2 * c];
+                v1[c] = vv[2 * c + 1];
             }
         }
     }
+    // ---- pair the x-neighbours: entry p carries corners 2p and 2p + 1 unless the code cannot describe their rows
+    uint32_t code[NP];
+    bool single[NP], any_single = false;
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+        const uint32_t r0 = row[2 * p], r1 = row[2 * p + 1];
+        if constexpr (MODE == 1) {
+            const uint32_t t = (uint32_t)__builtin_popcount(r0 ^ r1) - 1u;  // r0 ^ r1 = 2^(t+1) - 1
+            single[p] = t >= kCodeSingle;
+            code[p] = single[p] ? kCodeSingle : t;
+        } else if constexpr (MODE == 2) {
+            single[p] = (r0 & (kBucketRows - 1)) == kBucketRows - 1;        // r1 = r0 + 1 opens the next bucket
+            code[p] = single[p] ? kCodeSingle : 0u;
+        } else {
+            single[p] = true;
+            code[p] = kCodeSingle;
+        }
+        any_single |= single[p];
+    }
+    const bool wave_singles = MODE == 0 ? true : (__ballot(emit && any_single) != 0ull);  // wave-uniform, rare
     __syncthreads();
     // ---- reserve pool slots: LDS rank per (bucket), one global atomic per touched bucket per workgroup
-    uint32_t rank[PPT][NCORN];
+    uint32_t rank[NP], rank_x[NP];
 #pragma unroll
-    for (int q = 0; q < PPT; q++) {
+    for (int p = 0; p < NP; p++) {
+        // On dense (coarse) levels every emitting lane of the wave usually targets the SAME bucket: 64 returning
+        // LDS atomics on one counter serialise, so aggregate — one lane adds the population count, the others
+        // take their rank from the lane mask.  Mixed buckets (hashed levels) fall back to per-lane atomics.
+        const uint32_t bk = row[2 * p] >> kBucketRowsLog2;
+        rank[p] = 0;
+        if (lv.flags & LV_HASH) {  // workgroup-uniform: hashed level, buckets are mixed -> per-lane atomics
+            if (emit) rank[p] = atomicAdd(&lcnt[bk], 1u);
+            continue;
+        }
+        const unsigned long long em = __ballot(emit);
+        if (em == 0ull) continue;  // wave-uniform
+        const int leader = __builtin_ctzll(em);
+        const uint32_t bk0 = __shfl(bk, leader, 64);
+        const bool uniform = __ballot(emit && bk != bk0) == 0ull;
+        if (uniform) {
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(&lcnt[bk0], (uint32_t)__builtin_popcountll(em));
+            base = __shfl(base, leader, 64);
+            rank[p] = base + (uint32_t)__builtin_popcountll(em & ((1ull << lane) - 1ull));
+        } else if (emit) {
+            rank[p] = atomicAdd(&lcnt[bk], 1u);
+        }
+    }
+    if (wave_singles) {  // the second corners of pairs that travel as two singles
 #pragma unroll
-        for (uint32_t c = 0; c < (uint32_t)NCORN; c++) {
-            // On dense (coarse) levels every emitting lane of the wave usually targets the SAME bucket: 64 returning
-            // LDS atomics on one counter serialise, so aggregate — one lane adds the population count, the others
-            // take their rank from the lane mask.  Mixed buckets (hashed levels) fall back to per-lane atomics.
-            const uint32_t bk = row[q][c] >> kBucketRowsLog2;
-            if (lv.flags & LV_HASH) {  // workgroup-uniform: hashed level, buckets are mixed -> per-lane atomics
-                if (emit[q]) rank[q][c] = atomicAdd(&lcnt[bk], 1u);
-                continue;
-            }
-            const unsigned long long em = __ballot(emit[q]);
-            if (em == 0ull) continue;  // wave-uniform
-            const int leader = __builtin_ctzll(em);
-            const uint32_t bk0 = __shfl(bk, leader, 64);
-            const bool uniform = __ballot(emit[q] && bk != bk0) == 0ull;
-            if (uniform) {
-                uint32_t base = 0;
-                if (lane == leader) base = atomicAdd(&lcnt[bk0], (uint32_t)__builtin_popcountll(em));
-                base = __shfl(base, leader, 64);
-                rank[q][c] = base + (uint32_t)__builtin_popcountll(em & ((1ull << lane) - 1ull));
-            } else if (emit[q]) {
-                rank[q][c] = atomicAdd(&lcnt[bk], 1u);
-            }
+        for (int p = 0; p < NP; p++) {
+            rank_x[p] = 0;
+            if (emit && single[p]) rank_x[p] = atomicAdd(&lcnt[row[2 * p + 1] >> kBucketRowsLog2], 1u);
         }
     }
     __syncthreads();
-    // global reservation + exclusive scan of the workgroup's bucket counts (first wave; 128 counters = 2 per lane)
+    // global reservation + exclusive scan of the workgroup's bucket counts (first wave: one bucket counter per lane)
     if (threadIdx.x < 64) {
         static_assert(kMaxBucketsPerLevel == 64, "one bucket counter per lane of the first wave");
         const uint32_t n0 = lcnt[lane];
@@ -698,66 +741,85 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
         lsp[lane] = sp0 + (oincl - over) - (st + fit);
     }
     __syncthreads();
-    // ---- stage the entries in LDS grouped by bucket, then stream them out: consecutive lanes write consecutive pool
-    //      slots (a per-lane scatter of 8-byte stores costs one cache-line transaction per lane)
-#pragma unroll
-    for (int q = 0; q < PPT; q++)
-        if (emit[q]) {
-#pragma unroll
-            for (uint32_t c = 0; c < (uint32_t)NCORN; c++) {
-                PoolEntry<T> e;
-                entry_set(e, row[q][c], v0[q][c], v1[q][c]);  // full row: its high bits name the bucket at write-out
-                stage[lstart[row[q][c] >> kBucketRowsLog2] + rank[q][c]] = e;
+    V2 *pvals = reinterpret_cast<V2 *>(pool_bytes + plan.pool_off[level]);                            // [slot][2]
+    unsigned short *prows = reinterpret_cast<unsigned short *>(pool_bytes + plan.rows_off[level]);    // [slot]
+    SpillEntry<T> *spill = reinterpret_cast<SpillEntry<T> *>(pool_bytes + plan.spill_off[level]);
+    // entry at staging position `pos` -> its pool slot (bucket-local row | code << 13) or, pool full, the spill list
+    auto to_global = [&](uint32_t pos, uint32_t k, V2 a, V2 b, uint2 o) {
+        if (pos < o.y) {
+            const uint32_t slot = o.x + pos;
+            pvals[2 * (size_t)slot] = a;
+            pvals[2 * (size_t)slot + 1] = b;
+            prows[slot] = (unsigned short)((k & (kBucketRows - 1)) | ((k >> 29) << kBucketRowsLog2));
+        } else {
+            const uint32_t sp = lsp[(k & 0x7ffffu) >> kBucketRowsLog2] + pos;
+            if (sp < plan.spill_cap) {  // (always true: a level emits at most B * 2^D entries)
+                spill[sp].key = k;
+                spill[sp].a = a;
+                spill[sp].b = b;
             }
         }
+    };
+    // ---- stage the entries in LDS grouped by bucket, then stream them out: consecutive lanes write consecutive pool
+    //      slots (a per-lane scatter of small stores costs one cache-line transaction per lane)
+    auto put = [&](uint32_t r, uint32_t cd, V2 a, V2 b, uint32_t rk) {
+        const uint32_t bk = r >> kBucketRowsLog2, pos = lstart[bk] + rk, k = r | (cd << 29);
+        if (pos < (uint32_t)CAP) {
+            skey[pos] = k;
+            sa[pos] = a;
+            sb[pos] = b;
+        } else {
+            to_global(pos, k, a, b, lout[bk]);
+        }
+    };
+    if (emit) {
+#pragma unroll
+        for (int p = 0; p < NP; p++)
+            put(row[2 * p], code[p], make_v2<T>(v0[2 * p], v1[2 * p]), make_v2<T>(v0[2 * p + 1], v1[2 * p + 1]), rank[p]);
+    }
+    if (wave_singles && emit) {
+#pragma unroll
+        for (int p = 0; p < NP; p++)
+            if (single[p])
+                put(row[2 * p + 1], kCodeSingle, make_v2<T>(v0[2 * p + 1], v1[2 * p + 1]), make_v2<T>(0.0f, 0.0f),
+                    rank_x[p]);
+    }
     __syncthreads();
-    // fp16 tables keep the pool as two streams (4-byte value pairs | 2-byte bucket-local rows): 6 bytes per entry
-    // instead of 8 through HBM, twice
-    char *pool_bytes = reinterpret_cast<char *>(pool);
-    PoolEntry<T> *lp = reinterpret_cast<PoolEntry<T> *>(pool_bytes + plan.pool_off[level]);
-    half2_t *lvals = reinterpret_cast<half2_t *>(pool_bytes + plan.pool_off[level]);
-    unsigned short *lrows = reinterpret_cast<unsigned short *>(pool_bytes + plan.rows_off[level]);
-    PoolEntry<T> *spill = reinterpret_cast<PoolEntry<T> *>(pool_bytes + plan.spill_off[level]);
-    const uint32_t total = lstart[kMaxBucketsPerLevel];
-    // every thread moves up to PPT * 2^D entries: all their LDS reads (entry, then the bucket's slot map) are issued
-    // before the first use — one round trip for the batch instead of two dependent ones per entry
-    constexpr int NW = PPT * NCORN;
-    PoolEntry<T> es[NW];
+    const uint32_t total = min(lstart[kMaxBucketsPerLevel], (uint32_t)CAP);
+    // every thread moves up to CAP / 1024 staged entries: all their LDS reads (entry, then the bucket's slot map) are
+    // issued before the first use — one round trip for the batch instead of two dependent ones per entry
+    constexpr int NW = CAP / NTHREADS;
+    static_assert(CAP % NTHREADS == 0, "staging slots are dealt to the threads in rounds");
+    uint32_t ks[NW];
+    V2 as[NW], bs[NW];
     uint2 os[NW];
 #pragma unroll
     for (int i = 0; i < NW; i++) {
-        const uint32_t pos = threadIdx.x + (uint32_t)i * NTHREADS;
-        es[i] = stage[pos < total ? pos : 0u];
+        const uint32_t pos = threadIdx.x + (uint32_t)i * NTHREADS, pc = pos < total ? pos : 0u;
+        ks[i] = skey[pc];
+        as[i] = sa[pc];
+        bs[i] = sb[pc];
     }
 #pragma unroll
-    for (int i = 0; i < NW; i++) os[i] = lout[(es[i].row >> kBucketRowsLog2) & (kMaxBucketsPerLevel - 1)];
+    for (int i = 0; i < NW; i++) os[i] = lout[((ks[i] & 0x7ffffu) >> kBucketRowsLog2) & (kMaxBucketsPerLevel - 1)];
 #pragma unroll
     for (int i = 0; i < NW; i++) {
         const uint32_t pos = threadIdx.x + (uint32_t)i * NTHREADS;
         if (pos >= total) break;
-        PoolEntry<T> e = es[i];
-        const uint32_t bk = e.row >> kBucketRowsLog2;
-        const uint2 o = os[i];
-        if (pos < o.y) {
-            e.row &= kBucketRows - 1;
-            if constexpr (sizeof(T) == 2) {
-                lvals[o.x + pos] = pool_value(e);  // (non-temporal stores here: scatter +40 us, reduce -8 us)
-                lrows[o.x + pos] = (unsigned short)e.row;
-            } else {
-                lp[o.x + pos] = e;
-            }
-        } else {  // the bucket's pool is full: level-local row + value go to the spill list (consumed by pass 2)
-            const uint32_t sp = lsp[bk] + pos;
-            if (sp < plan.spill_cap) spill[sp] = e;  // (always true: a level emits at most B * 2^D entries)
-        }
+        to_global(pos, ks[i], as[i], bs[i], os[i]);
     }
-    (void)grad_table;
     };
     const bool plain = align_rt == 0 && interp_rt == 0;
     if (plain && (lv_rt.flags & (LV_HASH | LV_POW2)) == (LV_HASH | LV_POW2)) body(std::integral_constant<int, 1>{});
     else if (plain && !(lv_rt.flags & LV_HASH) && (lv_rt.flags & LV_NOWRAP) && (lv_rt.flags & 15u) == (uint32_t)D)
         body(std::integral_constant<int, 2>{});
     else body(std::integral_constant<int, 0>{});
+}
+// true when every corner of the level travels as a single (generic class): 8 entries per point
+__host__ __device__ inline bool level_is_generic(const LevelParams &lv, uint32_t D, bool plain) {
+    if (plain && (lv.flags & (LV_HASH | LV_POW2)) == (LV_HASH | LV_POW2)) return false;
+    if (plain && !(lv.flags & LV_HASH) && (lv.flags & LV_NOWRAP) && (lv.flags & 15u) == D) return false;
+    return true;
 }
 
 // A bucket with many entries (coarse dense levels: every ray passes the same few cells; very large batches) is split
@@ -787,14 +849,14 @@ struct ReduceOrder {
 
 template <typename T>
 __global__ void __launch_bounds__(1024)
-k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, const PoolEntry<T> *__restrict__ pool,
+k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, const char *__restrict__ pool_bytes,
                   const uint32_t *__restrict__ cursor, const uint32_t *__restrict__ spill_cursor,
                   uint32_t *__restrict__ done, uint32_t L, ReduceOrder ord) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     unsigned long long *acc = reinterpret_cast<unsigned long long *>(smem_raw);  // [kBucketRows][2] fixed point
     __shared__ uint32_t sh_sum, sh_item[4], sh_wave[2][16];
-    // fp16 contributions are exact multiples of 2^-24; fp32 ones get 2^-40 resolution and +-8e6 of range
-    constexpr int K = sizeof(T) == 2 ? 24 : 40;
+    constexpr int K = sizeof(T) == 2 ? 24 : 40;  // scale of the fixed-point image (to_fixed)
+    typedef v2_t<T> V2;
     // ---- which (bucket, slice) is this workgroup?
     const bool is_extra = blockIdx.x < ord.n_extra;
     uint32_t bid = ord.bucket0, slice = 0, slot0 = 0;
@@ -839,6 +901,7 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
     for (uint32_t l = 0; l < L; l++)
         if (bid >= plan.first_bucket[l]) level = l;
     const LevelParams lv = meta.lv[level];
+    const bool hashed = (lv.flags & (LV_HASH | LV_POW2)) == (LV_HASH | LV_POW2);  // pair rule of the level (pair_row)
     const uint32_t bk = bid - plan.first_bucket[level], cap = plan.cap[level];
     const uint32_t n_tot = cursor[bid];          // every entry reserved for this bucket, pool + spill
     const uint32_t n_all = min(n_tot, cap);      // ... of which in the pool
@@ -849,54 +912,67 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
     const uint32_t n = i_end - i_begin;
     const uint32_t rows = min(kBucketRows, lv.hashmap_size - bk * kBucketRows);
     // channel-planar image: acc[row] | acc[kBucketRows + row].  With the two channels of a row interleaved, each
-    // ds_add_u64 instruction of a wave would touch only every other pair of banks (row*4 + {0,1} mod 32) and pay twice
-    // the conflicts; planar, the 64 random rows of an instruction spread over all 32 banks.
+    // ds_add_u64 instruction of a wave would touch only every other pair of banks and pay twice the conflicts; planar,
+    // the 64 random rows of an instruction spread over all banks.
     for (uint32_t i = threadIdx.x; i < kBucketRows * 2; i += blockDim.x) acc[i] = 0ull;
     __syncthreads();
-    // One workgroup streams its whole slice; what bounds it is the number of bytes in flight per CU, so every lane keeps
-    // UNROLL independent loads outstanding (unconditional, from clamped indices: a predicated load would be branched
-    // around and waited for one by one).
-    if constexpr (sizeof(T) == 2) {
-        // fp16 tables: two streams, read as aligned QUADS of entries (16 bytes of values + 8 bytes of rows per load
-        // pair); slots outside [a_begin, a_end) are masked
-        constexpr uint32_t UNROLL = 4;  // (2 and 8 measured within noise of 4)
-        const char *pool_bytes = reinterpret_cast<const char *>(pool);
-        const uint4 *vals4 = reinterpret_cast<const uint4 *>(pool_bytes + plan.pool_off[level]);
-        const uint2 *rows4 = reinterpret_cast<const uint2 *>(pool_bytes + plan.rows_off[level]);
+    auto add_entry = [&](uint32_t row0, uint32_t code, const V2 &a, const V2 &b) {
+        long long qa, qb;
+        to_fixed<T>(a, qa, qb);
+        atomicAdd(&acc[row0], (unsigned long long)qa);  // ds_add_u64
+        atomicAdd(&acc[kBucketRows + row0], (unsigned long long)qb);
+        if (code != kCodeSingle) {
+            const uint32_t row1 = pair_row(row0, code, hashed) & (kBucketRows - 1);
+            to_fixed<T>(b, qa, qb);
+            atomicAdd(&acc[row1], (unsigned long long)qa);
+            atomicAdd(&acc[kBucketRows + row1], (unsigned long long)qb);
+        }
+    };
+    // One workgroup streams its whole slice; every lane keeps UNROLL independent QUADS of entries outstanding
+    // (unconditional, non-temporal loads from clamped indices: a predicated load would be branched around and waited
+    // for one by one; the pool is written once and read once).  A quad = 4 entries = 4 * sizeof(2 V2) bytes of values
+    // (aligned 16-byte loads) + 8 bytes of rows; slots outside [a_begin, a_end) are masked.
+    {
+        constexpr uint32_t UNROLL = sizeof(T) == 2 ? 2 : 1;
+        constexpr uint32_t VQ = sizeof(V2) * 2 * 4 / 16;  // 16-byte loads per quad: 2 (fp16) / 4 (fp32)
+        const uint4_t *vals4 = reinterpret_cast<const uint4_t *>(pool_bytes + plan.pool_off[level]);
+        const uint2_t *rows4 = reinterpret_cast<const uint2_t *>(pool_bytes + plan.rows_off[level]);
         const uint32_t a_begin = bk * cap + i_begin, a_end = a_begin + n;  // level-relative slots (< 2^32, checked)
         const uint32_t q_begin = a_begin >> 2, q_end = (a_end + 3) >> 2;
         const uint32_t nquads = n ? q_end - q_begin : 0u, stride = blockDim.x * UNROLL;
         // double-buffered: the loads of batch i+1 are in flight while the LDS adds of batch i execute
-        uint4 rv[2][UNROLL];
-        uint2 rr[2][UNROLL];
-        auto fetch = [&](uint32_t j0, uint4 (&v)[UNROLL], uint2 (&r)[UNROLL]) {
+        uint4_t rv[2][UNROLL][VQ];
+        uint2_t rr[2][UNROLL];
+        auto fetch = [&](uint32_t j0, uint4_t (&v)[UNROLL][VQ], uint2_t (&r)[UNROLL]) {
 #pragma unroll
             for (uint32_t u = 0; u < UNROLL; u++) {
                 const uint32_t j = j0 + u * blockDim.x, q = q_begin + (j < nquads ? j : nquads - 1);
-                // the pool is written once and read once: non-temporal loads (measured: reduce 415 -> 375 us)
-                const uint4_t tv = __builtin_nontemporal_load(reinterpret_cast<const uint4_t *>(vals4) + q);
-                const uint2_t tr = __builtin_nontemporal_load(reinterpret_cast<const uint2_t *>(rows4) + q);
-                v[u] = make_uint4(tv.x, tv.y, tv.z, tv.w);
-                r[u] = make_uint2(tr.x, tr.y);
+#pragma unroll
+                for (uint32_t w = 0; w < VQ; w++) v[u][w] = __builtin_nontemporal_load(vals4 + (size_t)q * VQ + w);
+                r[u] = __builtin_nontemporal_load(rows4 + q);
             }
         };
-        auto consume = [&](uint32_t j0, const uint4 (&v)[UNROLL], const uint2 (&r)[UNROLL]) {
+        auto consume = [&](uint32_t j0, const uint4_t (&v)[UNROLL][VQ], const uint2_t (&r)[UNROLL]) {
 #pragma unroll
             for (uint32_t u = 0; u < UNROLL; u++) {
                 const uint32_t j = j0 + u * blockDim.x;
                 const uint32_t e0 = (q_begin + j) * 4;
-                const uint32_t vw[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                uint32_t words[VQ * 4];
+#pragma unroll
+                for (uint32_t w = 0; w < VQ; w++) {
+                    words[4 * w] = v[u][w].x; words[4 * w + 1] = v[u][w].y;
+                    words[4 * w + 2] = v[u][w].z; words[4 * w + 3] = v[u][w].w;
+                }
                 const uint32_t rw[2] = {r[u].x, r[u].y};
 #pragma unroll
                 for (int h = 0; h < 4; h++) {
                     if (j < nquads && e0 + h >= a_begin && e0 + h < a_end) {
-                        PoolEntry<T> e;
-                        e.v = __builtin_bit_cast(half2_t, vw[h]);
-                        const uint32_t row = (rw[h >> 1] >> (16 * (h & 1))) & 0xffffu;
-                        long long qa, qb;
-                        entry_fixed(e, K, qa, qb);
-                        atomicAdd(&acc[row], (unsigned long long)qa);  // ds_add_u64
-                        atomicAdd(&acc[kBucketRows + row], (unsigned long long)qb);
+                        constexpr uint32_t EW = VQ;  // dwords per entry: 2 (fp16: a | b) / 4 (fp32: a0 a1 | b0 b1)
+                        V2 a, b;
+                        __builtin_memcpy(&a, &words[h * EW], sizeof(V2));
+                        __builtin_memcpy(&b, &words[h * EW + EW / 2], sizeof(V2));
+                        const uint32_t key = (rw[h >> 1] >> (16 * (h & 1))) & 0xffffu;
+                        add_entry(key & (kBucketRows - 1), key >> kBucketRowsLog2, a, b);
                     }
                 }
             }
@@ -913,42 +989,17 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
             consume(j1, rv[1], rr[1]);
             j0 = j2;
         }
-
-    } else {
-        constexpr uint32_t UNROLL = 8;
-        const PoolEntry<T> *src = reinterpret_cast<const PoolEntry<T> *>(reinterpret_cast<const char *>(pool) +
-                                                                         plan.pool_off[level]) + (size_t)bk * cap + i_begin;
-        const uint32_t stride = blockDim.x * UNROLL;
-        for (uint32_t i0 = threadIdx.x; i0 < n; i0 += stride) {
-            PoolEntry<T> e[UNROLL];
-#pragma unroll
-            for (uint32_t u = 0; u < UNROLL; u++) {
-                const uint32_t i = i0 + u * blockDim.x;
-                e[u] = src[i < n ? i : n - 1];
-            }
-#pragma unroll
-            for (uint32_t u = 0; u < UNROLL; u++) {
-                const uint32_t i = i0 + u * blockDim.x;
-                if (i < n) {
-                    long long qa, qb;
-                    entry_fixed(e[u], K, qa, qb);
-                    atomicAdd(&acc[e[u].row], (unsigned long long)qa);  // ds_add_u64
-                    atomicAdd(&acc[kBucketRows + e[u].row], (unsigned long long)qb);
-                }
-            }
-        }
     }
     // ---- this bucket overflowed its pool: its remaining entries sit somewhere in the level's spill list (among those
     //      of the level's other overflowing buckets).  Each slice filters its share of the list.
     if (n_tot > cap) {  // workgroup-uniform
-        const PoolEntry<T> *spill = reinterpret_cast<const PoolEntry<T> *>(reinterpret_cast<const char *>(pool) +
-                                                                           plan.spill_off[level]);
+        const SpillEntry<T> *spill = reinterpret_cast<const SpillEntry<T> *>(pool_bytes + plan.spill_off[level]);
         const uint32_t s_all = min(spill_cursor[level], plan.spill_cap);
         const uint32_t s_begin = (uint32_t)((uint64_t)s_all * slice / slices);
         const uint32_t s_end = (uint32_t)((uint64_t)s_all * (slice + 1) / slices);
         constexpr uint32_t UNROLL = 4;
         for (uint32_t i0 = s_begin + threadIdx.x; i0 < s_end; i0 += blockDim.x * UNROLL) {
-            PoolEntry<T> e[UNROLL];
+            SpillEntry<T> e[UNROLL];
 #pragma unroll
             for (uint32_t u = 0; u < UNROLL; u++) {
                 const uint32_t i = i0 + u * blockDim.x;
@@ -957,13 +1008,8 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
 #pragma unroll
             for (uint32_t u = 0; u < UNROLL; u++) {
                 const uint32_t i = i0 + u * blockDim.x;
-                if (i < s_end && (e[u].row >> kBucketRowsLog2) == bk) {
-                    const uint32_t row = e[u].row & (kBucketRows - 1);
-                    long long qa, qb;
-                    entry_fixed(e[u], K, qa, qb);
-                    atomicAdd(&acc[row], (unsigned long long)qa);
-                    atomicAdd(&acc[kBucketRows + row], (unsigned long long)qb);
-                }
+                const uint32_t r = e[u].key & 0x7ffffu;
+                if (i < s_end && (r >> kBucketRowsLog2) == bk) add_entry(r & (kBucketRows - 1), e[u].key >> 29, e[u].a, e[u].b);
             }
         }
     }
@@ -994,7 +1040,7 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
         // slice image -> workspace (coalesced 16-byte stores of the whole image); the slice that finishes LAST adds the
         // images up (integers: the sum does not depend on which slice that is) and adds the rows into the table
         if (slot0 + slices > plan.partial_slots) return;  // (never: plan_buckets sizes the region for the worst case)
-        char *images = const_cast<char *>(reinterpret_cast<const char *>(pool)) + plan.partial_off;
+        char *images = const_cast<char *>(pool_bytes) + plan.partial_off;
         uint4 *dst = reinterpret_cast<uint4 *>(images) + (size_t)(slot0 + slice) * kBucketRows;
         const uint4 *src = reinterpret_cast<const uint4 *>(acc);
         for (uint32_t i = threadIdx.x; i < kBucketRows; i += blockDim.x) dst[i] = src[i];
@@ -1027,46 +1073,45 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
 // Host: bucket layout + pool sizing.  Returns the number of bytes of workspace needed:
 //   [cursor: one u32 per bucket | spill cursor: one u32 per level | slice arrival counter: one u32 per bucket]
 //                                                                      (zeroed by every launch)
-//   [pool of every level] [spill list of every level] [slice images]
-// Pool slots per bucket = even split of the level's worst case (B * 2^D entries) + 12.5 % + 12 sigma of a Poisson
-// count (hashed levels are statistically even; correlated corners of neighbouring samples widen the spread, so the
-// margin is generous) — whatever does not fit goes to the spill list, which holds the level's worst case.
+//   [pool of every level: value stream | row stream] [spill list of every level] [slice images]
+// Pool slots per bucket = even split of the level's expected entries (pair format: B * 2^D / 2, + 1/64 for the pairs
+// that travel as two singles; generic level classes: B * 2^D) + 12.5 % + 12 sigma of a Poisson count (hashed levels are
+// statistically even; correlated corners of neighbouring samples widen the spread, so the margin is generous) —
+// whatever does not fit goes to the spill list, which holds the level's worst case (B * 2^D entries).
 constexpr uint32_t kCursorAlign = 256;
 template <typename T>
-uint64_t plan_buckets(BucketPlan &plan, const GridMeta &m, uint32_t L, uint32_t B, uint32_t D, uint32_t &total_buckets) {
-    const uint64_t per_level = (uint64_t)B << D;  // worst-case entries of one level
+uint64_t plan_buckets(BucketPlan &plan, const GridMeta &m, uint32_t L, uint32_t B, uint32_t D, bool plain,
+                      uint32_t &total_buckets) {
+    const uint64_t worst = (uint64_t)B << D;  // worst-case entries of one level (all singles)
     uint64_t bytes = 0;
     uint32_t nbt = 0;
     for (uint32_t l = 0; l < L; l++) {
         const uint32_t nb = (m.lv[l].hashmap_size + kBucketRows - 1) / kBucketRows;
         plan.first_bucket[l] = nbt;
-        const uint64_t mean = (per_level + nb - 1) / nb;
+        const uint64_t expect = level_is_generic(m.lv[l], D, plain) ? worst : worst / 2 + worst / 128;
+        const uint64_t mean = (expect + nb - 1) / nb;
         uint64_t cap = mean + mean / 8 + (uint64_t)(12.0 * sqrt((double)mean)) + 64;
-        if (cap > per_level) cap = per_level;
+        if (cap > worst) cap = worst;
         if (cap > 0xffffffffull) cap = 0xffffffffull;
         plan.cap[l] = (uint32_t)cap;
         const uint64_t slots = cap * nb;
+        // value stream (2 V2 per slot) | row stream (2 B per slot), each padded so that aligned quad reads stay inside
         plan.pool_off[l] = bytes;
-        if (sizeof(T) == 2) {  // values (4 B) | rows (2 B), each stream padded so that aligned quad reads stay inside
-            const uint64_t vals_bytes = (slots * 4 + 16 + 15) / 16 * 16;
-            plan.rows_off[l] = bytes + vals_bytes;
-            bytes += vals_bytes + (slots * 2 + 8 + 15) / 16 * 16;
-        } else {
-            plan.rows_off[l] = 0;
-            bytes += (slots * sizeof(PoolEntry<T>) + 15) / 16 * 16;
-        }
+        const uint64_t vals_bytes = (slots * 2 * sizeof(v2_t<T>) + 64 + 15) / 16 * 16;
+        plan.rows_off[l] = bytes + vals_bytes;
+        bytes += vals_bytes + (slots * 2 + 8 + 15) / 16 * 16;
         nbt += nb;
     }
     plan.first_bucket[L] = nbt;
     total_buckets = nbt;
-    plan.spill_cap = per_level > 0xffffffffull ? 0xffffffffu : (uint32_t)per_level;
+    plan.spill_cap = worst > 0xffffffffull ? 0xffffffffu : (uint32_t)worst;
     for (uint32_t l = 0; l < L; l++) {
         plan.spill_off[l] = bytes;
-        bytes += ((uint64_t)plan.spill_cap * sizeof(PoolEntry<T>) + 15) / 16 * 16;
+        bytes += ((uint64_t)plan.spill_cap * sizeof(SpillEntry<T>) + 15) / 16 * 16;
     }
     // slice images: a split bucket has n > kSliceEntries entries and ceil(n / kSliceEntries) < 2 n / kSliceEntries
     // slices, so all split buckets together have fewer than 2 * (entries of all levels) / kSliceEntries of them
-    uint64_t slots = 2 * (per_level * L) / kSliceEntries + 1;
+    uint64_t slots = 2 * (worst * L) / kSliceEntries + 1;
     if (slots > (uint64_t)nbt * kMaxSlices) slots = (uint64_t)nbt * kMaxSlices;
     plan.partial_slots = (uint32_t)slots;
     plan.partial_off = bytes;
@@ -1128,7 +1173,8 @@ int launch_backward_bucketed_chunk(const T *grad, const float *inputs, T *ge, ui
                                    uint32_t B_all, uint32_t B_plan) {
     BucketPlan plan;
     uint32_t nbt = 0;
-    const uint64_t need = plan_buckets<T>(plan, m, L, B_plan, 3, nbt);  // (the plan of a full chunk serves the last, shorter one)
+    const bool plain = align == 0 && interp == 0;
+    const uint64_t need = plan_buckets<T>(plan, m, L, B_plan, 3, plain, nbt);  // (a full chunk's plan serves the last, shorter one)
     if (workspace == nullptr || workspace_bytes < need) {
         lnh_set_error("grid backward: workspace too small (%llu < %llu bytes)", (unsigned long long)workspace_bytes,
                       (unsigned long long)need);
@@ -1151,18 +1197,25 @@ int launch_backward_bucketed_chunk(const T *grad, const float *inputs, T *ge, ui
     const uint64_t cursor_bytes = ((uint64_t)(2 * nbt + L) * 4 + kCursorAlign - 1) / kCursorAlign * kCursorAlign;
     uint32_t *cursor = reinterpret_cast<uint32_t *>(workspace);
     uint32_t *spill_cursor = cursor + nbt, *done = spill_cursor + L;
-    PoolEntry<T> *pool = reinterpret_cast<PoolEntry<T> *>(reinterpret_cast<char *>(workspace) + cursor_bytes);
+    char *pool = reinterpret_cast<char *>(workspace) + cursor_bytes;
     (void)hipGetLastError();
     if (hipMemsetAsync(cursor, 0, cursor_bytes, s) != hipSuccess) {
         lnh_set_error("grid backward: hipMemsetAsync failed");
         return LNH_ERR_LAUNCH;
     }
     // 1024 threads x 1 point: the per-workgroup cost that matters is the one returning device atomic per touched
-    // bucket (measured: 256- and 512-thread workgroups are 2.3x / 1.5x slower), and 8 entries/thread keep the LDS
-    // staging buffer at 64 KiB (two workgroups per CU)
+    // bucket (measured: 256- and 512-thread workgroups are 2.3x / 1.5x slower); 5 staged pair entries per thread keep
+    // the LDS staging at 60 KiB (two workgroups per CU).  A window with a generic-class level (8 singles per point)
+    // takes the instantiation with the larger staging area.
     const uint32_t n_win = level_end - level_begin;
-    LNH_LAUNCH((k_grid_bwd_scatter<T, 3, 1, 1024>), dim3(div_up(B, 1024) * n_win), dim3(1024), 0, s, grad, inputs, ge, B,
-               m, plan, pool, cursor, spill_cursor, align, interp, n_win, level_begin, b_begin, B_all);
+    bool generic = false;
+    for (uint32_t l = level_begin; l < level_end; l++) generic |= level_is_generic(m.lv[l], 3, plain);
+    if (generic)
+        LNH_LAUNCH((k_grid_bwd_scatter<T, 3, 6144>), dim3(div_up(B, 1024) * n_win), dim3(1024), 0, s, grad, inputs, B, m,
+                   plan, pool, cursor, spill_cursor, align, interp, n_win, level_begin, b_begin, B_all);
+    else
+        LNH_LAUNCH((k_grid_bwd_scatter<T, 3, 5120>), dim3(div_up(B, 1024) * n_win), dim3(1024), 0, s, grad, inputs, B, m,
+                   plan, pool, cursor, spill_cursor, align, interp, n_win, level_begin, b_begin, B_all);
     int rc = lnh_check_launch("lnh_grid_encode_backward_ws(scatter)");
     if (rc) return rc;
     auto k = k_grid_bwd_reduce<T>;
@@ -1487,7 +1540,14 @@ uint64_t lnh_grid_backward_workspace_size(const int32_t *offsets_host, uint32_t 
     for (uint32_t l = 0; l < L; l++)
         if ((m.lv[l].hashmap_size + kBucketRows - 1) / kBucketRows > kMaxBucketsPerLevel) return 0;
     const uint32_t Bc = chunk_points(B);  // the workspace serves one chunk at a time
-    return dtype == LNH_F16 ? plan_buckets<half_t>(plan, m, L, Bc, D, nbt) : plan_buckets<float>(plan, m, L, Bc, D, nbt);
+    // (the interpolation mode is not an argument here: size for the larger of the two pool layouts it can select)
+    uint64_t need = 0;
+    for (int plain = 0; plain <= (align_corners ? 0 : 1); plain++) {
+        const uint64_t n = dtype == LNH_F16 ? plan_buckets<half_t>(plan, m, L, Bc, D, plain != 0, nbt)
+                                            : plan_buckets<float>(plan, m, L, Bc, D, plain != 0, nbt);
+        need = n > need ? n : need;
+    }
+    return need;
 }
 
 int lnh_grid_backward_plan_info(const int32_t *offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
@@ -1500,8 +1560,8 @@ int lnh_grid_backward_plan_info(const int32_t *offsets_host, uint32_t B, uint32_
     (void)build_meta(m, offsets_host, D, L, S, H, gridtype, align_corners != 0);
     BucketPlan plan;
     uint32_t nbt = 0;
-    if (dtype == LNH_F16) (void)plan_buckets<half_t>(plan, m, L, chunk_points(B), D, nbt);
-    else (void)plan_buckets<float>(plan, m, L, chunk_points(B), D, nbt);
+    if (dtype == LNH_F16) (void)plan_buckets<half_t>(plan, m, L, chunk_points(B), D, align_corners == 0, nbt);
+    else (void)plan_buckets<float>(plan, m, L, chunk_points(B), D, align_corners == 0, nbt);
     out4[0] = plan.first_bucket[level + 1] - plan.first_bucket[level];
     out4[1] = plan.cap[level];
     out4[2] = kBucketRows;

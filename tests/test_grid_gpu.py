@@ -230,10 +230,25 @@ def test_backward_bucketed_overflow_by_a_few(dt):
     cells = np.array([[0.3, 0.3, 0.3], [0.41, 0.41, 0.41]], dtype=np.float32)
     idx = c_oracle.grid_indices(base, OFF, CH, S, H)[level] // CH          # [B, 8] level-local rows
     cidx = c_oracle.grid_indices(cells, OFF, CH, S, H)[level] // CH        # [2, 8]
+
+    def entry_buckets(ix):
+        """Pool entries of points with corner rows ix [n, 8] (grid.hip, "pool entries"): one entry per x-neighbour pair of
+        corners (2p, 2p + 1) in the bucket of the first row, plus one in the bucket of the second row when the rows differ
+        in more than 7 low bits (r0 ^ r1 = 2^(t+1) - 1 with t >= 7: the pair travels as two singles).  -> (point, bucket)."""
+        r0, r1 = ix[:, 0::2], ix[:, 1::2]
+        t = np.array([[bin(int(v)).count("1") - 1 for v in row] for row in (r0 ^ r1)])
+        pts = np.repeat(np.arange(ix.shape[0]), 4)
+        p_all, b_all = [pts], [(r0 >> 13).ravel()]
+        sel = (t >= 7).ravel()
+        p_all.append(pts[sel])
+        b_all.append((r1 >> 13).ravel()[sel])
+        return np.concatenate(p_all), np.concatenate(b_all)
+
+    pts, bks = entry_buckets(idx)
     onehot = np.zeros((B + 1, nb), dtype=np.int64)
-    np.add.at(onehot[1:], (np.repeat(np.arange(B), 8), (idx >> 13).ravel()), 1)
+    np.add.at(onehot[1:], (pts, bks), 1)
     prefix = np.cumsum(onehot, axis=0)                                      # entries of the first k random points
-    per_pair = np.bincount((cidx >> 13).ravel(), minlength=nb)              # entries one (cell A, cell B) pair adds
+    per_pair = np.bincount(entry_buckets(cidx)[1], minlength=nb)            # entries one (cell A, cell B) pair adds
     n_pairs = None
     for k in range(1, B // 2):
         over = (prefix[B - 2 * k] + k * per_pair).max() - cap
@@ -252,9 +267,10 @@ def test_backward_bucketed_overflow_by_a_few(dt):
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.float16])
 def test_backward_bucketed_sliced_and_spilled(dt):
-    """One cell receives 164 K points (every other point lies outside the grid, so no two neighbours merge): 1.3 M
+    """One cell receives 164 K points (every other point lies outside the grid, so no two neighbours merge): 655 K pair
     entries per level in at most 8 rows.  Level 0 (one bucket): reduced in slices, no spill; dense levels 2-3: buckets
-    both sliced and overflowing; hashed levels: 8 buckets overflow their pools four-fold.  All against the oracle."""
+    both sliced and overflowing; hashed levels: up to 4 buckets overflow their pools several-fold.  All against the
+    oracle."""
     code = 0 if dt == torch.float32 else 1
     B = 320 * 1024
     x = np.empty((B, 3), dtype=np.float32)
@@ -262,7 +278,7 @@ def test_backward_bucketed_sliced_and_spilled(dt):
     x[1::2] = 1.5
     nb0, cap0, _, slice_entries = _plan(B, 0, code)
     nb9, cap9, _, _ = _plan(B, 9, code)
-    assert nb0 == 1 and (B // 2) * 8 > slice_entries                # level 0 is cut into slices
+    assert nb0 == 1 and (B // 2) * 4 > slice_entries                # level 0 is cut into slices (4 pair entries per point)
     assert (B // 2) > cap9                                           # a hashed bucket holding one corner row overflows
     nd = np.float32 if dt == torch.float32 else np.float16
     g = (np.random.default_rng(8).standard_normal((L, B, CH)) * 0.1).astype(nd)
