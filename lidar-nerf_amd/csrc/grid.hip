@@ -582,8 +582,9 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
     const uint32_t align = MODE ? 0u : align_rt, interp = MODE ? 0u : interp_rt;
     if (threadIdx.x < kMaxBucketsPerLevel) lcnt[threadIdx.x] = 0;
 
-    float v0[NCORN], v1[NCORN];
+    V2 val[NCORN];      // (w * g0, w * g1) per corner, already in the pool's element type
     uint32_t row[NCORN];
+    uint32_t xterm_xor;  // x term of corner 0 ^ x term of corner 1 (hashed levels: x ^ (x + 1))
     bool emit;
     {
         const uint32_t bl = chunk * blockDim.x + threadIdx.x;
@@ -635,44 +636,41 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
         const int run_start = 63 - __builtin_clzll(below);
         const unsigned long long heads_above = (lane == 63) ? 0ull : (heads >> (lane + 1));
         emit = ok && ((lane == 63) || (heads_above & 1ull));
+        xterm_xor = cell.term[0][0] ^ cell.term[0][1];
+        const f32x2_t gg = {g0, g1};
 #pragma unroll
         for (uint32_t c = 0; c < (uint32_t)NCORN; c++) {
-            const float w = corner_weight<D>(cell, c);
-            v0[c] = w * g0;
-            v1[c] = w * g1;
-            if constexpr (sizeof(T) == 2) {  // per-contribution rounding of the reference (gridencoder.cu:350)
-                v0[c] = (float)(half_t)v0[c];
-                v1[c] = (float)(half_t)v1[c];
-            }
+            // w * (g0, g1) as one packed multiply, narrowed with one packed conversion: float product first, then the
+            // per-contribution rounding to the table type, as the reference does (gridencoder.cu:350)
+            const f32x2_t p = gg * corner_weight<D>(cell, c);
+            val[c] = __builtin_convertvector(p, V2);
             row[c] = corner_row<D>(cell, lv, c);
         }
-        if (any_merge) {  // wave-uniform
+        if (any_merge) {  // wave-uniform: sum the runs in fp32 (one rounding of the sum when it is stored again)
             const SegScanMask sm = wave_segscan_mask(lane, run_start);
             float vv[2 * NCORN];
 #pragma unroll
             for (uint32_t c = 0; c < (uint32_t)NCORN; c++) {
-                vv[2 * c] = v0[c];
-                vv[2 * c + 1] = v1[c];
+                vv[2 * c] = (float)val[c][0];
+                vv[2 * c + 1] = (float)val[c][1];
             }
             row_segscan_add_n(vv, sm);
             if (!row_local) cross_segscan_add_n(vv, sm);
 #pragma unroll
-            for (uint32_t c = 0; c < (uint32_t)NCORN; c++) {
-                v0[c] = vv[2 * c];
-                v1[c] = vv[2 * c + 1];
-            }
+            for (uint32_t c = 0; c < (uint32_t)NCORN; c++) val[c] = make_v2<T>(vv[2 * c], vv[2 * c + 1]);
         }
     }
     // ---- pair the x-neighbours: entry p carries corners 2p and 2p + 1 unless the code cannot describe their rows
     uint32_t code[NP];
     bool single[NP], any_single = false;
+    // hashed level: r0 ^ r1 = (x ^ (x + 1)) & (rows - 1) = 2^(t+1) - 1 for ALL four pairs of the point
+    const uint32_t t_hash = (uint32_t)__builtin_popcount(xterm_xor & (lv.hashmap_size - 1u)) - 1u;
 #pragma unroll
     for (int p = 0; p < NP; p++) {
-        const uint32_t r0 = row[2 * p], r1 = row[2 * p + 1];
+        const uint32_t r0 = row[2 * p];
         if constexpr (MODE == 1) {
-            const uint32_t t = (uint32_t)__builtin_popcount(r0 ^ r1) - 1u;  // r0 ^ r1 = 2^(t+1) - 1
-            single[p] = t >= kCodeSingle;
-            code[p] = single[p] ? kCodeSingle : t;
+            single[p] = t_hash >= kCodeSingle;
+            code[p] = single[p] ? kCodeSingle : t_hash;
         } else if constexpr (MODE == 2) {
             single[p] = (r0 & (kBucketRows - 1)) == kBucketRows - 1;        // r1 = r0 + 1 opens the next bucket
             code[p] = single[p] ? kCodeSingle : 0u;
@@ -775,14 +773,13 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
     if (emit) {
 #pragma unroll
         for (int p = 0; p < NP; p++)
-            put(row[2 * p], code[p], make_v2<T>(v0[2 * p], v1[2 * p]), make_v2<T>(v0[2 * p + 1], v1[2 * p + 1]), rank[p]);
+            put(row[2 * p], code[p], val[2 * p], val[2 * p + 1], rank[p]);
     }
     if (wave_singles && emit) {
 #pragma unroll
         for (int p = 0; p < NP; p++)
             if (single[p])
-                put(row[2 * p + 1], kCodeSingle, make_v2<T>(v0[2 * p + 1], v1[2 * p + 1]), make_v2<T>(0.0f, 0.0f),
-                    rank_x[p]);
+                put(row[2 * p + 1], kCodeSingle, val[2 * p + 1], make_v2<T>(0.0f, 0.0f), rank_x[p]);
     }
     __syncthreads();
     const uint32_t total = min(lstart[kMaxBucketsPerLevel], (uint32_t)CAP);
