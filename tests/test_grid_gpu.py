@@ -292,6 +292,35 @@ def test_backward_bucketed_sliced_and_spilled(dt):
     assert np.all(got[want == 0] == 0)
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16])
+@pytest.mark.parametrize("interp,gridtype,align", [(1, 0, False), (0, 1, False), (0, 0, True)])
+def test_backward_bucketed_generic_level_classes(dt, interp, gridtype, align):
+    """Smoothstep interpolation, tiled grids and align_corners take the generic class of the bucketed backward: every
+    corner travels as a single entry (8 per point, more than the workgroup's LDS staging holds — the excess is written
+    straight to its slot).  Same table as the oracle, ray-ordered points (run-merge active) and random ones."""
+    from gpu_util import call, dev, host
+    from lidarnerf import _hip
+    off = grid_ref.make_offsets(3, L, PLS, H, 19, align_corners=align)
+    x = np.concatenate([_ray_points(24, 256, 13), _points(3000, 14)])
+    B, rows = x.shape[0], int(off[-1])
+    nd = np.float32 if dt == torch.float32 else np.float16
+    g = (np.random.default_rng(15).standard_normal((L, B, CH)) * 0.1).astype(nd)
+    want = c_oracle.grid_backward(g, x, off, rows, S, H, gridtype, align, interp)
+    code = 0 if dt == torch.float32 else 1
+    offh = torch.from_numpy(off)
+    need = _hip.lib().lnh_grid_backward_workspace_size(offh.data_ptr(), B, 3, CH, L, S, H, gridtype, int(align), code)
+    assert need > 0
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    outs = []
+    for _ in range(2):
+        ge = torch.zeros((rows, CH), dtype=dt, device="cuda")
+        call("lnh_grid_encode_backward_ws", dev(g), dev(x), offh, ge, B, 3, CH, L, S, H, gridtype, int(align), interp,
+             code, ws, need)
+        outs.append(ge)
+    assert torch.equal(outs[0], outs[1])
+    _check_table(host(outs[0]).astype(np.float64), want, dt)
+
+
 def test_error_paths():
     from lidarnerf import _hip
     x = torch.rand((8, 3), device="cuda")
