@@ -930,7 +930,7 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
     // for one by one; the pool is written once and read once).  A quad = 4 entries = 4 * sizeof(2 V2) bytes of values
     // (aligned 16-byte loads) + 8 bytes of rows; slots outside [a_begin, a_end) are masked.
     {
-        constexpr uint32_t UNROLL = sizeof(T) == 2 ? 2 : 1;
+        constexpr uint32_t UNROLL = sizeof(T) == 2 ? 2 : 1;  // (fp16: 1 / 2 / 4 quads in flight per lane measure the same)
         constexpr uint32_t VQ = sizeof(V2) * 2 * 4 / 16;  // 16-byte loads per quad: 2 (fp16) / 4 (fp32)
         const uint4_t *vals4 = reinterpret_cast<const uint4_t *>(pool_bytes + plan.pool_off[level]);
         const uint2_t *rows4 = reinterpret_cast<const uint2_t *>(pool_bytes + plan.rows_off[level]);

@@ -41,6 +41,18 @@ class FieldSpec:
         self.n_color_mats = n_color_mats
 
 
+def _bucketed_backward_ok(enc):
+    """The fused chain's table gradient takes the bucketed backward; tables with more than 64 buckets of 8192 rows per
+    level (log2_hashmap_size > 19) are outside its plan (workspace size 0) and must take the modular path instead of
+    failing in the middle of backward.  Cached on the encoder."""
+    ok = getattr(enc, "_lnh_bucketed_ok", None)
+    if ok is None:
+        ok = _hip.lib().lnh_grid_backward_workspace_size(enc._offsets_host.data_ptr(), 1024, 3, 2, enc.num_levels,
+                                                         enc.log2_scale, enc.base_resolution, 0, 0, _hip.LNH_F16) > 0
+        enc._lnh_bucketed_ok = ok
+    return ok
+
+
 def supported(model, cal_lidar_color, num_steps, upsample_steps):
     """True when `model` has exactly the shapes the fused kernels are specialised for."""
     try:
@@ -53,7 +65,7 @@ def supported(model, cal_lidar_color, num_steps, upsample_steps):
               and sp.n_color_mats == 3 and 1 <= sp.n_dir <= 128 and tuple(sp.wc0.shape) == (64, sp.n_dir + 15)
               and tuple(sp.wc1.shape) == (64, 64) and tuple(sp.wc2.shape) == (2, 64)
               and model.geo_feat_dim == 15 and (num_steps + upsample_steps) % 16 == 0
-              and sp.table.is_cuda)
+              and sp.table.is_cuda and _bucketed_backward_ok(enc))
         return bool(ok)
     except AttributeError:
         return False
