@@ -358,8 +358,11 @@ k_mlp_backward_wi(MlpBwdArgs a) {
         return r;
     };
 
-    for (uint64_t base = (uint64_t)wave * NT * 16; base < a.B; base += (uint64_t)nwaves * NT * 16) {
-        half8_t bx[NT][IN_KS], by[NT];
+    // The kernel runs at 2 waves per SIMD (176 VGPRs: every weight-gradient tile lives in registers), too few to hide the
+    // HBM latency of a tile's input rows behind another wave's arithmetic: the rows of the NEXT tile are requested
+    // before the current tile is processed (software pipelining, one tile deep: 153 -> 137 us; two deep measures the
+    // same and makes the wider instantiations spill).
+    auto load_tile = [&](uint64_t base, half8_t (&bx)[NT][IN_KS], half8_t (&by)[NT]) {
 #pragma unroll
         for (int n = 0; n < NT; n++) {
             const uint64_t p = base + n * 16 + c;
@@ -375,6 +378,19 @@ k_mlp_backward_wi(MlpBwdArgs a) {
             const half8_t vy = *reinterpret_cast<const half8_t *>(a.dY + IO::out_row(oky ? p : 0, a.io) * 16 + (oky ? 8 * g : 0));
             by[n] = oky ? vy : zero_h8();
         }
+    };
+    const uint64_t stride = (uint64_t)nwaves * NT * 16;
+    half8_t nx[NT][IN_KS], ny[NT];
+    load_tile((uint64_t)wave * NT * 16, nx, ny);
+    for (uint64_t base = (uint64_t)wave * NT * 16; base < a.B; base += stride) {
+        half8_t bx[NT][IN_KS], by[NT];
+#pragma unroll
+        for (int n = 0; n < NT; n++) {
+#pragma unroll
+            for (int s = 0; s < IN_KS; s++) bx[n][s] = nx[n][s];
+            by[n] = ny[n];
+        }
+        load_tile(base + stride, nx, ny);  // (beyond the batch: clamped addresses, zero fragments, never used)
         // ---- channel-major chain: hidden, its gradient, dX
         half8_t bd[NT][HS];
 #pragma unroll
