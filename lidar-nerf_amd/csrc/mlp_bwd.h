@@ -379,18 +379,23 @@ k_mlp_backward_wi(MlpBwdArgs a) {
             by[n] = oky ? vy : zero_h8();
         }
     };
+    constexpr bool PREFETCH = IN_KS == 1;  // (the 64-input instantiations have no registers to spare)
     const uint64_t stride = (uint64_t)nwaves * NT * 16;
     half8_t nx[NT][IN_KS], ny[NT];
-    load_tile((uint64_t)wave * NT * 16, nx, ny);
+    if constexpr (PREFETCH) load_tile((uint64_t)wave * NT * 16, nx, ny);
     for (uint64_t base = (uint64_t)wave * NT * 16; base < a.B; base += stride) {
         half8_t bx[NT][IN_KS], by[NT];
+        if constexpr (PREFETCH) {
 #pragma unroll
-        for (int n = 0; n < NT; n++) {
+            for (int n = 0; n < NT; n++) {
 #pragma unroll
-            for (int s = 0; s < IN_KS; s++) bx[n][s] = nx[n][s];
-            by[n] = ny[n];
+                for (int s = 0; s < IN_KS; s++) bx[n][s] = nx[n][s];
+                by[n] = ny[n];
+            }
+            load_tile(base + stride, nx, ny);  // (beyond the batch: clamped addresses, zero fragments, never used)
+        } else {
+            load_tile(base, bx, by);
         }
-        load_tile(base + stride, nx, ny);  // (beyond the batch: clamped addresses, zero fragments, never used)
         // ---- channel-major chain: hidden, its gradient, dX
         half8_t bd[NT][HS];
 #pragma unroll
