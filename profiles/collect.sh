@@ -9,9 +9,10 @@ tag=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 out=gpurun_out/profiles; mkdir -p $out
 STEPS=10; WARM=3
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -o r -- python bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-eval > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -o r -- python bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-eval > /dev/null 2>&1
 find /tmp/prof_kt -name "*kernel_stats.csv" -exec cp {} $out/${tag}_kernel_stats.csv \;
-python - $out/${tag}_kernel_stats.csv $((STEPS+WARM+5)) > $out/${tag}_kernel_summary.txt  # (+5: the MFMA pass of bench.py) <<'PY'
+# (+5 steps: the MFMA pass bench.py runs after the timed region)
+python - $out/${tag}_kernel_stats.csv $((STEPS+WARM+5)) > $out/${tag}_kernel_summary.txt <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1]))); n = float(sys.argv[2])
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
@@ -21,7 +22,7 @@ for r in rows[:40]:
     print(f"{float(r['TotalDurationNs'])/n/1e6:8.3f} ms/step {int(r['Calls'])/n:6.1f} calls/step  avg {float(r['AverageNs'])/1e3:9.1f} us  {r['Name'][:110]}")
 PY
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/prof_$c -o r -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-eval > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/prof_$c -o r -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-eval > /dev/null 2>&1
 done
 python - $out/${tag}_pmc.json <<'PY'
 import csv, glob, json, sys, collections
@@ -51,5 +52,5 @@ json.dump({"command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace --
            "kernels": res},
           open(sys.argv[1], "w"), indent=1)
 PY
-python bench.py > $out/${tag}_bench.json 2> /dev/null
+timeout 400 python bench.py > $out/${tag}_bench.json 2> /dev/null
 tail -c 600 $out/${tag}_bench.json; echo; cat $out/${tag}_pmc.json | head -40

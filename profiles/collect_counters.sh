@@ -21,7 +21,7 @@ groups=(
 i=0
 for g in "${groups[@]}"; do
   rm -rf /tmp/pmc_$i
-  rocprofv3 --pmc $g --kernel-trace --output-format csv -d /tmp/pmc_$i -o r -- python tools/bench_grid.py --reps 2 > /tmp/pmc_$i.log 2>&1 || echo "group $i failed: $g"
+  timeout 300 rocprofv3 --pmc $g --kernel-trace --output-format csv -d /tmp/pmc_$i -o r -- python tools/bench_grid.py --reps 2 > /tmp/pmc_$i.log 2>&1 || echo "group $i failed: $g"
   i=$((i+1))
 done
 python - $out/${tag}_grid_counters.json <<'PY'
