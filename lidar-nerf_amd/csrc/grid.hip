@@ -232,16 +232,57 @@ k_grid_forward(const float *__restrict__ inputs, const T *__restrict__ table, T 
         // issue all 2^D gathers before consuming any of them
         Vec<T, C> g[1 << D];
         if constexpr (D == 3 && C == 2) {
-            // The two x-neighbours of a cell edge are adjacent table rows whenever the x term is dense (row, row+1) or
-            // the hashed x coordinate is even ((x ^ h) and ((x+1) ^ h) differ in bit 0 only): fetch such a pair with ONE
-            // load of 2 rows.  The gather rate of this kernel is set by distinct cache lines per wave instruction
-            // (measured ~1 line/clk/CU), so halving the accesses of most pairs is a direct win.
+            // The x-neighbours of a cell edge lie close together in the table: rows r0, r0 + 1 when the x term is dense,
+            // and r1 = r0 ^ (2^(t+1) - 1) on a hashed level (the x term of the hash is x itself; t = trailing ones of the
+            // x coordinate).  Measured on MI355X (A/B builds over tools/bench_grid.py): a wave's gather costs per DISTINCT
+            // line per INSTRUCTION — a second instruction touching the lines of the first still costs a third of a miss
+            // (tag look-up), its width (4 / 8 / 16 bytes per lane) costs nothing — so each (y,z) corner pair is fetched
+            // with one wide load wherever its two rows share an aligned block.
             const bool hash = lv.flags & LV_HASH;
             const bool x_dense = !hash && (lv.flags & 15u) >= 1 && (lv.flags & LV_NOWRAP);
             const bool hash_pair = hash && (lv.flags & LV_POW2);   // level-uniform
             const bool x_odd = cell.term[0][0] & 1u;               // per lane
             // All loads first, every use after the loop, and no per-lane branch around a load: a consumer (or the end of
             // a divergent region) pins an s_waitcnt and serialises the four (y,z) iterations into dependent round trips.
+            // Lanes that need no second load read row 0 instead (one broadcast line): selecting the address keeps the
+            // load unconditional.
+            //
+            // Hashed level, 4-byte rows: the aligned block of FOUR rows (16 bytes) around r0 also holds r1 for t <= 1,
+            // i.e. for 3 lanes in 4; the others fetch r1 on its own (540 -> 505 us per 3.41 M points against the 2-row
+            // blocks below; without the second load at all: 445 us).
+            if constexpr (sizeof(T) * C == 4) {
+            if (hash_pair) {
+                Vec<T, 8> blk[4];
+                Vec<T, C> solo[4];
+                uint32_t r0s[4], r1s[4];
+                const uint32_t xm = cell.term[0][0] ^ cell.term[0][1];   // 2^(t+1) - 1 (before the table mask)
+                const bool far = (xm & (lv.hashmap_size - 1)) > 3u;
+#pragma unroll
+                for (uint32_t yz = 0; yz < 4; yz++) {
+                    const uint32_t c0 = yz << 1;
+                    const uint32_t r0 = corner_row<D>(cell, lv, c0);
+                    const uint32_t r1 = corner_row<D>(cell, lv, c0 | 1u);
+                    r0s[yz] = r0;
+                    r1s[yz] = r1;
+                    blk[yz] = load_vec<T, 8>(tab + (size_t)(r0 & ~3u) * C);
+                    solo[yz] = load_vec<T, C>(tab + (size_t)(far ? r1 : 0u) * C);
+                }
+#pragma unroll
+                for (uint32_t yz = 0; yz < 4; yz++) {
+                    const uint32_t c0 = yz << 1, c1 = c0 | 1u;
+                    uint32_t w[4], so;
+                    __builtin_memcpy(w, &blk[yz], 16);
+                    __builtin_memcpy(&so, &solo[yz], 4);
+                    const uint32_t i0 = r0s[yz] & 3u, i1 = r1s[yz] & 3u;
+                    const uint32_t a0 = (i0 & 2u) ? ((i0 & 1u) ? w[3] : w[2]) : ((i0 & 1u) ? w[1] : w[0]);
+                    const uint32_t a1 = (i1 & 2u) ? ((i1 & 1u) ? w[3] : w[2]) : ((i1 & 1u) ? w[1] : w[0]);
+                    const uint32_t b1 = far ? so : a1;
+                    __builtin_memcpy(&g[c0], &a0, 4);
+                    __builtin_memcpy(&g[c1], &b1, 4);
+                }
+            }
+            }
+            if (!(sizeof(T) * C == 4 && hash_pair)) {
             //   pair[yz]: the aligned row pair holding corner c0 (hashed levels) / rows r0, r0+1 (dense x)
             //   solo[yz]: corner c1 on its own, fetched only where it is not the sibling of c0 (hashed level, odd x)
             Vec<T, 4> pair[4];
@@ -274,6 +315,7 @@ k_grid_forward(const float *__restrict__ inputs, const T *__restrict__ table, T 
                     g[c1].v[0] = own ? solo[yz].v[0] : (swap ? pair[yz].v[0] : pair[yz].v[2]);
                     g[c1].v[1] = own ? solo[yz].v[1] : (swap ? pair[yz].v[1] : pair[yz].v[3]);
                 }
+            }
             }
         } else {
 #pragma unroll

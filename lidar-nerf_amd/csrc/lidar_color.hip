@@ -28,7 +28,11 @@ struct ColorArgs {
     uint32_t N, T;
 };
 
-__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+// v_exp_f32 / v_rcp_f32 (1 ulp each) instead of the IEEE division and the range-reduced expf: the two outputs of a
+// sample are computed by whole-wave instructions, and the exact forms cost ~40 of them per output
+__device__ __forceinline__ float sigmoidf(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+// exp of the clamped density pre-activation (trunc_exp backward, activation.py:14-17)
+__device__ __forceinline__ float exp_clamped(float x) { return __expf(fminf(fmaxf(x, -15.0f), 15.0f)); }
 
 __global__ void __launch_bounds__(256)
 k_color_forward(ColorArgs a) {
@@ -117,32 +121,34 @@ k_color_forward(ColorArgs a) {
 __global__ void __launch_bounds__(256)
 k_color_backward_wi(ColorArgs a) {
     constexpr int HT = 4, HS = 2, NT = 2, NTILE = HT + HT * HT + HT;
-    // Weight fragments live in LDS in per-lane order (one conflict-free ds_read_b128 each) instead of 112 VGPRs: the
-    // 24 gradient tiles (96 accumulators) plus the pipeline state already fill the register file of a wave.
+    // The 28 weight fragments (112 registers) stay in registers for the whole kernel: the 24 gradient tiles live in
+    // AGPRs (mfma16_acc_agpr), which leaves the VGPRs to the fragments and the pipeline state, and hipcc places the
+    // fragments that do not fit there in AGPRs as well (an MFMA reads its A operand from either file).  Re-reading them
+    // from LDS every iteration (48 ds_read_b128 issued just ahead of their MFMAs) cost 11 % of the kernel.
     enum { F_W0 = 0, F_W1 = 4, F_W2 = 12, F_W2T = 14, F_W1T = 18, F_W0T = 26, NFRAG = 28 };
-    __shared__ half8_t wfrag[NFRAG][64];
     __shared__ float red[NTILE * 256];
     const uint32_t wid = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
-    const uint32_t nw = blockDim.x >> 6, wave = blockIdx.x * nw + wid, nwaves = gridDim.x * nw;
-    if (wid == 0) {
+    const uint32_t nw = blockDim.x >> 6, nwaves = gridDim.x * nw;
+    const uint32_t wave = blockIdx.x * nw + (uint32_t)__builtin_amdgcn_readfirstlane((int)wid);  // known wave-uniform
+    half8_t wreg[NFRAG];
+    {
 #pragma unroll
         for (int t = 0; t < HT; t++) {
-            wfrag[F_W0 + t][lane] = load_a_natural(a.W + kW0g, 16, 16 * t + c, 0, g, 16);
-            wfrag[F_W2T + t][lane] = load_at_natural(a.W + kW2, 64, 16 * t + c, 0, g, 16);
+            wreg[F_W0 + t] = load_a_natural(a.W + kW0g, 16, 16 * t + c, 0, g, 16);
+            wreg[F_W2T + t] = load_at_natural(a.W + kW2, 64, 16 * t + c, 0, g, 16);
 #pragma unroll
             for (int s = 0; s < HS; s++) {
-                wfrag[F_W1 + 2 * t + s][lane] = load_a_nu(a.W + kW1, 64, 16 * t + c, s, g);
-                wfrag[F_W1T + 2 * t + s][lane] = load_at_nu(a.W + kW1, 64, 16 * t + c, s, g);
+                wreg[F_W1 + 2 * t + s] = load_a_nu(a.W + kW1, 64, 16 * t + c, s, g);
+                wreg[F_W1T + 2 * t + s] = load_at_nu(a.W + kW1, 64, 16 * t + c, s, g);
             }
         }
 #pragma unroll
         for (int s = 0; s < HS; s++) {
-            wfrag[F_W2 + s][lane] = load_a_nu(a.W + kW2, 64, c, s, g);
-            wfrag[F_W0T + s][lane] = load_at_nu(a.W + kW0g, 16, c, s, g);
+            wreg[F_W2 + s] = load_a_nu(a.W + kW2, 64, c, s, g);
+            wreg[F_W0T + s] = load_at_nu(a.W + kW0g, 16, c, s, g);
         }
     }
-    __syncthreads();
-#define WF(i) (wfrag[(i)][lane])
+#define WF(i) (wreg[(i)])
     // identity fragments: idn selects natural-k element c (k = 8g + j); idv[tt] selects nu-enumerated channel
     // 16 * (2s + tt) + c out of k-step s (element j of lane group g is channel 16 * (2s + (j >> 2)) + 4g + (j & 3))
     half8_t idn, idv[2];
@@ -167,28 +173,116 @@ k_color_backward_wi(ColorArgs a) {
         return r;
     };
 
+    // ---- work items.  A wave walks its rays (wave, wave + nwaves, ...) and, inside a ray, only the 32-sample spans that
+    // hold at least one sample above the mask threshold.  The iterator is wave-uniform (scalar registers): when it enters a
+    // ray (a group of 32 spans of it) it reads the ray's weights one sample per lane, forms the span bits from ballots,
+    // and stores the gradient rows of the TRANSPARENT spans right there — colour is defined as 0 on them, only the
+    // compositing gradient of sigma flows back.  The loop below therefore sees active spans only, and its body has no
+    // branch around the MFMA chain: with a transparent / active diamond inside the loop hipcc copied all 96
+    // weight-gradient accumulators to other registers and back at every latch (192 moves per iteration).
+    constexpr uint32_t kGroupSpans = 32, kGroupSamples = 32 * kGroupSpans, kGroupLoads = kGroupSamples / 64;
+    const uint32_t nsteps = (a.T + 31) / 32, ngroups = (nsteps + kGroupSpans - 1) / kGroupSpans;
+    const uint32_t nrays = wave < a.N ? (a.N - wave + nwaves - 1) / nwaves : 0;
+    struct Iter {
+        uint32_t rr, grp, act;
+        bool fresh, ray_any;
+    };
+    Iter it = {0u, 0u, 0u, true, false};
+    struct Item {
+        bool live;
+        uint32_t ray, s0;
+    };
+    auto enter_group = [&](uint32_t ray, uint32_t grp) -> uint32_t {
+        const uint32_t i0 = grp * kGroupSamples;
+        bool v[kGroupLoads];
+        uint32_t m[kGroupLoads];
+        float w[kGroupLoads];
+#pragma unroll
+        for (uint32_t j = 0; j < kGroupLoads; j++) {
+            const uint32_t i = i0 + j * 64 + lane;
+            v[j] = i < a.T;
+            m[j] = v[j] ? ray * a.T + i : 0;  // N*T < 2^32 (checked by the launcher)
+            w[j] = a.weights[m[j]];
+        }
+        uint32_t act = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < kGroupLoads; j++) {
+            const unsigned long long b = __ballot(v[j] && w[j] > kMaskThresh);
+            act |= ((uint32_t)b != 0u ? 1u : 0u) << (2 * j);
+            act |= ((uint32_t)(b >> 32) != 0u ? 1u : 0u) << (2 * j + 1);
+        }
+        // rows of the transparent spans (lane = sample): d(row) = (g_sigma * exp(h0), 0, ..., 0); loads batched, all
+        // unconditional from clamped indices
+        uint32_t slot[kGroupLoads];
+        float gs[kGroupLoads];
+        half_t h0[kGroupLoads];
+#pragma unroll
+        for (uint32_t j = 0; j < kGroupLoads; j++) {
+            slot[j] = (uint32_t)a.perm[m[j]];
+            gs[j] = a.g_sigma[m[j]];
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kGroupLoads; j++) {
+            const size_t src = v[j] ? (size_t)ray * a.T + slot[j] : (size_t)0;
+            h0[j] = a.h16[src * 16];
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kGroupLoads; j++) {
+            const bool transparent = !((act >> (2 * j + (lane >> 5))) & 1u);
+            if (v[j] && transparent) {
+                half8_t lo = zero_h8();
+                lo[0] = (half_t)(gs[j] * exp_clamped((float)h0[j]));
+                half8_t *q = reinterpret_cast<half8_t *>(a.g_h16 + ((size_t)ray * a.T + slot[j]) * 16);
+                q[0] = lo;
+                q[1] = zero_h8();
+            }
+        }
+        return act;
+    };
+    auto zero_ray_sum = [&](uint32_t ray) { a.S[(size_t)ray * 64 + lane] = 0.0f; };
+    auto next_item = [&]() {
+        Item I = {false, 0u, 0u};
+        while (it.act == 0u) {
+            if (!it.fresh) {
+                if (++it.grp >= ngroups) {
+                    if (!it.ray_any && it.rr < nrays) zero_ray_sum(wave + it.rr * nwaves);  // a ray without any active span
+                    it.ray_any = false;
+                    it.grp = 0;
+                    if (it.rr < nrays) it.rr++;
+                }
+            }
+            if (it.rr >= nrays) return I;  // exhausted (stays exhausted: rr no longer moves)
+            it.fresh = false;
+            it.act = enter_group(wave + it.rr * nwaves, it.grp);
+            it.ray_any = it.ray_any || it.act != 0u;
+        }
+        const uint32_t sp = (uint32_t)__builtin_ctz(it.act);
+        it.act &= it.act - 1u;
+        I.live = true;
+        I.ray = wave + it.rr * nwaves;
+        I.s0 = (it.grp * kGroupSpans + sp) * 32;
+        return I;
+    };
+
     // The per-sample operands form a dependent chain (perm -> sigma-net row) of HBM round trips; left in program order
-    // they cost ~4 exposed latencies per step.  The (ray, step) iteration space of the wave is therefore flattened and
-    // software-pipelined: stage A (weights, perm, incoming gradients) runs two iterations ahead, stage B (the gathered
-    // sigma-net row) one iteration ahead.  All loads are unconditional from clamped addresses.
+    // they cost ~4 exposed latencies per step.  The item sequence is therefore software-pipelined: stage A (weights,
+    // perm, incoming gradients) runs two items ahead, stage B (the gathered sigma-net row) one item ahead.  All loads
+    // are unconditional from clamped addresses.
     struct StageA {
-        bool valid[NT];
+        bool live, valid[NT];
         uint32_t ray, m[NT], slot[NT];
         float wgt[NT], gs[NT];
         float2 gr[NT];
     };
-    const uint32_t nsteps = (a.T + 31) / 32;
-    const uint32_t nrays = wave < a.N ? (a.N - wave + nwaves - 1) / nwaves : 0;
-    const uint32_t K = nrays * nsteps;
-    auto load_a = [&](uint32_t k) {
+    auto load_a = [&](const Item &I) {
         StageA A;
-        const uint32_t rr = k / nsteps, s0 = (k - rr * nsteps) * 32;
-        A.ray = wave + rr * nwaves;
+        A.live = I.live;
+        A.ray = I.ray;
 #pragma unroll
         for (int n = 0; n < NT; n++) {
-            const uint32_t i = s0 + 16 * n + c;
-            A.valid[n] = k < K && i < a.T;
-            A.m[n] = A.valid[n] ? A.ray * a.T + i : 0;  // N*T < 2^32 (checked by the launcher)
+            const uint32_t i = I.s0 + 16 * n + c;
+            A.valid[n] = I.live && i < a.T;
+            A.m[n] = A.valid[n] ? I.ray * a.T + i : 0;
             A.wgt[n] = a.weights[A.m[n]];
             A.slot[n] = (uint32_t)a.perm[A.m[n]];
             A.gs[n] = a.g_sigma[A.m[n]];
@@ -210,46 +304,44 @@ k_color_backward_wi(ColorArgs a) {
 #pragma unroll
         for (int t = 0; t < HT; t++) cb[t] = *reinterpret_cast<const f32x4 *>(a.cdir + (size_t)r * 64 + 16 * t + 4 * g);
     };
-    StageA A0 = load_a(0), A1 = load_a(1);
+    // S[ray][channel 16t + c] = sum over the ray's samples of dH0 (lane (g,c) holds samples 4g + r)
+    auto store_ray_sum = [&](uint32_t ray, const float (&ssum)[HT]) {
+#pragma unroll
+        for (int t = 0; t < HT; t++) {
+            float v = ssum[t];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (g == 0) a.S[(size_t)ray * 64 + 16 * t + c] = v;
+        }
+    };
+    StageA A0 = load_a(next_item()), A1 = load_a(next_item());
     StageB B0 = load_b(A0);
     f32x4 cb[HT], cb_next[HT];
-    load_cb(wave, cb_next);
-    float ssum[HT];
+    load_cb(A0.ray, cb_next);
+    float ssum[HT] = {0.0f, 0.0f, 0.0f, 0.0f};
+    bool first_of_ray = true;
 
-    for (uint32_t k = 0; k < K; k++) {
-        __asm__ volatile("" ::: "memory");  // keep the weight-fragment LDS reads inside the loop (no hoist + spill)
-        const uint32_t rr = k / nsteps, sidx = k - rr * nsteps;
-        const uint32_t ray = wave + rr * nwaves;
-        const StageA A2 = load_a(k + 2);
+    while (A0.live) {
+        const uint32_t ray = A0.ray;
+        const StageA A2 = load_a(next_item());
         const StageB B1 = load_b(A1);
-        if (sidx == 0) {
+        if (first_of_ray) {
 #pragma unroll
             for (int t = 0; t < HT; t++) {
                 cb[t] = cb_next[t];
                 ssum[t] = 0.0f;
             }
-            load_cb(ray + nwaves, cb_next);
         }
+        const bool last_of_ray = !A1.live || A1.ray != ray;
+        if (last_of_ray) load_cb(A1.ray, cb_next);   // the next item opens another ray: its direction term, one item ahead
         bool msk[NT];
         half8_t bx[NT];
-        bool any = false;
 #pragma unroll
         for (int n = 0; n < NT; n++) {
             msk[n] = A0.valid[n] && A0.wgt[n] > kMaskThresh;
-            any |= msk[n];
             bx[n] = (A0.valid[n] && g < 2) ? B0.x[n] : zero_h8();
         }
-        if (!__any(any)) {
-            // the wave's 32 samples are transparent: colour is defined as 0 there, only the compositing gradient of
-            // sigma flows back
-#pragma unroll
-            for (int n = 0; n < NT; n++)
-                if (A0.valid[n]) {
-                    half4_t v = {(half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f};
-                    if (g == 0) v[0] = (half_t)(A0.gs[n] * expf(fminf(fmaxf((float)bx[n][0], -15.0f), 15.0f)));
-                    *reinterpret_cast<half4_t *>(a.g_h16 + src_of(A0, n) * 16 + 4 * g) = v;
-                }
-        } else {
+        {
             half8_t by[NT], bh0[NT][HS], bh1[NT][HS], bd1[NT][HS], bd0[NT][HS];
 #pragma unroll
             for (int n = 0; n < NT; n++) {
@@ -296,7 +388,7 @@ k_color_backward_wi(ColorArgs a) {
 #pragma unroll
                 for (int s = 0; s < HS; s++) dx = MFMA16(WF(F_W0T + s), bd0[n][s], dx);
                 if (A0.valid[n]) {
-                    if (g == 0) dx[0] = A0.gs[n] * expf(fminf(fmaxf((float)bx[n][0], -15.0f), 15.0f));
+                    if (g == 0) dx[0] = A0.gs[n] * exp_clamped((float)bx[n][0]);
                     half4_t v = {(half_t)dx[0], (half_t)dx[1], (half_t)dx[2], (half_t)dx[3]};
                     *reinterpret_cast<half4_t *>(a.g_h16 + src_of(A0, n) * 16 + 4 * g) = v;
                 }
@@ -314,27 +406,27 @@ k_color_backward_wi(ColorArgs a) {
             for (int t = 0; t < HT; t++) {
                 const half8_t fh1 = pack2(MFMA16(bh1[0][t >> 1], idv[t & 1], zero_f4()),
                                           MFMA16(bh1[1][t >> 1], idv[t & 1], zero_f4()));
-                gW2[t] = MFMA16(fy, fh1, gW2[t]);  // dW2[o = 4g + r][16t + c]
+                mfma16_acc_agpr(gW2[t], fy, fh1);  // dW2[o = 4g + r][16t + c]
                 const f32x4 e0 = MFMA16(bd0[0][t >> 1], idv[t & 1], zero_f4());
                 const f32x4 e1 = MFMA16(bd0[1][t >> 1], idv[t & 1], zero_f4());
                 ssum[t] += (e0[0] + e0[1]) + (e0[2] + e0[3]) + (e1[0] + e1[1]) + (e1[2] + e1[3]);
-                gW0[t] = MFMA16(pack2(e0, e1), fx, gW0[t]);  // dW0g[16t + 4g + r][c]
+                mfma16_acc_agpr(gW0[t], pack2(e0, e1), fx);  // dW0g[16t + 4g + r][c]
 #pragma unroll
-                for (int i = 0; i < HT; i++) gW1[t][i] = MFMA16(fd1[t], fh0[i], gW1[t][i]);  // dW1[16t + 4g + r][16i + c]
+                for (int i = 0; i < HT; i++) mfma16_acc_agpr(gW1[t][i], fd1[t], fh0[i]);  // dW1[16t + 4g + r][16i + c]
             }
         }
+        if (last_of_ray) store_ray_sum(ray, ssum);
+        first_of_ray = last_of_ray;
         A0 = A1;
         A1 = A2;
         B0 = B1;
-        if (sidx + 1 < nsteps) continue;
-        // ---- S[ray][channel 16t + c] = sum over the ray's samples of dH0 (lane (g,c) holds samples 4g + r)
+    }
 #pragma unroll
-        for (int t = 0; t < HT; t++) {
-            float v = ssum[t];
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            if (g == 0) a.S[(size_t)ray * 64 + 16 * t + c] = v;
-        }
+    for (int t = 0; t < HT; t++) {
+        agpr_settle(gW2[t]);
+        agpr_settle(gW0[t]);
+#pragma unroll
+        for (int i = 0; i < HT; i++) agpr_settle(gW1[t][i]);
     }
 
     // ---- combine the waves of the workgroup through LDS, then one atomic per weight

@@ -31,10 +31,12 @@ typedef _Float16 feat2_t __attribute__((ext_vector_type(2)));
 #define LNH_MLP_NS lnh_mlp_bf16
 #define LNH_MLP_FN(name) name##_bf16
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#define LNH_MFMA16_MNEMONIC "v_mfma_f32_16x16x32_bf16"
 #else
 #define LNH_MLP_NS lnh_mlp_f16
 #define LNH_MLP_FN(name) name
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#define LNH_MFMA16_MNEMONIC "v_mfma_f32_16x16x32_f16"
 #endif
 
 namespace LNH_MLP_NS {
@@ -103,6 +105,20 @@ __device__ __forceinline__ f32x4 zero_f4() {
     f32x4 z = {0.f, 0.f, 0.f, 0.f};
     return z;
 }
+
+// acc += a * b with the accumulator tile pinned to ACCUMULATION registers (AGPRs).  The MLP translation units are built
+// with VGPR-form MFMA destinations (build.py) because the layer chain feeds every product straight into VALU work; the
+// weight-gradient tiles of the wave-independent backward kernels are the opposite case — 24 tiles that are only ever
+// accumulated into for the whole kernel.  Left to the register allocator they share the 256 VGPRs with the pipeline
+// state, and hipcc then moves all 96 of them to other registers and back around the loop latch (192 v_mov per
+// iteration, a fifth of the colour backward's VALU time) and spills pipeline state into AGPRs besides.  In AGPRs they
+// cost nothing.  The instruction is opaque to the compiler's hazard recogniser, so the two wait states a VALU-written
+// A / B operand needs before an MFMA reads it are part of the statement (both operands always come from packed
+// conversions here), and `agpr_settle` covers the MFMA -> v_accvgpr_read distance before the tiles are read back.
+__device__ __forceinline__ void mfma16_acc_agpr(f32x4 &acc, const half8_t &a, const half8_t &b) {
+    asm("s_nop 1\n\t" LNH_MFMA16_MNEMONIC " %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void agpr_settle(f32x4 &acc) { asm volatile("s_nop 15\n\ts_nop 3" : "+a"(acc)); }
 
 // A fragment of a row-major [rows, ld] matrix with the NATURAL k enumeration (first layer: k = 32s + 8g + j).
 __device__ __forceinline__ half8_t load_a_natural(const half_t *__restrict__ W, uint32_t ld, uint32_t row, uint32_t s,

@@ -113,13 +113,24 @@ def _color_reference(h16, perm, weights, cdir, W0g, W1, W2, g_rgb=None, g_sigma=
 
 # (2100, 64): more rays than resident waves (256 workgroups x 4), so waves walk SEVERAL rays — the flattened, software-
 # pipelined (ray, step) loop crosses ray boundaries (direction-term reload, per-ray S write)
-@pytest.mark.parametrize("N,T", [(8, 64), (5, 832), (3, 48), (2100, 64)])
-def test_color_head_forward_backward(N, T):
+# (6, 1100): a ray spans two 1024-sample groups of the backward's span iterator, the second one partial
+# "front": only a leading stretch of every ray is active (what a LiDAR ray looks like once trained) — most 32-sample spans
+# are transparent and take the batched row store of the iterator; single active samples in otherwise transparent rays
+@pytest.mark.parametrize("N,T,pattern", [(8, 64, "random"), (5, 832, "random"), (3, 48, "random"), (2100, 64, "random"),
+                                         (6, 1100, "random"), (9, 832, "front"), (7, 1100, "front"), (1300, 96, "front")])
+def test_color_head_forward_backward(N, T, pattern):
     from gpu_util import call
     g = torch.Generator().manual_seed(N + T)
     h16 = (torch.randn(N * T, 16, generator=g) * 0.5).half()
     perm = torch.stack([torch.randperm(T, generator=g) for _ in range(N)]).int()
     weights = torch.rand(N, T, generator=g) * 2.5e-4  # ~60 % of the samples above the 1e-4 mask threshold
+    if pattern == "front":
+        n_act = torch.randint(0, T // 2, (N,), generator=g)
+        weights = torch.where(torch.arange(T)[None, :] < n_act[:, None], weights, torch.full_like(weights, 1e-6))
+        weights[1] = 1e-6
+        weights[1, T - 1] = 1e-2   # one active sample, in the last span of the ray
+        weights[2] = 1e-6
+        weights[2, 33] = 1e-2      # ... in the second span
     weights[0] = 0.0  # a fully masked ray
     cdir = torch.randn(N, 64, generator=g)
     W0g = torch.cat([torch.zeros(64, 1), torch.randn(64, 15, generator=g) * 0.3], 1)

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the colour-head and sigma-net entry points on FIXED synthetic inputs (4096 rays x 832 merged samples;
+the bench.py numbers move with the mask fraction of the model being trained, these do not).
+
+    python tools/bench_mlp.py [--rays 4096] [--samples 832] [--active 0.6] [--reps 7]
+
+`--active` = fraction of every ray (its front part) whose compositing weight lies above the colour mask threshold."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "lidar-nerf_amd")]
+from lidarnerf import _hip  # noqa: E402
+
+
+def timed(fn, reps):
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) * 1e3)
+    return min(ts), float(np.median(ts))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rays", type=int, default=4096)
+    ap.add_argument("--samples", type=int, default=832)
+    ap.add_argument("--active", type=float, default=0.6)
+    ap.add_argument("--reps", type=int, default=7)
+    a = ap.parse_args()
+    _hip.lib()
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(0)
+    N, T = a.rays, a.samples
+    h16 = (torch.randn(N * T, 16, device=dev, generator=g) * 0.5).half()
+    perm = torch.stack([torch.randperm(T, device=dev, generator=g) for _ in range(64)])[
+        torch.randint(0, 64, (N,), device=dev, generator=g)].int().contiguous()
+    n_act = int(round(a.active * T))
+    weights = torch.full((N, T), 1e-6, device=dev)
+    weights[:, :n_act] = 1e-2
+    cdir = torch.randn(N, 64, device=dev, generator=g) * 0.3
+    wcol = (torch.randn(64 * 16 + 64 * 64 + 16 * 64, device=dev, generator=g) * 0.15).half()
+    rgb = torch.empty(N, T, 2, device=dev)
+    g_rgb = torch.randn(N, T, 2, device=dev, generator=g) * 1e-3
+    g_sigma = torch.randn(N, T, device=dev, generator=g) * 1e-3
+    g_h16 = torch.empty(N * T, 16, device=dev, dtype=torch.half)
+    g_w = torch.zeros(wcol.numel(), device=dev)
+    ray_sum = torch.empty(N, 64, device=dev)
+
+    def fwd():
+        _hip.call("lnh_lidar_color_forward", h16.data_ptr(), perm.data_ptr(), weights.data_ptr(), cdir.data_ptr(),
+                  wcol.data_ptr(), N, T, rgb.data_ptr())
+
+    def bwd():
+        _hip.call("lnh_lidar_color_backward", g_rgb.data_ptr(), g_sigma.data_ptr(), h16.data_ptr(), perm.data_ptr(),
+                  weights.data_ptr(), cdir.data_ptr(), wcol.data_ptr(), N, T, g_h16.data_ptr(), g_w.data_ptr(),
+                  ray_sum.data_ptr())
+
+    for name, fn in (("lnh_lidar_color_forward", fwd), ("lnh_lidar_color_backward", bwd)):
+        fn()
+        torch.cuda.synchronize()
+        lo, med = timed(fn, a.reps)
+        print(f"{name:28s} active {a.active:.2f}  min {lo:8.1f} us  median {med:8.1f} us")
+    print("checksum", float(g_h16.float().abs().sum()), float(g_w.abs().sum()), float(ray_sum.abs().sum()))
+
+
+if __name__ == "__main__":
+    main()
