@@ -264,6 +264,12 @@ LNH_API int lnh_lidar_composite_backward(const float *grad_weights_sum, const fl
 LNH_API int lnh_lidar_resample(const float *z, const float *sigma, const float *sample_dist, const float *u,
                                uint32_t N, uint32_t T, uint32_t n_new, float density_scale, uint32_t sorted_new,
                                float *new_z, float *z_out, int32_t *perm, lnh_stream_t stream);
+/* The same with the rows of `sigma` sigma_stride (>= T) floats apart: the fused render step keeps the coarse and the
+ * importance samples of a ray side by side in one [N, T+n_new] buffer and resamples from its first T columns. */
+LNH_API int lnh_lidar_resample_strided(const float *z, const float *sigma, uint32_t sigma_stride,
+                                       const float *sample_dist, const float *u, uint32_t N, uint32_t T,
+                                       uint32_t n_new, float density_scale, uint32_t sorted_new, float *new_z,
+                                       float *z_out, int32_t *perm, lnh_stream_t stream);
 
 
 /* ------------------------------------------------------------------ fused LiDAR field step ------------------ */

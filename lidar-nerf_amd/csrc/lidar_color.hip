@@ -212,29 +212,36 @@ k_color_backward_wi(ColorArgs a) {
             act |= ((uint32_t)(b >> 32) != 0u ? 1u : 0u) << (2 * j + 1);
         }
         // rows of the transparent spans (lane = sample): d(row) = (g_sigma * exp(h0), 0, ..., 0); loads batched, all
-        // unconditional from clamped indices
-        uint32_t slot[kGroupLoads];
-        float gs[kGroupLoads];
-        half_t h0[kGroupLoads];
+        // unconditional from clamped indices; skipped (wave-uniform) when every span of the group is active
+        bool tr[kGroupLoads], any_tr = false;
 #pragma unroll
         for (uint32_t j = 0; j < kGroupLoads; j++) {
-            slot[j] = (uint32_t)a.perm[m[j]];
-            gs[j] = a.g_sigma[m[j]];
+            tr[j] = v[j] && !((act >> (2 * j + (lane >> 5))) & 1u);
+            any_tr |= tr[j];
         }
+        if (__any(any_tr)) {
+            uint32_t slot[kGroupLoads];
+            float gs[kGroupLoads];
+            half_t h0[kGroupLoads];
 #pragma unroll
-        for (uint32_t j = 0; j < kGroupLoads; j++) {
-            const size_t src = v[j] ? (size_t)ray * a.T + slot[j] : (size_t)0;
-            h0[j] = a.h16[src * 16];
-        }
+            for (uint32_t j = 0; j < kGroupLoads; j++) {
+                slot[j] = (uint32_t)a.perm[m[j]];
+                gs[j] = a.g_sigma[m[j]];
+            }
 #pragma unroll
-        for (uint32_t j = 0; j < kGroupLoads; j++) {
-            const bool transparent = !((act >> (2 * j + (lane >> 5))) & 1u);
-            if (v[j] && transparent) {
-                half8_t lo = zero_h8();
-                lo[0] = (half_t)(gs[j] * exp_clamped((float)h0[j]));
-                half8_t *q = reinterpret_cast<half8_t *>(a.g_h16 + ((size_t)ray * a.T + slot[j]) * 16);
-                q[0] = lo;
-                q[1] = zero_h8();
+            for (uint32_t j = 0; j < kGroupLoads; j++) {
+                const size_t src = v[j] ? (size_t)ray * a.T + slot[j] : (size_t)0;
+                h0[j] = a.h16[src * 16];
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < kGroupLoads; j++) {
+                if (tr[j]) {
+                    half8_t lo = zero_h8();
+                    lo[0] = (half_t)(gs[j] * exp_clamped((float)h0[j]));
+                    half8_t *q = reinterpret_cast<half8_t *>(a.g_h16 + ((size_t)ray * a.T + slot[j]) * 16);
+                    q[0] = lo;
+                    q[1] = zero_h8();
+                }
             }
         }
         return act;
@@ -343,47 +350,71 @@ k_color_backward_wi(ColorArgs a) {
         }
         {
             half8_t by[NT], bh0[NT][HS], bh1[NT][HS], bd1[NT][HS], bd0[NT][HS];
+            // the two 16-sample tiles go through every layer side by side: one tile's MFMAs run while the other tile's
+            // results are narrowed and activated (a single wave per SIMD has nothing else to hide MFMA latency with)
+            f32x4 acc[NT][HT];
 #pragma unroll
-            for (int n = 0; n < NT; n++) {
-                f32x4 acc[HT];
+            for (int n = 0; n < NT; n++)
 #pragma unroll
-                for (int t = 0; t < HT; t++) acc[t] = MFMA16(WF(F_W0 + t), bx[n], cb[t]);
+                for (int t = 0; t < HT; t++) acc[n][t] = MFMA16(WF(F_W0 + t), bx[n], cb[t]);
 #pragma unroll
-                for (int s = 0; s < HS; s++)
-                    bh0[n][s] = pack_pair_relu(acc[2 * s], acc[2 * s + 1]);
+            for (int n = 0; n < NT; n++)
+#pragma unroll
+                for (int s = 0; s < HS; s++) bh0[n][s] = pack_pair_relu(acc[n][2 * s], acc[n][2 * s + 1]);
+#pragma unroll
+            for (int n = 0; n < NT; n++)
 #pragma unroll
                 for (int t = 0; t < HT; t++) {
-                    acc[t] = zero_f4();
+                    acc[n][t] = zero_f4();
 #pragma unroll
-                    for (int s = 0; s < HS; s++) acc[t] = MFMA16(WF(F_W1 + 2 * t + s), bh0[n][s], acc[t]);
+                    for (int s = 0; s < HS; s++) acc[n][t] = MFMA16(WF(F_W1 + 2 * t + s), bh0[n][s], acc[n][t]);
                 }
 #pragma unroll
-                for (int s = 0; s < HS; s++)
-                    bh1[n][s] = pack_pair_relu(acc[2 * s], acc[2 * s + 1]);
-                f32x4 o = zero_f4();
+            for (int n = 0; n < NT; n++)
 #pragma unroll
-                for (int s = 0; s < HS; s++) o = MFMA16(WF(F_W2 + s), bh1[n][s], o);
-                // output gradient through the sigmoid (only outputs 0,1 exist; lanes g == 0 hold them)
+                for (int s = 0; s < HS; s++) bh1[n][s] = pack_pair_relu(acc[n][2 * s], acc[n][2 * s + 1]);
+            f32x4 o[NT];
+#pragma unroll
+            for (int n = 0; n < NT; n++) {
+                o[n] = zero_f4();
+#pragma unroll
+                for (int s = 0; s < HS; s++) o[n] = MFMA16(WF(F_W2 + s), bh1[n][s], o[n]);
+            }
+            // output gradient through the sigmoid (only outputs 0,1 exist; lanes g == 0 hold them)
+#pragma unroll
+            for (int n = 0; n < NT; n++) {
                 by[n] = zero_h8();
                 if (g == 0 && msk[n]) {
-                    const float r0 = sigmoidf((float)(half_t)o[0]), r1 = sigmoidf((float)(half_t)o[1]);
+                    const float r0 = sigmoidf((float)(half_t)o[n][0]), r1 = sigmoidf((float)(half_t)o[n][1]);
                     by[n][0] = (half_t)(A0.gr[n].x * r0 * (1.0f - r0));
                     by[n][1] = (half_t)(A0.gr[n].y * r1 * (1.0f - r1));
                 }
-                f32x4 d[HT];
+            }
 #pragma unroll
-                for (int t = 0; t < HT; t++) d[t] = MFMA16(WF(F_W2T + t), by[n], zero_f4());
+            for (int n = 0; n < NT; n++)
 #pragma unroll
-                for (int s = 0; s < HS; s++) bd1[n][s] = pack_pair_relu_bwd(d[2 * s], d[2 * s + 1], bh1[n][s]);
+                for (int t = 0; t < HT; t++) acc[n][t] = MFMA16(WF(F_W2T + t), by[n], zero_f4());
+#pragma unroll
+            for (int n = 0; n < NT; n++)
+#pragma unroll
+                for (int s = 0; s < HS; s++)
+                    bd1[n][s] = pack_pair_relu_bwd(acc[n][2 * s], acc[n][2 * s + 1], bh1[n][s]);
+#pragma unroll
+            for (int n = 0; n < NT; n++)
 #pragma unroll
                 for (int t = 0; t < HT; t++) {
-                    d[t] = zero_f4();
+                    acc[n][t] = zero_f4();
 #pragma unroll
-                    for (int s = 0; s < HS; s++) d[t] = MFMA16(WF(F_W1T + 2 * t + s), bd1[n][s], d[t]);
+                    for (int s = 0; s < HS; s++) acc[n][t] = MFMA16(WF(F_W1T + 2 * t + s), bd1[n][s], acc[n][t]);
                 }
 #pragma unroll
-                for (int s = 0; s < HS; s++) bd0[n][s] = pack_pair_relu_bwd(d[2 * s], d[2 * s + 1], bh0[n][s]);
-                // d(sigma-net row) = W0g^T dH0, col 0 <- trunc_exp backward of the compositing gradient
+            for (int n = 0; n < NT; n++)
+#pragma unroll
+                for (int s = 0; s < HS; s++)
+                    bd0[n][s] = pack_pair_relu_bwd(acc[n][2 * s], acc[n][2 * s + 1], bh0[n][s]);
+            // d(sigma-net row) = W0g^T dH0, col 0 <- trunc_exp backward of the compositing gradient
+#pragma unroll
+            for (int n = 0; n < NT; n++) {
                 f32x4 dx = zero_f4();
 #pragma unroll
                 for (int s = 0; s < HS; s++) dx = MFMA16(WF(F_W0T + s), bd0[n][s], dx);

@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(64)
 k_lidar_resample(const float *__restrict__ z, const float *__restrict__ sigma, const float *__restrict__ sample_dist,
                  const float *__restrict__ u, uint32_t N, uint32_t T, uint32_t n_new, uint32_t P,
                  float density_scale, uint32_t sorted_new, float *__restrict__ new_z, float *__restrict__ z_out,
-                 int32_t *__restrict__ perm) {
+                 int32_t *__restrict__ perm, uint32_t sigma_stride) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float *zs = reinterpret_cast<float *>(smem_raw);
     float *cdf = zs + T;
@@ -200,7 +200,7 @@ k_lidar_resample(const float *__restrict__ z, const float *__restrict__ sigma, c
 
     const int lane = threadIdx.x;
     const uint32_t ray = blockIdx.x;
-    const float *zr = z + (size_t)ray * T, *sr = sigma + (size_t)ray * T;
+    const float *zr = z + (size_t)ray * T, *sr = sigma + (size_t)ray * sigma_stride;
     const float sd = sample_dist[ray];
     const uint32_t nb = T - 1;  // number of bins (z_mid entries) = cdf entries
     const uint32_t nw = T - 2;  // number of pdf weights: weights[1:-1]
@@ -384,11 +384,12 @@ int lnh_lidar_composite_backward(const float *grad_weights_sum, const float *gra
     return lnh_check_launch("lnh_lidar_composite_backward");
 }
 
-int lnh_lidar_resample(const float *z, const float *sigma, const float *sample_dist, const float *u, uint32_t N,
-                       uint32_t T, uint32_t n_new, float density_scale, uint32_t sorted_new, float *new_z, float *z_out,
-                       int32_t *perm, lnh_stream_t stream) {
+int lnh_lidar_resample_strided(const float *z, const float *sigma, uint32_t sigma_stride, const float *sample_dist,
+                               const float *u, uint32_t N, uint32_t T, uint32_t n_new, float density_scale,
+                               uint32_t sorted_new, float *new_z, float *z_out, int32_t *perm, lnh_stream_t stream) {
     LNH_REQUIRE(z && sigma && sample_dist && u && new_z && z_out && perm, LNH_ERR_INVALID_ARG,
                 "lidar_resample: null pointer");
+    LNH_REQUIRE(sigma_stride >= T, LNH_ERR_INVALID_ARG, "lidar_resample: sigma_stride %u < T %u", sigma_stride, T);
     LNH_REQUIRE(T >= 3, LNH_ERR_INVALID_ARG, "lidar_resample: needs T >= 3 coarse samples (got %u)", T);
     LNH_REQUIRE(n_new >= 1 && n_new <= 1024, LNH_ERR_UNSUPPORTED, "lidar_resample: n_new must be in 1..1024 (got %u)", n_new);
     uint32_t P = 64;
@@ -401,8 +402,15 @@ int lnh_lidar_resample(const float *z, const float *sigma, const float *sample_d
     if (lds > 64 * 1024)
         hipFuncSetAttribute((const void *)k_lidar_resample, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     LNH_LAUNCH(k_lidar_resample, dim3(N), dim3(64), lds, s, z, sigma, sample_dist, u, N, T, n_new, P,
-                       density_scale, sorted_new, new_z, z_out, perm);
+                       density_scale, sorted_new, new_z, z_out, perm, sigma_stride);
     return lnh_check_launch("lnh_lidar_resample");
+}
+
+int lnh_lidar_resample(const float *z, const float *sigma, const float *sample_dist, const float *u, uint32_t N,
+                       uint32_t T, uint32_t n_new, float density_scale, uint32_t sorted_new, float *new_z, float *z_out,
+                       int32_t *perm, lnh_stream_t stream) {
+    return lnh_lidar_resample_strided(z, sigma, T, sample_dist, u, N, T, n_new, density_scale, sorted_new, new_z, z_out,
+                                      perm, stream);
 }
 
 }  // extern "C"

@@ -141,6 +141,20 @@ def _no_autocast(fn):
     return wrapped
 
 
+_SAMPLE_DIST = {}
+
+
+def _sample_dist(N, value, dev):
+    """[N] fp32 tensor filled with `value` — the same every step, so it is kept instead of re-filled (read-only)."""
+    key = (N, value, str(dev))
+    t = _SAMPLE_DIST.get(key)
+    if t is None:
+        if len(_SAMPLE_DIST) > 16:
+            _SAMPLE_DIST.clear()
+        t = _SAMPLE_DIST[key] = torch.full((N,), value, dtype=torch.float32, device=dev)
+    return t
+
+
 class FusedLidarRender(Function):
     @staticmethod
     @_no_autocast
@@ -158,8 +172,7 @@ class FusedLidarRender(Function):
         aabb = (model.aabb_train if model.training else model.aabb_infer).float().contiguous()
         # sample_dist = (fars - nears) / T with the fp32 roundings of renderer.py:129-156, formed on the host
         near32 = np.float32(model.min_near_lidar)
-        sd = torch.full((N,), float((np.float32(near32 * np.float32(81.0)) - near32) / np.float32(T)),
-                        dtype=torch.float32, device=dev)
+        sd = _sample_dist(N, float((np.float32(near32 * np.float32(81.0)) - near32) / np.float32(T)), dev)
 
         # fp16 copy of the table: maintained by the fused table optimizer when there is one (train_step.LidarTrainer),
         # otherwise cast here (the autocast rule of grid.py:54-57)
@@ -194,12 +207,12 @@ class FusedLidarRender(Function):
                       h16.data_ptr(), sigma_pt.data_ptr())
 
         density(z, T, 0)
-        sigma_c = sigma_pt[:, :T].contiguous()
         new_z = torch.empty((N, t_new), dtype=torch.float32, device=dev)
         z_all = torch.empty((N, Ttot), dtype=torch.float32, device=dev)
         perm = torch.empty((N, Ttot), dtype=torch.int32, device=dev)
-        _hip.call("lnh_lidar_resample", z.data_ptr(), sigma_c.data_ptr(), sd.data_ptr(), u.data_ptr(), N, T, t_new,
-                  float(density_scale), 1, new_z.data_ptr(), z_all.data_ptr(), perm.data_ptr())
+        # (stage-1 densities = the first T columns of the [N, T+t] buffer: read in place, row stride T+t)
+        _hip.call("lnh_lidar_resample_strided", z.data_ptr(), sigma_pt.data_ptr(), Ttot, sd.data_ptr(), u.data_ptr(), N, T,
+                  t_new, float(density_scale), 1, new_z.data_ptr(), z_all.data_ptr(), perm.data_ptr())
         density(new_z, t_new, T)
 
         sigma_m = torch.empty((N, Ttot), dtype=torch.float32, device=dev)
@@ -227,6 +240,9 @@ class FusedLidarRender(Function):
         ctx.table_param, ctx.mdt = spec.table_param, mdt
         ctx.param_dtypes = (embeddings.dtype, ws0.dtype, ws1.dtype, wc0.dtype, wc1.dtype, wc2.dtype)
         ctx.mark_non_differentiable(weights, z_all)
+        # outputs the loss does not use (weights_sum in the LiDAR loss) arrive as None instead of a zero tensor filled
+        # for the occasion; the compositing backward takes a null pointer for them
+        ctx.set_materialize_grads(False)
         return ws, depth, image, weights, z_all
 
     @staticmethod
@@ -238,11 +254,12 @@ class FusedLidarRender(Function):
         dev = h16.device
         mdt, sfx = ctx.mdt, _hip.mlp_suffix(ctx.mdt)
         Ttot = T + t_new
-        g_ws, g_depth, g_image = g_ws.contiguous().float(), g_depth.contiguous().float(), g_image.contiguous().float()
+        g_ws, g_depth, g_image = (None if g is None else g.contiguous().float() for g in (g_ws, g_depth, g_image))
+        ptr = lambda t: None if t is None else t.data_ptr()
 
         g_sigma = torch.empty((N, Ttot), dtype=torch.float32, device=dev)
         g_rgb = torch.empty((N, Ttot, 2), dtype=torch.float32, device=dev)
-        _hip.call("lnh_lidar_composite_backward", g_ws.data_ptr(), g_depth.data_ptr(), g_image.data_ptr(),
+        _hip.call("lnh_lidar_composite_backward", ptr(g_ws), ptr(g_depth), ptr(g_image),
                   z_all.data_ptr(), sigma_m.data_ptr(), rgb.data_ptr(), sd.data_ptr(), N, Ttot, 2, float(ds),
                   g_sigma.data_ptr(), g_rgb.data_ptr())
 

@@ -31,16 +31,18 @@ class _FusedLidarLoss(torch.autograd.Function):
         depth, image, gt = depth.reshape(n).float().contiguous(), image.reshape(n, 2).float().contiguous(), \
             gt.reshape(n, 3).float().contiguous()
         loss = torch.empty((), dtype=torch.float32, device=depth.device)
-        g_depth, g_image = torch.empty_like(depth), torch.empty_like(image)
+        grads = torch.empty(3 * n, dtype=torch.float32, device=depth.device)  # [d/d depth (n) | d/d image (n, 2)]
         _hip.call("lnh_lidar_loss", depth.data_ptr(), image.data_ptr(), gt.data_ptr(), n, float(ad), float(ar), float(ai),
-                  loss.data_ptr(), g_depth.data_ptr(), g_image.data_ptr())
-        ctx.save_for_backward(g_depth, g_image)
+                  loss.data_ptr(), grads.data_ptr(), grads.data_ptr() + 4 * n)
+        ctx.save_for_backward(grads)
+        ctx.n = n
         return loss
 
     @staticmethod
     def backward(ctx, g):
-        g_depth, g_image = ctx.saved_tensors
-        return g_depth * g, g_image * g, None, None, None, None
+        (grads,) = ctx.saved_tensors
+        scaled = grads * g  # one launch for both
+        return scaled[:ctx.n], scaled[ctx.n:].view(ctx.n, 2), None, None, None, None
 
 
 def fused_lidar_loss(outputs, images_lidar, alpha_d=1000.0, alpha_r=1.0, alpha_i=10.0):
@@ -109,6 +111,12 @@ class LidarTrainer:
                 self.loss_scale = torch.full((), 65536.0, dtype=torch.float32, device=tp.device)
                 self.growth_tracker = torch.zeros((), dtype=torch.int32, device=tp.device)
         params = [g for g in params if len(g["params"])]
+        # the reference's groups differ in nothing but their parameter lists (network.py get_params: every group at `lr`):
+        # step them as ONE group — torch launches its fused Adam once per group — and keep the reference's grouping for
+        # the checkpoint layout only (_optimizer_state_ref_layout)
+        if len(params) > 1 and all({k: v for k, v in g.items() if k != "params"} ==
+                                   {k: v for k, v in params[0].items() if k != "params"} for g in params):
+            params = [dict(params[0], params=[p for g in params for p in g["params"]])]
         self.optimizer = torch.optim.Adam(params, betas=(0.9, 0.99), eps=1e-15, fused=on_gpu)
         self.scheduler = torch.optim.lr_scheduler.LambdaLR(self.optimizer, lambda it: 0.1 ** min(it / iters, 1))
         self.scaler = torch.amp.GradScaler("cuda", enabled=fp16)
@@ -135,14 +143,15 @@ class LidarTrainer:
         tp._lnh_grad_reduced = False
         with torch.autocast("cuda", dtype=self.amp_dtype):
             loss = self.loss(rays_o, rays_d, images_lidar, patch)
-        (loss * self.loss_scale).backward()
+        loss.backward(gradient=self.loss_scale.to(loss.dtype))  # = (loss * scale).backward() without the product and its ones_like
         if self.world > 1:
             parallel.allreduce_gradients(self.params, self.world)
         # --- GradScaler.step / update, with the table handled by the fused kernels
         found_inf = torch.zeros((), dtype=torch.float32, device=tp.device)
         inv_scale = self.loss_scale.reciprocal()
         # data parallel: the fp16 table gradient arrives as the sum over ranks; its mean is taken here, in fp32
-        inv_scale_table = inv_scale / float(getattr(tp, "_lnh_grad16_div", 1))
+        div = float(getattr(tp, "_lnh_grad16_div", 1))
+        inv_scale_table = inv_scale / div if div != 1.0 else inv_scale
         grads = [p.grad for p in self.params if p.grad is not None]
         if grads:
             torch._amp_foreach_non_finite_check_and_unscale_(grads, found_inf, inv_scale)
@@ -240,9 +249,13 @@ class LidarTrainer:
                     elif id(p) in own_ids:
                         own["state"][own_ids[id(p)]] = st
                 idx += 1
+        # learning rates: the reference's groups that hold parameters stepped here, in order; when they are stepped as
+        # one merged group (see __init__) they all carry the same value and the first one is taken
         lr_by_pos = [g.get("lr") for g in sd["param_groups"]]
-        for g, lr in zip(own["param_groups"], [l for l, grp in zip(lr_by_pos, self._ref_layout)
-                                               if any(id(p) in own_ids for p in grp)]):
+        lrs = [l for l, grp in zip(lr_by_pos, self._ref_layout) if any(id(p) in own_ids for p in grp)]
+        if len(own["param_groups"]) == 1:
+            lrs = lrs[:1]
+        for g, lr in zip(own["param_groups"], lrs):
             if lr is not None:
                 g["lr"] = lr
         self.optimizer.load_state_dict(own)
