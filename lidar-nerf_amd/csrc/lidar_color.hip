@@ -51,15 +51,29 @@ k_color_forward(ColorArgs a) {
     for (int s = 0; s < HS; s++) w2[s] = load_a_nu(a.W + kW2, 64, c, s, g);
 
     const uint32_t total = a.N * a.T;  // < 2^32 (checked by the launcher)
-    for (uint32_t base = wave * NT * 16; base < total; base += nwaves * NT * 16) {
-        float wgt[NT];
+    // weight -> (mask) -> perm -> sigma-net row is a chain of three dependent round trips per 64 samples, and a SIMD holds
+    // only four such waves: the kernel ran at the speed of that chain.  The weights and the permutation of the NEXT
+    // span are requested before the current one is processed (8 registers), so a span waits for its rows only.
+    auto load_wp = [&](uint32_t base, float (&wgt)[NT], uint32_t (&slot)[NT]) {
+#pragma unroll
+        for (int n = 0; n < NT; n++) {
+            const uint32_t m = base + n * 16 + c;
+            const uint32_t mc = m < total ? m : 0;  // unconditional loads + selects
+            const float wv = a.weights[mc];
+            slot[n] = (uint32_t)a.perm[mc];
+            wgt[n] = m < total ? wv : 0.0f;
+        }
+    };
+    float wgt[NT], wgt_next[NT];
+    uint32_t slot[NT], slot_next[NT];
+    const uint32_t stride = nwaves * NT * 16;
+    load_wp(wave * NT * 16, wgt, slot);
+    for (uint32_t base = wave * NT * 16; base < total; base += stride) {
+        load_wp(base + stride < total ? base + stride : base, wgt_next, slot_next);
         bool msk[NT];
         bool any = false;
 #pragma unroll
         for (int n = 0; n < NT; n++) {
-            const uint32_t m = base + n * 16 + c;
-            const float wv = a.weights[m < total ? m : 0];  // unconditional load + select
-            wgt[n] = m < total ? wv : 0.0f;
             msk[n] = wgt[n] > kMaskThresh;
             any |= msk[n];
         }
@@ -71,43 +85,48 @@ k_color_forward(ColorArgs a) {
                     if (m < total) *reinterpret_cast<float2 *>(a.rgb + (size_t)m * 2) = make_float2(0.0f, 0.0f);
                 }
             }
-            continue;
+        } else {
+#pragma unroll
+            for (int n = 0; n < NT; n++) {
+                const uint32_t m = base + n * 16 + c;
+                const bool valid = m < total;
+                const uint32_t mc = valid ? m : 0, ray = mc / a.T;
+                const size_t src = (size_t)ray * a.T + (valid ? slot[n] : 0u);
+                const half8_t bxl = *reinterpret_cast<const half8_t *>(a.h16 + src * 16 + (g < 2 ? 8 * g : 0));
+                const half8_t bx = (valid && g < 2) ? bxl : zero_h8();
+                f32x4 acc[HT];
+#pragma unroll
+                for (int t = 0; t < HT; t++) acc[t] = *reinterpret_cast<const f32x4 *>(a.cdir + (size_t)ray * 64 + 16 * t + 4 * g);
+#pragma unroll
+                for (int t = 0; t < HT; t++) acc[t] = MFMA16(w0[t], bx, acc[t]);
+                half8_t bh[HS];
+#pragma unroll
+                for (int s = 0; s < HS; s++)
+                    bh[s] = pack_pair_relu(acc[2 * s], acc[2 * s + 1]);
+#pragma unroll
+                for (int t = 0; t < HT; t++) {
+                    acc[t] = zero_f4();
+#pragma unroll
+                    for (int s = 0; s < HS; s++) acc[t] = MFMA16(w1[t][s], bh[s], acc[t]);
+                }
+#pragma unroll
+                for (int s = 0; s < HS; s++)
+                    bh[s] = pack_pair_relu(acc[2 * s], acc[2 * s + 1]);
+                f32x4 o = zero_f4();
+#pragma unroll
+                for (int s = 0; s < HS; s++) o = MFMA16(w2[s], bh[s], o);
+                if (valid && g == 0) {
+                    // the unfused path rounds the MLP output to fp16 before the sigmoid (autocast Linear output)
+                    const float r0 = msk[n] ? sigmoidf((float)(half_t)o[0]) : 0.0f;
+                    const float r1 = msk[n] ? sigmoidf((float)(half_t)o[1]) : 0.0f;
+                    *reinterpret_cast<float2 *>(a.rgb + (size_t)m * 2) = make_float2(r0, r1);
+                }
+            }
         }
 #pragma unroll
         for (int n = 0; n < NT; n++) {
-            const uint32_t m = base + n * 16 + c;
-            const bool valid = m < total;
-            const uint32_t mc = valid ? m : 0, ray = mc / a.T;
-            const size_t src = (size_t)ray * a.T + (uint32_t)a.perm[mc];
-            const half8_t bxl = *reinterpret_cast<const half8_t *>(a.h16 + src * 16 + (g < 2 ? 8 * g : 0));
-            const half8_t bx = (valid && g < 2) ? bxl : zero_h8();
-            f32x4 acc[HT];
-#pragma unroll
-            for (int t = 0; t < HT; t++) acc[t] = *reinterpret_cast<const f32x4 *>(a.cdir + (size_t)ray * 64 + 16 * t + 4 * g);
-#pragma unroll
-            for (int t = 0; t < HT; t++) acc[t] = MFMA16(w0[t], bx, acc[t]);
-            half8_t bh[HS];
-#pragma unroll
-            for (int s = 0; s < HS; s++)
-                bh[s] = pack_pair_relu(acc[2 * s], acc[2 * s + 1]);
-#pragma unroll
-            for (int t = 0; t < HT; t++) {
-                acc[t] = zero_f4();
-#pragma unroll
-                for (int s = 0; s < HS; s++) acc[t] = MFMA16(w1[t][s], bh[s], acc[t]);
-            }
-#pragma unroll
-            for (int s = 0; s < HS; s++)
-                bh[s] = pack_pair_relu(acc[2 * s], acc[2 * s + 1]);
-            f32x4 o = zero_f4();
-#pragma unroll
-            for (int s = 0; s < HS; s++) o = MFMA16(w2[s], bh[s], o);
-            if (valid && g == 0) {
-                // the unfused path rounds the MLP output to fp16 before the sigmoid (autocast Linear output)
-                const float r0 = msk[n] ? sigmoidf((float)(half_t)o[0]) : 0.0f;
-                const float r1 = msk[n] ? sigmoidf((float)(half_t)o[1]) : 0.0f;
-                *reinterpret_cast<float2 *>(a.rgb + (size_t)m * 2) = make_float2(r0, r1);
-            }
+            wgt[n] = wgt_next[n];
+            slot[n] = slot_next[n];
         }
     }
 }
