@@ -56,25 +56,41 @@ k_merge_weights(const float *__restrict__ z, const float *__restrict__ sigma_pt,
     const float *sp = sigma_pt + (size_t)ray * T;
     const int32_t *pr = perm + (size_t)ray * T;
     const float sd = sample_dist[ray];
+    // kChunks 64-sample chunks are requested at once (perm, z, then the gathered sigma) and scanned from registers:
+    // one dependent round trip per chunk made this one-wave-per-ray kernel run at HBM latency (see lidar_render.hip)
+    constexpr int kChunks = 7;
     float carry = 1.0f;
-    for (uint32_t base = 0; base < T; base += 64) {
-        const uint32_t i = base + lane;
-        float alpha = 0.0f, om = 1.0f, sg = 0.0f;
-        if (i < T) {
-            sg = sp[pr[i]];
-            const float zi = zr[i];
-            const float delta = (i + 1 < T) ? (zr[i + 1] - zi) : sd;
-            alpha = 1.0f - expf(-delta * density_scale * sg);
-            om = 1.0f - alpha + 1e-15f;
+    for (uint32_t base0 = 0; base0 < T; base0 += 64 * kChunks) {
+        float zi[kChunks], zn[kChunks], sg[kChunks];
+        int32_t pi[kChunks];
+#pragma unroll
+        for (int u = 0; u < kChunks; u++) {
+            const uint32_t i = base0 + u * 64 + lane, ic = i < T ? i : 0, in = i + 1 < T ? i + 1 : ic;
+            pi[u] = pr[ic];
+            zi[u] = zr[ic];
+            zn[u] = zr[in];
         }
-        const float incl = wave_scan_mul(om, lane);
-        float excl = __shfl_up(incl, 1, 64);
-        if (lane == 0) excl = 1.0f;
-        if (i < T) {
-            sigma_m[(size_t)ray * T + i] = sg;
-            weights[(size_t)ray * T + i] = alpha * (carry * excl);
+#pragma unroll
+        for (int u = 0; u < kChunks; u++) sg[u] = sp[pi[u]];
+#pragma unroll
+        for (int u = 0; u < kChunks; u++) {
+            const uint32_t i = base0 + u * 64 + lane;
+            if (base0 + u * 64 >= T) break;  // wave-uniform
+            float alpha = 0.0f, om = 1.0f;
+            if (i < T) {
+                const float delta = (i + 1 < T) ? (zn[u] - zi[u]) : sd;
+                alpha = 1.0f - expf(-delta * density_scale * sg[u]);
+                om = 1.0f - alpha + 1e-15f;
+            }
+            const float incl = wave_scan_mul(om, lane);
+            float excl = __shfl_up(incl, 1, 64);
+            if (lane == 0) excl = 1.0f;
+            if (i < T) {
+                sigma_m[(size_t)ray * T + i] = sg[u];
+                weights[(size_t)ray * T + i] = alpha * (carry * excl);
+            }
+            carry *= __shfl(incl, 63, 64);
         }
-        carry *= __shfl(incl, 63, 64);
     }
 }
 

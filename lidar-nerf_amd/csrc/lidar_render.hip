@@ -34,6 +34,19 @@ __device__ __forceinline__ void sample_alpha(const float *__restrict__ z, const 
     om = 1.0f - alpha + kEps;
 }
 
+// The same from values already in registers (zn = z[i+1], ignored for the last sample).
+__device__ __forceinline__ void alpha_of(float zi, float zn, bool has_next, float sg, float sample_dist,
+                                         float density_scale, float &delta, float &alpha, float &om, float &e) {
+    delta = has_next ? (zn - zi) : sample_dist;
+    e = expf(-delta * density_scale * sg);
+    alpha = 1.0f - e;
+    om = 1.0f - alpha + kEps;
+}
+// The per-ray kernels below are one wave per ray walking the ray in 64-sample chunks with a scan carry: left as a plain
+// loop every chunk pays its own HBM round trip (13 dependent ones at 832 samples — the kernels ran at that latency, not
+// at bandwidth).  They therefore request kChunks chunks at once and scan them from registers.
+constexpr int kChunks = 7;
+
 // ------------------------------------------------------------------------------------------------ weights only
 __global__ void __launch_bounds__(256)
 k_lidar_weights(const float *__restrict__ z, const float *__restrict__ sigma, const float *__restrict__ sample_dist,
@@ -74,27 +87,34 @@ k_lidar_composite_fwd(const float *__restrict__ z, const float *__restrict__ sig
     float carry = 1.0f, ws = 0.0f, dep = 0.0f, img[K];
 #pragma unroll
     for (int k = 0; k < K; k++) img[k] = 0.0f;
-    for (uint32_t base = 0; base < T; base += 64) {
-        const uint32_t i = base + lane;
-        float zi = 0, delta, alpha = 0.0f, om = 1.0f, e;
-        float c[K];
+    for (uint32_t base0 = 0; base0 < T; base0 += 64 * kChunks) {
+        float zi[kChunks], zn[kChunks], sg[kChunks], c[kChunks][K];
 #pragma unroll
-        for (int k = 0; k < K; k++) c[k] = 0.0f;
-        if (i < T) {
-            sample_alpha(zr, sr, i, T, sd, density_scale, zi, delta, alpha, om, e);
+        for (int u = 0; u < kChunks; u++) {
+            const uint32_t i = base0 + u * 64 + lane, ic = i < T ? i : 0, in = i + 1 < T ? i + 1 : ic;
+            zi[u] = zr[ic];
+            zn[u] = zr[in];
+            sg[u] = sr[ic];
 #pragma unroll
-            for (int k = 0; k < K; k++) c[k] = cr[(size_t)i * K + k];
+            for (int k = 0; k < K; k++) c[u][k] = cr[(size_t)ic * K + k];
         }
-        const float incl = wave_scan_mul(om, lane);
-        float excl = __shfl_up(incl, 1, 64);
-        if (lane == 0) excl = 1.0f;
-        const float w = alpha * (carry * excl);
-        if (i < T && wr) wr[i] = w;
-        ws += w;
-        dep += w * zi;
 #pragma unroll
-        for (int k = 0; k < K; k++) img[k] += w * c[k];
-        carry *= __shfl(incl, 63, 64);
+        for (int u = 0; u < kChunks; u++) {
+            const uint32_t i = base0 + u * 64 + lane;
+            if (base0 + u * 64 >= T) break;  // wave-uniform
+            float delta, alpha = 0.0f, om = 1.0f, e;
+            if (i < T) alpha_of(zi[u], zn[u], i + 1 < T, sg[u], sd, density_scale, delta, alpha, om, e);
+            const float incl = wave_scan_mul(om, lane);
+            float excl = __shfl_up(incl, 1, 64);
+            if (lane == 0) excl = 1.0f;
+            const float w = alpha * (carry * excl);
+            if (i < T && wr) wr[i] = w;
+            ws += w;
+            dep += i < T ? w * zi[u] : 0.0f;
+#pragma unroll
+            for (int k = 0; k < K; k++) img[k] += i < T ? w * c[u][k] : 0.0f;
+            carry *= __shfl(incl, 63, 64);
+        }
     }
     ws = wave_sum(ws);
     dep = wave_sum(dep);
@@ -129,61 +149,81 @@ k_lidar_composite_bwd(const float *__restrict__ g_ws, const float *__restrict__ 
 #pragma unroll
     for (int k = 0; k < K; k++) gim[k] = g_image ? g_image[(size_t)ray * K + k] : 0.0f;
 
+    auto load_chunks = [&](uint32_t base0, float (&zi)[kChunks], float (&zn)[kChunks], float (&sg)[kChunks],
+                           float (&ci)[kChunks]) {
+#pragma unroll
+        for (int u = 0; u < kChunks; u++) {
+            const uint32_t i = base0 + u * 64 + lane, ic = i < T ? i : 0, in = i + 1 < T ? i + 1 : ic;
+            zi[u] = zr[ic];
+            zn[u] = zr[in];
+            sg[u] = sr[ic];
+            float c[K];
+#pragma unroll
+            for (int k = 0; k < K; k++) c[k] = cr[(size_t)ic * K + k];
+            ci[u] = gws + gdp * zi[u];
+#pragma unroll
+            for (int k = 0; k < K; k++) ci[u] += gim[k] * c[k];
+        }
+    };
     // pass 1: total = sum_i w_i c_i with c_i = g_ws + g_depth z_i + sum_k g_img_k rgb_ik
     float carry = 1.0f, total = 0.0f;
-    for (uint32_t base = 0; base < T; base += 64) {
-        const uint32_t i = base + lane;
-        float zi = 0, delta, alpha = 0.0f, om = 1.0f, e, ci = 0.0f;
-        if (i < T) {
-            sample_alpha(zr, sr, i, T, sd, density_scale, zi, delta, alpha, om, e);
-            ci = gws + gdp * zi;
+    for (uint32_t base0 = 0; base0 < T; base0 += 64 * kChunks) {
+        float zi[kChunks], zn[kChunks], sg[kChunks], ci[kChunks];
+        load_chunks(base0, zi, zn, sg, ci);
 #pragma unroll
-            for (int k = 0; k < K; k++) ci += gim[k] * cr[(size_t)i * K + k];
+        for (int u = 0; u < kChunks; u++) {
+            const uint32_t i = base0 + u * 64 + lane;
+            if (base0 + u * 64 >= T) break;  // wave-uniform
+            float delta, alpha = 0.0f, om = 1.0f, e;
+            if (i < T) alpha_of(zi[u], zn[u], i + 1 < T, sg[u], sd, density_scale, delta, alpha, om, e);
+            const float incl = wave_scan_mul(om, lane);
+            float excl = __shfl_up(incl, 1, 64);
+            if (lane == 0) excl = 1.0f;
+            total += i < T ? alpha * (carry * excl) * ci[u] : 0.0f;
+            carry *= __shfl(incl, 63, 64);
         }
-        const float incl = wave_scan_mul(om, lane);
-        float excl = __shfl_up(incl, 1, 64);
-        if (lane == 0) excl = 1.0f;
-        total += alpha * (carry * excl) * ci;
-        carry *= __shfl(incl, 63, 64);
     }
     total = wave_sum(total);
 
     // pass 2: prefix of w c, gradients
     carry = 1.0f;
     float pref_carry = 0.0f;
-    for (uint32_t base = 0; base < T; base += 64) {
-        const uint32_t i = base + lane;
-        float zi = 0, delta = 0.0f, alpha = 0.0f, om = 1.0f, e = 1.0f, ci = 0.0f;
-        if (i < T) {
-            sample_alpha(zr, sr, i, T, sd, density_scale, zi, delta, alpha, om, e);
-            ci = gws + gdp * zi;
+    for (uint32_t base0 = 0; base0 < T; base0 += 64 * kChunks) {
+        float zi[kChunks], zn[kChunks], sg[kChunks], ci[kChunks];
+        load_chunks(base0, zi, zn, sg, ci);
 #pragma unroll
-            for (int k = 0; k < K; k++) ci += gim[k] * cr[(size_t)i * K + k];
-        }
-        const float incl = wave_scan_mul(om, lane);
-        float excl = __shfl_up(incl, 1, 64);
-        if (lane == 0) excl = 1.0f;
-        const float Ti = carry * excl;
-        const float w = alpha * Ti;
-        const float wc = w * ci;
-        const float pref = pref_carry + wave_scan_add(wc, lane);  // inclusive prefix of w c
-        if (i < T) {
-            const float suffix = total - pref;  // sum_{j>i} w_j c_j
-            const float dalpha = Ti * ci - suffix / om;
-            gs[i] = dalpha * (delta * density_scale * e);  // d alpha / d sigma = delta * s * exp(-delta s sigma)
-            if (gc) {
+        for (int u = 0; u < kChunks; u++) {
+            const uint32_t i = base0 + u * 64 + lane;
+            if (base0 + u * 64 >= T) break;  // wave-uniform
+            float delta = 0.0f, alpha = 0.0f, om = 1.0f, e = 1.0f;
+            if (i < T) alpha_of(zi[u], zn[u], i + 1 < T, sg[u], sd, density_scale, delta, alpha, om, e);
+            const float cu = i < T ? ci[u] : 0.0f;
+            const float incl = wave_scan_mul(om, lane);
+            float excl = __shfl_up(incl, 1, 64);
+            if (lane == 0) excl = 1.0f;
+            const float Ti = carry * excl;
+            const float w = alpha * Ti;
+            const float wc = w * cu;
+            const float pref = pref_carry + wave_scan_add(wc, lane);  // inclusive prefix of w c
+            if (i < T) {
+                const float suffix = total - pref;  // sum_{j>i} w_j c_j
+                const float dalpha = Ti * cu - suffix / om;
+                gs[i] = dalpha * (delta * density_scale * e);  // d alpha / d sigma = delta * s * exp(-delta s sigma)
+                if (gc) {
 #pragma unroll
-                for (int k = 0; k < K; k++) gc[(size_t)i * K + k] = w * gim[k];
+                    for (int k = 0; k < K; k++) gc[(size_t)i * K + k] = w * gim[k];
+                }
             }
+            carry *= __shfl(incl, 63, 64);
+            pref_carry = __shfl(pref, 63, 64);
         }
-        carry *= __shfl(incl, 63, 64);
-        pref_carry = __shfl(pref, 63, 64);
     }
 }
 
 // ------------------------------------------------------------------------------------------------ resample + merge
 // One 64-thread workgroup (one wave) per ray.  Dynamic LDS layout (floats):
-//   zs[T] | cdf[T-1] | key[P] | val[P] | zo[T+n] | po[T+n] | cnt[n]   (P = n_new rounded up to a power of two, >= 64)
+//   zs[T] | cdf[T] | key[P] | val[P] | cnt[n]   (P = n_new rounded up to a power of two, >= 64): 6.9 KB at 768 + 64, so
+// that the 4096 one-wave workgroups of a batch are resident together (16 per CU) — the kernel is pure latency per ray
 __global__ void __launch_bounds__(64)
 k_lidar_resample(const float *__restrict__ z, const float *__restrict__ sigma, const float *__restrict__ sample_dist,
                  const float *__restrict__ u, uint32_t N, uint32_t T, uint32_t n_new, uint32_t P,
@@ -192,11 +232,9 @@ k_lidar_resample(const float *__restrict__ z, const float *__restrict__ sigma, c
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float *zs = reinterpret_cast<float *>(smem_raw);
     float *cdf = zs + T;
-    float *key = cdf + (T - 1);
+    float *key = cdf + T;
     int *val = reinterpret_cast<int *>(key + P);
-    float *zo = reinterpret_cast<float *>(val + P);
-    int *po = reinterpret_cast<int *>(zo + (T + n_new));
-    int *cnt = po + (T + n_new);
+    int *cnt = val + P;
 
     const int lane = threadIdx.x;
     const uint32_t ray = blockIdx.x;
@@ -205,10 +243,10 @@ k_lidar_resample(const float *__restrict__ z, const float *__restrict__ sigma, c
     const uint32_t nb = T - 1;  // number of bins (z_mid entries) = cdf entries
     const uint32_t nw = T - 2;  // number of pdf weights: weights[1:-1]
 
-    // 0) the ray's z and sigma rows into LDS with all loads in flight at once (zo[] doubles as the sigma scratch): the
-    //    scan loop below would otherwise pay one HBM round trip per 64-sample chunk, and this kernel is one wave per
-    //    ray, i.e. pure latency
-    float *sg = zo;
+    // 0) the ray's z and sigma rows into LDS with all loads in flight at once: the scan loop below would otherwise pay
+    //    one HBM round trip per 64-sample chunk.  sigma shares its words with cdf[]: step 1 reads sigma[i] and then
+    //    writes cdf[i] from the same lane, nothing else touches either before the barrier
+    float *sg = cdf;
 #pragma unroll 4
     for (uint32_t i = lane; i < T; i += 64) {
         zs[i] = zr[i];
@@ -313,21 +351,17 @@ k_lidar_resample(const float *__restrict__ z, const float *__restrict__ sigma, c
             const uint32_t mid = (lo + hi) >> 1;
             if ((uint32_t)cnt[mid] <= i) lo = mid + 1; else hi = mid;
         }
-        zo[i + lo] = zs[i];
-        po[i + lo] = (int)i;
+        // (positions grow with i: consecutive lanes write consecutive or nearly consecutive words of the ray's row)
+        z_out[(size_t)ray * (T + n_new) + i + lo] = zs[i];
+        perm[(size_t)ray * (T + n_new) + i + lo] = (int)i;
     }
     for (uint32_t r = lane; r < n_new; r += 64) {
         const uint32_t pos = (uint32_t)cnt[r] + r;
-        zo[pos] = key[r];
+        z_out[(size_t)ray * (T + n_new) + pos] = key[r];
         // sorted_new: the new samples are handed out in ascending order (slot T + r), so that the density pass sees
         // consecutive lanes = neighbouring positions along the ray, like the coarse samples
-        po[pos] = (int)(T + (sorted_new ? r : (uint32_t)val[r]));
+        perm[(size_t)ray * (T + n_new) + pos] = (int)(T + (sorted_new ? r : (uint32_t)val[r]));
         if (sorted_new) new_z[(size_t)ray * n_new + r] = key[r];
-    }
-    __syncthreads();
-    for (uint32_t i = lane; i < T + n_new; i += 64) {
-        z_out[(size_t)ray * (T + n_new) + i] = zo[i];
-        perm[(size_t)ray * (T + n_new) + i] = po[i];
     }
 }
 
@@ -394,7 +428,7 @@ int lnh_lidar_resample_strided(const float *z, const float *sigma, uint32_t sigm
     LNH_REQUIRE(n_new >= 1 && n_new <= 1024, LNH_ERR_UNSUPPORTED, "lidar_resample: n_new must be in 1..1024 (got %u)", n_new);
     uint32_t P = 64;
     while (P < n_new) P <<= 1;
-    const size_t lds = sizeof(float) * ((size_t)T + (T - 1) + 2 * (size_t)P + 2 * ((size_t)T + n_new) + n_new);
+    const size_t lds = sizeof(float) * (2 * (size_t)T + 2 * (size_t)P + n_new);
     LNH_REQUIRE(lds <= 160 * 1024, LNH_ERR_UNSUPPORTED, "lidar_resample: T=%u n_new=%u needs %zu B of LDS (> 160 KiB)", T,
                 n_new, lds);
     if (N == 0) return LNH_OK;
