@@ -65,9 +65,9 @@ k_mlp_forward(MlpArgs a) {
     for (int s = 0; s < HS; s++) wo[s] = load_a_nu(Wo, hidden, c, s, g);
 
     const uint32_t act = a.act, out_act = a.out_act;
-    for (uint64_t base = (uint64_t)wave * NT * 16; base < a.B; base += (uint64_t)nwaves * NT * 16) {
-        // ---- inputs: B operand, natural k enumeration
-        half8_t bx[NT][IN_KS];
+    // ---- inputs: B operand, natural k enumeration.  One-k-step nets (the sigma net) request the NEXT tile's rows before
+    // the current tile is processed: the kernel is a read -> 3 layers -> write chain per tile at HBM latency otherwise
+    auto load_in = [&](uint64_t base, half8_t (&bx)[NT][IN_KS]) {
 #pragma unroll
         for (int n = 0; n < NT; n++) {
             const uint64_t p = base + n * 16 + c;
@@ -81,6 +81,14 @@ k_mlp_forward(MlpArgs a) {
                 bx[n][s] = ok ? v : zero_h8();
             }
         }
+    };
+    constexpr bool PREFETCH = IN_KS == 1;
+    const uint64_t stride = (uint64_t)nwaves * NT * 16;
+    half8_t bx[NT][IN_KS], bx_next[NT][IN_KS];
+    if (PREFETCH) load_in((uint64_t)wave * NT * 16, bx);
+    for (uint64_t base = (uint64_t)wave * NT * 16; base < a.B; base += stride) {
+        if (PREFETCH) load_in(base + stride < a.B ? base + stride : base, bx_next);
+        else load_in(base, bx);
         // ---- layer 0
         half8_t bh[NT][HS];
         {
@@ -154,6 +162,12 @@ k_mlp_forward(MlpArgs a) {
                     if (g == 0) a.sigma[row] = expf((float)v[0]);
                 }
             }
+        }
+        if (PREFETCH) {
+#pragma unroll
+            for (int n = 0; n < NT; n++)
+#pragma unroll
+                for (int s = 0; s < IN_KS; s++) bx[n][s] = bx_next[n][s];
         }
     }
 }

@@ -71,6 +71,29 @@ def main():
         print(f"{name:28s} active {a.active:.2f}  min {lo:8.1f} us  median {med:8.1f} us")
     print("checksum", float(g_h16.float().abs().sum()), float(g_w.abs().sum()), float(ray_sum.abs().sum()))
 
+    # sigma net on the coarse pass of the same batch: [16, N*T, 2] level-major features -> 16-wide rows
+    Tc, B_all = T - 64, N * T
+    B = N * Tc
+    feat = (torch.randn(16, B_all, 2, device=dev, generator=g) * 0.3).half()
+    wsig = (torch.randn(64 * 32 + 16 * 64, device=dev, generator=g) * 0.2).half()
+    sigma = torch.empty(N * T, device=dev)
+    g_feat = torch.empty(16, B_all, 2, device=dev, dtype=torch.half)
+    g_ws = torch.zeros(wsig.numel(), device=dev)
+
+    def dfwd():
+        _hip.call("lnh_density_mlp_forward", feat.data_ptr(), wsig.data_ptr(), B, Tc, T, 0, B_all, h16.data_ptr(),
+                  sigma.data_ptr())
+
+    def dbwd():
+        _hip.call("lnh_density_mlp_backward", g_h16.data_ptr(), feat.data_ptr(), wsig.data_ptr(), B_all, T, T, 0,
+                  g_feat.data_ptr(), g_ws.data_ptr())
+
+    for name, fn, pts in (("lnh_density_mlp_forward", dfwd, B), ("lnh_density_mlp_backward", dbwd, B_all)):
+        fn()
+        torch.cuda.synchronize()
+        lo, med = timed(fn, a.reps)
+        print(f"{name:28s} {pts / 1e6:.2f} M points  min {lo:8.1f} us  median {med:8.1f} us")
+
 
 if __name__ == "__main__":
     main()
