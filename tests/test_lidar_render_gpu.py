@@ -119,6 +119,34 @@ def test_resample_sorted_new_samples():
     assert torch.equal(torch.gather(cat, 1, p1.long()), zo1)
 
 
+def test_resample_strided_reads_the_first_columns_of_a_wider_buffer():
+    """lnh_lidar_resample_strided on the [N, T+n] buffer the fused step keeps == lnh_lidar_resample on a contiguous copy of
+    its first T columns, bit for bit; a stride below T is refused."""
+    from gpu_util import call
+    from lidarnerf import _hip
+    N, T, n_new = 19, 768, 64
+    z, sigma, _, sd = _ray_inputs(N, T, 11)
+    u = torch.rand(N, n_new, generator=torch.Generator().manual_seed(12))
+    wide = torch.full((N, T + n_new), float("nan"))
+    wide[:, :T] = sigma
+    outs = []
+    for strided in (False, True):
+        new_z = torch.empty((N, n_new), device="cuda")
+        z_out = torch.empty((N, T + n_new), device="cuda")
+        perm = torch.empty((N, T + n_new), dtype=torch.int32, device="cuda")
+        if strided:
+            call("lnh_lidar_resample_strided", z.cuda(), wide.cuda(), T + n_new, sd.cuda(), u.cuda(), N, T, n_new, 1.0, 1,
+                 new_z, z_out, perm)
+        else:
+            call("lnh_lidar_resample", z.cuda(), sigma.cuda(), sd.cuda(), u.cuda(), N, T, n_new, 1.0, 1, new_z, z_out, perm)
+        outs.append((new_z, z_out, perm))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    with pytest.raises(RuntimeError, match="sigma_stride"):
+        call("lnh_lidar_resample_strided", z.cuda(), wide.cuda(), T - 1, sd.cuda(), u.cuda(), N, T, n_new, 1.0, 1,
+             outs[0][0], outs[0][1], outs[0][2])
+
+
 def test_resample_against_reference_golden(golden_dir):
     """G1: reference sample_pdf outputs; here the stage-1 weights are fed through sigma so that w == golden weights
     is not reproducible, so instead check the inverse-cdf stage alone by a degenerate construction: T-2 bins with
