@@ -8,7 +8,7 @@
 #define REP16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 
 template <int KIND>
-__global__ void __launch_bounds__(256) probe(float *out, int iters) {
+__global__ void __launch_bounds__(512) probe(float *out, int iters) {
     float v[16], w[16];
     typedef float f4 __attribute__((ext_vector_type(4)));
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -72,18 +72,20 @@ __global__ void __launch_bounds__(256) probe(float *out, int iters) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+static int g_threads = 256;  // 256 = one wave per SIMD, 512 = two
+
 template <int KIND>
 void run(const char *name, float *out, float ref_ms, float *ms_out) {
     const int iters = 20000;
     hipEvent_t a, b;
     hipEventCreate(&a);
     hipEventCreate(&b);
-    probe<KIND><<<256, 256>>>(out, 100);
+    probe<KIND><<<256, g_threads>>>(out, 100);
     hipDeviceSynchronize();
     float best = 1e9;
     for (int r = 0; r < 3; r++) {
         hipEventRecord(a);
-        probe<KIND><<<256, 256>>>(out, iters);
+        probe<KIND><<<256, g_threads>>>(out, iters);
         hipEventRecord(b);
         hipEventSynchronize(b);
         float ms;
@@ -97,9 +99,9 @@ void run(const char *name, float *out, float ref_ms, float *ms_out) {
     if (ms_out) *ms_out = best;
 }
 
-int main() {
+int main(int argc, char **argv) {
     float *out;
-    hipMalloc(&out, 256 * 256 * 4);
+    hipMalloc(&out, 256 * 512 * 4);
     float ref = 0;
     run<0>("v_add_f32", out, 0, &ref);
     run<1>("v_cvt_pk_f16_f32", out, ref, nullptr);
@@ -112,6 +114,13 @@ int main() {
     run<5>("v_exp_f32", out, ref, nullptr);
     run<6>("mfma 16x16x32 f16 (4 acc)", out, ref, nullptr);
     run<10>("mfma 16x16x32 f16 (1 acc)", out, ref, nullptr);
+    run<11>("mfma + 3 v_add (per group)", out, ref, nullptr);
+    // two waves per SIMD: the same per-wave instruction streams, twice the work — equal time = perfect interleave
+    g_threads = 512;
+    printf("-- two waves per SIMD (time for TWICE the instructions)\n");
+    run<0>("v_add_f32", out, ref, nullptr);
+    run<1>("v_cvt_pk_f16_f32", out, ref, nullptr);
+    run<6>("mfma 16x16x32 f16 (4 acc)", out, ref, nullptr);
     run<11>("mfma + 3 v_add (per group)", out, ref, nullptr);
     return 0;
 }
