@@ -309,6 +309,7 @@ def main():
     t0 = time.perf_counter()
     for s in range(args.steps):
         loss = trainer.step(*batches[(args.warmup + s) % len(batches)])
+    host_ms = (time.perf_counter() - t0) * 1e3 / args.steps  # time the host needs to ENQUEUE a step (no device wait)
     sync()
     elapsed = time.perf_counter() - t0
     timers = _hip.disable_timers()
@@ -416,6 +417,7 @@ def main():
         "value": round(rays_total / elapsed, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
+        "host_enqueue_ms_per_step": round(host_ms, 3),  # < ms_per_step: the launch queue runs ahead of the device
         "dtype": f"{'bf16' if args.mlp_dtype == 'bf16' else 'f16'} (fp16 hash tables + {args.mlp_dtype} MFMA MLP, fp32 accumulate)",
         "data": "synthetic",
         "config": {"workload": "KITTI-360 seq 1908 shaped: hash-grid L=16 F=2 (2^19 rows, res 16..32768) + 64-wide "
