@@ -781,22 +781,24 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
         lsp[lane] = sp0 + (oincl - over) - (st + fit);
     }
     __syncthreads();
-    V2 *pvals = reinterpret_cast<V2 *>(pool_bytes + plan.pool_off[level]);                            // [slot][2]
-    unsigned short *prows = reinterpret_cast<unsigned short *>(pool_bytes + plan.rows_off[level]);    // [slot]
-    SpillEntry<T> *spill = reinterpret_cast<SpillEntry<T> *>(pool_bytes + plan.spill_off[level]);
+    // pool streams of this level: values [slot][2] | rows [slot] | spill list; byte offsets inside a level fit 32 bits
+    // (<= 4 M points per launch), so every store is base (scalar) + 32-bit lane offset — no 64-bit address arithmetic
+    char *pvals = pool_bytes + plan.pool_off[level];
+    char *prows = pool_bytes + plan.rows_off[level];
+    char *spill = pool_bytes + plan.spill_off[level];
     // entry at staging position `pos` -> its pool slot (bucket-local row | code << 13) or, pool full, the spill list
     auto to_global = [&](uint32_t pos, uint32_t k, V2 a, V2 b, uint2 o) {
         if (pos < o.y) {
             const uint32_t slot = o.x + pos;
-            pvals[2 * (size_t)slot] = a;
-            pvals[2 * (size_t)slot + 1] = b;
-            prows[slot] = (unsigned short)((k & (kBucketRows - 1)) | ((k >> 29) << kBucketRowsLog2));
+            struct Pair { V2 a, b; } pr = {a, b};
+            *reinterpret_cast<Pair *>(pvals + slot * (uint32_t)sizeof(Pair)) = pr;
+            *reinterpret_cast<unsigned short *>(prows + slot * 2u) =
+                (unsigned short)((k & (kBucketRows - 1)) | ((k >> 29) << kBucketRowsLog2));
         } else {
             const uint32_t sp = lsp[(k & 0x7ffffu) >> kBucketRowsLog2] + pos;
             if (sp < plan.spill_cap) {  // (always true: a level emits at most B * 2^D entries)
-                spill[sp].key = k;
-                spill[sp].a = a;
-                spill[sp].b = b;
+                SpillEntry<T> e = {k, a, b};
+                *reinterpret_cast<SpillEntry<T> *>(spill + sp * (uint32_t)sizeof(SpillEntry<T>)) = e;
             }
         }
     };
