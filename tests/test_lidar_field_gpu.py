@@ -113,11 +113,13 @@ def _color_reference(h16, perm, weights, cdir, W0g, W1, W2, g_rgb=None, g_sigma=
 
 # (2100, 64): more rays than resident waves (256 workgroups x 4), so waves walk SEVERAL rays — the flattened, software-
 # pipelined (ray, step) loop crosses ray boundaries (direction-term reload, per-ray S write)
+# (5, 20): a ray shorter than one span; (3, 2200): three groups per ray, three busy waves
 # (6, 1100): a ray spans two 1024-sample groups of the backward's span iterator, the second one partial
 # "front": only a leading stretch of every ray is active (what a LiDAR ray looks like once trained) — most 32-sample spans
 # are transparent and take the batched row store of the iterator; single active samples in otherwise transparent rays
 @pytest.mark.parametrize("N,T,pattern", [(8, 64, "random"), (5, 832, "random"), (3, 48, "random"), (2100, 64, "random"),
-                                         (6, 1100, "random"), (9, 832, "front"), (7, 1100, "front"), (1300, 96, "front")])
+                                         (6, 1100, "random"), (9, 832, "front"), (7, 1100, "front"), (1300, 96, "front"),
+                                         (5, 20, "random"), (3, 2200, "front")])
 def test_color_head_forward_backward(N, T, pattern):
     from gpu_util import call
     g = torch.Generator().manual_seed(N + T)
