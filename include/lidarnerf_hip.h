@@ -351,6 +351,19 @@ LNH_API int lnh_lidar_loss(const float *depth, const float *image, const float *
 LNH_API int lnh_lidar_color_forward(const void *h16, const int32_t *perm, const float *weights, const float *cdir,
                                     const void *w16, uint32_t N, uint32_t T, float *rgb, lnh_stream_t stream);
 /*
+ * lnh_lidar_color_composite_forward: the forward tail of the fused render step in one launch, one wave per ray —
+ * lnh_lidar_merge_weights (renderer.py:217-243) + lnh_lidar_color_forward + lnh_lidar_composite_forward
+ * (renderer.py:233-271) with the weights and the merge permutation of a ray kept in LDS in between.  Inputs as for those
+ * three (z [N,T] merged depths, sigma_pt [N,T] point order, perm from lnh_lidar_resample); outputs sigma_m, weights
+ * [N,T], rgb [N,T,2], weights_sum, depth [N], image [N,2].  sigma_m, weights, weights_sum and depth are bit-identical
+ * to the separate entry points, image to fp32 rounding (different summation order).  T <= 2048.
+ */
+LNH_API int lnh_lidar_color_composite_forward(const float *z, const float *sigma_pt, const int32_t *perm,
+                                              const float *sample_dist, const void *h16, const float *cdir,
+                                              const void *w16, uint32_t N, uint32_t T, float density_scale,
+                                              float *sigma_m, float *weights, float *rgb, float *weights_sum,
+                                              float *depth, float *image, lnh_stream_t stream);
+/*
  * lnh_lidar_color_backward: grad_rgb [N,T,2], grad_sigma [N,T] (merged order, from lnh_lidar_composite_backward)
  * -> grad_h16 [N*T,16] fp16 in POINT order (col 0 = grad_sigma * exp(clamp(pre,-15,15)), activation.py:17-19;
  * cols 1..15 = colour-head input gradient), grad_w fp32 flat like w16 (accumulated), ray_sum [N,64] f32 = sum over
@@ -395,7 +408,7 @@ LNH_API int lnh_adam_table_step(float *param, float *exp_avg, float *exp_avg_sq,
 
 /* ------------------------------------------------------------------ bf16 MLP operands (BASELINE config 5) ---- */
 /*
- * The same eight entry points with v_mfma_f32_16x16x32_bf16 operands ("fp16 hash features + bf16 MFMA MLP"; the
+ * The same nine entry points with v_mfma_f32_16x16x32_bf16 operands ("fp16 hash features + bf16 MFMA MLP"; the
  * reference reaches the MLPs through torch.autocast, lidarnerf/nerf/utils.py:626,1212 — under
  * autocast(dtype=torch.bfloat16) its Linear stacks run in bf16 while the grid encoder keeps casting its table to half,
  * gridencoder/grid.py:54-57).  Every buffer that holds MLP-side 16-bit data is bf16 here — inputs / outputs /
@@ -423,6 +436,11 @@ LNH_API int lnh_lidar_pack_weights_bf16(const float *ws0, uint32_t ld_s0, const 
                                    const float *wc2, uint32_t ld_c2, void *wsig16, void *wcol16, lnh_stream_t stream);
 LNH_API int lnh_lidar_color_forward_bf16(const void *h16, const int32_t *perm, const float *weights, const float *cdir,
                                     const void *w16, uint32_t N, uint32_t T, float *rgb, lnh_stream_t stream);
+LNH_API int lnh_lidar_color_composite_forward_bf16(const float *z, const float *sigma_pt, const int32_t *perm,
+                                                   const float *sample_dist, const void *h16, const float *cdir,
+                                                   const void *w16, uint32_t N, uint32_t T, float density_scale,
+                                                   float *sigma_m, float *weights, float *rgb, float *weights_sum,
+                                                   float *depth, float *image, lnh_stream_t stream);
 LNH_API int lnh_lidar_color_backward_bf16(const float *grad_rgb, const float *grad_sigma, const void *h16,
                                      const int32_t *perm, const float *weights, const float *cdir, const void *w16,
                                      uint32_t N, uint32_t T, void *grad_h16, float *grad_w, float *ray_sum,

@@ -26,6 +26,14 @@ struct ColorArgs {
     float *dW;              // bwd out flat fp32 (kWTotal), atomically accumulated
     float *S;               // bwd out [N,64] fp32: sum over the ray of d(hidden0 pre-activation)
     uint32_t N, T;
+    // fused forward tail only (k_color_forward_ray): merge + weights + colour + compositing of a ray in one kernel
+    const float *z;         // [N,T] merged (sorted) depths
+    const float *sigma_pt;  // [N,T] densities in point order
+    const float *sample_dist;  // [N]
+    float density_scale;
+    float *sigma_m;         // out [N,T] densities in merged order
+    float *weights_out;     // out [N,T]
+    float *wsum, *depth, *image;  // out [N], [N], [N,2]
 };
 
 // v_exp_f32 / v_rcp_f32 (1 ulp each) instead of the IEEE division and the range-reduced expf: the two outputs of a
@@ -127,6 +135,154 @@ k_color_forward(ColorArgs a) {
         for (int n = 0; n < NT; n++) {
             wgt[n] = wgt_next[n];
             slot[n] = slot_next[n];
+        }
+    }
+}
+
+// Forward tail of a ray in ONE kernel, one wave per ray: merged densities and compositing weights (what
+// k_merge_weights computes: renderer.py:217-243), the colour head on the samples above the mask threshold, and the
+// compositing sums (k_lidar_composite_fwd: weights_sum, depth = sum w z, image = sum w rgb).  The three kernels it
+// replaces each walked the ray at HBM latency and handed weights / rgb to the next through HBM; here the weights and
+// the permutation of the ray stay in LDS between the scan and the colour head (6.6 KB per wave at 832 samples).
+// sigma_m, weights and rgb are still written: the backward pass reads them.  weights_sum and depth are summed in the
+// order of k_lidar_composite_fwd (bit-identical); image is summed by the lanes that hold the colours (same value to fp32
+// rounding).
+__global__ void __launch_bounds__(256)
+k_color_forward_ray(ColorArgs a) {
+    constexpr int HT = 4, HS = 2, NT = 4, kChunks = 7;
+    extern __shared__ __attribute__((aligned(16))) char smem_ray[];
+    const uint32_t wid = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+    const uint32_t nw = blockDim.x >> 6, nwaves = gridDim.x * nw;
+    float *wl = reinterpret_cast<float *>(smem_ray) + (size_t)wid * 2 * a.T;   // this wave's weights [T]
+    uint32_t *sl = reinterpret_cast<uint32_t *>(wl + a.T);                     // ... and slots [T]
+    half8_t w0[HT], w1[HT][HS], w2[HS];
+#pragma unroll
+    for (int t = 0; t < HT; t++) {
+        w0[t] = load_a_natural(a.W + kW0g, 16, 16 * t + c, 0, g, 16);
+#pragma unroll
+        for (int s = 0; s < HS; s++) w1[t][s] = load_a_nu(a.W + kW1, 64, 16 * t + c, s, g);
+    }
+#pragma unroll
+    for (int s = 0; s < HS; s++) w2[s] = load_a_nu(a.W + kW2, 64, c, s, g);
+
+    for (uint32_t ray = blockIdx.x * nw + wid; ray < a.N; ray += nwaves) {
+        const float *zr = a.z + (size_t)ray * a.T, *sp = a.sigma_pt + (size_t)ray * a.T;
+        const int32_t *pr = a.perm + (size_t)ray * a.T;
+        const float sd = a.sample_dist[ray];
+        // ---- 1) merged densities, transmittance scan, weights; weights_sum and depth
+        float carry = 1.0f, ws = 0.0f, dep = 0.0f;
+        for (uint32_t base0 = 0; base0 < a.T; base0 += 64 * kChunks) {
+            float zi[kChunks], zn[kChunks], sg[kChunks];
+            int32_t pi[kChunks];
+#pragma unroll
+            for (int u = 0; u < kChunks; u++) {
+                const uint32_t i = base0 + u * 64 + lane, ic = i < a.T ? i : 0, in = i + 1 < a.T ? i + 1 : ic;
+                pi[u] = pr[ic];
+                zi[u] = zr[ic];
+                zn[u] = zr[in];
+            }
+#pragma unroll
+            for (int u = 0; u < kChunks; u++) sg[u] = sp[pi[u]];
+#pragma unroll
+            for (int u = 0; u < kChunks; u++) {
+                const uint32_t i = base0 + u * 64 + lane;
+                if (base0 + u * 64 >= a.T) break;  // wave-uniform
+                float alpha = 0.0f, om = 1.0f;
+                if (i < a.T) {
+                    const float delta = (i + 1 < a.T) ? (zn[u] - zi[u]) : sd;
+                    alpha = 1.0f - expf(-delta * a.density_scale * sg[u]);
+                    om = 1.0f - alpha + 1e-15f;
+                }
+                const float incl = wave_scan_mul(om, (int)lane);
+                float excl = __shfl_up(incl, 1, 64);
+                if (lane == 0) excl = 1.0f;
+                const float w = alpha * (carry * excl);
+                if (i < a.T) {
+                    a.sigma_m[(size_t)ray * a.T + i] = sg[u];
+                    a.weights_out[(size_t)ray * a.T + i] = w;
+                    wl[i] = w;
+                    sl[i] = (uint32_t)pi[u];
+                }
+                ws += w;
+                dep += i < a.T ? w * zi[u] : 0.0f;
+                carry *= __shfl(incl, 63, 64);
+            }
+        }
+        ws = wave_sum(ws);
+        dep = wave_sum(dep);
+        // ---- 2) colour head on the spans that hold a sample above the mask threshold; image sums
+        f32x4 cb[HT];
+#pragma unroll
+        for (int t = 0; t < HT; t++) cb[t] = *reinterpret_cast<const f32x4 *>(a.cdir + (size_t)ray * 64 + 16 * t + 4 * g);
+        float img0 = 0.0f, img1 = 0.0f;
+        for (uint32_t s0 = 0; s0 < a.T; s0 += NT * 16) {
+            float wgt[NT];
+            uint32_t slot[NT];
+            bool valid[NT], msk[NT], any = false;
+#pragma unroll
+            for (int n = 0; n < NT; n++) {
+                const uint32_t i = s0 + 16 * n + c;
+                valid[n] = i < a.T;
+                wgt[n] = valid[n] ? wl[i] : 0.0f;
+                slot[n] = valid[n] ? sl[i] : 0u;
+                msk[n] = wgt[n] > kMaskThresh;
+                any |= msk[n];
+            }
+            float *rgb_row = a.rgb + ((size_t)ray * a.T + s0) * 2;
+            if (!__any(any)) {  // whole span transparent: colour is defined as 0 there
+                if (g == 0) {
+#pragma unroll
+                    for (int n = 0; n < NT; n++)
+                        if (valid[n]) *reinterpret_cast<float2 *>(rgb_row + (16 * n + c) * 2) = make_float2(0.0f, 0.0f);
+                }
+                continue;
+            }
+            half8_t bx[NT];
+#pragma unroll
+            for (int n = 0; n < NT; n++) {
+                const size_t src = (size_t)ray * a.T + slot[n];
+                const half8_t v = *reinterpret_cast<const half8_t *>(a.h16 + src * 16 + (g < 2 ? 8 * g : 0));
+                bx[n] = (valid[n] && g < 2) ? v : zero_h8();
+            }
+#pragma unroll
+            for (int n = 0; n < NT; n++) {
+                f32x4 acc[HT];
+#pragma unroll
+                for (int t = 0; t < HT; t++) acc[t] = MFMA16(w0[t], bx[n], cb[t]);
+                half8_t bh[HS];
+#pragma unroll
+                for (int s = 0; s < HS; s++) bh[s] = pack_pair_relu(acc[2 * s], acc[2 * s + 1]);
+#pragma unroll
+                for (int t = 0; t < HT; t++) {
+                    acc[t] = zero_f4();
+#pragma unroll
+                    for (int s = 0; s < HS; s++) acc[t] = MFMA16(w1[t][s], bh[s], acc[t]);
+                }
+#pragma unroll
+                for (int s = 0; s < HS; s++) bh[s] = pack_pair_relu(acc[2 * s], acc[2 * s + 1]);
+                f32x4 o = zero_f4();
+#pragma unroll
+                for (int s = 0; s < HS; s++) o = MFMA16(w2[s], bh[s], o);
+                if (valid[n] && g == 0) {
+                    // the unfused path rounds the MLP output to fp16 before the sigmoid (autocast Linear output)
+                    const float r0 = msk[n] ? sigmoidf((float)(half_t)o[0]) : 0.0f;
+                    const float r1 = msk[n] ? sigmoidf((float)(half_t)o[1]) : 0.0f;
+                    *reinterpret_cast<float2 *>(rgb_row + (16 * n + c) * 2) = make_float2(r0, r1);
+                    img0 += wgt[n] * r0;
+                    img1 += wgt[n] * r1;
+                }
+            }
+        }
+        // lanes 0..15 (g == 0) hold the partial image sums
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            img0 += __shfl_xor(img0, d, 64);
+            img1 += __shfl_xor(img1, d, 64);
+        }
+        if (lane == 0) {
+            a.wsum[ray] = ws;
+            a.depth[ray] = dep;
+            *reinterpret_cast<float2 *>(a.image + (size_t)ray * 2) = make_float2(img0, img1);
         }
     }
 }
@@ -530,6 +686,27 @@ int LNH_MLP_FN(lnh_lidar_color_forward)(const void *h16, const int32_t *perm, co
     const uint32_t tiles = div_up((uint64_t)N * T, 4 * 16 * 4);
     LNH_LAUNCH(k_color_forward, dim3(tiles < 2048 ? tiles : 2048), dim3(256), 0, (hipStream_t)stream, a);
     return lnh_check_launch("lnh_lidar_color_forward");
+}
+
+int LNH_MLP_FN(lnh_lidar_color_composite_forward)(const float *z, const float *sigma_pt, const int32_t *perm,
+                                                  const float *sample_dist, const void *h16, const float *cdir,
+                                                  const void *w16, uint32_t N, uint32_t T, float density_scale,
+                                                  float *sigma_m, float *weights, float *rgb, float *weights_sum,
+                                                  float *depth, float *image, lnh_stream_t stream) {
+    LNH_REQUIRE(z && sigma_pt && perm && sample_dist && h16 && cdir && w16 && sigma_m && weights && rgb && weights_sum &&
+                    depth && image, LNH_ERR_INVALID_ARG, "lidar_color_composite_forward: null pointer");
+    if (N == 0 || T == 0) return LNH_OK;
+    LNH_REQUIRE((uint64_t)N * T < 0xffffffffull, LNH_ERR_UNSUPPORTED, "lidar_color_composite_forward: N*T must fit 32 bits");
+    const size_t lds = (size_t)4 * 2 * T * sizeof(float);  // weights + slots of the four rays of a workgroup
+    LNH_REQUIRE(lds <= 64 * 1024, LNH_ERR_UNSUPPORTED,
+                "lidar_color_composite_forward: T=%u needs %zu B of LDS (> 64 KiB); use the three separate entry points", T, lds);
+    ColorArgs a{};
+    a.h16 = (const half_t *)h16; a.perm = perm; a.cdir = cdir; a.W = (const half_t *)w16; a.rgb = rgb; a.N = N; a.T = T;
+    a.z = z; a.sigma_pt = sigma_pt; a.sample_dist = sample_dist; a.density_scale = density_scale;
+    a.sigma_m = sigma_m; a.weights_out = weights; a.wsum = weights_sum; a.depth = depth; a.image = image;
+    const uint32_t wgs = (N + 3) / 4;
+    LNH_LAUNCH(k_color_forward_ray, dim3(wgs < 4096 ? wgs : 4096), dim3(256), lds, (hipStream_t)stream, a);
+    return lnh_check_launch("lnh_lidar_color_composite_forward");
 }
 
 int LNH_MLP_FN(lnh_lidar_color_backward)(const float *grad_rgb, const float *grad_sigma, const void *h16, const int32_t *perm,

@@ -55,16 +55,19 @@ k_dir_term_backward_partial(const float *__restrict__ S, const float *__restrict
                             float *__restrict__ partial) {
     constexpr int KPT = 32, CH = kDirChunk;  // k values per thread (k = kg + 4*j), rays per workgroup
     __shared__ float sS[CH][64];
-    __shared__ float sE[CH][128];
+    __shared__ __attribute__((aligned(16))) float sE[CH][128];
     const uint32_t o = threadIdx.x & 63, kg = threadIdx.x >> 6;
     const uint32_t n0 = blockIdx.x * CH, cnt = min((uint32_t)CH, N - n0);
     for (uint32_t i = threadIdx.x; i < CH * 64; i += 256) {  // coalesced staging, zero-filled beyond the valid part
         const uint32_t r = i >> 6;
         sS[r][i & 63] = r < cnt ? S[(size_t)(n0 + r) * 64 + (i & 63)] : 0.0f;
     }
+    // enc is staged as [ray][kg][j] (k = kg + 4 j): the 32 values a thread multiplies by one S element are contiguous, so
+    // the inner loop reads them with 8 wave-uniform 16-byte LDS loads instead of 32 4-byte ones (the kernel was bound by
+    // its LDS instruction count)
     for (uint32_t i = threadIdx.x; i < CH * 128; i += 256) {
         const uint32_t r = i >> 7, k = i & 127;
-        sE[r][k] = (r < cnt && k < K) ? enc16[(size_t)(n0 + r) * K + k] : 0.0f;
+        sE[r][(k & 3) * KPT + (k >> 2)] = (r < cnt && k < K) ? enc16[(size_t)(n0 + r) * K + k] : 0.0f;
     }
     __syncthreads();
     float acc[KPT];
@@ -72,8 +75,15 @@ k_dir_term_backward_partial(const float *__restrict__ S, const float *__restrict
     for (int j = 0; j < KPT; j++) acc[j] = 0.0f;
     for (uint32_t r = 0; r < CH; r++) {
         const float s = sS[r][o];
+        const float4 *e4 = reinterpret_cast<const float4 *>(&sE[r][kg * KPT]);
 #pragma unroll
-        for (int j = 0; j < KPT; j++) acc[j] = fmaf(s, sE[r][kg + 4 * j], acc[j]);  // wave-uniform address: broadcast
+        for (int q = 0; q < KPT / 4; q++) {
+            const float4 e = e4[q];
+            acc[4 * q + 0] = fmaf(s, e.x, acc[4 * q + 0]);
+            acc[4 * q + 1] = fmaf(s, e.y, acc[4 * q + 1]);
+            acc[4 * q + 2] = fmaf(s, e.z, acc[4 * q + 2]);
+            acc[4 * q + 3] = fmaf(s, e.w, acc[4 * q + 3]);
+        }
     }
     float *out = partial + (size_t)blockIdx.x * 64 * 128;
 #pragma unroll

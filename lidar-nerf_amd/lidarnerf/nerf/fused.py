@@ -217,23 +217,28 @@ class FusedLidarRender(Function):
 
         sigma_m = torch.empty((N, Ttot), dtype=torch.float32, device=dev)
         weights = torch.empty((N, Ttot), dtype=torch.float32, device=dev)
-        _hip.call("lnh_lidar_merge_weights", z_all.data_ptr(), sigma_pt.data_ptr(), perm.data_ptr(), sd.data_ptr(), N,
-                  Ttot, float(density_scale), sigma_m.data_ptr(), weights.data_ptr())
-
         enc_d = spec.dir_features(rays_d).contiguous()  # [N, kd] fp32, constant along a ray
         enc_d16 = torch.empty_like(enc_d)                # the same, rounded to fp16 (what the MLP would see)
         cdir = torch.empty((N, 64), dtype=torch.float32, device=dev)
         _hip.call("lnh_lidar_dir_term" + sfx, enc_d.data_ptr(), mats[2].data_ptr(), mats[2].stride(0), N, kd,
                   enc_d16.data_ptr(), cdir.data_ptr())
-
         rgb = torch.empty((N, Ttot, 2), dtype=torch.float32, device=dev)
-        _hip.call("lnh_lidar_color_forward" + sfx, h16.data_ptr(), perm.data_ptr(), weights.data_ptr(), cdir.data_ptr(),
-                  wcol16.data_ptr(), N, Ttot, rgb.data_ptr())
         ws = torch.empty(N, dtype=torch.float32, device=dev)
         depth = torch.empty(N, dtype=torch.float32, device=dev)
         image = torch.empty((N, 2), dtype=torch.float32, device=dev)
-        _hip.call("lnh_lidar_composite_forward", z_all.data_ptr(), sigma_m.data_ptr(), rgb.data_ptr(), sd.data_ptr(), N,
-                  Ttot, 2, float(density_scale), None, ws.data_ptr(), depth.data_ptr(), image.data_ptr())
+        if Ttot <= 2048:
+            # merged densities + weights, colour head, compositing sums: one launch, one wave per ray
+            _hip.call("lnh_lidar_color_composite_forward" + sfx, z_all.data_ptr(), sigma_pt.data_ptr(), perm.data_ptr(),
+                      sd.data_ptr(), h16.data_ptr(), cdir.data_ptr(), wcol16.data_ptr(), N, Ttot, float(density_scale),
+                      sigma_m.data_ptr(), weights.data_ptr(), rgb.data_ptr(), ws.data_ptr(), depth.data_ptr(),
+                      image.data_ptr())
+        else:
+            _hip.call("lnh_lidar_merge_weights", z_all.data_ptr(), sigma_pt.data_ptr(), perm.data_ptr(), sd.data_ptr(), N,
+                      Ttot, float(density_scale), sigma_m.data_ptr(), weights.data_ptr())
+            _hip.call("lnh_lidar_color_forward" + sfx, h16.data_ptr(), perm.data_ptr(), weights.data_ptr(),
+                      cdir.data_ptr(), wcol16.data_ptr(), N, Ttot, rgb.data_ptr())
+            _hip.call("lnh_lidar_composite_forward", z_all.data_ptr(), sigma_m.data_ptr(), rgb.data_ptr(), sd.data_ptr(),
+                      N, Ttot, 2, float(density_scale), None, ws.data_ptr(), depth.data_ptr(), image.data_ptr())
 
         ctx.save_for_backward(x01, feat, h16, perm, weights, z_all, sigma_m, rgb, sd, cdir, enc_d16, wsig16, wcol16)
         ctx.model, ctx.dims, ctx.density_scale, ctx.enc = model, (N, T, t_new), density_scale, enc

@@ -164,6 +164,43 @@ def test_color_head_forward_backward(N, T, pattern):
     torch.testing.assert_close(S.cpu().double(), want_gcd, rtol=1e-2, atol=5e-3 * want_gcd.abs().max().item())
 
 
+@pytest.mark.parametrize("N,T,pattern", [(9, 832, "random"), (7, 100, "front"), (1100, 96, "front"), (3, 2048, "random")])
+def test_color_composite_forward_equals_the_three_separate_entry_points(N, T, pattern):
+    """lnh_lidar_color_composite_forward (one wave per ray) against lnh_lidar_merge_weights + lnh_lidar_color_forward +
+    lnh_lidar_composite_forward on the same inputs: sigma_m, weights, weights_sum, depth and rgb bit for bit, image to
+    fp32 rounding (it is summed by other lanes)."""
+    from gpu_util import call
+    g = torch.Generator().manual_seed(3 * N + T)
+    z = torch.sort(torch.rand(N, T, generator=g) * 0.8 + 0.01, dim=1)[0].cuda()
+    perm = torch.stack([torch.randperm(T, generator=g) for _ in range(N)]).int().cuda()
+    sigma_pt = (torch.rand(N, T, generator=g) * (60.0 if pattern == "front" else 3.0)).cuda()
+    if pattern == "front":
+        sigma_pt[0] = 0.0  # a ray without any weight above the threshold
+    sd = torch.full((N,), 0.8 / T).cuda()
+    h16 = (torch.randn(N * T, 16, generator=g) * 0.5).half().cuda()
+    cdir = torch.randn(N, 64, generator=g).cuda()
+    w16 = (torch.randn(64 * 16 + 64 * 64 + 16 * 64, generator=g) * 0.2).half().cuda()
+    ds = 1.0
+    sig_a, wts_a = torch.empty(N, T, device="cuda"), torch.empty(N, T, device="cuda")
+    rgb_a = torch.full((N, T, 2), float("nan"), device="cuda")
+    ws_a, dp_a, im_a = torch.empty(N, device="cuda"), torch.empty(N, device="cuda"), torch.empty(N, 2, device="cuda")
+    call("lnh_lidar_merge_weights", z, sigma_pt, perm, sd, N, T, ds, sig_a, wts_a)
+    call("lnh_lidar_color_forward", h16, perm, wts_a, cdir, w16, N, T, rgb_a)
+    call("lnh_lidar_composite_forward", z, sig_a, rgb_a, sd, N, T, 2, ds, None, ws_a, dp_a, im_a)
+    sig_b, wts_b = torch.empty(N, T, device="cuda"), torch.empty(N, T, device="cuda")
+    rgb_b = torch.full((N, T, 2), float("nan"), device="cuda")
+    ws_b, dp_b, im_b = torch.empty(N, device="cuda"), torch.empty(N, device="cuda"), torch.empty(N, 2, device="cuda")
+    call("lnh_lidar_color_composite_forward", z, sigma_pt, perm, sd, h16, cdir, w16, N, T, ds, sig_b, wts_b, rgb_b, ws_b,
+         dp_b, im_b)
+    assert float((wts_a > 1e-4).float().mean()) > 0.02  # the colour head does run
+    for a, b in ((sig_a, sig_b), (wts_a, wts_b), (rgb_a, rgb_b), (ws_a, ws_b), (dp_a, dp_b)):
+        assert torch.equal(a, b)
+    torch.testing.assert_close(im_b, im_a, rtol=2e-6, atol=1e-7)
+    with pytest.raises(RuntimeError, match="LDS"):
+        call("lnh_lidar_color_composite_forward", z, sigma_pt, perm, sd, h16, cdir, w16, 1, 2049, ds, sig_b, wts_b, rgb_b,
+             ws_b, dp_b, im_b)
+
+
 # ---------------------------------------------------------------------------------------------- glue kernels
 def test_coarse_samples_match_torch_linspace_form():
     from lidarnerf import _hip
