@@ -71,6 +71,31 @@ def main():
         print(f"{name:28s} active {a.active:.2f}  min {lo:8.1f} us  median {med:8.1f} us")
     print("checksum", float(g_h16.float().abs().sum()), float(g_w.abs().sum()), float(ray_sum.abs().sum()))
 
+    # fused forward tail (merge + weights + colour + compositing, one wave per ray): densities chosen so that the first
+    # `active` fraction of every ray carries weights above the mask threshold and a wall absorbs the rest
+    z = (torch.arange(T, device=dev, dtype=torch.float32) + 0.5)[None, :].expand(N, T).contiguous() * (0.8 / T) + 0.01
+    delta = 0.8 / T
+    sig_m = torch.full((N, T), -np.log(1 - 2e-3) / delta, device=dev)
+    if n_act < T:
+        sig_m[:, n_act:] = 1e9
+    if n_act == 0:
+        sig_m[:] = 0.0
+    sigma_pt = torch.empty_like(sig_m)
+    sigma_pt.scatter_(1, perm.long(), sig_m)  # point order: sigma_pt[perm[i]] = merged[i]
+    sd = torch.full((N,), delta, device=dev)
+    o_sig, o_w = torch.empty(N, T, device=dev), torch.empty(N, T, device=dev)
+    o_ws, o_dp, o_im = torch.empty(N, device=dev), torch.empty(N, device=dev), torch.empty(N, 2, device=dev)
+
+    def tail():
+        _hip.call("lnh_lidar_color_composite_forward", z.data_ptr(), sigma_pt.data_ptr(), perm.data_ptr(), sd.data_ptr(),
+                  h16.data_ptr(), cdir.data_ptr(), wcol.data_ptr(), N, T, 1.0, o_sig.data_ptr(), o_w.data_ptr(),
+                  rgb.data_ptr(), o_ws.data_ptr(), o_dp.data_ptr(), o_im.data_ptr())
+
+    tail()
+    torch.cuda.synchronize()
+    lo, med = timed(tail, a.reps)
+    print(f"{'lnh_lidar_color_composite_forward':28s} active {float((o_w > 1e-4).float().mean()):.2f}  min {lo:8.1f} us  median {med:8.1f} us")
+
     # sigma net on the coarse pass of the same batch: [16, N*T, 2] level-major features -> 16-wide rows
     Tc, B_all = T - 64, N * T
     B = N * Tc
