@@ -299,8 +299,10 @@ def main():
     grid_calls = ["lnh_grid_encode_forward", "lnh_grid_encode_forward_mapped", "lnh_grid_encode_backward",
                   "lnh_grid_encode_backward_ws", "lnh_grid_encode_backward_ws_levels"]
     sfx = "_bf16" if args.mlp_dtype == "bf16" else ""
+    # (the colour head's forward runs inside the fused forward tail — merged weights + colour head + compositing sums of a
+    #  ray in one kernel — whose whole time is charged to the MLPs here)
     mlp_calls = [n + sfx for n in ("lnh_density_mlp_forward", "lnh_density_mlp_backward", "lnh_lidar_color_forward",
-                                   "lnh_lidar_color_backward")]
+                                   "lnh_lidar_color_composite_forward", "lnh_lidar_color_backward")]
     all_calls = grid_calls + mlp_calls + ["lnh_mlp_forward", "lnh_mlp_backward", "lnh_lidar_composite_forward",
                                           "lnh_lidar_composite_backward", "lnh_lidar_resample", "lnh_lidar_weights",
                                           "lnh_freq_encode_forward", "lnh_lidar_merge_weights",

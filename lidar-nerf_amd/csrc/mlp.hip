@@ -82,7 +82,7 @@ k_mlp_forward(MlpArgs a) {
             }
         }
     };
-    constexpr bool PREFETCH = IN_KS == 1;
+    constexpr bool PREFETCH = IN_KS == 1 && IO::kDensity;  // (measured on the sigma net; the generic instantiations keep their registers)
     const uint64_t stride = (uint64_t)nwaves * NT * 16;
     half8_t bx[NT][IN_KS], bx_next[NT][IN_KS];
     if (PREFETCH) load_in((uint64_t)wave * NT * 16, bx);
