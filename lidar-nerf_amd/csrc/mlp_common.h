@@ -108,13 +108,14 @@ __device__ __forceinline__ f32x4 zero_f4() {
 
 // acc += a * b with the accumulator tile pinned to ACCUMULATION registers (AGPRs).  The MLP translation units are built
 // with VGPR-form MFMA destinations (build.py) because the layer chain feeds every product straight into VALU work; the
-// weight-gradient tiles of the wave-independent backward kernels are the opposite case — 24 tiles that are only ever
+// weight-gradient tiles of the colour backward (lidar_color.hip) are the opposite case — 24 tiles that are only ever
 // accumulated into for the whole kernel.  Left to the register allocator they share the 256 VGPRs with the pipeline
 // state, and hipcc then moves all 96 of them to other registers and back around the loop latch (192 v_mov per
 // iteration, a fifth of the colour backward's VALU time) and spills pipeline state into AGPRs besides.  In AGPRs they
 // cost nothing.  The instruction is opaque to the compiler's hazard recogniser, so the two wait states a VALU-written
 // A / B operand needs before an MFMA reads it are part of the statement (both operands always come from packed
 // conversions here), and `agpr_settle` covers the MFMA -> v_accvgpr_read distance before the tiles are read back.
+// (Not a general win: the sigma-net backward, two waves per SIMD and no branch in its loop, got 8 % slower with it.)
 __device__ __forceinline__ void mfma16_acc_agpr(f32x4 &acc, const half8_t &a, const half8_t &b) {
     asm("s_nop 1\n\t" LNH_MFMA16_MNEMONIC " %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
