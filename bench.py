@@ -302,7 +302,8 @@ def main():
     # (the colour head's forward runs inside the fused forward tail — merged weights + colour head + compositing sums of a
     #  ray in one kernel — whose whole time is charged to the MLPs here)
     mlp_calls = [n + sfx for n in ("lnh_density_mlp_forward", "lnh_density_mlp_backward", "lnh_lidar_color_forward",
-                                   "lnh_lidar_color_composite_forward", "lnh_lidar_color_backward")]
+                                   "lnh_lidar_color_composite_forward", "lnh_lidar_color_backward",
+                                   "lnh_lidar_color_backward_image")]
     all_calls = grid_calls + mlp_calls + ["lnh_mlp_forward", "lnh_mlp_backward", "lnh_lidar_composite_forward",
                                           "lnh_lidar_composite_backward", "lnh_lidar_resample", "lnh_lidar_weights",
                                           "lnh_freq_encode_forward", "lnh_lidar_merge_weights",

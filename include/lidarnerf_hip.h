@@ -373,6 +373,13 @@ LNH_API int lnh_lidar_color_backward(const float *grad_rgb, const float *grad_si
                                      const int32_t *perm, const float *weights, const float *cdir, const void *w16,
                                      uint32_t N, uint32_t T, void *grad_h16, float *grad_w, float *ray_sum,
                                      lnh_stream_t stream);
+/* The same with grad_rgb formed on the fly from grad_image [N,2] = d loss / d image: grad_rgb[n,i,:] = weights[n,i] *
+ * grad_image[n,:], which is all lnh_lidar_composite_backward would have written there (call it with grad_rgb = NULL):
+ * the [N,T,2] gradient never travels through HBM. */
+LNH_API int lnh_lidar_color_backward_image(const float *grad_image, const float *grad_sigma, const void *h16,
+                                           const int32_t *perm, const float *weights, const float *cdir,
+                                           const void *w16, uint32_t N, uint32_t T, void *grad_h16, float *grad_w,
+                                           float *ray_sum, lnh_stream_t stream);
 
 /* ---- range image <-> point cloud (lidarnerf/convert.py:99-160, 194-237) ---------------------------
  * lnh_lidar_to_pano: points [N,4] f32 (x,y,z,intensity) in the sensor frame -> pano [H,W] f32 (distance of the nearest
@@ -408,7 +415,7 @@ LNH_API int lnh_adam_table_step(float *param, float *exp_avg, float *exp_avg_sq,
 
 /* ------------------------------------------------------------------ bf16 MLP operands (BASELINE config 5) ---- */
 /*
- * The same nine entry points with v_mfma_f32_16x16x32_bf16 operands ("fp16 hash features + bf16 MFMA MLP"; the
+ * The same ten entry points with v_mfma_f32_16x16x32_bf16 operands ("fp16 hash features + bf16 MFMA MLP"; the
  * reference reaches the MLPs through torch.autocast, lidarnerf/nerf/utils.py:626,1212 — under
  * autocast(dtype=torch.bfloat16) its Linear stacks run in bf16 while the grid encoder keeps casting its table to half,
  * gridencoder/grid.py:54-57).  Every buffer that holds MLP-side 16-bit data is bf16 here — inputs / outputs /
@@ -445,6 +452,10 @@ LNH_API int lnh_lidar_color_backward_bf16(const float *grad_rgb, const float *gr
                                      const int32_t *perm, const float *weights, const float *cdir, const void *w16,
                                      uint32_t N, uint32_t T, void *grad_h16, float *grad_w, float *ray_sum,
                                      lnh_stream_t stream);
+LNH_API int lnh_lidar_color_backward_image_bf16(const float *grad_image, const float *grad_sigma, const void *h16,
+                                                const int32_t *perm, const float *weights, const float *cdir,
+                                                const void *w16, uint32_t N, uint32_t T, void *grad_h16,
+                                                float *grad_w, float *ray_sum, lnh_stream_t stream);
 
 #ifdef __cplusplus
 }

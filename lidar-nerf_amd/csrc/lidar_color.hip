@@ -20,7 +20,8 @@ struct ColorArgs {
     const float *cdir;      // [N,64] fp32: W0_dir * freq(d) per ray
     const half_t *W;        // flat fp16 (kWTotal)
     float *rgb;             // fwd out [N,T,2]
-    const float *g_rgb;     // bwd in  [N,T,2]
+    const float *g_rgb;     // bwd in  [N,T,2], or null: then g_rgb[n,i,:] = weights[n,i] * g_image[n,:] is formed on the fly
+    const float *g_image;   // bwd in  [N,2] (used when g_rgb is null)
     const float *g_sigma;   // bwd in  [N,T] merged order
     half_t *g_h16;          // bwd out [N*T,16] point order
     float *dW;              // bwd out flat fp32 (kWTotal), atomically accumulated
@@ -293,6 +294,7 @@ k_color_forward_ray(ColorArgs a) {
 // fragment (the A and B operand layouts are mirror images: row/col = lane & 15, same k enumeration), which is exact.
 // Every wave owns all 24 gradient tiles (dW2 4, dW1 16, dW0g 4) in accumulators; the four waves of a workgroup are
 // combined through LDS once at the end and flushed with one atomic per weight.
+template <bool FROM_IMAGE>  // d loss / d rgb read from a.g_rgb, or formed as weights (x) a.g_image
 __global__ void __launch_bounds__(256)
 k_color_backward_wi(ColorArgs a) {
     constexpr int HT = 4, HS = 2, NT = 2, NTILE = HT + HT * HT + HT;
@@ -468,7 +470,12 @@ k_color_backward_wi(ColorArgs a) {
             A.wgt[n] = a.weights[A.m[n]];
             A.slot[n] = (uint32_t)a.perm[A.m[n]];
             A.gs[n] = a.g_sigma[A.m[n]];
-            A.gr[n] = *reinterpret_cast<const float2 *>(a.g_rgb + (size_t)A.m[n] * 2);
+            if constexpr (!FROM_IMAGE) {
+                A.gr[n] = *reinterpret_cast<const float2 *>(a.g_rgb + (size_t)A.m[n] * 2);
+            } else {        // what lnh_lidar_composite_backward would have written: w * d loss / d image, same product
+                const float2 gi = *reinterpret_cast<const float2 *>(a.g_image + (size_t)(I.live ? I.ray : 0) * 2);
+                A.gr[n] = make_float2(A.wgt[n] * gi.x, A.wgt[n] * gi.y);
+            }
         }
         return A;
     };
@@ -709,22 +716,43 @@ int LNH_MLP_FN(lnh_lidar_color_composite_forward)(const float *z, const float *s
     return lnh_check_launch("lnh_lidar_color_composite_forward");
 }
 
-int LNH_MLP_FN(lnh_lidar_color_backward)(const float *grad_rgb, const float *grad_sigma, const void *h16, const int32_t *perm,
+static int color_backward_launch(const float *grad_rgb, const float *grad_image, const float *grad_sigma, const void *h16, const int32_t *perm,
                              const float *weights, const float *cdir, const void *w16, uint32_t N, uint32_t T,
                              void *grad_h16, float *grad_w, float *ray_sum, lnh_stream_t stream) {
-    LNH_REQUIRE(grad_rgb && grad_sigma && h16 && perm && weights && cdir && w16 && grad_h16 && grad_w && ray_sum,
+    LNH_REQUIRE((grad_rgb || grad_image) && grad_sigma && h16 && perm && weights && cdir && w16 && grad_h16 && grad_w && ray_sum,
                 LNH_ERR_INVALID_ARG, "lidar_color_backward: null pointer");
     if (N == 0 || T == 0) return LNH_OK;
     LNH_REQUIRE((uint64_t)N * T < 0xffffffffull, LNH_ERR_UNSUPPORTED, "lidar_color_backward: N*T must fit 32 bits");
     ColorArgs a{};
     a.h16 = (const half_t *)h16; a.perm = perm; a.weights = weights; a.cdir = cdir; a.W = (const half_t *)w16;
-    a.g_rgb = grad_rgb; a.g_sigma = grad_sigma; a.g_h16 = (half_t *)grad_h16; a.dW = grad_w; a.S = ray_sum;
+    a.g_rgb = grad_rgb; a.g_image = grad_image; a.g_sigma = grad_sigma; a.g_h16 = (half_t *)grad_h16; a.dW = grad_w; a.S = ray_sum;
     a.N = N; a.T = T;
     // persistent workgroups: each flushes 6144 weight-gradient partials with device atomics (~20 G/s chip-wide), so
     // keep the workgroup count near the CU count rather than one per ray
     const uint32_t wgs = (N + 3) / 4;
-    LNH_LAUNCH(k_color_backward_wi, dim3(wgs < 256 ? wgs : 256), dim3(256), 0, (hipStream_t)stream, a);
+    if (grad_rgb) {
+        LNH_LAUNCH(k_color_backward_wi<false>, dim3(wgs < 256 ? wgs : 256), dim3(256), 0, (hipStream_t)stream, a);
+    } else {
+        LNH_LAUNCH(k_color_backward_wi<true>, dim3(wgs < 256 ? wgs : 256), dim3(256), 0, (hipStream_t)stream, a);
+    }
     return lnh_check_launch("lnh_lidar_color_backward");
+}
+
+int LNH_MLP_FN(lnh_lidar_color_backward)(const float *grad_rgb, const float *grad_sigma, const void *h16, const int32_t *perm,
+                             const float *weights, const float *cdir, const void *w16, uint32_t N, uint32_t T,
+                             void *grad_h16, float *grad_w, float *ray_sum, lnh_stream_t stream) {
+    LNH_REQUIRE(grad_rgb, LNH_ERR_INVALID_ARG, "lidar_color_backward: null pointer");
+    return color_backward_launch(grad_rgb, nullptr, grad_sigma, h16, perm, weights, cdir, w16, N, T, grad_h16, grad_w, ray_sum,
+                                 stream);
+}
+
+int LNH_MLP_FN(lnh_lidar_color_backward_image)(const float *grad_image, const float *grad_sigma, const void *h16,
+                                               const int32_t *perm, const float *weights, const float *cdir,
+                                               const void *w16, uint32_t N, uint32_t T, void *grad_h16, float *grad_w,
+                                               float *ray_sum, lnh_stream_t stream) {
+    LNH_REQUIRE(grad_image, LNH_ERR_INVALID_ARG, "lidar_color_backward_image: null pointer");
+    return color_backward_launch(nullptr, grad_image, grad_sigma, h16, perm, weights, cdir, w16, N, T, grad_h16, grad_w,
+                                 ray_sum, stream);
 }
 
 }  // extern "C"

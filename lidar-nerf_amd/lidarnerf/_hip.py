@@ -65,10 +65,11 @@ _SIGS = {
     "lnh_adam_table_step": [P, P, P, P, P, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_double, P, P, P, P],
     "lnh_lidar_loss": [P, P, P, U32, F32, F32, F32, P, P, P],
     "lnh_lidar_color_backward": [P, P, P, P, P, P, P, U32, U32, P, P, P],
+    "lnh_lidar_color_backward_image": [P, P, P, P, P, P, P, U32, U32, P, P, P],
 }
 for _n in ("lnh_mlp_forward", "lnh_mlp_backward", "lnh_density_mlp_forward", "lnh_density_mlp_backward",
            "lnh_lidar_dir_term", "lnh_lidar_pack_weights", "lnh_lidar_color_forward", "lnh_lidar_color_backward",
-           "lnh_lidar_color_composite_forward"):
+           "lnh_lidar_color_composite_forward", "lnh_lidar_color_backward_image"):
     _SIGS[_n + "_bf16"] = _SIGS[_n]  # bf16-operand build of the MLP kernels (include/lidarnerf_hip.h, last section)
 EXPORTS = sorted(list(_SIGS) + ["lnh_version", "lnh_last_error", "lnh_arch", "lnh_grid_backward_workspace_size",
                                  "lnh_grid_backward_plan_info"])

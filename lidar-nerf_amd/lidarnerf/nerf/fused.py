@@ -263,10 +263,13 @@ class FusedLidarRender(Function):
         ptr = lambda t: None if t is None else t.data_ptr()
 
         g_sigma = torch.empty((N, Ttot), dtype=torch.float32, device=dev)
-        g_rgb = torch.empty((N, Ttot, 2), dtype=torch.float32, device=dev)
+        # d loss / d rgb = weights (x) d loss / d image is formed inside the colour backward: the compositing backward
+        # writes the density gradient only (grad_rgb = NULL)
         _hip.call("lnh_lidar_composite_backward", ptr(g_ws), ptr(g_depth), ptr(g_image),
                   z_all.data_ptr(), sigma_m.data_ptr(), rgb.data_ptr(), sd.data_ptr(), N, Ttot, 2, float(ds),
-                  g_sigma.data_ptr(), g_rgb.data_ptr())
+                  g_sigma.data_ptr(), None)
+        if g_image is None:
+            g_image = torch.zeros((N, 2), dtype=torch.float32, device=dev)
 
         g_h16 = torch.empty((N * Ttot, 16), dtype=mdt, device=dev)
         kd = enc_d16.shape[1]
@@ -274,7 +277,7 @@ class FusedLidarRender(Function):
         zeros = torch.zeros(n_col + n_sig + n_c0, dtype=torch.float32, device=dev)  # one fill for all small gradients
         g_wcol, g_wsig = zeros[:n_col], zeros[n_col:n_col + n_sig]
         ray_sum = torch.empty((N, 64), dtype=torch.float32, device=dev)
-        _hip.call("lnh_lidar_color_backward" + sfx, g_rgb.data_ptr(), g_sigma.data_ptr(), h16.data_ptr(), perm.data_ptr(),
+        _hip.call("lnh_lidar_color_backward_image" + sfx, g_image.data_ptr(), g_sigma.data_ptr(), h16.data_ptr(), perm.data_ptr(),
                   weights.data_ptr(), cdir.data_ptr(), wcol16.data_ptr(), N, Ttot, g_h16.data_ptr(), g_wcol.data_ptr(),
                   ray_sum.data_ptr())
         g_w0g = g_wcol[:64 * 16].view(64, 16)
