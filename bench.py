@@ -338,6 +338,11 @@ def main():
         trainer.step(*batches[(args.warmup + args.steps + s) % len(batches)])
     sync()
     mlp_timers = event_table(_hip.disable_timers())
+    # the roofline below divides by the time of ALL MLP kernels of a step: a renamed entry point must not drop out silently
+    for role in ("density_mlp_forward", "density_mlp_backward", "color_backward", "color_"):
+        fw = [k for k in mlp_timers if role in k and (role != "color_" or "forward" in k)]
+        if not fw:
+            raise RuntimeError(f"bench: no '{role}' entry point was timed in the MFMA pass (got {sorted(mlp_timers)})")
     mask_frac = float(torch.stack(fused.MASK_STATS).mean().item()) if fused.MASK_STATS else 1.0
     fused.MASK_STATS = None
 
