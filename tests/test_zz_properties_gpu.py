@@ -201,3 +201,37 @@ def test_fused_table_trainer_checkpoint_resume(tmp_path):
     ref_opt = torch.optim.Adam(m1.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
     ref_opt.load_state_dict(torch.load(path, weights_only=False)["optimizer"])
     assert float(ref_opt.state[m1.encoder.embeddings]["step"]) == 3
+
+
+def test_empty_batches_are_no_ops_on_the_fused_step_entry_points():
+    """N = 0 rays / B = 0 points: every entry point of the fused render step returns success without touching a byte of
+    its outputs (and without launching anything: a zero-sized grid is a launch error on HIP)."""
+    from gpu_util import call
+    from lidarnerf.gridencoder.grid import level_offsets
+    canary = 123456.0
+    d = torch.full((4096,), canary, device="cuda")              # stands in for every fp32 / fp16 / int32 pointer
+    pls = float(np.exp2(np.log2(32768 / 16) / 15))
+    off = torch.from_numpy(level_offsets(3, 16, pls, 16, 19, False))  # host-side int32 offsets, as the encoder keeps them
+    S = float(np.log2(pls))
+    T, t = 768, 64
+    calls = [
+        ("lnh_lidar_coarse_samples", d, 0, T, 0.01, 0.8, d),
+        ("lnh_lidar_sample_points", d, d, d, d, 1.0, 0, T, T + t, 0, d),
+        ("lnh_grid_encode_forward_mapped", d, d, off, d, 0, T, T + t, 0, 0, 2, 16, S, 16, 1),
+        ("lnh_density_mlp_forward", d, d, 0, T, T + t, 0, 0, d, d),
+        ("lnh_lidar_resample_strided", d, d, T + t, d, d, 0, T, t, 1.0, 1, d, d, d),
+        ("lnh_lidar_merge_weights", d, d, d, d, 0, T + t, 1.0, d, d),
+        ("lnh_lidar_dir_term", d, d, 90, 0, 75, d, d),
+        ("lnh_lidar_color_forward", d, d, d, d, d, 0, T + t, d),
+        ("lnh_lidar_color_composite_forward", d, d, d, d, d, d, d, 0, T + t, 1.0, d, d, d, d, d, d),
+        ("lnh_lidar_composite_forward", d, d, d, d, 0, T + t, 2, 1.0, None, d, d, d),
+        ("lnh_lidar_composite_backward", d, d, d, d, d, d, d, 0, T + t, 2, 1.0, d, None),
+        ("lnh_lidar_color_backward", d, d, d, d, d, d, d, 0, T + t, d, d, d),
+        ("lnh_lidar_color_backward_image", d, d, d, d, d, d, d, 0, T + t, d, d, d),
+        ("lnh_lidar_dir_term_backward", d, d, 0, 75, d, d, 90),
+        ("lnh_density_mlp_backward", d, d, d, 0, T + t, T + t, 0, d, d),
+    ]
+    for c in calls:
+        call(*c)
+    torch.cuda.synchronize()
+    assert bool((d == canary).all())
