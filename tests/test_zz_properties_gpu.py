@@ -235,3 +235,18 @@ def test_empty_batches_are_no_ops_on_the_fused_step_entry_points():
         call(*c)
     torch.cuda.synchronize()
     assert bool((d == canary).all())
+
+
+def test_batches_beyond_32_bit_sample_indices_are_refused():
+    """N * T >= 2^32: the per-sample indices of the fused-step kernels are 32 bits wide; the entry points say so instead of
+    wrapping around (nothing is launched, the dummy pointers are never dereferenced)."""
+    from gpu_util import call
+    d = torch.zeros(64, device="cuda")
+    N, T = 1 << 22, 1 << 10
+    for c in (("lnh_lidar_sample_points", d, d, d, d, 1.0, N, T, T, 0, d),
+              ("lnh_lidar_color_forward", d, d, d, d, d, N, T, d),
+              ("lnh_lidar_color_composite_forward", d, d, d, d, d, d, d, N, T, 1.0, d, d, d, d, d, d),
+              ("lnh_lidar_color_backward", d, d, d, d, d, d, d, N, T, d, d, d),
+              ("lnh_lidar_color_backward_image", d, d, d, d, d, d, d, N, T, d, d, d)):
+        with pytest.raises(RuntimeError, match="32 bits"):
+            call(*c)
