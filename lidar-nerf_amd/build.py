@@ -43,11 +43,29 @@ def _newer(src, deps, out):
     return any(os.path.getmtime(d) > t for d in [src] + deps)
 
 
+def _local_includes(src, seen=None):
+    """Files of csrc/ a translation unit pulls in with #include "..." (transitively): the *_bf16.hip wrappers include the
+    .hip file they re-compile, so a change there must rebuild them too."""
+    import re
+    seen = set() if seen is None else seen
+    try:
+        text = open(src).read()
+    except OSError:
+        return seen
+    for name in re.findall(r'^\s*#\s*include\s+"([^"]+)"', text, flags=re.M):
+        path = os.path.join(CSRC, name)
+        if os.path.exists(path) and path not in seen:
+            seen.add(path)
+            _local_includes(path, seen)
+    return seen
+
+
 def _compile(src, force):
     out = os.path.join(OBJ, os.path.basename(src).replace(".hip", ".o"))
     if _VARIANT and os.path.basename(src) not in os.environ.get("LNH_VARIANT_FILES", "grid.hip").split():
         return os.path.join(HERE, "lib", "obj", os.path.basename(out)), False  # unchanged files: the product's objects
-    deps = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+    deps = (glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h")) +
+            sorted(_local_includes(src)))
     if not force and not _newer(src, deps, out):
         return out, False
     extra = [] if os.path.basename(src) in NO_VGPR_FORM else MFMA_VGPR_FORM

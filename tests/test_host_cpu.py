@@ -144,3 +144,19 @@ def test_tcnn_facade_api_and_state_dict_layout():
     for (dd, k, ph) in [(0, 0, 0), (0, 0, 1), (1, 3, 0), (2, 11, 1)]:
         want = np.sin(np.float32(2.0 ** k * np.pi) * np.float32(x[0, dd]) + ph * np.pi / 2)
         assert abs(float(f[dd * 24 + 2 * k + ph]) - want) < 2e-3 * max(1.0, 2.0 ** k * 1e-3)
+
+
+def test_build_tracks_the_sources_a_wrapper_translation_unit_includes():
+    """The *_bf16.hip translation units re-compile another .hip file through #include: the build must treat that file (and
+    what it includes) as a dependency, or the bf16 kernels silently lag behind the fp16 ones."""
+    import importlib.util
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lidar-nerf_amd")
+    spec = importlib.util.spec_from_file_location("lnh_build", os.path.join(root, "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    csrc = os.path.join(root, "csrc")
+    for wrapper, included in (("lidar_color_bf16.hip", "lidar_color.hip"), ("mlp_bf16.hip", "mlp.hip"),
+                              ("mlp_bwd_nhm0_bf16.hip", "mlp_bwd_nhm0.hip")):
+        deps = {os.path.basename(p) for p in mod._local_includes(os.path.join(csrc, wrapper))}
+        assert included in deps and "mlp_common.h" in deps, (wrapper, deps)
+    assert "mlp_bwd.h" in {os.path.basename(p) for p in mod._local_includes(os.path.join(csrc, "mlp_bwd_nhm0_bf16.hip"))}
