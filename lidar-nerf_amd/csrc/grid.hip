@@ -21,6 +21,10 @@ typedef uint32_t uint2_t __attribute__((ext_vector_type(2)));
 #include <algorithm>
 #include <cmath>
 
+#ifndef LNH_GATHER_PROBE
+#define LNH_GATHER_PROBE 0  // see k_grid_forward: timing probes of the gather cost model, 0 = the product
+#endif
+
 namespace {
 
 struct LevelParams {
@@ -265,7 +269,23 @@ k_grid_forward(const float *__restrict__ inputs, const T *__restrict__ table, T 
                     r0s[yz] = r0;
                     r1s[yz] = r1;
                     blk[yz] = load_vec<T, 8>(tab + (size_t)(r0 & ~3u) * C);
+#if LNH_GATHER_PROBE == 0
                     solo[yz] = load_vec<T, C>(tab + (size_t)(far ? r1 : 0u) * C);
+#else
+                    // Timing probes behind the gather cost model of DESIGN.md §3b (tools/probe_gather.sh builds one
+                    // library per value; results are WRONG by construction).  The second load of every lane goes to:
+                    //   1 row 0 (one line for the whole wave)   2 nowhere (no instruction)
+                    //   3 the other 16-byte half of the 32-byte block it already fetched
+                    //   4 r1 itself (same 128-byte line for 31 lanes in 32, any 64-byte half)   5 another random line
+                    {
+                        const uint32_t far_row = LNH_GATHER_PROBE == 1 ? 0u
+                                               : LNH_GATHER_PROBE == 3 ? ((r0 & ~3u) ^ 4u)
+                                               : LNH_GATHER_PROBE == 4 ? r1
+                                               : ((r1 * 2654435761u) & (lv.hashmap_size - 1));
+                        if (LNH_GATHER_PROBE == 2) solo[yz] = Vec<T, C>{};
+                        else solo[yz] = load_vec<T, C>(tab + (size_t)far_row * C);
+                    }
+#endif
                 }
 #pragma unroll
                 for (uint32_t yz = 0; yz < 4; yz++) {
@@ -276,7 +296,11 @@ k_grid_forward(const float *__restrict__ inputs, const T *__restrict__ table, T 
                     const uint32_t i0 = r0s[yz] & 3u, i1 = r1s[yz] & 3u;
                     const uint32_t a0 = (i0 & 2u) ? ((i0 & 1u) ? w[3] : w[2]) : ((i0 & 1u) ? w[1] : w[0]);
                     const uint32_t a1 = (i1 & 2u) ? ((i1 & 1u) ? w[3] : w[2]) : ((i1 & 1u) ? w[1] : w[0]);
+#if LNH_GATHER_PROBE == 0
                     const uint32_t b1 = far ? so : a1;
+#else
+                    const uint32_t b1 = (r0s[yz] & 64u) ? so : a1;  // (keeps the probe's second load alive)
+#endif
                     __builtin_memcpy(&g[c0], &a0, 4);
                     __builtin_memcpy(&g[c1], &b1, 4);
                 }
