@@ -284,6 +284,11 @@ LNH_API int lnh_lidar_resample_strided(const float *z, const float *sigma, uint3
 LNH_API int lnh_lidar_sample_points(const float *rays_o, const float *rays_d, const float *z, const float *aabb,
                                     float bound, uint32_t N, uint32_t T, uint32_t T_tot, uint32_t slot_off, float *x01,
                                     lnh_stream_t stream);
+/* lnh_lidar_coarse_samples (below: the stratified depths of renderer.py:140-156, u = NULL for the unperturbed ones) and
+ * lnh_lidar_sample_points of those depths (slot_off = 0) in one launch; z [N,T] and x01 rows n*T_tot + j are written. */
+LNH_API int lnh_lidar_coarse_sample_points(const float *u, const float *rays_o, const float *rays_d, const float *aabb,
+                                           float bound, uint32_t N, uint32_t T, uint32_t T_tot, float near, float far,
+                                           float *z, float *x01, lnh_stream_t stream);
 /*
  * lnh_grid_encode_forward_mapped: lnh_grid_encode_forward (D = 3, hash, linear) whose launch index b = r*T_cur + j
  * reads position row r*T_tot + slot_off + j of inputs_all [B_all,3] and writes the same row of

@@ -44,6 +44,29 @@ k_sample_points(const float *__restrict__ rays_o, const float *__restrict__ rays
     }
 }
 
+// The coarse pass of a step in one kernel: the stratified depths of lnh_lidar_coarse_samples (same arithmetic, bit for
+// bit) and the grid coordinates of those samples.
+__global__ void __launch_bounds__(256)
+k_coarse_sample_points(const float *__restrict__ u, const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                       const float *__restrict__ aabb, float bound, uint32_t N, uint32_t T, uint32_t T_tot, float near,
+                       float far, float *__restrict__ z, float *__restrict__ x01) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * T) return;
+    const uint32_t n = idx / T, i = idx - n * T;
+    const float step = T > 1 ? 1.0f / (float)(T - 1) : 0.0f;
+    const float lin = i < T / 2 ? step * (float)i : 1.0f - step * (float)(T - 1 - i);
+    float t = near + (far - near) * lin;
+    if (u) t = t + (u[idx] - 0.5f) * ((far - near) / (float)T);
+    z[idx] = t;
+    float *o = x01 + ((size_t)n * T_tot + i) * 3;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        float p = rays_o[n * 3 + d] + rays_d[n * 3 + d] * t;
+        p = fminf(fmaxf(p, aabb[d]), aabb[3 + d]);
+        o[d] = (p + bound) / (2 * bound);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ merge + weights
 __global__ void __launch_bounds__(256)
 k_merge_weights(const float *__restrict__ z, const float *__restrict__ sigma_pt, const int32_t *__restrict__ perm,
@@ -108,6 +131,19 @@ int lnh_lidar_sample_points(const float *rays_o, const float *rays_d, const floa
     LNH_LAUNCH(k_sample_points, dim3(div_up((uint64_t)N * T, 256)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, z,
                aabb, bound, N, T, T_tot, slot_off, x01);
     return lnh_check_launch("lnh_lidar_sample_points");
+}
+
+int lnh_lidar_coarse_sample_points(const float *u, const float *rays_o, const float *rays_d, const float *aabb, float bound,
+                                   uint32_t N, uint32_t T, uint32_t T_tot, float near, float far, float *z, float *x01,
+                                   lnh_stream_t stream) {
+    LNH_REQUIRE(rays_o && rays_d && aabb && z && x01, LNH_ERR_INVALID_ARG, "lidar_coarse_sample_points: null pointer");
+    LNH_REQUIRE(bound > 0.0f, LNH_ERR_INVALID_ARG, "lidar_coarse_sample_points: bound must be positive");
+    LNH_REQUIRE(T <= T_tot, LNH_ERR_INVALID_ARG, "lidar_coarse_sample_points: T must be <= T_tot");
+    if ((uint64_t)N * T == 0) return LNH_OK;
+    LNH_REQUIRE((uint64_t)N * T_tot < 0xffffffffull, LNH_ERR_UNSUPPORTED, "lidar_coarse_sample_points: N*T must fit 32 bits");
+    LNH_LAUNCH(k_coarse_sample_points, dim3(div_up((uint64_t)N * T, 256)), dim3(256), 0, (hipStream_t)stream, u, rays_o,
+               rays_d, aabb, bound, N, T, T_tot, near, far, z, x01);
+    return lnh_check_launch("lnh_lidar_coarse_sample_points");
 }
 
 int lnh_lidar_merge_weights(const float *z, const float *sigma_pt, const int32_t *perm, const float *sample_dist,

@@ -158,14 +158,16 @@ def _sample_dist(N, value, dev):
 class FusedLidarRender(Function):
     @staticmethod
     @_no_autocast
-    def forward(ctx, rays_o, rays_d, z, u, embeddings, ws0, ws1, wc0, wc1, wc2, model, density_scale, spec, mdt):
+    def forward(ctx, rays_o, rays_d, noise, u, embeddings, ws0, ws1, wc0, wc1, wc2, model, density_scale, spec, mdt, near,
+                far, T):
+        # noise: [N*T] uniforms of the stratified perturbation, or None (evaluation)
         # mdt: element type of everything MLP-side (packed weights, sigma-net rows, their gradients): torch.half, or
         # torch.bfloat16 for the bf16-operand build of the kernels (config 5); hash features stay fp16 either way
         sfx = _hip.mlp_suffix(mdt)
         enc = spec.grid
         kd = spec.n_dir
         dev = rays_o.device
-        N, T = z.shape
+        N = rays_o.shape[0]
         t_new = u.shape[1]
         Ttot = T + t_new
         bound = float(model.bound)
@@ -198,15 +200,21 @@ class FusedLidarRender(Function):
 
         def density(zz, Tc, off):
             B = N * Tc
-            _hip.call("lnh_lidar_sample_points", rays_o.data_ptr(), rays_d.data_ptr(), zz.data_ptr(), aabb.data_ptr(),
-                      bound, N, Tc, Ttot, off, x01.data_ptr())
+            if zz is None:  # coarse pass: the stratified depths and their grid coordinates in one launch
+                _hip.call("lnh_lidar_coarse_sample_points", None if noise is None else noise.data_ptr(), rays_o.data_ptr(),
+                          rays_d.data_ptr(), aabb.data_ptr(), bound, N, Tc, Ttot, float(near), float(far), z.data_ptr(),
+                          x01.data_ptr())
+            else:
+                _hip.call("lnh_lidar_sample_points", rays_o.data_ptr(), rays_d.data_ptr(), zz.data_ptr(), aabb.data_ptr(),
+                          bound, N, Tc, Ttot, off, x01.data_ptr())
             _hip.call("lnh_grid_encode_forward_mapped", x01.data_ptr(), table16.data_ptr(),
                       enc._offsets_host.data_ptr(), feat.data_ptr(), B, Tc, Ttot, off, B_all, 2, L, enc.log2_scale,
                       enc.base_resolution, _hip.LNH_F16, tag=B)
             _hip.call("lnh_density_mlp_forward" + sfx, feat.data_ptr(), wsig16.data_ptr(), B, Tc, Ttot, off, B_all,
                       h16.data_ptr(), sigma_pt.data_ptr())
 
-        density(z, T, 0)
+        z = torch.empty((N, T), dtype=torch.float32, device=dev)
+        density(None, T, 0)
         new_z = torch.empty((N, t_new), dtype=torch.float32, device=dev)
         z_all = torch.empty((N, Ttot), dtype=torch.float32, device=dev)
         perm = torch.empty((N, Ttot), dtype=torch.int32, device=dev)
@@ -315,7 +323,7 @@ class FusedLidarRender(Function):
                 g_table.div_(world)  # sum over ranks -> mean, after the widening
         return (None, None, None, None, g_table, g_wsig[:64 * 32].view(64, 32).to(dts[1]),
                 g_wsig[64 * 32:].view(16, 64).to(dts[2]), g_wc0.to(dts[3]), g_wc1.to(dts[4]), g_wc2.to(dts[5]),
-                None, None, None, None)
+                None, None, None, None, None, None, None)
 
 
 MASK_STATS = None  # bench.py: set to a list to collect, per render call, the fraction of samples with weight > 1e-4
@@ -331,14 +339,12 @@ def render_lidar(model, rays_o, rays_d, num_steps, upsample_steps, perturb):
     # products are formed exactly as the tensor code of the reference forms them
     near = torch.tensor(float(model.min_near_lidar), dtype=torch.float32)
     far = near * 81.0
-    z = torch.empty((N, num_steps), dtype=torch.float32, device=dev)
     # one random draw serves the stratified perturbation (first N*num_steps values) and, in training mode, the
     # importance-sampling positions u (the rest)
     n_noise = N * num_steps if perturb else 0
     n_u = N * upsample_steps if model.training else 0
     rnd = torch.rand(n_noise + n_u, device=dev) if n_noise + n_u else None
-    _hip.call("lnh_lidar_coarse_samples", rnd.data_ptr() if perturb else None, N, num_steps, float(near), float(far),
-              z.data_ptr())
+    noise = rnd[:n_noise] if perturb else None
     if model.training:
         u = rnd[n_noise:].view(N, upsample_steps)
     else:
@@ -346,8 +352,9 @@ def render_lidar(model, rays_o, rays_d, num_steps, upsample_steps, perturb):
                            device=dev).expand(N, upsample_steps).contiguous()
     sp = model.fused_spec()
     from ..ffmlp.ffmlp import mlp_dtype
-    ws, depth, image, weights, _ = FusedLidarRender.apply(rays_o, rays_d, z, u, sp.table, sp.ws0, sp.ws1, sp.wc0,
-                                                          sp.wc1, sp.wc2, model, model.density_scale, sp, mlp_dtype())
+    ws, depth, image, weights, _ = FusedLidarRender.apply(rays_o, rays_d, noise, u, sp.table, sp.ws0, sp.ws1, sp.wc0,
+                                                          sp.wc1, sp.wc2, model, model.density_scale, sp, mlp_dtype(),
+                                                          float(near), float(far), num_steps)
     if MASK_STATS is not None:
         MASK_STATS.append((weights > 1e-4).float().mean())
     return {"depth_lidar": depth.view(*prefix), "image_lidar": image.view(*prefix, 2), "weights_sum_lidar": ws}

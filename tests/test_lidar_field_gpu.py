@@ -248,6 +248,31 @@ def test_coarse_samples_match_torch_linspace_form():
         torch.testing.assert_close(z, want, rtol=0, atol=2.5e-7)  # same fp32 expression; linspace itself within an ulp or two
 
 
+def test_coarse_sample_points_equals_the_two_separate_entry_points():
+    """lnh_lidar_coarse_sample_points == lnh_lidar_coarse_samples followed by lnh_lidar_sample_points, bit for bit, and only
+    the coarse slots of the [N, T+t] coordinate buffer are written."""
+    from gpu_util import call
+    N, T, Ttot = 29, 768, 832
+    g = torch.Generator().manual_seed(21)
+    o = ((torch.rand(N, 3, generator=g) - 0.5) * 0.05).cuda()
+    d = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1).cuda()
+    aabb = torch.tensor([-1, -1, -1, 1, 1, 1], dtype=torch.float32).cuda()
+    near = float(np.float32(0.0107848535))
+    far = float(np.float32(near) * np.float32(81.0))
+    u = torch.rand(N * T, generator=g).cuda()
+    for noise in (None, u):
+        z_a = torch.empty(N, T, device="cuda")
+        x_a = torch.full((N * Ttot, 3), float("nan"), device="cuda")
+        call("lnh_lidar_coarse_samples", noise, N, T, near, far, z_a)
+        call("lnh_lidar_sample_points", o, d, z_a, aabb, 1.0, N, T, Ttot, 0, x_a)
+        z_b = torch.empty(N, T, device="cuda")
+        x_b = torch.full((N * Ttot, 3), float("nan"), device="cuda")
+        call("lnh_lidar_coarse_sample_points", noise, o, d, aabb, 1.0, N, T, Ttot, near, far, z_b, x_b)
+        assert torch.equal(z_a, z_b)
+        assert torch.equal(torch.nan_to_num(x_a, nan=-7.0), torch.nan_to_num(x_b, nan=-7.0))
+        assert bool(torch.isnan(x_b.view(N, Ttot, 3)[:, T:]).all())
+
+
 def test_dir_term_and_weight_packing():
     from lidarnerf import _hip
     torch.manual_seed(0)
