@@ -337,6 +337,10 @@ LNH_API int lnh_lidar_coarse_samples(const float *u, uint32_t N, uint32_t T, flo
                                      lnh_stream_t stream);
 LNH_API int lnh_lidar_dir_term(const float *dir_features, const float *w0, uint32_t ldw, uint32_t N, uint32_t K,
                                float *features16, float *cdir, lnh_stream_t stream);
+/* The same with the frequency encoder of the directions folded in: dirs [N,3] -> features [N, 3 + 6*degree]
+ * (lnh_freq_encode_forward's layout and arithmetic: x | sin(2^f x), sin(2^f x + pi/2) per band) -> features16, cdir. */
+LNH_API int lnh_lidar_dir_term_freq(const float *dirs, uint32_t degree, const float *w0, uint32_t ldw, uint32_t N,
+                                    float *features16, float *cdir, lnh_stream_t stream);
 /* grad_w0[o*ldw + k] += sum_n ray_sum[n,o] * features16[n,k]  (ray_sum [N,64] from lnh_lidar_color_backward);
  * scratch: ceil(N/32) * 64 * 128 floats. */
 LNH_API int lnh_lidar_dir_term_backward(const float *ray_sum, const float *features16, uint32_t N, uint32_t K,
@@ -420,7 +424,7 @@ LNH_API int lnh_adam_table_step(float *param, float *exp_avg, float *exp_avg_sq,
 
 /* ------------------------------------------------------------------ bf16 MLP operands (BASELINE config 5) ---- */
 /*
- * The same ten entry points with v_mfma_f32_16x16x32_bf16 operands ("fp16 hash features + bf16 MFMA MLP"; the
+ * The same eleven entry points with v_mfma_f32_16x16x32_bf16 operands ("fp16 hash features + bf16 MFMA MLP"; the
  * reference reaches the MLPs through torch.autocast, lidarnerf/nerf/utils.py:626,1212 — under
  * autocast(dtype=torch.bfloat16) its Linear stacks run in bf16 while the grid encoder keeps casting its table to half,
  * gridencoder/grid.py:54-57).  Every buffer that holds MLP-side 16-bit data is bf16 here — inputs / outputs /
@@ -443,6 +447,8 @@ LNH_API int lnh_density_mlp_backward_bf16(const void *grad_h16, const void *feat
                                      float *grad_weights, lnh_stream_t stream);
 LNH_API int lnh_lidar_dir_term_bf16(const float *dir_features, const float *w0, uint32_t ldw, uint32_t N, uint32_t K,
                                float *features16, float *cdir, lnh_stream_t stream);
+LNH_API int lnh_lidar_dir_term_freq_bf16(const float *dirs, uint32_t degree, const float *w0, uint32_t ldw, uint32_t N,
+                                         float *features16, float *cdir, lnh_stream_t stream);
 LNH_API int lnh_lidar_pack_weights_bf16(const float *ws0, uint32_t ld_s0, const float *ws1, uint32_t ld_s1,
                                    const float *wc0, uint32_t ld_c0, uint32_t n_dir, const float *wc1, uint32_t ld_c1,
                                    const float *wc2, uint32_t ld_c2, void *wsig16, void *wcol16, lnh_stream_t stream);

@@ -24,7 +24,10 @@ k_coarse_samples(const float *__restrict__ u, uint32_t N, uint32_t T, float near
 // ------------------------------------------------------------------------------------------------ direction term
 // enc16[n,k] = direction feature rounded to the MLP element type E (fp16 / bf16); cdir[n,o] = sum_k enc16[n,k] *
 // E(W0[o,k])  (fp32 accumulate).  One workgroup = 4 rays x 64 outputs; the feature row of a ray is broadcast through LDS.
-template <typename E>
+// FREQ: `enc` holds the raw directions [N,3] and the K = 3 + 6 * deg frequency features (encoders.hip k_freq_forward:
+// x | sin(2^f x), sin(2^f x + pi/2) per band, the same operations in the same order) are formed here instead of being
+// read — the direction encoder and the direction term in one launch.
+template <typename E, bool FREQ>
 __global__ void __launch_bounds__(256)
 k_dir_term(const float *__restrict__ enc, const float *__restrict__ W0, uint32_t ldw, uint32_t N, uint32_t K,
            float *__restrict__ enc16, float *__restrict__ cdir) {
@@ -33,7 +36,16 @@ k_dir_term(const float *__restrict__ enc, const float *__restrict__ W0, uint32_t
     const uint32_t n = blockIdx.x * 4 + r;
     const bool valid = n < N;
     for (uint32_t k = o; k < K; k += 64) {
-        const float v = (float)(E)enc[(size_t)(valid ? n : 0) * K + k];
+        float feat;
+        if constexpr (FREQ) {
+            const uint32_t q = k < 3 ? 0u : k - 3u, d = k < 3 ? k : q % 3u, f = q / 6u, c = (q / 3u) & 1u;
+            const float x = enc[(size_t)(valid ? n : 0) * 3 + d];
+            const float a = scalbnf(x, (int)f);
+            feat = k < 3 ? x : sinf(c ? a + 1.5707963267948966f : a);
+        } else {
+            feat = enc[(size_t)(valid ? n : 0) * K + k];
+        }
+        const float v = (float)(E)feat;
         row[r][k] = v;
         if (valid) enc16[(size_t)n * K + k] = v;
     }
@@ -169,9 +181,20 @@ static int dir_term(const float *dir_features, const float *w0, uint32_t ldw, ui
     LNH_REQUIRE(dir_features && w0 && features16 && cdir, LNH_ERR_INVALID_ARG, "lidar_dir_term: null pointer");
     LNH_REQUIRE(K >= 1 && K <= 128 && ldw >= K, LNH_ERR_INVALID_ARG, "lidar_dir_term: need 1 <= K <= 128 and ldw >= K");
     if (N == 0) return LNH_OK;
-    LNH_LAUNCH(k_dir_term<E>, dim3(div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, dir_features, w0, ldw, N, K,
+    LNH_LAUNCH((k_dir_term<E, false>), dim3(div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, dir_features, w0, ldw, N, K,
                features16, cdir);
     return lnh_check_launch("lnh_lidar_dir_term");
+}
+template <typename E>
+static int dir_term_freq(const float *dirs, uint32_t degree, const float *w0, uint32_t ldw, uint32_t N, float *features16,
+                         float *cdir, lnh_stream_t stream) {
+    const uint32_t K = 3 + 6 * degree;
+    LNH_REQUIRE(dirs && w0 && features16 && cdir, LNH_ERR_INVALID_ARG, "lidar_dir_term_freq: null pointer");
+    LNH_REQUIRE(K <= 128 && ldw >= K, LNH_ERR_INVALID_ARG, "lidar_dir_term_freq: need 3 + 6*degree <= 128 and ldw >= that");
+    if (N == 0) return LNH_OK;
+    LNH_LAUNCH((k_dir_term<E, true>), dim3(div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, dirs, w0, ldw, N, K,
+               features16, cdir);
+    return lnh_check_launch("lnh_lidar_dir_term_freq");
 }
 template <typename E>
 static int pack_weights(const float *ws0, uint32_t ld_s0, const float *ws1, uint32_t ld_s1, const float *wc0,
@@ -204,6 +227,15 @@ int lnh_lidar_dir_term(const float *dir_features, const float *w0, uint32_t ldw,
 int lnh_lidar_dir_term_bf16(const float *dir_features, const float *w0, uint32_t ldw, uint32_t N, uint32_t K,
                             float *features16, float *cdir, lnh_stream_t stream) {
     return dir_term<__bf16>(dir_features, w0, ldw, N, K, features16, cdir, stream);
+}
+
+int lnh_lidar_dir_term_freq(const float *dirs, uint32_t degree, const float *w0, uint32_t ldw, uint32_t N,
+                            float *features16, float *cdir, lnh_stream_t stream) {
+    return dir_term_freq<half_t>(dirs, degree, w0, ldw, N, features16, cdir, stream);
+}
+int lnh_lidar_dir_term_freq_bf16(const float *dirs, uint32_t degree, const float *w0, uint32_t ldw, uint32_t N,
+                                 float *features16, float *cdir, lnh_stream_t stream) {
+    return dir_term_freq<__bf16>(dirs, degree, w0, ldw, N, features16, cdir, stream);
 }
 
 int lnh_lidar_dir_term_backward(const float *ray_sum, const float *features16, uint32_t N, uint32_t K, float *scratch,

@@ -57,6 +57,7 @@ _SIGS = {
     "lnh_lidar_color_composite_forward": [P, P, P, P, P, P, P, U32, U32, F32, P, P, P, P, P, P],
     "lnh_lidar_coarse_samples": [P, U32, U32, F32, F32, P],
     "lnh_lidar_dir_term": [P, P, U32, U32, U32, P, P],
+    "lnh_lidar_dir_term_freq": [P, U32, P, U32, U32, P, P],
     "lnh_lidar_dir_term_backward": [P, P, U32, U32, P, P, U32],
     "lnh_lidar_pack_weights": [P, U32, P, U32, P, U32, U32, P, U32, P, U32, P, P],
     "lnh_lidar_to_pano": [P, U32, U32, U32, F32, F32, F32, P, P, P],
@@ -70,7 +71,7 @@ _SIGS = {
 }
 for _n in ("lnh_mlp_forward", "lnh_mlp_backward", "lnh_density_mlp_forward", "lnh_density_mlp_backward",
            "lnh_lidar_dir_term", "lnh_lidar_pack_weights", "lnh_lidar_color_forward", "lnh_lidar_color_backward",
-           "lnh_lidar_color_composite_forward", "lnh_lidar_color_backward_image"):
+           "lnh_lidar_color_composite_forward", "lnh_lidar_color_backward_image", "lnh_lidar_dir_term_freq"):
     _SIGS[_n + "_bf16"] = _SIGS[_n]  # bf16-operand build of the MLP kernels (include/lidarnerf_hip.h, last section)
 EXPORTS = sorted(list(_SIGS) + ["lnh_version", "lnh_last_error", "lnh_arch", "lnh_grid_backward_workspace_size",
                                  "lnh_grid_backward_plan_info"])

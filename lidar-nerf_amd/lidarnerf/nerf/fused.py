@@ -34,11 +34,15 @@ class FieldSpec:
     nn.Linear stacks + `encoder.embeddings`, `network_tcnn.NeRFNetwork` keeps flat tcnn-style `params` vectors):
     tensors that take part in autograd (possibly views of Parameters) + the per-ray direction features."""
 
-    def __init__(self, grid, table, ws0, ws1, wc0, wc1, wc2, n_dir, dir_features, n_color_mats=3, table_param=None):
+    def __init__(self, grid, table, ws0, ws1, wc0, wc1, wc2, n_dir, dir_features, n_color_mats=3, table_param=None,
+                 dir_freq_degree=None):
         self.grid, self.table, self.ws0, self.ws1 = grid, table, ws0, ws1
         self.table_param = table_param if table_param is not None else table  # the Parameter DP bookkeeping marks
         self.wc0, self.wc1, self.wc2, self.n_dir, self.dir_features = wc0, wc1, wc2, n_dir, dir_features
         self.n_color_mats = n_color_mats
+        # set when dir_features is the frequency encoder of that degree on raw directions (n_dir = 3 + 6 * degree): the fused
+        # chain then forms the features inside the direction-term kernel
+        self.dir_freq_degree = dir_freq_degree
 
 
 def _bucketed_backward_ok(enc):
@@ -225,11 +229,18 @@ class FusedLidarRender(Function):
 
         sigma_m = torch.empty((N, Ttot), dtype=torch.float32, device=dev)
         weights = torch.empty((N, Ttot), dtype=torch.float32, device=dev)
-        enc_d = spec.dir_features(rays_d).contiguous()  # [N, kd] fp32, constant along a ray
-        enc_d16 = torch.empty_like(enc_d)                # the same, rounded to fp16 (what the MLP would see)
+        # direction features [N, kd] (constant along a ray), rounded to the MLP element type (what the MLP would see), and
+        # the per-ray direction term of the colour head's first layer
+        enc_d16 = torch.empty((N, kd), dtype=torch.float32, device=dev)
         cdir = torch.empty((N, 64), dtype=torch.float32, device=dev)
-        _hip.call("lnh_lidar_dir_term" + sfx, enc_d.data_ptr(), mats[2].data_ptr(), mats[2].stride(0), N, kd,
-                  enc_d16.data_ptr(), cdir.data_ptr())
+        deg = getattr(spec, "dir_freq_degree", None)
+        if deg is not None and 3 + 6 * deg == kd:
+            _hip.call("lnh_lidar_dir_term_freq" + sfx, rays_d.data_ptr(), int(deg), mats[2].data_ptr(), mats[2].stride(0), N,
+                      enc_d16.data_ptr(), cdir.data_ptr())
+        else:
+            enc_d = spec.dir_features(rays_d).contiguous()
+            _hip.call("lnh_lidar_dir_term" + sfx, enc_d.data_ptr(), mats[2].data_ptr(), mats[2].stride(0), N, kd,
+                      enc_d16.data_ptr(), cdir.data_ptr())
         rgb = torch.empty((N, Ttot, 2), dtype=torch.float32, device=dev)
         ws = torch.empty(N, dtype=torch.float32, device=dev)
         depth = torch.empty(N, dtype=torch.float32, device=dev)

@@ -83,7 +83,7 @@ class NeRFNetwork(NeRFRenderer):
         return fused.FieldSpec(grid=self.encoder, table=self.encoder.embeddings, ws0=self.sigma_net[0].weight,
                                ws1=self.sigma_net[1].weight, wc0=c[0].weight,
                                wc1=c[1].weight if len(c) == 3 else None, wc2=c[-1].weight, n_dir=75,
-                               dir_features=self._lidar_dir_features, n_color_mats=len(c))
+                               dir_features=self._lidar_dir_features, dir_freq_degree=12, n_color_mats=len(c))
 
     def run(self, rays_o, rays_d, cal_lidar_color=False, num_steps=128, upsample_steps=128, bg_color=None,
             perturb=False, **kwargs):

@@ -299,6 +299,24 @@ def test_dir_term_and_weight_packing():
     assert torch.equal(wcol, torch.cat([w0g.reshape(-1), wc1.reshape(-1), w2p.reshape(-1)]).half())
 
 
+@pytest.mark.parametrize("sfx", ["", "_bf16"])
+def test_dir_term_with_the_frequency_encoder_folded_in(sfx):
+    """lnh_lidar_dir_term_freq(dirs) == lnh_freq_encode_forward followed by lnh_lidar_dir_term, bit for bit."""
+    from gpu_util import call
+    N, deg = 1001, 12
+    K = 3 + 6 * deg
+    g = torch.Generator().manual_seed(5)
+    d = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1).cuda()
+    W0 = (torch.randn(64, K + 15, generator=g) * 0.3).cuda()
+    enc = torch.empty(N, K, device="cuda")
+    call("lnh_freq_encode_forward", d, N, 3, deg, K, enc)
+    e_a, c_a = torch.empty(N, K, device="cuda"), torch.empty(N, 64, device="cuda")
+    call("lnh_lidar_dir_term" + sfx, enc, W0, K + 15, N, K, e_a, c_a)
+    e_b, c_b = torch.empty(N, K, device="cuda"), torch.empty(N, 64, device="cuda")
+    call("lnh_lidar_dir_term_freq" + sfx, d, deg, W0, K + 15, N, e_b, c_b)
+    assert torch.equal(e_a, e_b) and torch.equal(c_a, c_b)
+
+
 def test_fused_lidar_loss_matches_train_step_loss():
     from lidarnerf.nerf.train_step import fused_lidar_loss, lidar_loss
     torch.manual_seed(1)
