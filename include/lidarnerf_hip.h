@@ -270,6 +270,14 @@ LNH_API int lnh_lidar_resample_strided(const float *z, const float *sigma, uint3
                                        const float *sample_dist, const float *u, uint32_t N, uint32_t T,
                                        uint32_t n_new, float density_scale, uint32_t sorted_new, float *new_z,
                                        float *z_out, int32_t *perm, lnh_stream_t stream);
+/* lnh_lidar_resample_strided with sorted_new = 1 that also writes the grid coordinates of the new samples
+ * (lnh_lidar_sample_points for slots T .. T+n_new-1) into x01 [N*(T+n_new), 3]: the importance pass of the fused step
+ * needs no separate coordinate kernel. */
+LNH_API int lnh_lidar_resample_points(const float *z, const float *sigma, uint32_t sigma_stride,
+                                      const float *sample_dist, const float *u, uint32_t N, uint32_t T, uint32_t n_new,
+                                      float density_scale, float *new_z, float *z_out, int32_t *perm,
+                                      const float *rays_o, const float *rays_d, const float *aabb, float bound,
+                                      float *x01, lnh_stream_t stream);
 
 
 /* ------------------------------------------------------------------ fused LiDAR field step ------------------ */

@@ -228,7 +228,8 @@ __global__ void __launch_bounds__(64)
 k_lidar_resample(const float *__restrict__ z, const float *__restrict__ sigma, const float *__restrict__ sample_dist,
                  const float *__restrict__ u, uint32_t N, uint32_t T, uint32_t n_new, uint32_t P,
                  float density_scale, uint32_t sorted_new, float *__restrict__ new_z, float *__restrict__ z_out,
-                 int32_t *__restrict__ perm, uint32_t sigma_stride) {
+                 int32_t *__restrict__ perm, uint32_t sigma_stride, const float *__restrict__ rays_o,
+                 const float *__restrict__ rays_d, const float *__restrict__ aabb, float bound, float *__restrict__ x01) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float *zs = reinterpret_cast<float *>(smem_raw);
     float *cdf = zs + T;
@@ -362,6 +363,17 @@ k_lidar_resample(const float *__restrict__ z, const float *__restrict__ sigma, c
         // consecutive lanes = neighbouring positions along the ray, like the coarse samples
         perm[(size_t)ray * (T + n_new) + pos] = (int)(T + (sorted_new ? r : (uint32_t)val[r]));
         if (sorted_new) new_z[(size_t)ray * n_new + r] = key[r];
+        if (x01) {
+            // grid coordinates of the new samples (what lnh_lidar_sample_points computes for slots T .. T+n_new-1 of the
+            // ray's rows in the combined [N, T+n_new] buffer; sorted_new order), same arithmetic
+            float *o = x01 + ((size_t)ray * (T + n_new) + T + r) * 3;
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                float p = rays_o[ray * 3 + d] + rays_d[ray * 3 + d] * key[r];
+                p = fminf(fmaxf(p, aabb[d]), aabb[3 + d]);
+                o[d] = (p + bound) / (2 * bound);
+            }
+        }
     }
 }
 
@@ -418,9 +430,10 @@ int lnh_lidar_composite_backward(const float *grad_weights_sum, const float *gra
     return lnh_check_launch("lnh_lidar_composite_backward");
 }
 
-int lnh_lidar_resample_strided(const float *z, const float *sigma, uint32_t sigma_stride, const float *sample_dist,
-                               const float *u, uint32_t N, uint32_t T, uint32_t n_new, float density_scale,
-                               uint32_t sorted_new, float *new_z, float *z_out, int32_t *perm, lnh_stream_t stream) {
+static int resample_launch(const float *z, const float *sigma, uint32_t sigma_stride, const float *sample_dist,
+                           const float *u, uint32_t N, uint32_t T, uint32_t n_new, float density_scale,
+                           uint32_t sorted_new, float *new_z, float *z_out, int32_t *perm, const float *rays_o,
+                           const float *rays_d, const float *aabb, float bound, float *x01, lnh_stream_t stream) {
     LNH_REQUIRE(z && sigma && sample_dist && u && new_z && z_out && perm, LNH_ERR_INVALID_ARG,
                 "lidar_resample: null pointer");
     LNH_REQUIRE(sigma_stride >= T, LNH_ERR_INVALID_ARG, "lidar_resample: sigma_stride %u < T %u", sigma_stride, T);
@@ -436,15 +449,32 @@ int lnh_lidar_resample_strided(const float *z, const float *sigma, uint32_t sigm
     if (lds > 64 * 1024)
         hipFuncSetAttribute((const void *)k_lidar_resample, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     LNH_LAUNCH(k_lidar_resample, dim3(N), dim3(64), lds, s, z, sigma, sample_dist, u, N, T, n_new, P,
-                       density_scale, sorted_new, new_z, z_out, perm, sigma_stride);
+                       density_scale, sorted_new, new_z, z_out, perm, sigma_stride, rays_o, rays_d, aabb, bound, x01);
     return lnh_check_launch("lnh_lidar_resample");
+}
+
+int lnh_lidar_resample_strided(const float *z, const float *sigma, uint32_t sigma_stride, const float *sample_dist,
+                               const float *u, uint32_t N, uint32_t T, uint32_t n_new, float density_scale,
+                               uint32_t sorted_new, float *new_z, float *z_out, int32_t *perm, lnh_stream_t stream) {
+    return resample_launch(z, sigma, sigma_stride, sample_dist, u, N, T, n_new, density_scale, sorted_new, new_z, z_out, perm,
+                           nullptr, nullptr, nullptr, 1.0f, nullptr, stream);
+}
+
+int lnh_lidar_resample_points(const float *z, const float *sigma, uint32_t sigma_stride, const float *sample_dist,
+                              const float *u, uint32_t N, uint32_t T, uint32_t n_new, float density_scale, float *new_z,
+                              float *z_out, int32_t *perm, const float *rays_o, const float *rays_d, const float *aabb,
+                              float bound, float *x01, lnh_stream_t stream) {
+    LNH_REQUIRE(rays_o && rays_d && aabb && x01, LNH_ERR_INVALID_ARG, "lidar_resample_points: null pointer");
+    LNH_REQUIRE(bound > 0.0f, LNH_ERR_INVALID_ARG, "lidar_resample_points: bound must be positive");
+    return resample_launch(z, sigma, sigma_stride, sample_dist, u, N, T, n_new, density_scale, 1, new_z, z_out, perm, rays_o,
+                           rays_d, aabb, bound, x01, stream);
 }
 
 int lnh_lidar_resample(const float *z, const float *sigma, const float *sample_dist, const float *u, uint32_t N,
                        uint32_t T, uint32_t n_new, float density_scale, uint32_t sorted_new, float *new_z, float *z_out,
                        int32_t *perm, lnh_stream_t stream) {
-    return lnh_lidar_resample_strided(z, sigma, T, sample_dist, u, N, T, n_new, density_scale, sorted_new, new_z, z_out,
-                                      perm, stream);
+    return resample_launch(z, sigma, T, sample_dist, u, N, T, n_new, density_scale, sorted_new, new_z, z_out, perm, nullptr,
+                           nullptr, nullptr, 1.0f, nullptr, stream);
 }
 
 }  // extern "C"

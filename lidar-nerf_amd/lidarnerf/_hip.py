@@ -47,6 +47,7 @@ _SIGS = {
     "lnh_lidar_composite_backward": [P, P, P, P, P, P, P, U32, U32, U32, F32, P, P],
     "lnh_lidar_resample": [P, P, P, P, U32, U32, U32, F32, U32, P, P, P],
     "lnh_lidar_resample_strided": [P, P, U32, P, P, U32, U32, U32, F32, U32, P, P, P],
+    "lnh_lidar_resample_points": [P, P, U32, P, P, U32, U32, U32, F32, P, P, P, P, P, P, F32, P],
     "lnh_lidar_sample_points": [P, P, P, P, F32, U32, U32, U32, U32, P],
     "lnh_lidar_coarse_sample_points": [P, P, P, P, F32, U32, U32, U32, F32, F32, P, P],
     "lnh_grid_encode_forward_mapped": [P, P, P, P, U32, U32, U32, U32, U32, U32, U32, F32, U32, I32],

@@ -202,9 +202,11 @@ class FusedLidarRender(Function):
         x01 = torch.empty((B_all, 3), dtype=torch.float32, device=dev)
         feat = torch.empty((L, B_all, 2), dtype=torch.half, device=dev)
 
-        def density(zz, Tc, off):
+        def density(zz, Tc, off, have_points=False):
             B = N * Tc
-            if zz is None:  # coarse pass: the stratified depths and their grid coordinates in one launch
+            if have_points:  # (the resample kernel has written the coordinates of these samples)
+                pass
+            elif zz is None:  # coarse pass: the stratified depths and their grid coordinates in one launch
                 _hip.call("lnh_lidar_coarse_sample_points", None if noise is None else noise.data_ptr(), rays_o.data_ptr(),
                           rays_d.data_ptr(), aabb.data_ptr(), bound, N, Tc, Ttot, float(near), float(far), z.data_ptr(),
                           x01.data_ptr())
@@ -223,9 +225,11 @@ class FusedLidarRender(Function):
         z_all = torch.empty((N, Ttot), dtype=torch.float32, device=dev)
         perm = torch.empty((N, Ttot), dtype=torch.int32, device=dev)
         # (stage-1 densities = the first T columns of the [N, T+t] buffer: read in place, row stride T+t)
-        _hip.call("lnh_lidar_resample_strided", z.data_ptr(), sigma_pt.data_ptr(), Ttot, sd.data_ptr(), u.data_ptr(), N, T,
-                  t_new, float(density_scale), 1, new_z.data_ptr(), z_all.data_ptr(), perm.data_ptr())
-        density(new_z, t_new, T)
+        # ... and the grid coordinates of the new samples are written by the same kernel
+        _hip.call("lnh_lidar_resample_points", z.data_ptr(), sigma_pt.data_ptr(), Ttot, sd.data_ptr(), u.data_ptr(), N, T,
+                  t_new, float(density_scale), new_z.data_ptr(), z_all.data_ptr(), perm.data_ptr(), rays_o.data_ptr(),
+                  rays_d.data_ptr(), aabb.data_ptr(), bound, x01.data_ptr())
+        density(new_z, t_new, T, have_points=True)
 
         sigma_m = torch.empty((N, Ttot), dtype=torch.float32, device=dev)
         weights = torch.empty((N, Ttot), dtype=torch.float32, device=dev)

@@ -147,6 +147,38 @@ def test_resample_strided_reads_the_first_columns_of_a_wider_buffer():
              outs[0][0], outs[0][1], outs[0][2])
 
 
+def test_resample_points_writes_the_coordinates_of_the_new_samples():
+    """lnh_lidar_resample_points == lnh_lidar_resample_strided(sorted_new = 1) + lnh_lidar_sample_points of the new depths,
+    bit for bit; the coarse rows of the coordinate buffer are left alone."""
+    from gpu_util import call
+    N, T, n_new = 23, 768, 64
+    z, sigma, _, sd = _ray_inputs(N, T, 13)
+    g = torch.Generator().manual_seed(14)
+    u = torch.rand(N, n_new, generator=g).cuda()
+    o = ((torch.rand(N, 3, generator=g) - 0.5) * 0.05).cuda()
+    d = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1).cuda()
+    aabb = torch.tensor([-1, -1, -1, 1, 1, 1], dtype=torch.float32).cuda()
+    wide = torch.zeros(N, T + n_new)
+    wide[:, :T] = sigma
+    outs = []
+    for fused in (False, True):
+        new_z = torch.empty((N, n_new), device="cuda")
+        z_out = torch.empty((N, T + n_new), device="cuda")
+        perm = torch.empty((N, T + n_new), dtype=torch.int32, device="cuda")
+        x01 = torch.full((N * (T + n_new), 3), float("nan"), device="cuda")
+        if fused:
+            call("lnh_lidar_resample_points", z.cuda(), wide.cuda(), T + n_new, sd.cuda(), u, N, T, n_new, 1.0, new_z, z_out,
+                 perm, o, d, aabb, 1.0, x01)
+        else:
+            call("lnh_lidar_resample_strided", z.cuda(), wide.cuda(), T + n_new, sd.cuda(), u, N, T, n_new, 1.0, 1, new_z,
+                 z_out, perm)
+            call("lnh_lidar_sample_points", o, d, new_z, aabb, 1.0, N, n_new, T + n_new, T, x01)
+        outs.append((new_z, z_out, perm, torch.nan_to_num(x01, nan=-7.0)))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert bool((outs[1][3].view(N, T + n_new, 3)[:, :T] == -7.0).all())
+
+
 def test_resample_against_reference_golden(golden_dir):
     """G1: reference sample_pdf outputs; here the stage-1 weights are fed through sigma so that w == golden weights
     is not reproducible, so instead check the inverse-cdf stage alone by a degenerate construction: T-2 bins with
