@@ -1,4 +1,8 @@
 #!/bin/bash
+# One GPU call for the rest of profiles/: grid + MFMA counter passes and the bench lines of the other configurations
+# (16 384 rays, bf16 MLP operands, both, the occupancy-grid workload).  profiles/collect.sh writes the default bench line,
+# the kernel trace and the FETCH / WRITE_SIZE passes.  Run from the repository root on a GPU box; copy what you want judged
+# from gpurun_out/profiles/ to profiles/.
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 out=gpurun_out/profiles; mkdir -p $out
 timeout 400 bash profiles/collect_counters.sh r02 > gpurun_out/cc.log 2>&1
