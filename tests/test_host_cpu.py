@@ -160,3 +160,22 @@ def test_build_tracks_the_sources_a_wrapper_translation_unit_includes():
         deps = {os.path.basename(p) for p in mod._local_includes(os.path.join(csrc, wrapper))}
         assert included in deps and "mlp_common.h" in deps, (wrapper, deps)
     assert "mlp_bwd.h" in {os.path.basename(p) for p in mod._local_includes(os.path.join(csrc, "mlp_bwd_nhm0_bf16.hip"))}
+
+
+def test_header_is_plain_c():
+    """include/lidarnerf_hip.h is the drop-in boundary: it must compile as C99 (no C++-isms, no torch / HIP types), so that a
+    cgo / JNI / ctypes-generator binding can consume it as it is."""
+    import shutil
+    import subprocess
+    import tempfile
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "h.c")
+        with open(src, "w") as f:
+            f.write('#include "lidarnerf_hip.h"\nint main(void) { return 0; }\n')
+        r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(root, "include"),
+                            "-fsyntax-only", src], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
