@@ -179,3 +179,35 @@ def test_header_is_plain_c():
         r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(root, "include"),
                             "-fsyntax-only", src], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_ctypes_signatures_match_the_header():
+    """Every prototype of include/lidarnerf_hip.h against the argument list lidarnerf/_hip.py binds it with: same number of
+    arguments, same class per position (pointer / uint32 / int32 / float / uint64 / double), stream last.  A drifted
+    signature would not fail at load time — ctypes would pass garbage."""
+    import ctypes as C
+    from lidarnerf import _hip
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "include", "lidarnerf_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    protos = re.findall(r"LNH_API\s+int\s+(lnh_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S)
+    assert len(protos) >= 60
+
+    def cls(arg):
+        a = " ".join(arg.split())
+        if "*" in a:
+            return C.c_void_p
+        ty = a.rsplit(" ", 1)[0].replace("const ", "").strip()
+        return {"uint32_t": C.c_uint32, "int32_t": C.c_int, "int": C.c_int, "float": C.c_float, "uint64_t": C.c_uint64,
+                "size_t": C.c_uint64, "double": C.c_double, "lnh_stream_t": C.c_void_p}[ty]
+
+    checked = 0
+    for name, args in protos:
+        if name not in _hip._SIGS:
+            continue
+        want = [cls(a) for a in args.split(",")]
+        assert want[-1] is C.c_void_p and "lnh_stream_t" in args.split(",")[-1], name
+        got = list(_hip._SIGS[name]) + [C.c_void_p]
+        assert [w for w in want] == got, (name, [w.__name__ for w in want], [g.__name__ for g in got])
+        checked += 1
+    assert checked == len(_hip._SIGS), (checked, len(_hip._SIGS), sorted(set(_hip._SIGS) - {n for n, _ in protos}))
