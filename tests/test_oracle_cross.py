@@ -174,3 +174,21 @@ def test_sh_structure_form_matches_explicit_table_and_scipy():
             c = sph_harm_y(l, abs(m), theta, phi)
             ref = c.real if m == 0 else np.sqrt(2) * (c.real if m > 0 else c.imag)
             np.testing.assert_allclose(Y[:, l * l + l + m], ref, rtol=0, atol=1e-12)
+
+
+def test_bf16_rounding_of_the_mlp_oracle_matches_torch():
+    """oracle/mlp_ref.round_bf16 (integer arithmetic on the float32 bit pattern) == torch's float32 -> bfloat16 conversion
+    (round to nearest even) on random values, ties, subnormals, signed zeros and values next to the largest finite one."""
+    import torch
+    from oracle import mlp_ref
+    r = np.random.default_rng(0)
+    x = np.concatenate([
+        r.standard_normal(20000).astype(np.float32) * np.float32(10.0) ** r.integers(-30, 30, 20000).astype(np.float32),
+        np.array([0.0, -0.0, 1.0, -1.0, 1.00390625, 1.01171875, 3.3895314e38, -3.3895314e38, 1e-40, -1e-40, 65504.0],
+                 np.float32),
+        # exact ties: upper 16 bits + 0x8000 with even / odd last kept bit
+        (np.arange(0x3F80, 0x3F90, dtype=np.uint32) << 16 | 0x8000).view(np.float32),
+    ])
+    want = torch.from_numpy(x).to(torch.bfloat16).to(torch.float32).numpy()
+    got = mlp_ref.round_bf16(x)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
