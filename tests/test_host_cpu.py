@@ -211,3 +211,16 @@ def test_ctypes_signatures_match_the_header():
         assert [w for w in want] == got, (name, [w.__name__ for w in want], [g.__name__ for g in got])
         checked += 1
     assert checked == len(_hip._SIGS), (checked, len(_hip._SIGS), sorted(set(_hip._SIGS) - {n for n, _ in protos}))
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="needs a box without a GPU")
+def test_bench_refuses_to_run_without_a_gpu():
+    """bench.py measures the HIP path or nothing: on a box without a GPU it exits non-zero with a message instead of timing
+    a fallback."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "no CPU fallback" in (r.stdout + r.stderr)
+    assert not any(line.startswith("{") for line in r.stdout.splitlines())  # no result line
