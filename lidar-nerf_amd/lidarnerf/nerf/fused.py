@@ -230,6 +230,8 @@ class FusedLidarRender(Function):
                   t_new, float(density_scale), new_z.data_ptr(), z_all.data_ptr(), perm.data_ptr(), rays_o.data_ptr(),
                   rays_d.data_ptr(), aabb.data_ptr(), bound, x01.data_ptr())
         density(new_z, t_new, T, have_points=True)
+        if CAPTURE is not None:
+            CAPTURE.update(z=z, new_z=new_z, z_all=z_all, perm=perm)
 
         sigma_m = torch.empty((N, Ttot), dtype=torch.float32, device=dev)
         weights = torch.empty((N, Ttot), dtype=torch.float32, device=dev)
@@ -342,10 +344,12 @@ class FusedLidarRender(Function):
 
 
 MASK_STATS = None  # bench.py: set to a list to collect, per render call, the fraction of samples with weight > 1e-4
+CAPTURE = None  # parity tests: set to a dict to receive the sample depths (z, new_z, z_all, perm) of the next render call
 
 
-def render_lidar(model, rays_o, rays_d, num_steps, upsample_steps, perturb):
-    """Drop-in for NeRFRenderer.run(cal_lidar_color=True) on a supported NeRFNetwork."""
+def render_lidar(model, rays_o, rays_d, num_steps, upsample_steps, perturb, noise=None, u=None):
+    """Drop-in for NeRFRenderer.run(cal_lidar_color=True) on a supported NeRFNetwork.  `noise` [N, num_steps] / `u`
+    [N, upsample_steps] in [0, 1) replace the random draws (perturbation / sample_pdf), as in NeRFRenderer.run."""
     prefix = rays_o.shape[:-1]
     rays_o = rays_o.contiguous().view(-1, 3).float()
     rays_d = rays_d.contiguous().view(-1, 3).float()
@@ -356,11 +360,18 @@ def render_lidar(model, rays_o, rays_d, num_steps, upsample_steps, perturb):
     far = near * 81.0
     # one random draw serves the stratified perturbation (first N*num_steps values) and, in training mode, the
     # importance-sampling positions u (the rest)
-    n_noise = N * num_steps if perturb else 0
-    n_u = N * upsample_steps if model.training else 0
+    n_noise = N * num_steps if perturb and noise is None else 0
+    n_u = N * upsample_steps if model.training and u is None else 0
     rnd = torch.rand(n_noise + n_u, device=dev) if n_noise + n_u else None
-    noise = rnd[:n_noise] if perturb else None
-    if model.training:
+    if not perturb:
+        noise = None
+    elif noise is None:
+        noise = rnd[:n_noise]
+    else:
+        noise = noise.to(dev).float().reshape(N * num_steps).contiguous()
+    if u is not None:
+        u = u.to(dev).float().reshape(N, upsample_steps).contiguous()
+    elif model.training:
         u = rnd[n_noise:].view(N, upsample_steps)
     else:
         u = torch.linspace(0.5 / upsample_steps, 1.0 - 0.5 / upsample_steps, upsample_steps,

@@ -60,7 +60,8 @@ class NeRFNetwork(NeRFRenderer):
         if (self.fused_lidar and rays_o.is_cuda and torch.is_autocast_enabled()
                 and fused.supported(self, cal_lidar_color, num_steps, upsample_steps)):
             self.out_dim = self.out_lidar_color_dim
-            return fused.render_lidar(self, rays_o, rays_d, num_steps, upsample_steps, perturb)
+            return fused.render_lidar(self, rays_o, rays_d, num_steps, upsample_steps, perturb,
+                                      noise=kwargs.get("noise"), u=kwargs.get("u"))
         return super().run(rays_o, rays_d, cal_lidar_color=cal_lidar_color, num_steps=num_steps,
                            upsample_steps=upsample_steps, bg_color=bg_color, perturb=perturb, **kwargs)
 

@@ -50,10 +50,14 @@ def weights_from_sigma(z_vals, sigma, sample_dist, density_scale=1.0):
 
 
 def run_lidar(rays_o, rays_d, density_fn, color_fn, aabb, min_near_lidar, num_steps=768, upsample_steps=64,
-              perturb=False, training=False, density_scale=1.0, noise=None, u=None, out_dim=2):
+              perturb=False, training=False, density_scale=1.0, noise=None, u=None, out_dim=2, z_override=None,
+              new_z_override=None):
     """renderer.py:99-298 for cal_lidar_color=True.  density_fn(x[P,3]) -> (sigma[P], geo[P,G]);
     color_fn(x[P,3], d[P,3], mask[P], geo[P,G]) -> rgb[P,out_dim] (zeros where ~mask).
-    `noise` [N,num_steps] in [0,1) replaces torch.rand for the perturbation; `u` [N,upsample] for sample_pdf."""
+    `noise` [N,num_steps] in [0,1) replaces torch.rand for the perturbation; `u` [N,upsample] for sample_pdf.
+    `z_override` [N,num_steps] / `new_z_override` [N,upsample] inject the sample depths themselves (a parity test that
+    hands this function the depths the HIP chain drew compares everything downstream without the ill-conditioned
+    dependence of the importance samples on an ulp of the cdf)."""
     rays_o = rays_o.reshape(-1, 3)
     rays_d = rays_d.reshape(-1, 3)
     N = rays_o.shape[0]
@@ -66,6 +70,8 @@ def run_lidar(rays_o, rays_d, density_fn, color_fn, aabb, min_near_lidar, num_st
         if noise is None:
             noise = torch.rand(z_vals.shape)
         z_vals = z_vals + (noise - 0.5) * sample_dist
+    if z_override is not None:
+        z_vals = z_override.reshape(N, num_steps).to(rays_o.dtype)
     xyzs = rays_o.unsqueeze(-2) + rays_d.unsqueeze(-2) * z_vals.unsqueeze(-1)
     xyzs = torch.min(torch.max(xyzs, aabb[:3]), aabb[3:])
     sigma, geo = density_fn(xyzs.reshape(-1, 3))
@@ -75,6 +81,8 @@ def run_lidar(rays_o, rays_d, density_fn, color_fn, aabb, min_near_lidar, num_st
             weights, deltas = weights_from_sigma(z_vals, sigma, sample_dist, density_scale)
             z_mid = z_vals[..., :-1] + 0.5 * deltas[..., :-1]
             new_z = sample_pdf(z_mid, weights[:, 1:-1], upsample_steps, det=not training, u=u).detach()
+            if new_z_override is not None:
+                new_z = new_z_override.reshape(N, upsample_steps).to(rays_o.dtype)
             new_xyzs = rays_o.unsqueeze(-2) + rays_d.unsqueeze(-2) * new_z.unsqueeze(-1)
             new_xyzs = torch.min(torch.max(new_xyzs, aabb[:3]), aabb[3:])
         new_sigma, new_geo = density_fn(new_xyzs.reshape(-1, 3))

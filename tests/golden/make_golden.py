@@ -14,6 +14,14 @@ Vectors:
   G6 convert           lidarnerf/convert.py:99-160, 194-237  lidar_to_pano_with_intensities (per-point loop) on a
                        synthetic 20 k-point sweep incl. ties, out-of-range and beyond-max-depth points, and
                        pano_to_lidar_with_intensities of the result
+  G7 BASELINE config 1 end to end: the reference's OWN NeRFNetwork (lidarnerf/nerf/network.py:10-253 — __init__,
+                       density 162-179, color 199-237) through NeRFRenderer.run (renderer.py:99-298), with the
+                       pure-torch FreqEncoder of encoding.py:6-47 standing where the CUDA `freqencoder` package is
+                       imported (the alternative the reference itself keeps, commented, at encoding.py:67), fixed
+                       fp16-representable weights, N = 64 rays, 768 + 64 samples: outputs + EVERY weight gradient,
+                       eval and train (replayed draws); plus the two bias-free Linear stacks evaluated directly on
+                       2048 points (inputs, outputs, weight and input gradients) — reference-produced pins for the
+                       MFMA MLP kernels (lnh_mlp_forward / lnh_mlp_backward) and the HIP frequency encoder
 """
 import os
 import sys
@@ -186,8 +194,127 @@ def g6():
                         intensities=inten, back=back)
 
 
+def _reference_network_config1():
+    """The reference's NeRFNetwork for BASELINE config 1 (encoding="frequency": CPU-runnable).  encoding.py:68 imports
+    the CUDA extension package `freqencoder` (and network.py:63 `shencoder` for the RGB branch the LiDAR path never
+    calls); here those two names resolve to shims built from the reference's OWN pure-torch FreqEncoder
+    (encoding.py:6-47, constructed exactly as the commented line encoding.py:67 constructs it) — every line of
+    density / color / run that executes is the reference's."""
+    import lidarnerf.encoding as ref_encoding
+
+    class _Freq(ref_encoding.FreqEncoder):
+        def __init__(self, input_dim=3, degree=4):
+            super().__init__(input_dim=input_dim, max_freq_log2=degree - 1, N_freqs=degree, log_sampling=True)
+            self.degree = degree
+
+    class _SH(torch.nn.Module):  # constructed by network.py:63, never called in LiDAR mode
+        def __init__(self, input_dim=3, degree=4):
+            super().__init__()
+            self.output_dim = degree ** 2
+
+        def forward(self, x, **kw):
+            raise RuntimeError("RGB branch is not part of the LiDAR path")
+
+    fe, sh = types.ModuleType("freqencoder"), types.ModuleType("shencoder")
+    fe.FreqEncoder, sh.SHEncoder = _Freq, _SH
+    sys.modules["freqencoder"], sys.modules["shencoder"] = fe, sh
+    from lidarnerf.nerf.network import NeRFNetwork
+    net = NeRFNetwork(encoding="frequency", bound=1, min_near=SCALE, min_near_lidar=SCALE, density_scale=1,
+                      density_thresh=10, bg_radius=-1)
+    assert net.in_dim == 39 and net.in_dim_dir == 75
+    g = torch.Generator().manual_seed(77)
+    with torch.no_grad():
+        for lin in list(net.sigma_net) + list(net.lidar_color_net):
+            k = (3.0 / lin.in_features) ** 0.5
+            lin.weight.copy_((torch.rand(lin.weight.shape, generator=g) * 2 - 1) * k)
+        # a scene with structure: density pre-activation h0 spread over ~[-3, 9] so that weights concentrate on some
+        # rays, stay flat on others and the 1e-4 colour mask cuts through the batch
+        net.sigma_net[1].weight[0] = net.sigma_net[1].weight[0].abs() * 0.6 + net.sigma_net[1].weight[0] * 6.0
+        net.sigma_net[0].weight.mul_(1.5)
+        net.lidar_color_net[2].weight.mul_(3.0)
+        for lin in list(net.sigma_net) + list(net.lidar_color_net):  # fp16-representable: a 16-bit build sees the same
+            lin.weight.copy_(lin.weight.half().float())
+    return net
+
+
+def _lidar_loss(depth, image, gt):
+    """nerf/utils.py:712-746 (the Trainer cannot be imported here): L1 depth * 1000 + MSE raydrop + MSE intensity * 10."""
+    rd = gt[..., 0]
+    per_ray = (1000.0 * (depth * rd - gt[..., 2] * rd).abs() + (image[..., 0] - rd) ** 2
+               + 10.0 * (image[..., 1] * rd - gt[..., 1] * rd) ** 2)
+    return per_ray.mean()
+
+
+def g7():
+    net = _reference_network_config1()
+    names = [f"sigma_net.{i}.weight" for i in range(2)] + [f"lidar_color_net.{i}.weight" for i in range(3)]
+    params = dict(net.named_parameters())
+    out = {"w_" + n: params[n].detach().numpy().copy() for n in names}
+    N, T, t = 64, 768, 64
+    rays_o, rays_d = make_rays(N, 21)
+    g = torch.Generator().manual_seed(8)
+    raydrop = (torch.rand(N, generator=g) < 0.85).float()
+    gt = torch.stack([raydrop, torch.rand(N, generator=g), SCALE * (2 + 78 * torch.rand(N, generator=g)) * raydrop], -1)
+    cd, ci, cw = torch.linspace(0.5, 1.5, N), torch.linspace(-1, 1, N * 2).view(1, N, 2), torch.linspace(1, 0.2, N)
+    out.update(rays_o=rays_o.numpy(), rays_d=rays_d.numpy(), gt=gt.numpy(), cd=cd.numpy(), ci=ci.numpy(), cw=cw.numpy())
+    for tag, train in (("eval", False), ("train", True)):
+        net.train(train)
+        for loss_name in ("lin", "lidar"):
+            net.zero_grad(set_to_none=True)
+            torch.manual_seed(4242)
+            res = net.render(rays_o, rays_d, cal_lidar_color=True, staged=False, perturb=train, num_steps=T,
+                             upsample_steps=t)
+            if loss_name == "lin":
+                loss = (res["depth_lidar"] * cd).sum() + (res["image_lidar"] * ci).sum() + \
+                    (res["weights_sum_lidar"] * cw).sum()
+            else:
+                loss = _lidar_loss(res["depth_lidar"][0], res["image_lidar"][0], gt)
+            loss.backward()
+            out[f"{tag}_{loss_name}_loss"] = loss.detach().numpy()
+            for n in names:
+                out[f"{tag}_{loss_name}_grad_{n}"] = params[n].grad.numpy().copy()
+        out.update({f"{tag}_depth": res["depth_lidar"].detach().numpy(), f"{tag}_image": res["image_lidar"].detach().numpy(),
+                    f"{tag}_ws": res["weights_sum_lidar"].detach().numpy()})
+        if train:  # the two torch.rand draws inside run(): perturbation, then sample_pdf's u
+            torch.manual_seed(4242)
+            out["train_noise"] = torch.rand(N, T).numpy()
+            out["train_u"] = torch.rand(N, t).numpy()
+    # the two Linear stacks on their own (reference density() / color() called directly): 2048 points of rays 0..3 and
+    # some far outside the unit box, eval-mode sample positions
+    net.eval()
+    z = (SCALE + (81 * SCALE - SCALE) * torch.linspace(0, 1, 512))[None, :, None]
+    x = (rays_o[0, :4, None, :] + rays_d[0, :4, None, :] * z).reshape(-1, 3)
+    d = rays_d[0, :4, None, :].expand(4, 512, 3).reshape(-1, 3).contiguous()
+    P = x.shape[0]
+    net.zero_grad(set_to_none=True)
+    enc_x = net.encoder(x, bound=net.bound)
+    dens = net.density(x)
+    h = torch.cat([torch.log(dens["sigma"])[:, None], dens["geo_feat"]], -1)       # the 16-wide sigma-net row
+    gh = torch.randn(P, 16, generator=g) * 0.1
+    (h * gh).sum().backward()
+    out.update(mlp_x=x.numpy(), mlp_d=d.numpy(), sig_in=enc_x.detach().numpy(), sig_out=h.detach().numpy(), sig_gout=gh.numpy())
+    for i in range(2):
+        out[f"sig_gw{i}"] = params[f"sigma_net.{i}.weight"].grad.numpy().copy()
+    net.zero_grad(set_to_none=True)
+    geo = dens["geo_feat"].detach().half().float().requires_grad_(True)            # fp16-representable colour inputs
+    enc_d = net.encoder_lidar_dir(d)
+    net.out_dim = 2
+    rgb = net.color(x, d, cal_lidar_color=True, mask=torch.ones(P, dtype=torch.bool), geo_feat=geo)
+    pre = torch.log(rgb) - torch.log1p(-rgb)                                       # pre-sigmoid output of the stack
+    gc = torch.randn(P, 2, generator=g) * 0.1
+    (pre * gc).sum().backward()
+    out.update(col_dir=enc_d.detach().numpy(), col_geo=geo.detach().numpy(), col_rgb=rgb.detach().numpy(),
+               col_pre=pre.detach().numpy(), col_gout=gc.numpy(), col_ggeo=geo.grad.numpy().copy())
+    for i in range(3):
+        out[f"col_gw{i}"] = params[f"lidar_color_net.{i}.weight"].grad.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "g7_config1.npz"), **{k: np.asarray(v, dtype=np.float32) for k, v in out.items()})
+    return out
+
+
 if __name__ == "__main__":
-    g1(); g2(); g3(); g4(); g5(); g6()
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    for name in which:
+        globals()[name]()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))
