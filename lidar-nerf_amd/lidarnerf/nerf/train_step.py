@@ -172,6 +172,7 @@ class LidarTrainer:
                   shadow.data_ptr(), tp.numel(), lr, 0.9, 0.99, 1e-15, inv_scale_table.data_ptr(),
                   found_inf.data_ptr(), s_in.data_ptr(), s_out.data_ptr())
         self.t_flip = 1 - self.t_flip
+        self._last_scale = self.loss_scale.clone()  # the scale this step's gradient carries (table_grad divides by it)
         torch._amp_update_scale_(self.loss_scale, self.growth_tracker, found_inf, 2.0, 0.5, 2000)
         self.scheduler.step()
         return loss
@@ -185,7 +186,8 @@ class LidarTrainer:
         if g16 is None:
             return None
         div = float(getattr(self.table, "_lnh_grad16_div", 1))
-        return g16.float().reshape(self.table.shape) / (self.loss_scale * div)
+        # (the scale the backward ran with — _amp_update_scale_ has already moved self.loss_scale on growth / backoff steps)
+        return g16.float().reshape(self.table.shape) / (getattr(self, "_last_scale", self.loss_scale) * div)
 
     def state_dict(self):
         """Everything a resume needs: torch optimizer / scheduler / scaler state plus — fused table optimizer — the
@@ -260,6 +262,43 @@ class LidarTrainer:
                 g["lr"] = lr
         self.optimizer.load_state_dict(own)
 
+    def _own_group_of_ref_group(self):
+        """For every parameter group of the reference's optimizer: index of the group of self.optimizer that steps its
+        parameters (the table's group, stepped by the fused kernel, and empty groups follow group 0: every group of
+        model.get_params(lr) carries the same lr and the same lambda)."""
+        own = {id(p): gi for gi, g in enumerate(self.optimizer.param_groups) for p in g["params"]}
+        return [next((own[id(p)] for p in grp if id(p) in own), 0) for grp in self._ref_layout]
+
+    def _scheduler_state_ref_layout(self):
+        """LambdaLR.state_dict() as the reference's scheduler over Adam(model.get_params(lr)) writes it: `base_lrs`,
+        `_last_lr` and `lr_lambdas` carry one entry per REFERENCE parameter group (6, or 8 with a background net), not per
+        group of the merged optimizer stepped here — a stock scheduler loading the file zips them against its groups."""
+        sd = dict(self.scheduler.state_dict())
+        m = self._own_group_of_ref_group()
+        for key in ("base_lrs", "_last_lr"):
+            if key in sd:
+                sd[key] = [sd[key][i] for i in m]
+        if "lr_lambdas" in sd:
+            sd["lr_lambdas"] = [sd["lr_lambdas"][i] for i in m]
+        return sd
+
+    def _load_scheduler_state_ref_layout(self, sd):
+        """Inverse of the above (also accepts a state written per own group, e.g. by LidarTrainer.state_dict)."""
+        sd = dict(sd)
+        n_own, m = len(self.optimizer.param_groups), self._own_group_of_ref_group()
+        for key in ("base_lrs", "_last_lr", "lr_lambdas"):
+            vals = sd.get(key)
+            if vals is None or len(vals) == n_own:
+                continue
+            if len(vals) != len(m):
+                raise RuntimeError(f"lr_scheduler state: {len(vals)} entries in '{key}' for {len(m)} reference parameter "
+                                   f"groups / {n_own} groups stepped here")
+            first = {}
+            for ref_i, own_i in enumerate(m):
+                first.setdefault(own_i, vals[ref_i])
+            sd[key] = [first.get(i, vals[0]) for i in range(n_own)]
+        self.scheduler.load_state_dict(sd)
+
     def save_checkpoint(self, path, full=True):
         """Same dictionary as Trainer.save_checkpoint (utils.py:1449-1480): epoch, global_step, stats, model and — `full`
         — optimizer / lr_scheduler / scaler in the layout the reference's Trainer.load_checkpoint restores (a reference
@@ -267,12 +306,15 @@ class LidarTrainer:
         state = {"epoch": self.epoch, "global_step": self.global_step, "stats": self.stats}
         if full:
             state["optimizer"] = self._optimizer_state_ref_layout()
-            state["lr_scheduler"] = self.scheduler.state_dict()
+            state["lr_scheduler"] = self._scheduler_state_ref_layout()
             if self.table is not None:  # the dynamic loss scale lives with the fused table optimizer
                 state["scaler"] = {"scale": float(self.loss_scale), "growth_factor": 2.0, "backoff_factor": 0.5,
                                    "growth_interval": 2000, "_growth_tracker": int(self.growth_tracker)}
             else:
                 state["scaler"] = self.scaler.state_dict()
+        if getattr(self.model, "cuda_ray", False):  # a reference loader ignores the extra keys
+            state["mean_count"], state["mean_density"] = self.model.mean_count, self.model.mean_density
+            state["iter_density"], state["local_step"] = self.model.iter_density, self.model.local_step
         state["model"] = self.model.state_dict()
         torch.save(state, path)
         return path
@@ -284,13 +326,17 @@ class LidarTrainer:
             self.model.load_state_dict(ck)
             return [], []
         missing, unexpected = self.model.load_state_dict(ck["model"], strict=False)
+        if getattr(self.model, "cuda_ray", False):
+            for key in ("mean_count", "mean_density", "iter_density", "local_step"):
+                if key in ck:  # without them the next 16 grid updates are full sweeps and sample buffers are N * 1024
+                    setattr(self.model, key, ck[key])
         if model_only:
             return missing, unexpected
         self.stats, self.epoch, self.global_step = ck["stats"], ck["epoch"], ck["global_step"]
         if "optimizer" in ck:
             self._load_optimizer_state_ref_layout(ck["optimizer"])
         if "lr_scheduler" in ck:
-            self.scheduler.load_state_dict(ck["lr_scheduler"])
+            self._load_scheduler_state_ref_layout(ck["lr_scheduler"])
         if "scaler" in ck and ck["scaler"]:
             if self.table is not None:
                 self.loss_scale.fill_(float(ck["scaler"]["scale"]))

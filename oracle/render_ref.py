@@ -157,25 +157,48 @@ trunc_exp = _TruncExp.apply
 
 
 class _GridEncodeCPU(torch.autograd.Function):
-    """grid.py:24-138 on the CPU through the C oracle (fp32 tables)."""
+    """grid.py:24-138 on the CPU through the C oracle: fp32 tables, or — `half` — the autocast mode of grid.py:54-57: fp16
+    table, fp16 accumulation (gridencoder.cu:173-198) and an fp16 gradient whose w * g contributions are fp16 values
+    (gridencoder.cu:335-350: __half2 products)."""
 
     @staticmethod
-    def forward(ctx, x01, emb, offsets, S, H):
-        out, _ = c_oracle.grid_forward(x01.detach().numpy(), emb.detach().numpy(), offsets, S, H)
+    def forward(ctx, x01, emb, offsets, S, H, half=False):
+        table = emb.detach().numpy()
+        out, _ = c_oracle.grid_forward(x01.detach().numpy(), table.astype(np.float16) if half else table, offsets, S, H)
         ctx.save_for_backward(x01)
-        ctx.meta = (offsets, S, H, emb.shape[0])
+        ctx.meta = (offsets, S, H, emb.shape[0], half)
         L, B, Cc = out.shape
-        return torch.from_numpy(out).permute(1, 0, 2).reshape(B, L * Cc)
+        return torch.from_numpy(out.astype(np.float32)).permute(1, 0, 2).reshape(B, L * Cc)
 
     @staticmethod
     def backward(ctx, g):
         (x01,) = ctx.saved_tensors
-        offsets, S, H, rows = ctx.meta
+        offsets, S, H, rows, half = ctx.meta
         L = len(offsets) - 1
         B = g.shape[0]
-        gl = g.view(B, L, -1).permute(1, 0, 2).contiguous().numpy().astype(np.float32)
+        gl = g.view(B, L, -1).permute(1, 0, 2).contiguous().numpy().astype(np.float16 if half else np.float32)
         ge = c_oracle.grid_backward(gl, x01.numpy(), offsets, rows, S, H)
-        return None, torch.from_numpy(ge.astype(np.float32)), None, None, None
+        return None, torch.from_numpy(ge.astype(np.float32)), None, None, None, None
+
+
+class _Stored(torch.autograd.Function):
+    """A value that passes through a 16-bit buffer: rounded to `dt` on the way forward, and the gradient arriving for it
+    rounded to `dt` on the way back (the kernels keep activations AND their gradient rows in the MLP element type;
+    DESIGN.md §5b).  Model of where 16-bit storage sits in the fused chain — the reference's own fp16 mode (ffmlp: __half
+    activations, forward_buffer / backward_buffer) has the same storage points."""
+
+    @staticmethod
+    def forward(ctx, x, dt):
+        ctx.dt = dt
+        return x.to(dt).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dt).to(g.dtype), None
+
+
+def _stored(x, dt):
+    return x if dt is None else _Stored.apply(x, dt)
 
 
 def freq_encode_torch(d, degree):
@@ -192,8 +215,12 @@ class RefLidarField(torch.nn.Module):
 
     def __init__(self, desired_resolution=32768, log2_hashmap_size=19, num_levels=16, level_dim=2, base_resolution=16,
                  hidden_dim=64, geo_feat_dim=15, hidden_dim_color=64, num_layers_color=3, freq_degree=12, bound=1.0,
-                 out_dim=2):
+                 out_dim=2, storage=None):
         super().__init__()
+        # storage = torch.float16 / torch.bfloat16: model of the 16-bit mode (the reference's --fp16; BASELINE config 5 for
+        # bf16) — fp16 hash table / features / feature gradients, MLP activations and their gradient rows in `storage`,
+        # every dot product exact-ish (fp32) and rounded ONCE where it is stored.  None: fp32 throughout.
+        self.storage = storage
         self.bound = bound
         self.pls = grid_ref.per_level_scale(desired_resolution, base_resolution, num_levels)
         self.S = float(np.log2(self.pls))
@@ -211,21 +238,28 @@ class RefLidarField(torch.nn.Module):
         self.out_dim = out_dim
 
     def density(self, x):
+        st = self.storage
         x01 = (x + self.bound) / (2 * self.bound)
-        h = _GridEncodeCPU.apply(x01, self.embeddings, self.offsets, self.S, self.H)
-        h = torch.relu(self.sigma_net[0](h))
-        h = self.sigma_net[1](h)
+        h = _GridEncodeCPU.apply(x01, self.embeddings, self.offsets, self.S, self.H, st is not None)
+        if st is not None:
+            h = _stored(_stored(h, torch.float16), st)  # fp16 feature buffer (and its fp16 gradient), MLP operand type
+        h = _stored(torch.relu(self.sigma_net[0](h)), st)
+        h = _stored(self.sigma_net[1](h), st)           # the 16-wide row: density pre-activation | geo_feat
         return trunc_exp(h[..., 0]), h[..., 1:]
 
     def color(self, x, d, mask, geo):
+        st = self.storage
         rgbs = torch.zeros(mask.shape[0], self.out_dim, dtype=x.dtype)
         if not mask.any():
             return rgbs
-        h = torch.cat([freq_encode_torch(d[mask], self.freq_degree), geo[mask]], dim=-1)
+        enc_d = freq_encode_torch(d[mask], self.freq_degree)
+        if st is not None:
+            enc_d = enc_d.to(st).to(enc_d.dtype)        # direction features as the MLP sees them (no gradient)
+        h = torch.cat([enc_d, geo[mask]], dim=-1)
         for i, lin in enumerate(self.lidar_color_net):
             h = lin(h)
             if i != len(self.lidar_color_net) - 1:
-                h = torch.relu(h)
+                h = _stored(torch.relu(h), st)
         rgbs[mask] = torch.sigmoid(h)
         return rgbs
 
@@ -240,6 +274,7 @@ class RefFreqField(torch.nn.Module):
                  freq_degree=12, bound=1.0, out_dim=2):
         super().__init__()
         self.bound, self.pos_degree, self.freq_degree, self.out_dim = bound, pos_degree, freq_degree, out_dim
+        self.storage = None  # fp32 (config 1 is the reference's CPU path)
         self.sigma_net = torch.nn.ModuleList([torch.nn.Linear(3 + 6 * pos_degree, hidden_dim, bias=False),
                                               torch.nn.Linear(hidden_dim, 1 + geo_feat_dim, bias=False)])
         dims = [3 + 6 * freq_degree + geo_feat_dim] + [hidden_dim_color] * (num_layers_color - 1) + [out_dim]

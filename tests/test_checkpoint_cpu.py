@@ -53,3 +53,68 @@ def test_checkpoint_roundtrip_and_reference_layout(tmp_path):
     # a bare model state dict is accepted too (utils.py:1524-1527)
     torch.save(m.state_dict(), os.path.join(tmp_path, "bare.pth"))
     tr2.load_checkpoint(os.path.join(tmp_path, "bare.pth"))
+
+
+def test_lr_scheduler_cross_resume_both_directions(tmp_path):
+    """The `lr_scheduler` entry is in the reference layout too: the reference builds LambdaLR over
+    Adam(model.get_params(lr)) — 6 parameter groups (main_lidarnerf.py:389-410) — while LidarTrainer steps one merged group.
+    A stock scheduler must load our file and step; our trainer must load a reference-shaped file and step."""
+    from lidarnerf.nerf.train_step import LidarTrainer
+    iters = 1000
+    lam = lambda it: 0.1 ** min(it / iters, 1)  # noqa: E731  (main_lidarnerf.py:408-410)
+    m = _model()
+    tr = LidarTrainer(m, lr=1e-2, iters=iters, fp16=False)
+    for _ in range(7):
+        tr.optimizer.zero_grad()
+        for p in tr.params:
+            p.grad = torch.full_like(p, 1e-3)
+        tr.optimizer.step()
+        tr.scheduler.step()
+    path = tr.save_checkpoint(os.path.join(tmp_path, "a.pth"))
+    ck = torch.load(path, weights_only=False)
+    n_ref_groups = len(m.get_params(1e-2))
+    assert len(ck["lr_scheduler"]["base_lrs"]) == n_ref_groups == 6
+    assert len(ck["lr_scheduler"]["_last_lr"]) == 6 and len(ck["lr_scheduler"]["lr_lambdas"]) == 6
+    # -> reference side: stock optimizer + LambdaLR, as Trainer.load_checkpoint (utils.py:1549-1561) restores them
+    ref_opt = torch.optim.Adam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+    ref_sched = torch.optim.lr_scheduler.LambdaLR(ref_opt, lam)
+    ref_opt.load_state_dict(ck["optimizer"])
+    ref_sched.load_state_dict(ck["lr_scheduler"])
+    for p in m.parameters():
+        p.grad = torch.full_like(p, 1e-3)
+    ref_opt.step()
+    ref_sched.step()  # (raised "zip() argument 2 is shorter than argument 1" with a 1-group state)
+    assert ref_sched.last_epoch == 8
+    want = 1e-2 * lam(8)
+    assert all(abs(g["lr"] - want) < 1e-12 for g in ref_opt.param_groups)
+    # <- our side: a reference-shaped checkpoint (6 groups in optimizer and scheduler)
+    ref_ck = {"epoch": 1, "global_step": 8, "stats": tr.stats, "model": m.state_dict(),
+              "optimizer": ref_opt.state_dict(), "lr_scheduler": ref_sched.state_dict(), "scaler": {}}
+    torch.save(ref_ck, os.path.join(tmp_path, "ref.pth"))
+    tr2 = LidarTrainer(_model(), lr=1e-2, iters=iters, fp16=False)
+    tr2.load_checkpoint(os.path.join(tmp_path, "ref.pth"))
+    assert tr2.scheduler.last_epoch == 8 and len(tr2.scheduler.base_lrs) == len(tr2.optimizer.param_groups)
+    for p in tr2.params:
+        p.grad = torch.full_like(p, 1e-3)
+    tr2.optimizer.step()
+    tr2.scheduler.step()
+    assert abs(tr2.optimizer.param_groups[0]["lr"] - 1e-2 * lam(9)) < 1e-12
+
+
+def test_occupancy_bookkeeping_in_checkpoint(tmp_path):
+    """cuda_ray runs: mean_count / mean_density / iter_density / local_step travel with the checkpoint (torch-ngp, the
+    origin of the occupancy path, saves the first two), so a resumed run neither re-sweeps the full grid 16 times nor
+    allocates N x 1024 sample buffers."""
+    from lidarnerf.nerf.network import NeRFNetwork
+    from lidarnerf.nerf.train_step import LidarTrainer
+    torch.manual_seed(0)
+    kw = dict(encoding="hashgrid", desired_resolution=256, log2_hashmap_size=12, bound=1, min_near=0.01, min_near_lidar=0.01,
+              cuda_ray=True)
+    m = NeRFNetwork(**kw)
+    m.mean_count, m.mean_density, m.iter_density, m.local_step = 345678, 0.0123, 40, 7
+    tr = LidarTrainer(m, lr=1e-2, fp16=False)
+    path = tr.save_checkpoint(os.path.join(tmp_path, "occ.pth"))
+    m2 = NeRFNetwork(**kw)
+    tr2 = LidarTrainer(m2, lr=1e-2, fp16=False)
+    tr2.load_checkpoint(path)
+    assert (m2.mean_count, m2.mean_density, m2.iter_density, m2.local_step) == (345678, 0.0123, 40, 7)

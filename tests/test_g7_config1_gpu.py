@@ -17,9 +17,9 @@ are produced by the HIP path:
 Tolerances of the 16-bit paths.  Inputs, weights and stored activations are 16-bit values (2^-11 relative per rounding
 for fp16, 2^-8 for bf16), sums are fp32.  A weight gradient is dW[i,j] = sum_b dH[b,i] A[b,j]; rounding A and dH moves it
 by at most eps * sum_b |dH[b,i]| |A[b,j]| per rounding — and that bound IS approached, because the rounding error of a
-smooth input along a ray is not random from sample to sample.  The direct MLP tests therefore compare every entry with
-`c * eps * sum_b |dH||A|` computed from the fixture (c = 4: the operand roundings of the layer, its dH and the
-activations feeding the ReLU masks).  The end-to-end tests state their bounds relative to the largest entry of a
+smooth input along a ray is not random from sample to sample; hidden units that sit within rounding error of the ReLU
+kink move an entry by their whole contribution.  The direct MLP backward test therefore compares in norm with the
+reference and entry-wise with the CPU model of 16-bit storage (see MODEL_DISTANCE).  The end-to-end tests state their bounds relative to the largest entry of a
 gradient; `scratch`-free calibration: the reference's chain with 16-bit storage roundings inserted on the CPU
 (oracle/render_ref.py RefFreqField) differs from G7 by 6e-4 (depth) / 1.6e-4 abs (image) / <= 4.2e-3 (gradients) in fp16
 and 4.4e-3 / 7e-4 / 2.1e-2 in bf16; bounds below = ~3x those.
@@ -58,22 +58,12 @@ def _flat_weights(mats, in_pad):
     return np.concatenate([first.ravel()] + [m.ravel() for m in mats[1:-1]] + [last.ravel()])
 
 
-def _stack_f64(x, mats, gout):
-    """The bias-free ReLU stack in float64 on the fixture's inputs: per layer (input A_k, upstream gradient dH_k), the
-    ingredients of the storage bound; its outputs / gradients are NOT what the kernels are compared with (G7 is)."""
-    acts, h = [np.asarray(x, np.float64)], np.asarray(x, np.float64)
-    for k, W in enumerate(mats):
-        h = h @ np.asarray(W, np.float64).T
-        if k < len(mats) - 1:
-            h = np.maximum(h, 0)
-            acts.append(h)
-    dH, g = [None] * len(mats), np.asarray(gout, np.float64)
-    for k in range(len(mats) - 1, -1, -1):
-        dH[k] = g
-        g = g @ np.asarray(mats[k], np.float64)
-        if k > 0:
-            g = g * (acts[k] > 0)
-    return acts, dH, g
+def _abs_chain(x, mats):
+    """sum |w| |a| through the layers: the magnitude a chain of rounded dot products is priced with."""
+    mag = np.abs(np.asarray(x, np.float64))
+    for W in mats:
+        mag = mag @ np.abs(np.asarray(W, np.float64)).T
+    return mag
 
 
 def test_freq_encoder_matches_reference_encoder(g7):
@@ -102,10 +92,7 @@ def test_mfma_mlp_forward_on_reference_pairs(g7, dt):
         torch.cuda.synchronize()
         got = y.float().cpu().numpy()[:, :want.shape[1]]
         # every output is a chain of dot products of 16-bit operands: |error| <= c eps sum |w||a| through the layers
-        acts, _, _ = _stack_f64(x, mats, np.zeros_like(want))
-        mag = np.abs(acts[0])
-        for W in mats:
-            mag = mag @ np.abs(np.asarray(W, np.float64)).T
+        mag = _abs_chain(x, mats)
         bound = 3 * eps * mag + eps * np.abs(want)
         err = np.abs(got - want)
         assert (err <= bound).all(), (name, dt, float((err / bound).max()))
@@ -114,10 +101,26 @@ def test_mfma_mlp_forward_on_reference_pairs(g7, dt):
         assert np.abs(got[:, want.shape[1]:]).max(initial=0) == 0
 
 
+# relative L2 distance of the CPU model of 16-bit storage (oracle/mlp_ref.py: exact dot products, ONE rounding per stored
+# value) from the reference's fp32 numbers, per weight matrix / input gradient — what 16-bit storage costs on THIS fixture
+# (tests/test_oracle_golden.py::test_g7_storage_model_distance re-derives them on the CPU).  The inputs are smooth along a ray,
+# so their rounding errors are not random from sample to sample, and a hidden unit within rounding error of the ReLU kink
+# moves an entry by its whole contribution (7 of 131 072 units in the sigma net; one alone shifts dW0[17, 5] by 8 %).
+MODEL_DISTANCE = {
+    (torch.float16, "sigma"): [1.6e-2, 4e-4], (torch.float16, "colour"): [1.3e-2, 1.4e-2, 4e-4],
+    (torch.bfloat16, "sigma"): [4.8e-2, 3.4e-3], (torch.bfloat16, "colour"): [5.5e-2, 5.4e-2, 3.9e-3],
+}
+
+
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 def test_mfma_mlp_backward_on_reference_pairs(g7, dt):
+    """Two comparisons per weight gradient: (1) with the reference's own numbers, in norm, at 2x the distance 16-bit
+    storage itself puts between the two (MODEL_DISTANCE); (2) entry by entry with the CPU model of 16-bit storage, which
+    oracle/mlp_ref.py evaluates on the same fixture — the kernel (fp32 MFMA accumulation) has to land on the model, so the
+    whole residual of (1) is accounted for by storage roundings and none of it by the kernel."""
     from lidarnerf import _hip
-    sfx, eps = _hip.mlp_suffix(dt), EPS[dt]
+    from oracle import mlp_ref
+    sfx, f16 = _hip.mlp_suffix(dt), dt == torch.float16
     for name, x, mats, gout, gws, in_pad, nhm in (
             ("sigma", g7["sig_in"], [g7[f"w_sigma_net.{i}.weight"] for i in range(2)], g7["sig_gout"],
              [g7[f"sig_gw{i}"] for i in range(2)], 48, 0),
@@ -133,7 +136,7 @@ def test_mfma_mlp_backward_on_reference_pairs(g7, dt):
                   gx.data_ptr(), gw.data_ptr())
         torch.cuda.synchronize()
         gw = gw.cpu().numpy()
-        acts, dH, _ = _stack_f64(x, mats, gout)
+        model_gx, model_gw = mlp_ref.mlp_backward(x, mats, gout, half=True if f16 else "bf16")
         off = 0
         for k, want in enumerate(gws):
             rows, cols = (64, in_pad) if k == 0 else ((64, 64) if k < len(gws) - 1 else (16, 64))
@@ -141,15 +144,16 @@ def test_mfma_mlp_backward_on_reference_pairs(g7, dt):
             off += rows * cols
             assert np.abs(got[want.shape[0]:]).max(initial=0) == 0 and np.abs(got[:, want.shape[1]:]).max(initial=0) == 0
             got = got[:want.shape[0], :want.shape[1]]
-            bound = 4 * eps * (np.abs(dH[k]).T @ np.abs(acts[k])) + 1e-6
-            err = np.abs(got - want)
-            assert (err <= bound).all(), (name, k, dt, float((err / bound).max()))
-            # the bound is not vacuous: it sits far below the gradient itself
-            assert np.linalg.norm(err) <= (8e-3 if dt == torch.float16 else 5e-2) * np.linalg.norm(want), (name, k)
-        if name == "colour":  # d / d geo_feat of the colour head (per sample: a flipped ReLU unit moves an entry, so in norm)
-            got = gx.float().cpu().numpy()[:, 75:90]
-            want = g7["col_ggeo"]
-            assert np.linalg.norm(got - want) <= (2e-2 if dt == torch.float16 else 1.2e-1) * np.linalg.norm(want)
+            rel = np.linalg.norm(got - want) / np.linalg.norm(want)
+            assert rel <= 2 * MODEL_DISTANCE[(dt, name)][k], (name, k, dt, float(rel))
+            # (2) the kernel against the storage model: same operands, same roundings; fp32 vs exact accumulation and the
+            # odd hidden value that rounds the other way (a sum that lands within fp32 error of a 16-bit tie)
+            rel_m = np.linalg.norm(got - model_gw[k]) / np.linalg.norm(model_gw[k])
+            assert rel_m <= (1e-3 if f16 else 5e-3), (name, k, dt, float(rel_m))
+        if name == "colour":  # d / d geo_feat of the colour head, per sample
+            got, want = gx.float().cpu().numpy()[:, 75:90], g7["col_ggeo"]
+            assert np.linalg.norm(got - want) <= (3e-2 if f16 else 1.2e-1) * np.linalg.norm(want)
+            assert np.linalg.norm(got - model_gx[:, 75:90]) <= (2e-3 if f16 else 1.5e-2) * np.linalg.norm(want)
 
 
 def _product_net(g7):
@@ -194,10 +198,13 @@ def test_config1_fp32_end_to_end_matches_reference(g7, tag, loss_name):
     and of the scans; an ulp of the cdf moves an importance sample."""
     net = _product_net(g7)
     res, loss, grads = _render_and_grads(net, g7, tag, loss_name, None)
-    np.testing.assert_allclose(res["depth_lidar"].detach().cpu().numpy(), g7[f"{tag}_depth"], rtol=2e-5, atol=2e-6)
-    np.testing.assert_allclose(res["image_lidar"].detach().cpu().numpy(), g7[f"{tag}_image"], rtol=2e-5, atol=3e-6)
-    np.testing.assert_allclose(res["weights_sum_lidar"].detach().cpu().numpy(), g7[f"{tag}_ws"], rtol=2e-5, atol=3e-6)
-    np.testing.assert_allclose(loss, float(g7[f"{tag}_{loss_name}_loss"]), rtol=1e-5)
+    np.testing.assert_allclose(res["depth_lidar"].detach().cpu().numpy(), g7[f"{tag}_depth"], rtol=2e-5, atol=5e-6)
+    # image: the colour head sees the degree-12 direction features, where the kernel follows the reference's CUDA encoder
+    # (cos(x) = sin(x + fl(pi/2)), freqencoder.cu:61) and the fixture the pure-torch one (torch.cos): 1e-4 at 2^11 x
+    np.testing.assert_allclose(res["image_lidar"].detach().cpu().numpy(), g7[f"{tag}_image"], rtol=2e-5, atol=1.5e-4)
+    # (degree-6 position features differ by up to 2^5 * 2^-24 the same way; x 6-fold weights on h0: sigma to ~1e-5)
+    np.testing.assert_allclose(res["weights_sum_lidar"].detach().cpu().numpy(), g7[f"{tag}_ws"], rtol=2e-5, atol=1e-5)
+    np.testing.assert_allclose(loss, float(g7[f"{tag}_{loss_name}_loss"]), rtol=1e-4)
     for n in ("sigma_net.0.weight", "sigma_net.1.weight", "lidar_color_net.0.weight", "lidar_color_net.1.weight",
               "lidar_color_net.2.weight"):
         want = g7[f"{tag}_{loss_name}_grad_{n}"]
@@ -225,7 +232,7 @@ def test_config1_mfma_end_to_end_matches_reference(g7, tag, loss_name, dt):
                                rtol=2e-3 if f16 else 1.5e-2, atol=5e-4 if f16 else 2.5e-3)
     np.testing.assert_allclose(res["weights_sum_lidar"].detach().float().cpu().numpy(), g7[f"{tag}_ws"],
                                rtol=2e-3 if f16 else 1.5e-2, atol=2e-4 if f16 else 2e-3)
-    np.testing.assert_allclose(loss, float(g7[f"{tag}_{loss_name}_loss"]), rtol=2e-4 if f16 else 2e-3)
+    np.testing.assert_allclose(loss, float(g7[f"{tag}_{loss_name}_loss"]), rtol=5e-4 if f16 else 5e-3)
     for n in ("sigma_net.0.weight", "sigma_net.1.weight", "lidar_color_net.0.weight", "lidar_color_net.1.weight",
               "lidar_color_net.2.weight"):
         want = g7[f"{tag}_{loss_name}_grad_{n}"]

@@ -100,3 +100,82 @@ def test_g6_convert_oracle_matches_reference_bit_exactly(golden_dir):
     back = convert_ref.pano_to_lidar_with_intensities(g["pano"].astype(np.float32),
                                                       g["intensities"].astype(np.float32), K)
     assert np.array_equal(back, g["back"])
+
+
+# ---------------------------------------------------------------------------------------------- G7: BASELINE config 1
+# The reference's own NeRFNetwork + NeRFRenderer.run (imported; tests/golden/make_golden.py g7): pins oracle/mlp_ref.py (the
+# checker of the MFMA MLP kernels), oracle/encoders_ref.py (frequency encoder) and oracle/render_ref.py's RefFreqField
+# (the cpu_baseline model of bench.py) to reference-PRODUCED numbers.
+def _g7_stacks(g):
+    return (("sigma", g["sig_in"], [g[f"w_sigma_net.{i}.weight"] for i in range(2)], g["sig_out"], g["sig_gout"],
+             [g[f"sig_gw{i}"] for i in range(2)]),
+            ("colour", np.concatenate([g["col_dir"], g["col_geo"]], 1),
+             [g[f"w_lidar_color_net.{i}.weight"] for i in range(3)], g["col_pre"], g["col_gout"],
+             [g[f"col_gw{i}"] for i in range(3)]))
+
+
+def test_g7_mlp_oracle_matches_reference_linear_stacks(golden_dir):
+    from oracle import mlp_ref
+    g = _load(golden_dir, "g7_config1.npz")
+    for name, x, mats, want, gout, gws in _g7_stacks(g):
+        out, _ = mlp_ref.mlp_forward(x, mats, half=False)
+        np.testing.assert_allclose(out, want, rtol=2e-5, atol=2e-5, err_msg=name)  # fp32 GEMMs there, float64 here
+        gx, dW = mlp_ref.mlp_backward(x, mats, gout, half=False)
+        for k, w in enumerate(gws):
+            np.testing.assert_allclose(dW[k], w, rtol=0, atol=2e-6 * np.abs(w).max(), err_msg=f"{name} dW{k}")
+        if name == "colour":
+            np.testing.assert_allclose(gx[:, 75:], g["col_ggeo"], rtol=0, atol=2e-6 * np.abs(g["col_ggeo"]).max())
+
+
+def test_g7_storage_model_distance(golden_dir):
+    """What 16-bit storage costs on this fixture (the MODEL_DISTANCE table of tests/test_g7_config1_gpu.py): the oracle's
+    model — exact dot products, one rounding per stored value — against the reference's fp32 numbers."""
+    from oracle import mlp_ref
+    g = _load(golden_dir, "g7_config1.npz")
+    table = {(True, "sigma"): [1.6e-2, 4e-4], (True, "colour"): [1.3e-2, 1.4e-2, 4e-4],
+             ("bf16", "sigma"): [4.8e-2, 3.4e-3], ("bf16", "colour"): [5.5e-2, 5.4e-2, 3.9e-3]}
+    for half in (True, "bf16"):
+        for name, x, mats, want, gout, gws in _g7_stacks(g):
+            _, dW = mlp_ref.mlp_backward(x, mats, gout, half=half)
+            for k, w in enumerate(gws):
+                rel = np.linalg.norm(dW[k] - w) / np.linalg.norm(w)
+                assert 0.5 * table[(half, name)][k] <= rel <= table[(half, name)][k], (half, name, k, rel)
+
+
+def test_g7_freq_encoder_oracle(golden_dir):
+    g = _load(golden_dir, "g7_config1.npz")
+    np.testing.assert_allclose(encoders_ref.freq_forward(g["mlp_x"], 6), g["sig_in"], rtol=0, atol=3e-6)
+    np.testing.assert_allclose(encoders_ref.freq_forward(g["mlp_d"], 12), g["col_dir"], rtol=0, atol=2e-4)
+
+
+@pytest.mark.parametrize("tag", ["eval", "train"])
+def test_g7_config1_restatement_end_to_end(golden_dir, tag):
+    """RefFreqField + run_lidar (what bench.py times as cpu_baseline) reproduce the reference's run: outputs, both losses
+    and every weight gradient."""
+    g = _load(golden_dir, "g7_config1.npz")
+    f = render_ref.RefFreqField()
+    with torch.no_grad():
+        for i in range(2):
+            f.sigma_net[i].weight.copy_(torch.from_numpy(g[f"w_sigma_net.{i}.weight"]))
+        for i in range(3):
+            f.lidar_color_net[i].weight.copy_(torch.from_numpy(g[f"w_lidar_color_net.{i}.weight"]))
+    train = tag == "train"
+    res = render_ref.run_lidar(torch.from_numpy(g["rays_o"][0]), torch.from_numpy(g["rays_d"][0]), f.density, f.color,
+                               torch.tensor([-1.0, -1, -1, 1, 1, 1]), 0.010784853507573345, 768, 64, perturb=train,
+                               training=train, noise=torch.from_numpy(g["train_noise"]) if train else None,
+                               u=torch.from_numpy(g["train_u"]) if train else None)
+    for k, kk in (("depth_lidar", "depth"), ("image_lidar", "image"), ("weights_sum_lidar", "ws")):
+        np.testing.assert_allclose(res[k].detach().numpy().reshape(-1), g[f"{tag}_{kk}"].reshape(-1), rtol=1e-6, atol=1e-8)
+    for loss_name in ("lin", "lidar"):
+        f.zero_grad(set_to_none=True)
+        if loss_name == "lin":
+            loss = ((res["depth_lidar"] * torch.from_numpy(g["cd"])).sum()
+                    + (res["image_lidar"] * torch.from_numpy(g["ci"][0])).sum()
+                    + (res["weights_sum_lidar"] * torch.from_numpy(g["cw"])).sum())
+        else:
+            loss = render_ref.lidar_loss(res["depth_lidar"], res["image_lidar"], torch.from_numpy(g["gt"]))
+        loss.backward(retain_graph=True)
+        np.testing.assert_allclose(float(loss.detach()), float(g[f"{tag}_{loss_name}_loss"]), rtol=1e-6)
+        for n, p in f.named_parameters():
+            w = g[f"{tag}_{loss_name}_grad_{n}"]
+            np.testing.assert_allclose(p.grad.numpy(), w, rtol=0, atol=2e-6 * np.abs(w).max(), err_msg=n)
