@@ -1395,7 +1395,8 @@ k_grad_tv(const T *__restrict__ inputs, const T *__restrict__ table, T *__restri
     }
 #pragma unroll
     for (int ch = 0; ch < C; ch++) {
-        const float v = (float)w * results[ch] * rsqrtf(idelta[ch] + 1e-9f);
+        // `w * results[ch]` is a scalar_t product in the reference (rounded to the table type), then a float product
+        const float v = (float)(T)((float)w * results[ch]) * rsqrtf(idelta[ch] + 1e-9f);
         if constexpr (sizeof(T) == 4) {
             unsafeAtomicAdd((float *)gt + index + ch, v);
         } else {

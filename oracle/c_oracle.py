@@ -96,6 +96,34 @@ def grid_backward(grad, inputs, offsets, n_rows, S, H, gridtype=0, align_corners
     return ge
 
 
+def grad_total_variation(inputs, embeddings, offsets, weight, S, H, gridtype=0, align_corners=False):
+    """kernel_grad_tv (gridencoder.cu:695-807).  embeddings float32 or float16 [rows, C]; returns the increment of
+    grad_embeddings as float64 [rows, C] (an order-free sum of what the kernel adds with atomics)."""
+    inputs, offsets = _f32(inputs), _i32(offsets)
+    emb = np.ascontiguousarray(embeddings)
+    assert emb.dtype in (np.float32, np.float16)
+    dtype = 0 if emb.dtype == np.float32 else 1
+    if dtype == 1:  # the reference's kernel reads `inputs` as scalar_t too
+        inputs = _f32(inputs.astype(np.float16))
+    table = _f32(emb.astype(np.float32))
+    B, D = inputs.shape
+    L, Cc = offsets.shape[0] - 1, emb.shape[1]
+    out = np.zeros((emb.shape[0], Cc), dtype=np.float64)
+    lib().lnh_oracle_grad_tv(_p(inputs), _p(table), _p(offsets), _p(out), C.c_float(weight), C.c_uint32(B), C.c_uint32(D),
+                             C.c_uint32(Cc), C.c_uint32(L), C.c_float(S), C.c_uint32(H), C.c_uint32(gridtype),
+                             C.c_int(int(align_corners)), C.c_int(dtype))
+    return out
+
+
+def sph_from_ray(rays_o, rays_d, radius):
+    """kernel_sph_from_ray (raymarching.cu:182-217) -> coords [N, 2] in [-1, 1]."""
+    rays_o, rays_d = _f32(rays_o), _f32(rays_d)
+    N = rays_o.shape[0]
+    out = np.empty((N, 2), dtype=np.float32)
+    lib().lnh_oracle_sph_from_ray(_p(rays_o), _p(rays_d), C.c_float(radius), C.c_uint32(N), _p(out))
+    return out
+
+
 def grid_input_backward(grad, dy_dx):
     g, dy = _f32(grad), _f32(dy_dx)
     L, B, Cc = g.shape

@@ -135,3 +135,33 @@ def backward(grad, inputs, offsets, n_rows, S, H, gridtype=0, align_corners=Fals
             v = v[valid]
             np.add.at(ge, base + rows[valid, c].astype(np.int64), v.astype(np.float64))
     return ge
+
+
+def grad_total_variation(inputs, embeddings, offsets, weight, S, H, gridtype=0, align_corners=False):
+    """kernel_grad_tv (gridencoder.cu:695-807), second restatement (float64 arithmetic on the fp32 table values):
+    increment of grad_embeddings [rows, C] for the cells visited by `inputs` [B, D] in [0, 1]."""
+    emb = np.asarray(embeddings, dtype=np.float64)
+    x = np.asarray(inputs, dtype=np.float32)
+    B, D = x.shape
+    out = np.zeros_like(emb)
+    L = len(offsets) - 1
+    valid = np.all((x >= 0) & (x <= 1), axis=1)
+    for l in range(L):
+        scale, res = level_geometry(l, S, H)
+        hm = int(offsets[l + 1] - offsets[l])
+        tab = emb[offsets[l]:offsets[l + 1]]
+        pg = np.floor(_fma32(x, scale, 0.0 if align_corners else 0.5)).astype(np.int64)
+        base = grid_index(pg.astype(np.uint32), hm, res, gridtype, align_corners).astype(np.int64)
+        results = np.zeros((B, emb.shape[1]))
+        idelta = np.zeros((B, emb.shape[1]))
+        for d in range(D):
+            for step, ok in ((1, pg[:, d] < res), (-1, pg[:, d] > 0)):
+                q = pg.copy()
+                q[:, d] = np.where(ok, q[:, d] + step, q[:, d])
+                nb = grid_index(q.astype(np.uint32), hm, res, gridtype, align_corners).astype(np.int64)
+                diff = (tab[base] - tab[nb]) * ok[:, None]
+                results += diff
+                idelta += diff * diff
+        val = (weight / (2 * D)) * results / np.sqrt(idelta + 1e-9)
+        np.add.at(out[offsets[l]:offsets[l + 1]], base[valid], val[valid])
+    return out

@@ -323,6 +323,64 @@ ORACLE_API void lnh_oracle_grid_backward(const void *grad, const float *inputs, 
     }
 }
 
+/*
+ * kernel_grad_tv (gridencoder.cu:695-807): total-variation regulariser gradient of the cells visited by `inputs`.
+ * Per (point, level): base cell pos_grid = floor(x * scale + 0.5) (the kernel never subtracts it: 738-742), its row
+ * `index` and, per axis, the rows of the right (if cur < resolution) and left (if cur > 0) lattice neighbours;
+ * results[ch] = sum of (grid[index] - grid[neighbour]), idelta[ch] = sum of their squares;
+ * grad[index + ch] += (weight / (2 D)) * results[ch] * rsqrtf(idelta[ch] + 1e-9f)   (atomicAdd, 800-805).
+ * Every local of the kernel is `scalar_t`: dtype = 1 (__half tables; `inputs` are __half there too, so the caller hands
+ * over fp16-representable coordinates) rounds each difference, each running sum, each square and w * results to
+ * fp16 (explicit __h* calls, no contraction); the atomicAdd operand is the fp16 rounding of the float product.
+ * grad_out is double (order-free reference for an accumulation the GPU performs with atomics).
+ */
+static float rsqrt_ref(float v) { return (float)(1.0 / sqrt((double)v)); }
+
+ORACLE_API void lnh_oracle_grad_tv(const float *inputs, const float *table, const int32_t *offsets, double *grad_out,
+                                   float weight, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                   uint32_t gridtype, int align_corners, int dtype) {
+#define TVR(v) (dtype == 1 ? round_f16(v) : (v))
+    for (uint32_t l = 0; l < L; l++) {
+        float scale;
+        uint32_t res;
+        lnh_oracle_grid_level(l, S, H, &scale, &res);
+        uint32_t hm = (uint32_t)(offsets[l + 1] - offsets[l]);
+        const float *tab = table + (size_t)(uint32_t)offsets[l] * C;
+        double *g = grad_out + (size_t)(uint32_t)offsets[l] * C;
+        const float w = TVR(weight / (float)(2 * D));
+        for (uint32_t b = 0; b < B; b++) {
+            const float *x = inputs + (size_t)b * D;
+            int oob = 0;
+            for (uint32_t d = 0; d < D; d++)
+                if (x[d] < 0 || x[d] > 1) oob = 1;
+            if (oob) continue;
+            uint32_t pg[8];
+            for (uint32_t d = 0; d < D; d++) pg[d] = (uint32_t)floorf(fmaf(x[d], scale, align_corners ? 0.0f : 0.5f));
+            uint32_t index = grid_index(D, C, gridtype, align_corners, 0, hm, res, pg);
+            float results[8] = {0}, idelta[8] = {0};
+            for (uint32_t d = 0; d < D; d++) {
+                uint32_t cur = pg[d];
+                for (int side = 0; side < 2; side++) {
+                    if (side == 0 ? !(cur < res) : !(cur > 0)) continue;
+                    pg[d] = side == 0 ? cur + 1 : cur - 1;
+                    uint32_t in = grid_index(D, C, gridtype, align_corners, 0, hm, res, pg);
+                    for (uint32_t ch = 0; ch < C; ch++) {
+                        float gv = TVR(tab[index + ch] - tab[in + ch]);
+                        results[ch] = TVR(results[ch] + gv);
+                        idelta[ch] = TVR(idelta[ch] + TVR(gv * gv));
+                    }
+                }
+                pg[d] = cur;
+            }
+            for (uint32_t ch = 0; ch < C; ch++) {
+                float v = TVR(w * results[ch]) * rsqrt_ref(idelta[ch] + 1e-9f);
+                g[index + ch] += (double)TVR(v);
+            }
+        }
+    }
+#undef TVR
+}
+
 /* kernel_input_backward (gridencoder.cu:364-390): grad_x[b,d] = sum_{l,c} grad[l,b,c]*dy_dx[b,l,d,c] (fp32 only) */
 ORACLE_API void lnh_oracle_grid_input_backward(const float *grad, const float *dy_dx, float *grad_inputs, uint32_t B,
                                                uint32_t D, uint32_t C, uint32_t L) {
@@ -339,6 +397,27 @@ ORACLE_API void lnh_oracle_grid_input_backward(const float *grad, const float *d
 /* ------------------------------------------------------------------------ */
 /* Occupancy indexing + marching — raymarching/src/raymarching.cu            */
 /* ------------------------------------------------------------------------ */
+
+/* kernel_sph_from_ray (raymarching.cu:182-217): far intersection of o + t d with the sphere |p| = radius, expressed as
+ * (theta, phi) with y up, normalised to [-1, 1]: coords = (2 theta / pi - 1, phi / pi).  Float arithmetic in the
+ * reference's operation order (nvcc contracts a*b + c; the comparison is by tolerance, see the test). */
+ORACLE_API void lnh_oracle_sph_from_ray(const float *rays_o, const float *rays_d, float radius, uint32_t N,
+                                        float *coords) {
+    const float RPI = 0.3183098861837907f;
+    for (uint32_t n = 0; n < N; n++) {
+        const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+        const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
+        const float A = dx * dx + dy * dy + dz * dz;
+        const float Bh = ox * dx + oy * dy + oz * dz;
+        const float Cc = ox * ox + oy * oy + oz * oz - radius * radius;
+        const float t = (-Bh + sqrtf(Bh * Bh - A * Cc)) / A;
+        const float x = ox + t * dx, y = oy + t * dy, z = oz + t * dz;
+        const float theta = atan2f(sqrtf(x * x + z * z), y);
+        const float phi = atan2f(z, x);
+        coords[n * 2] = 2 * theta * RPI - 1;
+        coords[n * 2 + 1] = phi * RPI;
+    }
+}
 
 /* raymarching.cu:71-77 */
 static uint32_t expand_bits(uint32_t v) {

@@ -335,3 +335,51 @@ def test_error_paths():
     # empty batch is a no-op
     _hip.call("lnh_grid_encode_forward", x.data_ptr(), emb.data_ptr(), torch.from_numpy(OFF).data_ptr(),
               out.data_ptr(), 0, 3, 2, L, S, H, None, 0, 0, 0, 0)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16])
+@pytest.mark.parametrize("gridtype,align", [(0, False), (1, False), (0, True)])
+def test_grad_total_variation(dt, gridtype, align):
+    """lnh_grad_total_variation vs the C restatement of kernel_grad_tv (gridencoder.cu:695-807): the increment added to
+    an existing gradient.  fp32: float atomics (order) and the hardware rsqrt; fp16: the kernel's locals are __half in the
+    reference (every difference, running sum and square rounded), accumulated with fp16 atomics."""
+    from gpu_util import call, dev, host
+    x = _points(3000, 21)
+    off = grid_ref.make_offsets(3, L, PLS, H, 19, align_corners=align)
+    r = np.random.default_rng(22)
+    npdt = np.float32 if dt == torch.float32 else np.float16
+    emb = r.standard_normal((int(off[-1]), CH)).astype(npdt)
+    g0 = (r.standard_normal((int(off[-1]), CH)) * 1e-3).astype(npdt)
+    xin = x.astype(npdt)  # the entry point reads `inputs` in the table type, as the reference's kernel does
+    want = c_oracle.grad_total_variation(xin.astype(np.float32), emb, off, 1e-2, S, H, gridtype, align)
+    grad = dev(g0.copy())
+    call("lnh_grad_total_variation", dev(xin), dev(emb), grad, torch.from_numpy(off), 1e-2, x.shape[0], 3, CH, L, S, H,
+         gridtype, int(align), 0 if dt == torch.float32 else 1)
+    got = host(grad).astype(np.float64) - g0.astype(np.float64)
+    touched = want != 0
+    assert touched.sum() > 1000
+    if dt == torch.float32:
+        np.testing.assert_allclose(got, want, rtol=0, atol=3e-6 * np.abs(want).max())
+    else:
+        # rows hit by many points (coarse levels) accumulate fp16 roundings of a running sum: compare in norm and loosely
+        # per entry; untouched rows must stay bit-identical
+        assert np.linalg.norm(got - want) <= 3e-3 * np.linalg.norm(want)
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-2 * np.abs(want).max())
+    assert np.all(got[~touched] == 0)
+
+
+def test_grad_total_variation_module_matches_entry_point():
+    """GridEncoder.grad_total_variation (grid.py:237-277 API): adds into embeddings.grad, bound mapping included."""
+    from lidarnerf.gridencoder import GridEncoder
+    enc = GridEncoder(input_dim=3, num_levels=8, level_dim=2, base_resolution=16, log2_hashmap_size=15,
+                      desired_resolution=512).cuda()
+    with torch.no_grad():
+        enc.embeddings.uniform_(-1, 1)
+    enc.embeddings.grad = torch.zeros_like(enc.embeddings)
+    pts = (torch.rand(500, 3, device="cuda") * 2 - 1) * 2.0  # bound = 2
+    enc.grad_total_variation(weight=1e-3, inputs=pts, bound=2)
+    off = enc.offsets.cpu().numpy()
+    x01 = ((pts + 2) / 4).cpu().numpy()
+    want = c_oracle.grad_total_variation(x01, enc.embeddings.detach().cpu().numpy(), off, 1e-3, enc.log2_scale,
+                                         enc.base_resolution)
+    np.testing.assert_allclose(enc.embeddings.grad.cpu().numpy(), want, rtol=0, atol=3e-6 * np.abs(want).max())

@@ -47,6 +47,39 @@ def test_grid_indices_c_vs_numpy(gridtype, align):
         assert rows[valid].max() < off[l + 1] - off[l]
 
 
+@pytest.mark.parametrize("gridtype,align", [(0, False), (1, False), (0, True)])
+def test_grad_total_variation_c_vs_numpy(gridtype, align):
+    """kernel_grad_tv (gridencoder.cu:695-807): C restatement vs the NumPy one, plus two hand-checkable properties."""
+    x = _points(700, 11)
+    off = grid_ref.make_offsets(3, L, PLS, H, 19, align_corners=align)
+    emb = np.random.default_rng(12).standard_normal((int(off[-1]), CH)).astype(np.float32)
+    a = c_oracle.grad_total_variation(x, emb, off, 1e-2, S, H, gridtype, align)
+    b = grid_ref.grad_total_variation(x, emb, off, 1e-2, S, H, gridtype, align)
+    np.testing.assert_allclose(a, b, rtol=0, atol=2e-6 * np.abs(b).max())
+    # a constant table has no variation: zero gradient (0 * rsqrt(1e-9))
+    flat = np.full_like(emb, 0.37)
+    assert np.abs(c_oracle.grad_total_variation(x, flat, off, 1e-2, S, H, gridtype, align)).max() == 0
+    # each visited (point, level, channel) adds at most weight / (2 D) * sqrt(2 D) in magnitude (Cauchy-Schwarz)
+    one = c_oracle.grad_total_variation(x[4:5], emb, off, 1e-2, S, H, gridtype, align)
+    assert 0 < np.abs(one).max() <= 1e-2 / 6 * np.sqrt(6) * (1 + 1e-5)
+    assert (one != 0).sum() <= L * CH
+
+
+def test_sph_from_ray_lands_on_the_sphere():
+    """kernel_sph_from_ray (raymarching.cu:182-217): the coordinates invert to a point at |p| = radius on the ray."""
+    r = np.random.default_rng(5)
+    o = r.uniform(-0.5, 0.5, (256, 3)).astype(np.float32)
+    d = r.standard_normal((256, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    radius = 2.0
+    c = c_oracle.sph_from_ray(o, d, radius).astype(np.float64)
+    theta, phi = (c[:, 0] + 1) * np.pi / 2, c[:, 1] * np.pi
+    p = radius * np.stack([np.sin(theta) * np.cos(phi), np.cos(theta), np.sin(theta) * np.sin(phi)], 1)  # y up
+    t = ((p - o) * d).sum(1)
+    assert (t > 0).all()
+    np.testing.assert_allclose(o + t[:, None] * d, p, atol=2e-5)
+
+
 def test_hash_known_answers():
     # fast_hash (gridencoder.cu:53-67) on hand-computed values, level 15 (hashed, 2^19 rows)
     pg = np.array([[1, 1, 1], [5, 0, 0], [0, 3, 0], [123456, 654321, 999]], dtype=np.uint32)

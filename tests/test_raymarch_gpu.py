@@ -186,3 +186,30 @@ def test_march_and_composite_rays_inference(cascade, bound, dt_gamma):
         rounds += 1
     assert rounds >= 3 and n_alive == 0          # every ray left the grid or saturated
     assert float(ws.max()) <= 1.0 + 1e-5 and float(ws.max()) > 0.5
+
+
+def test_sph_from_ray():
+    """lnh_sph_from_ray vs the C restatement of kernel_sph_from_ray (raymarching.cu:182-217) — float transcendental
+    functions on both sides (atan2f, sqrtf): agreement to a few ulp of the [-1, 1] coordinates; and through the module API
+    (raymarching.py sph_from_ray)."""
+    from gpu_util import call, dev, host
+    from lidarnerf import raymarching
+    r = np.random.default_rng(17)
+    N = 4097
+    o = r.uniform(-0.5, 0.5, (N, 3)).astype(np.float32)  # inside the smallest sphere: every ray has its far hit
+    d = r.standard_normal((N, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[0] = [0, 1, 0]     # straight up: theta = 0
+    d[1] = [1, 0, 0]
+    d[2] = [0, 0, -1]
+    for radius in (1.0, 2.0, 32.0):
+        want = c_oracle.sph_from_ray(o, d, radius)
+        out = torch.empty((N, 2), device="cuda")
+        call("lnh_sph_from_ray", dev(o), dev(d), radius, N, out)
+        got = host(out)
+        # phi jumps by 2 at the +-pi seam (z = 0-, x < 0): compare on the circle
+        dphi = np.abs(got[:, 1] - want[:, 1])
+        dphi = np.minimum(dphi, 2 - dphi)
+        assert np.abs(got[:, 0] - want[:, 0]).max() <= 2e-6 and dphi.max() <= 2e-6
+        via_module = raymarching.sph_from_ray(dev(o), dev(d), radius)
+        assert torch.equal(via_module, out)
