@@ -14,6 +14,10 @@
 //     coarse levels, where one cell spans many consecutive samples of a ray) are summed with a segmented shuffle
 //     scan and only the run tail issues the atomic.
 #include "common.h"
+
+#ifndef LNH_FWD_LEVEL_LOOP
+#define LNH_FWD_LEVEL_LOOP 0  // 1: timing probe, see k_grid_forward
+#endif
 typedef uint32_t uint4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t uint2_t __attribute__((ext_vector_type(2)));
 #include <type_traits>
@@ -204,10 +208,19 @@ __global__ void __launch_bounds__(256)
 k_grid_forward(const float *__restrict__ inputs, const T *__restrict__ table, T *__restrict__ outputs,
                T *__restrict__ dy_dx, uint32_t B, uint32_t L, GridMeta meta, uint32_t align_rt, uint32_t interp_rt,
                RowMap map) {
-    const uint32_t level = blockIdx.y;
-    const LevelParams lv_rt = meta.lv[level];
     const uint32_t b0 = blockIdx.x * blockDim.x + threadIdx.x;
     if (b0 >= B) return;
+#if LNH_FWD_LEVEL_LOOP
+    // A/B probe of the encode -> sigma-net fusion question (tools/probe_fusion.sh, profiles/r03_fusion_probe.txt): a fused
+    // kernel has to walk a point tile through ALL levels inside one workgroup.  This build does exactly that to the encode
+    // alone (same gathers, same outputs, grid.y = 1, the workgroups start together and drift apart as they please) and so
+    // prices what the fusion would give up: the level-major launch order that keeps ONE level's ~2 MB table in each XCD's L2.
+    for (uint32_t level = 0; level < L; level++) {
+#else
+    {
+    const uint32_t level = blockIdx.y;
+#endif
+    const LevelParams lv_rt = meta.lv[level];
     // optional row map: launch index b0 = r*T_cur + j addresses row r*T_tot + slot_off + j of buffers holding
     // B_all rows (coarse and fine samples of a ray side by side); identity when T_cur == 0
     const uint32_t b = map.T_cur ? (b0 / map.T_cur) * map.T_tot + map.slot_off + b0 % map.T_cur : b0;
@@ -402,6 +415,7 @@ k_grid_forward(const float *__restrict__ inputs, const T *__restrict__ table, T 
     else if (plain && !(lv_rt.flags & LV_HASH) && (lv_rt.flags & LV_NOWRAP) && (lv_rt.flags & 15u) == (uint32_t)D)
         body(std::integral_constant<int, 2>{});
     else body(std::integral_constant<int, 0>{});
+    }  // level (loop in the LNH_FWD_LEVEL_LOOP probe build)
 }
 
 // Debug kernel for the bit-exact index contract.
@@ -1412,7 +1426,7 @@ k_grad_tv(const T *__restrict__ inputs, const T *__restrict__ table, T *__restri
 template <typename T, int D>
 int launch_forward_c(const float *inputs, const T *emb, T *out, T *dy_dx, uint32_t B, uint32_t C, uint32_t L,
                      const GridMeta &m, uint32_t align, uint32_t interp, hipStream_t s, RowMap map = RowMap{0, 0, 0, 0}) {
-    dim3 grid(div_up(B, 256), L), block(256);
+    dim3 grid(div_up(B, 256), LNH_FWD_LEVEL_LOOP ? 1 : L), block(256);
 #define LNH_FWD(CC)                                                                                               \
     if (dy_dx)                                                                                                    \
         LNH_LAUNCH((k_grid_forward<T, D, CC, true>), grid, block, 0, s, inputs, emb, out, dy_dx, B, L, m, \
