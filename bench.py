@@ -56,17 +56,40 @@ def synthetic_frames(n_frames, device):
     return poses.to(device)
 
 
-def make_batch(poses, step, n_rays, rank, device):
-    """One frame, n_rays pixels (patch size 1), synthetic ground truth (raydrop, intensity, depth*scale)."""
+def analytic_scene(o, d):
+    """A learnable synthetic scene (SURVEY.md §8(d) "trained-like" table): the sensor drives inside a sphere of 32 m radius
+    over a ground plane 1.9 m below it — depth = first hit along the ray (scene units), intensity = a smooth pattern on the
+    hit point, ray-drop = 1 where the hit lies within the 80 m range.  o, d [..., 3] -> gt [..., 3] = (raydrop, intensity,
+    depth), consistent between frames, so a field can actually learn it (the default ground truth is random per ray)."""
+    R, ground = 32.0 * SCALE, -1.9 * SCALE
+    b = (o * d).sum(-1)
+    t_sphere = -b + torch.sqrt((b * b - ((o * o).sum(-1) - R * R)).clamp(min=0))
+    dz = d[..., 2]
+    t_ground = torch.where(dz < -1e-6, (ground - o[..., 2]) / dz.clamp(max=-1e-6), torch.full_like(dz, float("inf")))
+    t = torch.minimum(t_sphere, t_ground)
+    hit = o + d * t.unsqueeze(-1)
+    raydrop = (t < 80.0 * SCALE).float()
+    intensity = 0.5 + 0.25 * torch.sin(hit[..., 0] / SCALE * 0.7) + 0.25 * torch.cos(hit[..., 1] / SCALE * 0.45)
+    return torch.stack([raydrop, intensity * raydrop, t * raydrop], -1)
+
+
+def make_batch(poses, step, n_rays, rank, device, patch=(1, 1), scene="random"):
+    """One frame, n_rays pixels drawn as patches of `patch` pixels (base_dataset.py:50-70: 1x1, or 2x8 on the reference's
+    patch epochs), synthetic ground truth (raydrop, intensity, depth*scale): random per ray or the analytic
+    scene above."""
     from lidarnerf.dataset.rays import get_lidar_rays
     g = torch.Generator(device="cpu").manual_seed(1234 + step * 131 + rank * 7919)
     torch.manual_seed(1234 + step * 131 + rank * 7919)
     pose = poses[step % poses.shape[0]][None]
-    r = get_lidar_rays(pose, INTRINSICS, H_IMG, W_IMG, n_rays, patch_size=1)
-    raydrop = (torch.rand(n_rays, generator=g) < 0.85).float()
-    intensity = torch.rand(n_rays, generator=g)
-    depth = SCALE * (2 + 78 * torch.rand(n_rays, generator=g)) * raydrop
-    gt = torch.stack([raydrop, intensity, depth], -1)[None].to(device)
+    r = get_lidar_rays(pose, INTRINSICS, H_IMG, W_IMG, n_rays, patch_size=1 if tuple(patch) == (1, 1) else list(patch))
+    n = r["rays_o"].shape[1]
+    if scene == "analytic":
+        gt = analytic_scene(r["rays_o"][0].float(), r["rays_d"][0].float())[None].to(device)
+    else:
+        raydrop = (torch.rand(n, generator=g) < 0.85).float()
+        intensity = torch.rand(n, generator=g)
+        depth = SCALE * (2 + 78 * torch.rand(n, generator=g)) * raydrop
+        gt = torch.stack([raydrop, intensity, depth], -1)[None].to(device)
     return r["rays_o"].contiguous(), r["rays_d"].contiguous(), gt
 
 
@@ -79,10 +102,37 @@ def build_model(device):
     return model.to(device).train()
 
 
-def _cpu_config1(n_rays, threads, budget_s, max_steps=10):
-    """Median step time of BASELINE config 1 on `threads` host threads: RefFreqField (pure-torch positional encoder +
-    bias-free nn.Linear stacks, fp32) through run_lidar (NeRFRenderer.run restated), forward + LiDAR loss + backward,
-    n_rays x 832 samples of KITTI-360-shaped synthetic rays.  Returns (seconds per step, timed steps, warmed_up)."""
+def usable_cores():
+    """Host cores this process may actually use: os.cpu_count() capped by the scheduler affinity and the cgroup CPU quota
+    (the GPU boxes show 256 logical CPUs behind a 16-CPU quota: 256 torch threads then run 45 s per step, 16 threads 1 s)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]  # cgroup v2
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, quota
+
+
+def _cpu_config1(n_rays, threads, warmup, steps, budget_s):
+    """Step times of BASELINE config 1 on `threads` host threads: RefFreqField (pure-torch positional encoder + bias-free
+    nn.Linear stacks, fp32) through run_lidar (NeRFRenderer.run restated), forward + LiDAR loss + backward, n_rays x 832
+    samples of KITTI-360-shaped synthetic rays.  `warmup` untimed steps, then up to `steps` timed ones, stopping early once
+    `budget_s` of wall time is spent (at least 3 timed steps).  Returns the list of timed step durations."""
     from oracle import render_ref
     torch.set_num_threads(threads)
     torch.manual_seed(0)
@@ -92,49 +142,53 @@ def _cpu_config1(n_rays, threads, budget_s, max_steps=10):
     o, d, gt = o[0], d[0], gt[0]
     aabb = torch.tensor([-1.0, -1, -1, 1, 1, 1])
     times, t_begin = [], time.perf_counter()
-    for it in range(max_steps + 1):
+    for it in range(warmup + steps):
         t0 = time.perf_counter()
         ref.zero_grad(set_to_none=True)
         res = render_ref.run_lidar(o, d, ref.density, ref.color, aabb, SCALE, NUM_STEPS, UPSAMPLE, perturb=True,
                                    training=True)
         render_ref.lidar_loss(res["depth_lidar"], res["image_lidar"], gt).backward()
-        dt = time.perf_counter() - t0
-        if it == 0 and dt > budget_s:  # one step already blows the budget: it is the sample, warm-up included
-            return dt, 1, False
-        if it:  # first step = warm-up (thread pools, allocator)
-            times.append(dt)
-        if times and time.perf_counter() - t_begin > budget_s:
+        if it >= warmup:
+            times.append(time.perf_counter() - t0)
+        if len(times) >= 3 and time.perf_counter() - t_begin > budget_s:
             break
-    return float(np.median(times)), len(times), True
+    return times
 
 
-def cpu_baseline():
-    """config 1, N = 1024 rays x 832 samples, forward + loss + backward, fp32, on k host threads for
-    k = 1, k = 16 and k = all (`os.cpu_count()`), each leg bounded to ~10 s of wall time (median of up to 10 steps).
-    `value` / `cores` = the fastest leg (on a 256-thread host torch's CPU ops are far slower with k = all than with a
-    handful of threads — every leg is listed).  Validated against the imported reference in the build container
-    (tests/test_config1_cpu.py) and pinned on the GPU box by golden vectors G2 / G4."""
+def cpu_baseline(full=False):
+    """config 1, N = 1024 rays x 832 samples, forward + loss + backward, fp32, median step time on k = 1 and
+    k = ALL usable host cores (see usable_cores(): os.cpu_count() capped by affinity and cgroup quota — both stated).
+    `full` runs the protocol as written there (10 warm-up + 30 timed steps per leg, ~2 min of CPU time); the default is a
+    bounded sample of it (1 + up to 10 steps per leg inside ~12 s each, at least 3 timed) so that the default bench run stays
+    within its few minutes.  `value` / `cores` = the k = all leg.  Validated against the imported reference in the build
+    container (tests/test_config1_cpu.py, golden vector G7) and pinned on the GPU box by golden vectors G2 / G4 / G7."""
     import platform
-    cores = os.cpu_count() or 1
+    k_all, quota = usable_cores()
     saved = torch.get_num_threads()
     legs = []
     try:
-        for k in sorted({1, min(16, cores), cores}):
-            t, n, warm = _cpu_config1(1024, k, budget_s=10.0)
-            legs.append({"cores": k, "value": round(1024 / t, 2), "unit": "rays/s", "steps": n,
-                         "sample": f"median of {n} step(s) x 1024 rays" + ("" if warm else " (single cold step: over budget)")})
+        for k in sorted({1, k_all}):
+            ts = _cpu_config1(1024, k, 10 if full else 1, 30 if full else 10, 1e9 if full else 12.0)
+            med = float(np.median(ts))
+            legs.append({"cores": k, "value": round(1024 / med, 2), "unit": "rays/s", "steps": len(ts),
+                         "warmup": 10 if full else 1, "s_per_step_median": round(med, 3),
+                         "s_per_step_min_max": [round(min(ts), 3), round(max(ts), 3)]})
     finally:
         torch.set_num_threads(saved)
     try:
         model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
         model = platform.processor()
-    best = max(legs, key=lambda l: l["value"])
-    return {"value": best["value"], "unit": "rays/s", "cores": best["cores"], "kind": "port",
-            "sample": f"BASELINE config 1 (pure-torch freq encoder + nn.Linear 39->64->16 / 90->64->64->2, fp32), "
-                      f"{best['sample']} x {NUM_STEPS + UPSAMPLE} samples, fwd+loss+bwd, "
-                      f"torch.set_num_threads({best['cores']}); oracle/render_ref.py RefFreqField",
-            "legs": legs, "host": {"cpu": model, "os_cpu_count": cores, "torch": torch.__version__}}
+    top = legs[-1]
+    return {"value": top["value"], "unit": "rays/s", "cores": top["cores"], "kind": "port",
+            "sample": f"BASELINE config 1 (pure-torch freq encoder + nn.Linear 39->64->16 / 90->64->64->2, fp32), 1024 rays x "
+                      f"{NUM_STEPS + UPSAMPLE} samples, fwd+loss+bwd; median of {top['steps']} timed steps after "
+                      f"{top['warmup']} warm-up, torch.set_num_threads({top['cores']}) = all usable cores"
+                      + ("" if full else " (bounded sample of BASELINE.md §3's 10 + 30 protocol: --cpu-baseline-full runs it whole)")
+                      + "; oracle/render_ref.py RefFreqField",
+            "legs": legs,
+            "host": {"cpu": model, "os_cpu_count": os.cpu_count(), "cgroup_cpu_quota": quota, "usable_cores": k_all,
+                     "torch": torch.__version__}}
 
 
 def _relaunch_distributed(n):
@@ -251,7 +305,18 @@ def main():
                     help="MFMA operand type of the MLP kernels (bf16 = BASELINE config 5; hash features stay fp16)")
     ap.add_argument("--workload", choices=("kitti360", "nerfmvl"), default="kitti360",
                     help="kitti360 = the headline benchmark (BASELINE configs[1]); nerfmvl = configs[3], occupancy-grid path")
+    ap.add_argument("--table", choices=("init", "trained"), default="init",
+                    help="init = fresh-init field, random ground truth (SURVEY 8(d) default: flat weights, the colour head sees "
+                         "most samples); trained = the 'trained-like' variant: the field is first trained --pretrain-steps steps on "
+                         "the analytic scene (sphere + ground plane), so the weights concentrate on surfaces, then timed on it")
+    ap.add_argument("--pretrain-steps", type=int, default=600)
+    ap.add_argument("--patch", default="1x1", help="rays drawn as PXxPY pixel patches; 2x8 = the reference's patch epochs "
+                                                   "(structural-gradient loss term, utils.py:760-876)")
+    ap.add_argument("--dp-windows", action="store_true",
+                    help="1 GPU: run the table-gradient backward the way data parallel does (4 level windows, the exchange a "
+                         "no-op) to price the compute side of the DP pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="BASELINE.md 3 protocol in full: 10 warm-up + 30 timed steps per leg")
     ap.add_argument("--no-eval", action="store_true", help="skip the secondary full-frame evaluation measurement")
     ap.add_argument("--kernel-timers", action="store_true", help="HIP-event timing of every C-ABI call (adds ~4 %)")
     args = ap.parse_args()
@@ -263,14 +328,16 @@ def main():
         return run_nerfmvl(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         _relaunch_distributed(args.gpus)
-    rank, local, world = parallel.init_from_env()
-    if world != args.gpus:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} ranks were launched")
+    # (checked BEFORE the rendezvous: a rank that is going to refuse must not leave the others waiting for it)
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if env_world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world} ranks were launched")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP extension is the product path (no CPU fallback)")
-    if world > torch.cuda.device_count() and os.environ.get("LNH_DIST_BACKEND") != "gloo":
-        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible (one rank per GPU; "
+    if env_world > torch.cuda.device_count() and os.environ.get("LNH_DIST_BACKEND") != "gloo":
+        raise SystemExit(f"bench.py: {env_world} ranks but only {torch.cuda.device_count()} GPU(s) visible (one rank per GPU; "
                          "LNH_DIST_BACKEND=gloo allows functional runs with several ranks on one GPU)")
+    rank, local, world = parallel.init_from_env()
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
@@ -283,7 +350,26 @@ def main():
                            mlp_dtype=torch.bfloat16 if args.mlp_dtype == "bf16" else torch.float16)
     poses = synthetic_frames(60, device)
     n_steps_total = args.warmup + args.steps
-    batches = [make_batch(poses, s, args.rays, rank, device) for s in range(min(n_steps_total, 60))]
+    patch = tuple(int(v) for v in args.patch.lower().split("x"))
+    scene = "analytic" if args.table == "trained" else "random"
+    batches = [make_batch(poses, s, args.rays, rank, device, patch, scene) for s in range(60 if args.table == "trained"
+                                                                                          else min(n_steps_total, 60))]
+    step_kw = {} if patch == (1, 1) else {"patch": patch}
+    if args.dp_windows:
+        if world != 1:
+            raise SystemExit("bench.py: --dp-windows prices the data-parallel backward on ONE GPU")
+        from lidarnerf.nerf import fused as _fused
+        _fused.FORCE_DP_WINDOWS = True
+    pretrain = None
+    if args.table == "trained":  # let the field learn the scene (untimed): weights concentrate, the colour mask thins out
+        first = last = None
+        for s in range(args.pretrain_steps):
+            l = trainer.step(*batches[s % len(batches)], **step_kw)
+            if s == 0:
+                first = l
+            last = l
+        pretrain = {"steps": args.pretrain_steps, "first_loss": round(float(first.detach()), 4),
+                    "last_loss": round(float(last.detach()), 4)}
 
     def sync():
         torch.cuda.synchronize()
@@ -292,7 +378,7 @@ def main():
             torch.cuda.synchronize()
 
     for s in range(args.warmup):
-        trainer.step(*batches[s % len(batches)])
+        trainer.step(*batches[s % len(batches)], **step_kw)
     sync()
     # HIP events around the encoder entry points only (the roofline candidates): every timed call costs two event
     # records on the stream, and timing all ~25 calls of a step inflates the step by ~4 % (--kernel-timers for all)
@@ -311,7 +397,7 @@ def main():
     _hip.enable_timers(all_calls if args.kernel_timers else grid_calls)
     t0 = time.perf_counter()
     for s in range(args.steps):
-        loss = trainer.step(*batches[(args.warmup + s) % len(batches)])
+        loss = trainer.step(*batches[(args.warmup + s) % len(batches)], **step_kw)
     host_ms = (time.perf_counter() - t0) * 1e3 / args.steps  # time the host needs to ENQUEUE a step (no device wait)
     sync()
     elapsed = time.perf_counter() - t0
@@ -335,9 +421,18 @@ def main():
     fused.MASK_STATS = []
     _hip.enable_timers(mlp_calls)
     for s in range(n_prof):
-        trainer.step(*batches[(args.warmup + args.steps + s) % len(batches)])
+        trainer.step(*batches[(args.warmup + args.steps + s) % len(batches)], **step_kw)
     sync()
     mlp_timers = event_table(_hip.disable_timers())
+    # ---- spread: the timed region is short (K x ~2.3 ms); repeat it twice more (outside the reported number) and list all
+    spread = [round(1e3 * elapsed / args.steps, 3)]
+    for rep in range(2):
+        sync()
+        t_r = time.perf_counter()
+        for s in range(args.steps):
+            trainer.step(*batches[(args.warmup + s + 7 * (rep + 1)) % len(batches)], **step_kw)
+        sync()
+        spread.append(round(1e3 * parallel.max_over_ranks(time.perf_counter() - t_r, device) / args.steps, 3))
     # the roofline below divides by the time of ALL MLP kernels of a step: a renamed entry point must not drop out silently
     for role in ("density_mlp_forward", "density_mlp_backward", "color_backward", "color_"):
         fw = [k for k in mlp_timers if role in k and (role != "color_" or "forward" in k)]
@@ -354,11 +449,11 @@ def main():
         parallel.world_size = lambda: 1
         n_nc = min(args.steps, 10)
         for s in range(2):
-            trainer.step(*batches[s % len(batches)])
+            trainer.step(*batches[s % len(batches)], **step_kw)
         sync()
         t0 = time.perf_counter()
         for s in range(n_nc):
-            trainer.step(*batches[(2 + s) % len(batches)])
+            trainer.step(*batches[(2 + s) % len(batches)], **step_kw)
         sync()
         t_nc = parallel_max = time.perf_counter() - t0
         parallel.world_size, trainer.world = saved_ws, world
@@ -431,7 +526,11 @@ def main():
         "config": {"workload": "KITTI-360 seq 1908 shaped: hash-grid L=16 F=2 (2^19 rows, res 16..32768) + 64-wide "
                                "fused MLPs, 66x1030 range image", "rays_per_gpu_per_step": args.rays,
                    "samples_per_ray": NUM_STEPS + UPSAMPLE, "parallelism": f"dp{world}",
+                   "table": "fresh init, random per-ray ground truth" if args.table == "init" else
+                            f"trained-like: {args.pretrain_steps} untimed steps on the analytic scene (sphere + ground plane)",
+                   "patch": args.patch, "dp_windows_forced": bool(args.dp_windows),
                    "optimizer": "Adam + dynamic loss scaling, in the timed region (hash table: fused lnh_adam_table_step; MLPs: torch fused Adam)", "final_loss": round(loss_val, 5)},
+        "ms_per_step_repeats": spread,  # [the reported timed region, two more of the same length]
         "roofline": hbm_roofline(dom),
         "roofline_fwd": hbm_roofline(max(fwd_names, key=lambda k: kernels.get(k, {}).get("total_ms", 0))),
         "roofline_mfma": roofline_mfma,
@@ -439,6 +538,8 @@ def main():
     }
     if comm is not None:
         result["comm"] = comm
+    if pretrain is not None:
+        result["pretrain"] = pretrain
     # secondary number of SURVEY §8(d): full-frame evaluation (67 980 rays of a 66 x 1030 range image, staged in
     # chunks of 4096, no perturbation, no gradient) — reported beside the headline metric, never instead of it
     if world == 1 and not args.no_eval:
@@ -460,7 +561,7 @@ def main():
                           "unit": "rays/s", "ms_per_frame": round(1e3 * dt, 3)}
         model.train()
     if world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline()
+        result["cpu_baseline"] = cpu_baseline(full=args.cpu_baseline_full)
     print(json.dumps(result))
 
 

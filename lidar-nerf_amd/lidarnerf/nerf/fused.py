@@ -97,6 +97,7 @@ def _grid_bwd(g_feat, x01, g_table16, enc, B):
 # pair has run, so its all-reduce (fp16, RCCL's own stream) overlaps with the kernels of the following windows; only the
 # last window's ~23 % of the 27 MB stays exposed.  Windows are cut so that each holds a similar number of pool entries.
 _DP_LEVEL_WINDOWS = ((0, 7), (7, 10), (10, 13), (13, 16))
+FORCE_DP_WINDOWS = False  # bench.py --dp-windows: take the windowed backward on one GPU too (the exchange is a no-op)
 
 
 def _grid_bwd_overlapped(g_feat, x01, g_table16, enc, B, table_param):
@@ -118,6 +119,36 @@ def _grid_bwd_overlapped(g_feat, x01, g_table16, enc, B, table_param):
     return handles
 
 
+def _grid_bwd_sharded(g_feat, x01, enc, B, table_param):
+    """Data parallel, sharded table optimizer (parallel.py "second cut"): per level window, the table gradient is computed
+    into a window buffer padded to world * shard rows and REDUCE-SCATTERED (fp16, SUM) — each rank keeps only its rows.
+    Returns [(r0, r1, shard tensor [s, 2] fp16, handle, padded buffer)] per window of table rows [r0, r1): this rank's shard
+    holds rows [r0 + rank * s, r0 + (rank + 1) * s) (cut at r1).  Pipelined like the all-reduce: the collective of a window
+    runs behind the kernels of the following windows."""
+    import torch.distributed as dist
+    L = enc.num_levels
+    off = enc._offsets_host
+    need = _hip.lib().lnh_grid_backward_workspace_size(off.data_ptr(), B, 3, 2, L, enc.log2_scale,
+                                                       enc.base_resolution, 0, 0, _hip.LNH_F16)
+    ws = _workspace(g_feat.device, need)
+    world = dist.get_world_size()
+    windows = _DP_LEVEL_WINDOWS if L == 16 else ((0, L),)
+    shards = []
+    for l0, l1 in windows:
+        r0, r1 = int(off[l0]), int(off[l1])
+        s = parallel.shard_rows(r1 - r0, world)
+        padded = torch.zeros((world * s, 2), dtype=torch.half, device=g_feat.device)
+        # the kernels address level l at `base + offsets[l] * 2`: shift the base so that this window lands at row 0
+        _hip.call("lnh_grid_encode_backward_ws_levels", g_feat.data_ptr(), x01.data_ptr(), off.data_ptr(),
+                  padded.data_ptr() - r0 * 2 * 2, B, 3, 2, L, enc.log2_scale, enc.base_resolution, 0, 0, 0, _hip.LNH_F16,
+                  ws.data_ptr(), ws.numel(), l0, l1)
+        mine = torch.empty((s, 2), dtype=torch.half, device=g_feat.device)
+        h = parallel.reduce_scatter_half(padded, mine)
+        shards.append((r0, r1, mine, h, padded))
+    table_param._lnh_grad_reduced = True
+    return shards
+
+
 def table16_of(param, embeddings=None, training=True):
     """fp16 compute copy of the hash table.  With the fused table optimizer (train_step.LidarTrainer) the copy is a
     persistent shadow that the optimizer kernel rewrites together with the fp32 master; it is tied to the master's
@@ -128,6 +159,10 @@ def table16_of(param, embeddings=None, training=True):
     shadow the table is cast per call (the autocast rule of grid.py:54-57)."""
     src = param if embeddings is None else embeddings
     shadow = getattr(param, "_lnh_table16", None)
+    if shadow is not None and getattr(param, "_lnh_shard_optimizer", False):
+        # sharded table optimizer: the fp32 master of this rank is current on its own rows only; the all-gathered shadow
+        # IS the table (LidarTrainer.gather_table_state() completes the master for checkpoints)
+        return shadow
     if shadow is None or not training:
         return src.detach().to(torch.half).contiguous()
     if getattr(param, "_lnh_table16_version", None) != param._version:
@@ -314,12 +349,21 @@ class FusedLidarRender(Function):
         g_wc1 = g_wcol[64 * 16:64 * 16 + 64 * 64].view(64, 64)
         g_wc2 = g_wcol[64 * 16 + 64 * 64:].view(16, 64)[:2]
 
-        g_table16 = torch.zeros((int(enc._offsets_host[-1]), 2), dtype=torch.half, device=dev)
         B_all = N * Ttot
         g_feat = torch.empty((enc.num_levels, B_all, 2), dtype=torch.half, device=dev)
         _hip.call("lnh_density_mlp_backward" + sfx, g_h16.data_ptr(), feat.data_ptr(), wsig16.data_ptr(), B_all, Ttot, Ttot, 0,
                   g_feat.data_ptr(), g_wsig.data_ptr())
-        if parallel.world_size() > 1:
+        if parallel.world_size() > 1 and getattr(ctx.table_param, "_lnh_shard_optimizer", False):
+            # data parallel, sharded table optimizer: reduce-scatter per window; the trainer steps this rank's rows
+            ctx.table_param._lnh_grad16_shards = _grid_bwd_sharded(g_feat, x01, enc, B_all, ctx.table_param)
+            ctx.table_param._lnh_grad16_div = parallel.world_size()
+            ctx.table_param._lnh_grad16 = None
+            dts = ctx.param_dtypes
+            return (None, None, None, None, None, g_wsig[:64 * 32].view(64, 32).to(dts[1]),
+                    g_wsig[64 * 32:].view(16, 64).to(dts[2]), g_wc0.to(dts[3]), g_wc1.to(dts[4]), g_wc2.to(dts[5]),
+                    None, None, None, None, None, None, None)
+        g_table16 = torch.zeros((int(enc._offsets_host[-1]), 2), dtype=torch.half, device=dev)
+        if parallel.world_size() > 1 or FORCE_DP_WINDOWS:
             # data parallel: the table gradient goes on the wire as fp16, window by window, behind the kernels of the
             # following windows
             for handle in _grid_bwd_overlapped(g_feat, x01, g_table16, enc, B_all, ctx.table_param):

@@ -75,7 +75,7 @@ class LidarTrainer:
 
     def __init__(self, model, lr=1e-2, iters=30000, fp16=True, alpha_d=1000.0, alpha_r=1.0, alpha_i=10.0,
                  alpha_grad=100.0, scale=1.0, world_size=1, render_kwargs=None, fused_table_optimizer=True,
-                 mlp_dtype=torch.float16):
+                 mlp_dtype=torch.float16, shard_table_optimizer=False):
         # mlp_dtype: the autocast dtype — torch.float16 (the reference's --fp16) or torch.bfloat16 (BASELINE config 5:
         # bf16 MFMA MLPs; the hash table and its gradient stay fp16, so the dynamic loss scale is kept either way)
         self.model, self.fp16, self.world, self.amp_dtype = model, fp16, world_size, mlp_dtype
@@ -90,7 +90,7 @@ class LidarTrainer:
         self._ref_layout = [[p for p in g["params"]] for g in params]
         self.epoch, self.stats = 0, {"loss": [], "valid_loss": [], "results": [], "checkpoints": [], "best_result": None}
         on_gpu = all(p.is_cuda for g in params for p in g["params"])
-        self.table = None
+        self.table, self.sharded = None, False
         # occupancy-grid sampling renders through the modular density()/color() path: the table gradient is a normal .grad
         self.occupancy = bool(getattr(model, "cuda_ray", False))
         self.update_extra_interval, self.global_step = 16, 0
@@ -110,6 +110,11 @@ class LidarTrainer:
                 tp._lnh_table16_version = tp._version  # fused.table16_of re-casts when the parameter is written elsewhere
                 self.loss_scale = torch.full((), 65536.0, dtype=torch.float32, device=tp.device)
                 self.growth_tracker = torch.zeros((), dtype=torch.int32, device=tp.device)
+                # data parallel, second cut (parallel.py): reduce-scatter of the table gradient, every rank steps 1/N of
+                # the rows, all-gather of the fp16 compute copy.  The fp32 master table and the Adam moments of a rank are
+                # then current on ITS rows only: gather_table_state() completes them (checkpoints call it).
+                self.sharded = bool(shard_table_optimizer and world_size > 1)
+                tp._lnh_shard_optimizer = self.sharded
         params = [g for g in params if len(g["params"])]
         # the reference's groups differ in nothing but their parameter lists (network.py get_params: every group at `lr`):
         # step them as ONE group — torch launches its fused Adam once per group — and keep the reference's grouping for
@@ -155,11 +160,23 @@ class LidarTrainer:
         grads = [p.grad for p in self.params if p.grad is not None]
         if grads:
             torch._amp_foreach_non_finite_check_and_unscale_(grads, found_inf, inv_scale)
+        shards = getattr(tp, "_lnh_grad16_shards", None) if self.sharded else None
         g16 = tp._lnh_grad16
-        if g16 is None:
+        if g16 is None and not shards:
             raise RuntimeError("fused table optimizer: the backward pass produced no fp16 table gradient "
                                "(render did not go through the fused LiDAR chain)")
-        _hip.call("lnh_grad_check_f16", g16.data_ptr(), g16.numel(), found_inf.data_ptr())
+        if shards:
+            import torch.distributed as dist
+            rank = dist.get_rank()
+            for r0, r1, mine, handle, _padded in shards:
+                handle.wait()
+                rows = max(0, min(mine.shape[0], r1 - (r0 + rank * mine.shape[0])))
+                if rows:
+                    _hip.call("lnh_grad_check_f16", mine.data_ptr(), rows * 2, found_inf.data_ptr())
+            # every rank has looked at its own rows only: the skip / back-off decision must be the same everywhere
+            dist.all_reduce(found_inf, op=dist.ReduceOp.MAX)
+        else:
+            _hip.call("lnh_grad_check_f16", g16.data_ptr(), g16.numel(), found_inf.data_ptr())
         self.optimizer.grad_scale, self.optimizer.found_inf = None, found_inf
         try:
             self.optimizer.step()
@@ -168,14 +185,73 @@ class LidarTrainer:
         lr = float(self.optimizer.param_groups[0]["lr"])
         s_in, s_out = self.t_steps[self.t_flip], self.t_steps[1 - self.t_flip]
         shadow = table16_of(tp)  # (re-cast first if somebody wrote the parameter since the last step)
-        _hip.call("lnh_adam_table_step", tp.data_ptr(), self.t_m.data_ptr(), self.t_v.data_ptr(), g16.data_ptr(),
-                  shadow.data_ptr(), tp.numel(), lr, 0.9, 0.99, 1e-15, inv_scale_table.data_ptr(),
-                  found_inf.data_ptr(), s_in.data_ptr(), s_out.data_ptr())
+        if shards:
+            self._step_table_shards(shards, shadow, lr, inv_scale_table, found_inf, s_in, s_out)
+        else:
+            _hip.call("lnh_adam_table_step", tp.data_ptr(), self.t_m.data_ptr(), self.t_v.data_ptr(), g16.data_ptr(),
+                      shadow.data_ptr(), tp.numel(), lr, 0.9, 0.99, 1e-15, inv_scale_table.data_ptr(),
+                      found_inf.data_ptr(), s_in.data_ptr(), s_out.data_ptr())
         self.t_flip = 1 - self.t_flip
         self._last_scale = self.loss_scale.clone()  # the scale this step's gradient carries (table_grad divides by it)
         torch._amp_update_scale_(self.loss_scale, self.growth_tracker, found_inf, 2.0, 0.5, 2000)
         self.scheduler.step()
         return loss
+
+    def _step_table_shards(self, shards, shadow, lr, inv_scale_table, found_inf, s_in, s_out):
+        """Sharded table optimizer: Adam on this rank's rows of every level window, then the all-gather of the fp16 compute
+        copy (the only part of the table the next forward pass reads)."""
+        from .. import _hip
+        import torch.distributed as dist
+        tp = self.table
+        rank = dist.get_rank()
+        flat16, table16 = shadow.view(-1), shadow.view(-1, 2)
+        gathers, stepped = [], False
+        for r0, r1, mine, _h, padded in shards:
+            s = mine.shape[0]
+            row0 = r0 + rank * s
+            rows = max(0, min(s, r1 - row0))
+            if rows:
+                o = row0 * 2  # element offset of the shard in the [rows, 2] table
+                # (the device-side step counter: every window reads s_in and writes s_in + 1 to s_out)
+                _hip.call("lnh_adam_table_step", tp.data_ptr() + 4 * o, self.t_m.data_ptr() + 4 * o,
+                          self.t_v.data_ptr() + 4 * o, mine.data_ptr(), flat16.data_ptr() + 2 * o, rows * 2, lr, 0.9, 0.99,
+                          1e-15, inv_scale_table.data_ptr(), found_inf.data_ptr(), s_in.data_ptr(), s_out.data_ptr())
+                stepped = True
+            mine16 = torch.zeros_like(mine)
+            if rows:
+                mine16[:rows] = table16[row0:row0 + rows]
+            # (the window's padded gradient buffer has served its purpose: it receives the gathered copy)
+            gathers.append((dist.all_gather_into_tensor(padded, mine16, async_op=True), padded, r0, r1))
+        if not stepped:  # a rank without rows (more ranks than shards): keep the double-buffered step counter moving
+            s_out.copy_(torch.where(found_inf != 0, s_in, s_in + 1))
+        for handle, out, r0, r1 in gathers:
+            handle.wait()
+            table16[r0:r1] = out[:r1 - r0]  # the shards back to back; what lies beyond r1 is padding
+        tp._lnh_grad16_shards = None
+
+    def gather_table_state(self):
+        """Sharded table optimizer: complete the fp32 master table and the Adam moments on every rank from their owners
+        (checkpoints, evaluation through `embeddings`, a switch back to the replicated optimizer).  Collective."""
+        if not self.sharded:
+            return
+        import torch.distributed as dist
+        from .fused import _DP_LEVEL_WINDOWS
+        enc = self.model.fused_spec().grid
+        off, world, rank = enc._offsets_host, dist.get_world_size(), dist.get_rank()
+        windows = _DP_LEVEL_WINDOWS if enc.num_levels == 16 else ((0, enc.num_levels),)
+        for t in (self.table.data, self.t_m, self.t_v):
+            rows = t.view(-1, 2)
+            for l0, l1 in windows:
+                r0, r1 = int(off[l0]), int(off[l1])
+                s = parallel.shard_rows(r1 - r0, world)
+                mine = torch.zeros((s, 2), dtype=t.dtype, device=t.device)
+                a = r0 + rank * s
+                n = max(0, min(s, r1 - a))
+                if n:
+                    mine[:n] = rows[a:a + n]
+                full = torch.empty((world * s, 2), dtype=t.dtype, device=t.device)
+                dist.all_gather_into_tensor(full, mine)
+                rows[r0:r1] = full[:r1 - r0]
 
     # ---- what lives outside torch.optim / GradScaler when the table is stepped by the fused kernel
     def table_grad(self):
@@ -192,6 +268,7 @@ class LidarTrainer:
     def state_dict(self):
         """Everything a resume needs: torch optimizer / scheduler / scaler state plus — fused table optimizer — the
         table's Adam moments, its device-side step counter and the dynamic loss scale (99.8 % of the optimizer state)."""
+        self.gather_table_state()
         sd = {"optimizer": self.optimizer.state_dict(), "scheduler": self.scheduler.state_dict(),
               "scaler": self.scaler.state_dict(), "fused_table": None}
         if self.table is not None:
@@ -303,6 +380,7 @@ class LidarTrainer:
         """Same dictionary as Trainer.save_checkpoint (utils.py:1449-1480): epoch, global_step, stats, model and — `full`
         — optimizer / lr_scheduler / scaler in the layout the reference's Trainer.load_checkpoint restores (a reference
         run can resume from it and vice versa: the state dict keys of the model are the reference's, see network.py)."""
+        self.gather_table_state()  # (sharded table optimizer: every rank completes master table + moments first)
         state = {"epoch": self.epoch, "global_step": self.global_step, "stats": self.stats}
         if full:
             state["optimizer"] = self._optimizer_state_ref_layout()

@@ -88,6 +88,59 @@ def allreduce_half_table(g_table16, param):
     return dist.all_reduce(g_table16, op=dist.ReduceOp.SUM, async_op=True)
 
 
+# ---- second cut: the table's optimizer state is SHARDED over the ranks (ZeRO-1 for the 13.7 M-parameter hash table) -------
+# all-reduce + replicated Adam moves 2 x 27 MB per rank over xGMI and makes every rank read/write the whole 55 MB master
+# table and its moments (383 MB of HBM traffic per step).  Sharded: reduce-scatter of the fp16 gradient (27 MB in, 27/N out),
+# each rank steps ITS 1/N of the rows (lnh_adam_table_step on a row range), all-gather of the fp16 compute copy (27 MB) — the
+# same bytes on the wire as an all-reduce (which IS reduce-scatter + all-gather), 1/N of the optimizer traffic per GPU, and
+# the master table / moments of a rank only ever hold its own rows (SURVEY.md §8e, §5 "direct reduce-scatter + all-gather").
+def shard_rows(n_rows, world, align=4):
+    """Rows per rank when `n_rows` rows are dealt to `world` ranks in equal, `align`-row-aligned shards (the last may be
+    partly or wholly padding): the collectives need equal shards, lnh_adam_table_step counts in multiples of 4 values."""
+    per = (n_rows + world - 1) // world
+    return (per + align - 1) // align * align
+
+
+def reduce_scatter_half(padded, out_shard):
+    """SUM-reduce `padded` [world * s, 2] fp16 over ranks and leave rows [rank * s, (rank + 1) * s) in `out_shard`
+    (async handle).  fp16 on the wire, sum-then-divide like allreduce_half_table."""
+    return dist.reduce_scatter_tensor(out_shard, padded, op=dist.ReduceOp.SUM, async_op=True)
+
+
+def all_gather_half(out_padded, shard):
+    """Inverse of the above for the fp16 compute copy of the table (async handle)."""
+    return dist.all_gather_into_tensor(out_padded, shard, async_op=True)
+
+
+def render_sharded(model, rays_o, rays_d, **render_kwargs):
+    """Evaluation of a full range image on all ranks: each rank renders a contiguous range of the rays (shard_rays), the
+    depth / image pieces are all-gathered, every rank returns the complete result (the reference's dormant hooks:
+    lidarnerf/nerf/utils.py:1327-1350 gather `preds` the same way).  rays_o / rays_d [1, N, 3]."""
+    world = world_size()
+    if world <= 1:
+        return model.render(rays_o, rays_d, **render_kwargs)
+    rank = dist.get_rank()
+    N = rays_o.shape[1]
+    a, b = shard_rays(N, rank, world)
+    per = (N + world - 1) // world
+    part = model.render(rays_o[:, a:b].contiguous(), rays_d[:, a:b].contiguous(), **render_kwargs) if b > a else None
+    out = {}
+    for key, width in (("depth_lidar", 1), ("image_lidar", None)):
+        if part is not None:
+            piece = part[key].reshape(b - a, -1).float()
+            width = piece.shape[1]
+        if width is None:  # a rank without rays still has to know the channel count: the LiDAR image has 2
+            width = 2
+        mine = torch.zeros((per, width), dtype=torch.float32, device=rays_o.device)
+        if part is not None:
+            mine[:b - a] = piece
+        full = torch.empty((world * per, width), dtype=torch.float32, device=rays_o.device)
+        dist.all_gather_into_tensor(full, mine)
+        full = full[:N]
+        out[key] = full.reshape(1, N) if key == "depth_lidar" else full.reshape(1, N, width)
+    return out
+
+
 def broadcast_parameters(module, src=0):
     """Make every replica start from rank `src`'s weights."""
     if not dist.is_initialized() or dist.get_world_size() <= 1:

@@ -9,8 +9,9 @@ import torch, bench
 from lidarnerf import parallel
 from lidarnerf.nerf.train_step import LidarTrainer
 rank, local, world = parallel.init_from_env()
-torch.cuda.set_device(0)
-device = torch.device("cuda", 0)
+_dev = local if os.environ.get("LNH_DP_WORKER_ONE_GPU_PER_RANK") else 0  # RCCL run: one GPU per rank; gloo run: both on GPU 0
+torch.cuda.set_device(_dev)
+device = torch.device("cuda", _dev)
 torch.manual_seed(0)
 model = bench.build_model(device)
 parallel.broadcast_parameters(model)
@@ -44,4 +45,44 @@ torch.distributed.all_gather(all_chk, chk)
 same = all(float(c) == float(all_chk[0]) for c in all_chk)
 print(f"rank {rank}: table checksum after 3 DP steps {chk.item():.9f} identical across ranks: {same}")
 assert same
+# ---- second cut: reduce-scatter + sharded table optimizer + all-gather must leave the SAME tables as all-reduce + replicated
+def run(sharded, steps):
+    torch.manual_seed(0)
+    m = bench.build_model(device)
+    parallel.broadcast_parameters(m)
+    t = LidarTrainer(m, fp16=True, scale=bench.SCALE, world_size=world, render_kwargs=dict(num_steps=768, upsample_steps=64),
+                     shard_table_optimizer=sharded)
+    assert t.sharded == sharded
+    for s in range(steps):
+        torch.manual_seed(100 + s)  # same random draws in both runs
+        t.step(*bench.make_batch(poses, s, 512, rank, device))   # different rays on every rank
+    shadow = m.encoder.embeddings._lnh_table16.clone()
+    t.gather_table_state()
+    return shadow, m.encoder.embeddings.detach().clone(), t.t_m.clone(), t.t_v.clone()
+# one step: the same gradient sum (2 ranks: a + b in either order), the same Adam arithmetic row by row -> bit-identical
+a, b = run(False, 1), run(True, 1)
+for name, x, y in zip(("fp16 table", "fp32 master table", "exp_avg", "exp_avg_sq"), a, b):
+    assert torch.equal(x, y), f"rank {rank}: sharded optimizer differs from the replicated one in {name}: {(x.float() - y.float()).abs().max().item()}"
+assert float((a[1] - bench.build_model(device).encoder.embeddings.detach()).abs().max()) > 0  # (the step did move the table)
+print(f"rank {rank}: sharded table optimizer == replicated (fp16 table, master, moments bit-identical after a step)")
+# three steps: two runs of the SAME mode already differ in a few dozen rows from the second step on (the MLP weight gradients
+# meet in fp32 device atomics, so the MLP weights of two runs differ in their last bits, and Adam with eps = 1e-15 turns a
+# last-bit difference of a tiny gradient into a visible one); the sharded run must sit inside that spread
+a, a2, b = run(False, 3), run(False, 3), run(True, 3)
+def spread(x, y):
+    d = (x[0].float() - y[0].float()).abs()
+    return float(d.max()), int((d.sum(1) > 0).sum())
+s_same, s_shard = spread(a, a2), spread(a, b)
+print(f"rank {rank}: after 3 steps, fp16 table: replicated vs replicated max {s_same[0]:.2e} in {s_same[1]} rows; sharded vs replicated max {s_shard[0]:.2e} in {s_shard[1]} rows")
+assert s_shard[1] <= max(4 * s_same[1], 2000) and s_shard[0] <= max(4 * s_same[0], 2e-2)
+# ---- sharded evaluation: every rank renders its range of a frame, the pieces are all-gathered
+model.eval()
+frame = bench.make_batch(poses, 0, 1500, 0, device)
+kw = dict(cal_lidar_color=True, staged=True, max_ray_batch=512, perturb=False, num_steps=768, upsample_steps=64)
+with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+    whole = model.render(frame[0], frame[1], **kw)
+    parts = parallel.render_sharded(model, frame[0], frame[1], **kw)
+for k in ("depth_lidar", "image_lidar"):
+    assert parts[k].shape == whole[k].shape and torch.equal(parts[k].float(), whole[k].float()), k
+print(f"rank {rank}: sharded evaluation == whole-frame evaluation")
 print(f"rank {rank}: DP-OK")

@@ -1,0 +1,78 @@
+"""End-to-end learning checks of the benchmarked path (fused fp16 chain + fused table optimizer + loss scaling) on the
+analytic scene of bench.py (`--table trained`: sensor inside a 32 m sphere over a ground plane, consistent between frames):
+the depth error on a HELD-OUT ray set must fall from ~11 m at initialisation to decimetres — with 1x1 rays and with the
+reference's 2x8 patch epochs (structural-gradient term, nerf/utils.py:760-876, 1057-1065; patch rays of
+dataset/base_dataset.py:50-70).  A path that computes plausible numbers but wrong gradients does not pass this."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _train(patch, steps):
+    import bench
+    from lidarnerf.nerf.train_step import LidarTrainer
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    model = bench.build_model(dev)
+    tr = LidarTrainer(model, lr=1e-2, iters=30000, fp16=True, scale=bench.SCALE,
+                      render_kwargs=dict(num_steps=768, upsample_steps=64))
+    poses = bench.synthetic_frames(60, dev)
+    batches = [bench.make_batch(poses, s, 4096, 0, dev, patch, "analytic") for s in range(60)]
+    held = bench.make_batch(poses, 30, 4096, 1, dev, (1, 1), "analytic")
+
+    def depth_error_m():
+        model.eval()
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            out = model.render(held[0], held[1], cal_lidar_color=True, staged=False, perturb=False, num_steps=768,
+                               upsample_steps=64)
+        model.train()
+        return float(((out["depth_lidar"][0].float() - held[2][0, :, 2]).abs() / bench.SCALE).median())
+
+    e0 = depth_error_m()
+    losses = []
+    for s in range(steps):
+        losses.append(tr.step(*batches[s % 60], **({} if patch == (1, 1) else {"patch": patch})).detach())
+    return e0, depth_error_m(), torch.stack(losses).float().cpu().numpy(), tr
+
+
+def test_dense_path_learns_the_analytic_scene():
+    e0, e1, losses, tr = _train((1, 1), 400)
+    assert np.isfinite(losses).all()
+    # measured on MI355X: 11.6 m -> 0.10 m (median over 4096 held-out rays) after 400 steps
+    assert e0 > 5.0 and e1 < 0.5 and e1 < e0 / 20, (e0, e1)
+    assert float(tr.loss_scale) >= 1024.0  # the dynamic loss scale did not collapse
+
+
+def test_patch_mode_step_learns_too():
+    e0, e1, losses, _ = _train((2, 8), 400)
+    assert np.isfinite(losses).all()
+    # 256 patches of 16 neighbouring rays per step + the structural-gradient term; measured 11.6 m -> 0.3 .. 0.7 m
+    assert e0 > 5.0 and e1 < 1.5 and e1 < e0 / 6, (e0, e1)
+
+
+def test_patch_gradient_term_matches_the_restatement():
+    """The GPU-side torch ops of the patch term (train_step.patch_gradient_loss) against oracle/render_ref.patch_grad_loss on
+    the same depths (the term enters the step above through the non-fused loss path)."""
+    from lidarnerf.nerf.train_step import patch_gradient_loss
+    from oracle import render_ref
+    g = torch.Generator().manual_seed(1)
+    scale = 0.010784853507573345
+    n = 256 * 16
+    # ground truth: smooth inside a patch (neighbours differ by millimetres: below the 0.01 m gate of utils.py:789-797),
+    # prediction: the same surface + 5 cm of noise
+    base = (torch.rand(256, 1, generator=g) * 0.6).expand(256, 16).reshape(n)
+    gt_depth = base + 0.003 * scale * torch.randn(n, generator=g)
+    depth = gt_depth + 0.05 * scale * torch.randn(n, generator=g)
+    gt = torch.stack([(torch.rand(n, generator=g) > 0.15).float(), torch.rand(n, generator=g), gt_depth], -1)
+    rd = gt[:, 0]
+    want = render_ref.patch_grad_loss(depth, gt, 2, 8, scale)
+    got = patch_gradient_loss((depth * rd).cuda(), (gt[:, 2] * rd).cuda(), rd.cuda(), 2, 8, scale)
+    assert abs(float(got) - float(want)) <= 1e-5 * abs(float(want)) and float(want) > 0

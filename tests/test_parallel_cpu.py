@@ -54,6 +54,30 @@ def _worker(rank, world, port, out):
     a, b = parallel.shard_rays(67980, rank, world)
     assert (a, b) == ((0, 33990) if rank == 0 else (33990, 67980))
     assert parallel.max_over_ranks(float(rank), "cpu") == float(world - 1)
+    # ---- second cut: reduce-scatter of padded fp16 windows, all-gather of the compute copy, sharded evaluation
+    assert parallel.shard_rows(4920, 2) == 2460 and parallel.shard_rows(4921, 2) == 2464 and parallel.shard_rows(10, 8) == 4
+    n_rows = 13                                               # a "window" of 13 rows: shards of 8 rows, 3 rows of padding
+    s = parallel.shard_rows(n_rows, world)
+    padded = torch.zeros((world * s, 2), dtype=torch.float16)
+    padded[:n_rows] = torch.arange(n_rows * 2, dtype=torch.float16).view(n_rows, 2) * (rank + 1)
+    mine = torch.empty((s, 2), dtype=torch.float16)
+    parallel.reduce_scatter_half(padded, mine).wait()
+    want = torch.zeros((world * s, 2), dtype=torch.float16)
+    want[:n_rows] = torch.arange(n_rows * 2, dtype=torch.float16).view(n_rows, 2) * 3
+    torch.testing.assert_close(mine, want[rank * s:(rank + 1) * s], rtol=0, atol=0)
+    back = torch.empty((world * s, 2), dtype=torch.float16)
+    parallel.all_gather_half(back, mine).wait()
+    torch.testing.assert_close(back, want, rtol=0, atol=0)
+
+    class Stub:                                               # render = a function of the ray alone
+        def render(self, o, d, **kw):
+            return {"depth_lidar": (o * d).sum(-1), "image_lidar": torch.stack([o[..., 0] + d[..., 1], d[..., 2]], -1)}
+    g = torch.Generator().manual_seed(3)
+    o, d = torch.rand(1, 1001, 3, generator=g), torch.rand(1, 1001, 3, generator=g)   # odd count: the last shard is short
+    whole, parts = Stub().render(o, d), parallel.render_sharded(Stub(), o, d)
+    for k in whole:
+        assert parts[k].shape == whole[k].shape
+        torch.testing.assert_close(parts[k], whole[k], rtol=0, atol=0)
     dist.barrier()
     dist.destroy_process_group()
     out.put(rank)

@@ -1,0 +1,57 @@
+"""RCCL smoke test of the data-parallel path: one process per GPU, backend "nccl" (= RCCL on ROCm) over xGMI — what the
+2-rank gloo tests cannot cover.  SKIPS on a box with fewer than 2 visible GPUs (every box this build has seen so far); it runs
+the day a multi-GPU node exists: tests/dp_worker.py under torch.distributed.run with LNH_DIST_BACKEND=nccl — windowed fp16
+all-reduce == single-process gradient, identical tables after DP steps, sharded table optimizer == replicated, sharded
+evaluation == whole-frame evaluation — and `bench.py --gpus 2` with its `comm` block."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _n_gpus():
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs >= 2 GPUs on one node (RCCL refuses two ranks on one device)")
+def test_rccl_two_ranks_dp_worker():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(LNH_DIST_BACKEND="nccl", LNH_DP_WORKER_ONE_GPU_PER_RANK="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "tests", "dp_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-3000:]
+    assert out.count("DP-OK") == 2, out[-3000:]
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs >= 2 GPUs on one node")
+def test_rccl_bench_two_gpus():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                            "LNH_DIST_BACKEND")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--no-eval",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["comm"]["allreduce_exposed_ms"] is not None
+
+
+def test_rccl_refuses_two_ranks_on_one_gpu_loudly():
+    """With fewer GPUs than ranks bench.py must refuse (no silent gloo / single-GPU fallback) unless the functional
+    gloo mode is asked for explicitly."""
+    if _n_gpus() >= 2:
+        pytest.skip("a multi-GPU box runs the real test above")
+    env = {k: v for k, v in os.environ.items() if k not in ("LNH_DIST_BACKEND",)}
+    env.update(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29548")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "GPU(s) visible" in (r.stdout + r.stderr) or "nccl" in (r.stdout + r.stderr).lower()
