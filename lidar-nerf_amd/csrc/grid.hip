@@ -635,7 +635,7 @@ __global__ void __launch_bounds__(1024)
 k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs, uint32_t B, GridMeta meta,
                    BucketPlan plan, char *__restrict__ pool_bytes, uint32_t *__restrict__ cursor,
                    uint32_t *__restrict__ spill_cursor, uint32_t align_rt, uint32_t interp_rt, uint32_t n_levels,
-                   uint32_t level0, uint32_t b_begin, uint32_t B_all) {
+                   uint32_t level0, uint32_t b_begin, uint32_t B_all, T *__restrict__ grad_table) {
     // this launch handles the points [b_begin, b_begin + B) of a batch of B_all (large batches are walked in chunks)
     constexpr int C = 2, NCORN = 1 << D, NP = NCORN / 2, NTHREADS = 1024;
     typedef v2_t<T> V2;
@@ -834,9 +834,20 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
                 (unsigned short)((k & (kBucketRows - 1)) | ((k >> 29) << kBucketRowsLog2));
         } else {
             const uint32_t sp = lsp[(k & 0x7ffffu) >> kBucketRowsLog2] + pos;
-            if (sp < plan.spill_cap) {  // (always true: a level emits at most B * 2^D entries)
+            if (sp < plan.spill_cap) {
                 SpillEntry<T> e = {k, a, b};
                 *reinterpret_cast<SpillEntry<T> *>(spill + sp * (uint32_t)sizeof(SpillEntry<T>)) = e;
+            } else {
+                // The spill list is full too (it holds 1/16 of a level's worst case: a batch whose points crowd into a
+                // few buckets of a DENSE level without merging): these entries go straight into the table with device
+                // atomics — always correct, slow (~20 G/s), and the one place where a sum depends on arrival order.
+                const uint32_t r0 = k & 0x7ffffu, cd = k >> 29;
+                T *gt = grad_table + (size_t)lv.offset * 2;
+                atomic_add_pair(gt + (size_t)r0 * 2, (float)a[0], (float)a[1]);
+                if (cd != kCodeSingle) {
+                    // (pairs never leave their bucket: a hashed pair differs in the low 7 bits, a dense one is r0 + 1)
+                    atomic_add_pair(gt + (size_t)pair_row(r0, cd, MODE == 1) * 2, (float)b[0], (float)b[1]);
+                }
             }
         }
     };
@@ -1156,7 +1167,8 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
 // Pool slots per bucket = even split of the level's expected entries (pair format: B * 2^D / 2, + 1/64 for the pairs
 // that travel as two singles; generic level classes: B * 2^D) + 12.5 % + 12 sigma of a Poisson count (hashed levels are
 // statistically even; correlated corners of neighbouring samples widen the spread, so the margin is generous) —
-// whatever does not fit goes to the spill list, which holds the level's worst case (B * 2^D entries).
+// whatever does not fit goes to the level's spill list (1/16 of the level's worst case B * 2^D), and beyond that into the
+// table with device atomics.
 constexpr uint32_t kCursorAlign = 256;
 template <typename T>
 uint64_t plan_buckets(BucketPlan &plan, const GridMeta &m, uint32_t L, uint32_t B, uint32_t D, bool plain,
@@ -1183,7 +1195,11 @@ uint64_t plan_buckets(BucketPlan &plan, const GridMeta &m, uint32_t L, uint32_t 
     }
     plan.first_bucket[L] = nbt;
     total_buckets = nbt;
-    plan.spill_cap = worst > 0xffffffffull ? 0xffffffffu : (uint32_t)worst;
+    // spill list of a level: 1/16 of its worst case (every entry of the level overflowing), at least 1 M entries (or the worst case itself: small batches never reach the atomics); what
+    // does not fit there either is added with device atomics by the scatter pass itself (see to_global)
+    uint64_t spill_cap = std::max<uint64_t>(worst / 16, 1u << 20);
+    if (spill_cap > worst) spill_cap = worst;
+    plan.spill_cap = spill_cap > 0xffffffffull ? 0xffffffffu : (uint32_t)spill_cap;
     for (uint32_t l = 0; l < L; l++) {
         plan.spill_off[l] = bytes;
         bytes += ((uint64_t)plan.spill_cap * sizeof(SpillEntry<T>) + 15) / 16 * 16;
@@ -1218,8 +1234,12 @@ void allow_big_lds(K kernel, size_t lds) {
 // 6.5 ms in one piece vs 4 x 1.2 ms in chunks), and the workspace would grow with the batch.  The sum stays a
 // fixed-order, bit-reproducible one: integer per chunk, chunks added to the table in order.
 constexpr uint32_t kChunkPoints = 4u << 20;
-__host__ inline uint32_t chunk_points(uint32_t B) {
-    const uint32_t n = div_up(B, kChunkPoints);
+// `plain` = linear interpolation, align_corners off (the x-pair pool format: 4 entries per point and level); the generic
+// level classes emit 8 singles per point and level, so their chunks are half as long — both fit the SAME workspace, whose
+// size does not depend on an interpolation mode the sizing call does not know.
+__host__ inline uint32_t chunk_points(uint32_t B, bool plain = true) {
+    uint32_t n = div_up(B, kChunkPoints);
+    if (!plain && B > 65536) n *= 2;
     return n <= 1 ? B : div_up(div_up(B, n), 1024) * 1024;
 }
 
@@ -1235,7 +1255,7 @@ int launch_backward_bucketed(const T *grad, const float *inputs, T *ge, uint32_t
                              hipStream_t s, uint32_t level_begin = 0, uint32_t level_end = 0xffffffffu) {
     if (level_end > L) level_end = L;
     if (level_begin >= level_end) return LNH_OK;
-    const uint32_t step = chunk_points(B);
+    const uint32_t step = chunk_points(B, align == 0 && interp == 0);
     for (uint32_t b0 = 0; b0 < B; b0 += step) {
         const int rc = launch_backward_bucketed_chunk<T>(grad, inputs, ge, std::min(step, B - b0), L, m, align, interp,
                                                          workspace, workspace_bytes, s, level_begin, level_end, b0, B,
@@ -1291,10 +1311,10 @@ int launch_backward_bucketed_chunk(const T *grad, const float *inputs, T *ge, ui
     for (uint32_t l = level_begin; l < level_end; l++) generic |= level_is_generic(m.lv[l], 3, plain);
     if (generic)
         LNH_LAUNCH((k_grid_bwd_scatter<T, 3, 6144>), dim3(div_up(B, 1024) * n_win), dim3(1024), 0, s, grad, inputs, B, m,
-                   plan, pool, cursor, spill_cursor, align, interp, n_win, level_begin, b_begin, B_all);
+                   plan, pool, cursor, spill_cursor, align, interp, n_win, level_begin, b_begin, B_all, ge);
     else
         LNH_LAUNCH((k_grid_bwd_scatter<T, 3, 5120>), dim3(div_up(B, 1024) * n_win), dim3(1024), 0, s, grad, inputs, B, m,
-                   plan, pool, cursor, spill_cursor, align, interp, n_win, level_begin, b_begin, B_all);
+                   plan, pool, cursor, spill_cursor, align, interp, n_win, level_begin, b_begin, B_all, ge);
     int rc = lnh_check_launch("lnh_grid_encode_backward_ws(scatter)");
     if (rc) return rc;
     auto k = k_grid_bwd_reduce<T>;
@@ -1619,10 +1639,11 @@ uint64_t lnh_grid_backward_workspace_size(const int32_t *offsets_host, uint32_t 
     uint32_t nbt = 0;
     for (uint32_t l = 0; l < L; l++)
         if ((m.lv[l].hashmap_size + kBucketRows - 1) / kBucketRows > kMaxBucketsPerLevel) return 0;
-    const uint32_t Bc = chunk_points(B);  // the workspace serves one chunk at a time
-    // (the interpolation mode is not an argument here: size for the larger of the two pool layouts it can select)
+    // the workspace serves one chunk at a time.  (The interpolation mode is not an argument here: size for the larger of the
+    // two pool layouts it can select — each with ITS chunk length, see chunk_points.)
     uint64_t need = 0;
     for (int plain = 0; plain <= (align_corners ? 0 : 1); plain++) {
+        const uint32_t Bc = chunk_points(B, plain != 0);
         const uint64_t n = dtype == LNH_F16 ? plan_buckets<half_t>(plan, m, L, Bc, D, plain != 0, nbt)
                                             : plan_buckets<float>(plan, m, L, Bc, D, plain != 0, nbt);
         need = n > need ? n : need;
@@ -1640,8 +1661,8 @@ int lnh_grid_backward_plan_info(const int32_t *offsets_host, uint32_t B, uint32_
     (void)build_meta(m, offsets_host, D, L, S, H, gridtype, align_corners != 0);
     BucketPlan plan;
     uint32_t nbt = 0;
-    if (dtype == LNH_F16) (void)plan_buckets<half_t>(plan, m, L, chunk_points(B), D, align_corners == 0, nbt);
-    else (void)plan_buckets<float>(plan, m, L, chunk_points(B), D, align_corners == 0, nbt);
+    if (dtype == LNH_F16) (void)plan_buckets<half_t>(plan, m, L, chunk_points(B, align_corners == 0), D, align_corners == 0, nbt);
+    else (void)plan_buckets<float>(plan, m, L, chunk_points(B, align_corners == 0), D, align_corners == 0, nbt);
     out4[0] = plan.first_bucket[level + 1] - plan.first_bucket[level];
     out4[1] = plan.cap[level];
     out4[2] = kBucketRows;

@@ -267,29 +267,63 @@ def test_backward_bucketed_overflow_by_a_few(dt):
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.float16])
 def test_backward_bucketed_sliced_and_spilled(dt):
-    """One cell receives 164 K points (every other point lies outside the grid, so no two neighbours merge): 655 K pair
-    entries per level in at most 8 rows.  Level 0 (one bucket): reduced in slices, no spill; dense levels 2-3: buckets
-    both sliced and overflowing; hashed levels: up to 4 buckets overflow their pools several-fold.  All against the
-    oracle."""
+    """One cell receives every 16th point of 320 K (its neighbours in the batch are random points, so nothing merges), the
+    rest is uniform: level 0 (one bucket, 1.3 M pair entries) is reduced in slices; on the hashed levels the buckets holding
+    that cell's corner rows receive 20 K entries on top of their even share and overflow into the spill list (which holds 1/16
+    of a level's worst case: 164 K entries).  Against the oracle, repeated for bit equality."""
     code = 0 if dt == torch.float32 else 1
     B = 320 * 1024
-    x = np.empty((B, 3), dtype=np.float32)
-    x[0::2] = np.float32(0.3) + np.random.default_rng(1).random((B // 2, 3), dtype=np.float32) * np.float32(1e-6)
-    x[1::2] = 1.5
+    r = np.random.default_rng(1)
+    x = r.random((B, 3), dtype=np.float32)
+    x[0::16] = np.float32(0.3) + r.random((B // 16, 3), dtype=np.float32) * np.float32(1e-6)
     nb0, cap0, _, slice_entries = _plan(B, 0, code)
     nb9, cap9, _, _ = _plan(B, 9, code)
-    assert nb0 == 1 and (B // 2) * 4 > slice_entries                # level 0 is cut into slices (4 pair entries per point)
-    assert (B // 2) > cap9                                           # a hashed bucket holding one corner row overflows
+    assert nb0 == 1 and B * 4 > 2 * slice_entries                   # level 0 is cut into slices (4 pair entries per point)
+    mean9 = B * 4 / nb9
+    assert mean9 + B // 16 > cap9 + 1000                             # a hashed bucket holding one corner row overflows
+    assert 4 * (mean9 + B // 16 - cap9) < B * 8 // 16                # ... and the level's spill list holds the excess
     nd = np.float32 if dt == torch.float32 else np.float16
     g = (np.random.default_rng(8).standard_normal((L, B, CH)) * 0.1).astype(nd)
     got = _run_bucketed(x, g, dt, times=2)
     want = c_oracle.grid_backward(g, x, OFF, int(OFF[-1]), S, H)
     if dt == torch.float32:
-        # 164 K addends per row, each truncated to 2^-40 before the integer sum: |error| < 1.5e-7 + one fp32 rounding
+        # up to 20 K addends per row, each truncated to 2^-40 before the integer sum: one fp32 rounding on top
         np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
     else:
         np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-3)
     assert np.all(got[want == 0] == 0)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16])
+def test_backward_bucketed_spill_list_full_falls_back_to_atomics(dt):
+    """HALF of 320 K points in one cell (the other half outside the grid, so no two neighbours merge): 655 K pair entries per
+    level in at most 8 rows.  The hashed buckets holding those rows overflow their pools several-fold AND the level's spill
+    list (164 K entries): the rest goes into the table with device atomics — the reference's own method
+    (gridencoder.cu:335-350).  Still the right sums: fp32 to the accuracy of 164 K float atomics per row; fp16 tables to what
+    164 K fp16 atomic adds on one row leave (the running sum outgrows the addends' precision: ~10 % — this is what the
+    reference's backward does to such a batch everywhere; the bucketed path does it only past a full spill list)."""
+    from gpu_util import call, dev, host
+    code = 0 if dt == torch.float32 else 1
+    B = 320 * 1024
+    x = np.empty((B, 3), dtype=np.float32)
+    x[0::2] = np.float32(0.3) + np.random.default_rng(1).random((B // 2, 3), dtype=np.float32) * np.float32(1e-6)
+    x[1::2] = 1.5
+    nb9, cap9, bucket_rows, _ = _plan(B, 9, code)
+    # level 9: the four x-pair entries of a point go to the buckets of their even corners' rows
+    rows9 = c_oracle.grid_indices(x[:1], OFF, CH, S, H)[9][0][0::2] // CH
+    per_bucket = np.bincount(rows9 // bucket_rows, minlength=nb9) * (B // 2)
+    assert np.maximum(per_bucket - cap9, 0).sum() > B * 8 // 16      # the excess of its buckets exceeds the level's spill list
+    nd = np.float32 if dt == torch.float32 else np.float16
+    g = (np.random.default_rng(8).standard_normal((L, B, CH)) * 0.1).astype(nd)
+    got = _run_bucketed(x, g, dt, times=1)
+    want = c_oracle.grid_backward(g, x, OFF, int(OFF[-1]), S, H)
+    assert np.isfinite(got).all() and np.all(got[want == 0] == 0)
+    rel = np.linalg.norm(got - want) / np.linalg.norm(want)
+    assert rel < (1e-4 if dt == torch.float32 else 0.25), rel
+    # the levels that never overflow (level 0: one bucket, its pool holds the level's worst case) stay exact
+    lvl0 = slice(0, int(OFF[1]))
+    np.testing.assert_allclose(got[lvl0], want[lvl0], rtol=1e-5 if dt == torch.float32 else 2e-3,
+                               atol=1e-6 if dt == torch.float32 else 2e-3)
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.float16])
