@@ -268,20 +268,54 @@ def run_nerfmvl(args):
         return o[sel][None].contiguous(), d[sel][None].contiguous(), gt[sel][None].contiguous()
 
     n_pre = 192  # let the occupancy grid settle (12 grid updates) before anything is timed
-    batches = [batch(s) for s in range(n_pre + args.warmup + args.steps)]
+    n_prof = min(args.steps, 5)
+    batches = [batch(s) for s in range(n_pre + args.warmup + args.steps + n_prof)]
     for s in range(n_pre + args.warmup):
         trainer.step(*batches[s])
     torch.cuda.synchronize()
+    grid_calls = ["lnh_grid_encode_forward", "lnh_grid_encode_backward_ws", "lnh_grid_encode_backward"]
+    _hip.enable_timers(grid_calls)
     t0 = time.perf_counter()
     counts = []
     for s in range(args.steps):
         loss = trainer.step(*batches[n_pre + args.warmup + s])
         counts.append(model.step_counter[(model.local_step - 1) % 16, 0])
+    host_ms = (time.perf_counter() - t0) * 1e3 / args.steps
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    n_rays = sum(b[0].shape[1] for b in batches[n_pre + args.warmup:])
-    samples = float(torch.stack(counts).float().mean()) / (n_rays / args.steps)
+    timers = _hip.disable_timers()
+    n_rays = sum(b[0].shape[1] for b in batches[n_pre + args.warmup:n_pre + args.warmup + args.steps])
+    samples_total = float(torch.stack(counts).float().sum())
+    samples = samples_total / n_rays
     occ = float((model.density_grid > min(model.mean_density, model.density_thresh)).float().mean())
+
+    def event_table(tm):
+        out = {}
+        for name, evs in tm.items():
+            ms = [a.elapsed_time(b) for a, b, _ in evs]
+            out[name] = {"calls": len(ms), "total_ms": round(sum(ms), 3), "avg_us": round(1e3 * sum(ms) / len(ms), 2),
+                         "points": int(sum(t for _, _, t in evs if t))}
+        return out
+    kernels = event_table(timers)
+    # every entry point of a few more steps (outside the timed region: the events cost ~4 %)
+    _hip.enable_timers(None)
+    for s in range(n_prof):
+        trainer.step(*batches[n_pre + args.warmup + args.steps + s])
+    torch.cuda.synchronize()
+    per_call = {k: v["avg_us"] for k, v in event_table(_hip.disable_timers()).items()}
+
+    def roof(name, per_pt):
+        k = kernels.get(name)
+        if not k or not k["points"]:
+            return None
+        gbs = per_pt * k["points"] / (k["total_ms"] * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "bytes_per_point": per_pt,
+                "points_per_launch": int(k["points"] / k["calls"]), "avg_launch_us": k["avg_us"],
+                "algorithmic_bytes_per_launch": int(per_pt * k["points"] / k["calls"]),
+                "note": "marched samples per launch are two orders of magnitude below the dense workload's 3.4 M: the launch "
+                        "is dominated by per-launch costs (bucket images, cursors), not by bytes per point"}
+    bwd_name = "lnh_grid_encode_backward_ws" if "lnh_grid_encode_backward_ws" in kernels else "lnh_grid_encode_backward"
     print(json.dumps({
         "metric": "train rays/sec (occupancy-grid sampling + encode + MLP + ragged composite + bwd), NeRF-MVL-shaped 256x1800",
         "value": round(n_rays / elapsed, 1), "unit": "rays/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -292,7 +326,12 @@ def run_nerfmvl(args):
                                "16 steps), synthetic 2 m sphere seen from a 6 m ring",
                    "rays_per_gpu_per_step": int(n_rays / args.steps), "mean_samples_per_ray": round(samples, 2),
                    "dense_samples_per_ray": NUM_STEPS + UPSAMPLE, "occupied_cell_fraction": round(occ, 5),
-                   "pretrain_steps": n_pre, "final_loss": round(float(loss.detach()), 5)}}))
+                   "pretrain_steps": n_pre, "final_loss": round(float(loss.detach()), 5),
+                   "render_path": "fused ragged chain (nerf/fused.py FusedLidarRagged) + fused table optimizer"
+                   if trainer.table is not None else "modular density()/color() path"},
+        "samples_per_s": round(samples_total / elapsed, 1), "host_enqueue_ms_per_step": round(host_ms, 3),
+        "roofline": roof(bwd_name, GRID_BWD_BYTES), "roofline_fwd": roof("lnh_grid_encode_forward", GRID_FWD_BYTES),
+        "kernels": kernels, "entry_points_avg_us": per_call}))
 
 
 def main():

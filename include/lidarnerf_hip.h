@@ -360,6 +360,31 @@ LNH_API int lnh_lidar_loss(const float *depth, const float *image, const float *
                            float alpha_r, float alpha_i, float *loss, float *grad_depth, float *grad_image,
                            lnh_stream_t stream);
 /*
+ * Element-wise stages of the occupancy-grid render chain over the marcher's flat sample list [M] (BASELINE config 4; the
+ * reference kept torch-ngp's kernels, raymarching.cu:331-772, and dropped this caller — what runs between them are the
+ * tensor expressions of network.py:162-237 on [M, *] tensors: one launch each here).
+ * lnh_ragged_points: x01 = (xyz + bound) / (2 bound) (gridencoder/grid.py:213).
+ * lnh_ragged_pack_weights: fp32 master matrices -> wsig16 [64,32 | 16,64] and wcol16 [64,96 (wc0[:, :n_in], zero-padded) |
+ *   64,64 | 16,64 (wc2 in rows 0..1)] — the flat vectors of lnh_density_mlp_* / lnh_mlp_*(input_dim 96, one hidden matrix).
+ * lnh_ragged_color_input: cin [M,96] = [x | sin(2^f x), sin(2^f x + pi/2), f < degree (freqencoder.cu:34-63) of the
+ *   sample's direction | geo_feat = h16[m, 1:16] | 0] (network.py:215-221), in the MLP element type.
+ * lnh_ragged_color_output: rgb [M,2] f32 = sigmoid(y16[m, 0:2]) (network.py:224).  _backward: grad_y16 [M,16] =
+ *   (grad_rgb * rgb * (1 - rgb) | 0).
+ * lnh_ragged_grad_rows: grad_h16[m,0] = grad_sigma[m] * density_scale * exp(clamp(h16[m,0], -15, 15)) (trunc_exp backward,
+ *   activation.py:17-19), grad_h16[m,1:16] = grad_cin[m, n_dir : n_dir + 15], n_dir = 3 + 6 * degree.
+ */
+LNH_API int lnh_ragged_points(const float *xyz, float bound, uint32_t M, float *x01, lnh_stream_t stream);
+LNH_API int lnh_ragged_pack_weights(const float *ws0, uint32_t ld_s0, const float *ws1, uint32_t ld_s1, const float *wc0,
+                                    uint32_t ld_c0, uint32_t n_in, const float *wc1, uint32_t ld_c1, const float *wc2,
+                                    uint32_t ld_c2, void *wsig16, void *wcol16, lnh_stream_t stream);
+LNH_API int lnh_ragged_color_input(const float *dirs, const void *h16, uint32_t M, uint32_t degree, void *cin,
+                                   lnh_stream_t stream);
+LNH_API int lnh_ragged_color_output(const void *y16, uint32_t M, float *rgb, lnh_stream_t stream);
+LNH_API int lnh_ragged_color_output_backward(const float *grad_rgb, const float *rgb, uint32_t M, void *grad_y16,
+                                             lnh_stream_t stream);
+LNH_API int lnh_ragged_grad_rows(const float *grad_sigma, float density_scale, const void *h16, const void *grad_cin,
+                                 uint32_t degree, uint32_t M, void *grad_h16, lnh_stream_t stream);
+/*
  * lnh_lidar_color_forward: LiDAR colour head (network.py:199-237 with cal_lidar_color=True) on merged samples:
  * rgb[n,i,0:2] = sigmoid(MLP([freq(d_n) | geo_feat(sample)])) where weights[n,i] > 1e-4, else 0.
  * h16 [N*T,16] sigma-net rows in point order, perm [N,T], cdir [N,64] f32 = W0[:, :75] freq(d_n) (per ray),
@@ -453,6 +478,16 @@ LNH_API int lnh_density_mlp_forward_bf16(const void *features, const void *weigh
 LNH_API int lnh_density_mlp_backward_bf16(const void *grad_h16, const void *features, const void *weights, uint32_t B,
                                      uint32_t T_cur, uint32_t T_tot, uint32_t slot_off, void *grad_features,
                                      float *grad_weights, lnh_stream_t stream);
+LNH_API int lnh_ragged_pack_weights_bf16(const float *ws0, uint32_t ld_s0, const float *ws1, uint32_t ld_s1, const float *wc0,
+                                         uint32_t ld_c0, uint32_t n_in, const float *wc1, uint32_t ld_c1, const float *wc2,
+                                         uint32_t ld_c2, void *wsig16, void *wcol16, lnh_stream_t stream);
+LNH_API int lnh_ragged_color_input_bf16(const float *dirs, const void *h16, uint32_t M, uint32_t degree, void *cin,
+                                        lnh_stream_t stream);
+LNH_API int lnh_ragged_color_output_bf16(const void *y16, uint32_t M, float *rgb, lnh_stream_t stream);
+LNH_API int lnh_ragged_color_output_backward_bf16(const float *grad_rgb, const float *rgb, uint32_t M, void *grad_y16,
+                                                  lnh_stream_t stream);
+LNH_API int lnh_ragged_grad_rows_bf16(const float *grad_sigma, float density_scale, const void *h16, const void *grad_cin,
+                                      uint32_t degree, uint32_t M, void *grad_h16, lnh_stream_t stream);
 LNH_API int lnh_lidar_dir_term_bf16(const float *dir_features, const float *w0, uint32_t ldw, uint32_t N, uint32_t K,
                                float *features16, float *cdir, lnh_stream_t stream);
 LNH_API int lnh_lidar_dir_term_freq_bf16(const float *dirs, uint32_t degree, const float *w0, uint32_t ldw, uint32_t N,

@@ -428,3 +428,136 @@ def render_lidar(model, rays_o, rays_d, num_steps, upsample_steps, perturb, nois
     if MASK_STATS is not None:
         MASK_STATS.append((weights > 1e-4).float().mean())
     return {"depth_lidar": depth.view(*prefix), "image_lidar": image.view(*prefix, 2), "weights_sum_lidar": ws}
+
+
+# ------------------------------------------------------------------------------------------------ occupancy-grid chain
+class FusedLidarRagged(Function):
+    """The occupancy-grid render step (BASELINE config 4; renderer.run_cuda) as one autograd node over the marcher's ragged
+    samples: hash-grid encode -> sigma net -> LiDAR colour head -> ragged compositing, and the mirror image backward, on the
+    same kernels as the dense chain.  What the modular path does through four autograd nodes, a torch.cat of [M, 90] colour
+    inputs in fp32 and per-module casts, runs here as ~12 launches forward / ~12 backward; the hash-table gradient comes out
+    of the bucketed scatter-reduce in fp16 and feeds the fused table optimizer (LidarTrainer) like the dense chain's.
+
+    Differences to the dense chain that are properties of the path, not of this implementation: every marched sample lies in
+    an occupied cell, so the colour head runs on ALL of them (no weight mask) through the generic MFMA MLP kernel on an
+    assembled [M, 96] input — [freq(d) (75) | geo_feat (15) | 0 (6)] — rather than the per-ray direction-term kernels
+    (which need the dense [N, T] layout)."""
+
+    @staticmethod
+    @_no_autocast
+    def forward(ctx, xyzs, dirs, deltas, rays, rays_o, rays_d, embeddings, ws0, ws1, wc0, wc1, wc2, model, spec, mdt,
+                T_thresh):
+        sfx = _hip.mlp_suffix(mdt)
+        enc = spec.grid
+        dev = xyzs.device
+        M, N, L = xyzs.shape[0], rays.shape[0], enc.num_levels
+        bound, ds = float(model.bound), float(model.density_scale)
+        table16 = table16_of(spec.table_param, embeddings, model.training)
+        kd, deg = spec.n_dir, int(spec.dir_freq_degree)  # 75, 12
+        mats = [m.detach() if m.dtype == torch.float32 and m.stride(-1) == 1 else m.detach().float().contiguous()
+                for m in (ws0, ws1, wc0, wc1, wc2)]
+        wsig16 = torch.empty(64 * 32 + 16 * 64, dtype=mdt, device=dev)
+        wcol16 = torch.empty(64 * 96 + 64 * 64 + 16 * 64, dtype=mdt, device=dev)
+        _hip.call("lnh_ragged_pack_weights" + sfx, mats[0].data_ptr(), mats[0].stride(0), mats[1].data_ptr(),
+                  mats[1].stride(0), mats[2].data_ptr(), mats[2].stride(0), kd + 15, mats[3].data_ptr(), mats[3].stride(0),
+                  mats[4].data_ptr(), mats[4].stride(0), wsig16.data_ptr(), wcol16.data_ptr())
+        x01 = torch.empty((M, 3), dtype=torch.float32, device=dev)
+        _hip.call("lnh_ragged_points", xyzs.data_ptr(), bound, M, x01.data_ptr())
+        feat = torch.empty((L, M, 2), dtype=torch.half, device=dev)
+        _hip.call("lnh_grid_encode_forward", x01.data_ptr(), table16.data_ptr(), enc._offsets_host.data_ptr(),
+                  feat.data_ptr(), M, 3, 2, L, enc.log2_scale, enc.base_resolution, None, 0, 0, 0, _hip.LNH_F16, tag=M)
+        h16 = torch.empty((M, 16), dtype=mdt, device=dev)
+        sigma = torch.empty(M, dtype=torch.float32, device=dev)
+        _hip.call("lnh_density_mlp_forward" + sfx, feat.data_ptr(), wsig16.data_ptr(), M, M, M, 0, 0, h16.data_ptr(),
+                  sigma.data_ptr())
+        # colour head: [freq(d) | geo_feat | 0] -> MFMA MLP 96 -> 64 -> 64 -> 16 -> sigmoid of the first two outputs
+        cin = torch.empty((M, 96), dtype=mdt, device=dev)
+        _hip.call("lnh_ragged_color_input" + sfx, dirs.data_ptr(), h16.data_ptr(), M, deg, cin.data_ptr())
+        y = torch.empty((M, 16), dtype=mdt, device=dev)
+        _hip.call("lnh_mlp_forward" + sfx, cin.data_ptr(), wcol16.data_ptr(), M, 96, 16, 64, 1, 0, 6, None, y.data_ptr())
+        rgb = torch.empty((M, 2), dtype=torch.float32, device=dev)
+        _hip.call("lnh_ragged_color_output" + sfx, y.data_ptr(), M, rgb.data_ptr())
+        sig_s = sigma * ds if ds != 1.0 else sigma
+        ws = torch.empty(N, dtype=torch.float32, device=dev)
+        depth = torch.empty(N, dtype=torch.float32, device=dev)
+        image = torch.empty((N, 2), dtype=torch.float32, device=dev)
+        _hip.call("lnh_lidar_composite_rays_train_forward", sig_s.data_ptr(), rgb.data_ptr(), deltas.data_ptr(),
+                  xyzs.data_ptr(), rays_o.data_ptr(), rays_d.data_ptr(), rays.data_ptr(), M, N, 2, float(T_thresh),
+                  ws.data_ptr(), depth.data_ptr(), image.data_ptr())
+        ctx.save_for_backward(x01, feat, h16, sig_s, cin, rgb, deltas, xyzs, rays_o, rays_d, rays, ws, depth, image, wsig16,
+                              wcol16)
+        ctx.meta = (model, enc, spec.table_param, mdt, float(T_thresh), kd, ds,
+                    (embeddings.dtype, ws0.dtype, ws1.dtype, wc0.dtype, wc1.dtype, wc2.dtype))
+        ctx.set_materialize_grads(False)
+        return ws, depth, image
+
+    @staticmethod
+    @_no_autocast
+    def backward(ctx, g_ws, g_depth, g_image):
+        (x01, feat, h16, sig_s, cin, rgb, deltas, xyzs, rays_o, rays_d, rays, ws, depth, image, wsig16,
+         wcol16) = ctx.saved_tensors
+        model, enc, table_param, mdt, T_thresh, kd, ds, dts = ctx.meta
+        sfx = _hip.mlp_suffix(mdt)
+        dev = x01.device
+        M, N, L = x01.shape[0], rays.shape[0], enc.num_levels
+        zN = lambda g, shape: torch.zeros(shape, dtype=torch.float32, device=dev) if g is None else g.contiguous().float()
+        g_ws, g_depth, g_image = zN(g_ws, (N,)), zN(g_depth, (N,)), zN(g_image, (N, 2))
+        gs = torch.zeros(M, dtype=torch.float32, device=dev)
+        gf = torch.zeros((M, 2), dtype=torch.float32, device=dev)
+        _hip.call("lnh_lidar_composite_rays_train_backward", g_ws.data_ptr(), g_depth.data_ptr(), g_image.data_ptr(),
+                  sig_s.data_ptr(), rgb.data_ptr(), deltas.data_ptr(), xyzs.data_ptr(), rays_o.data_ptr(),
+                  rays_d.data_ptr(), rays.data_ptr(), ws.data_ptr(), depth.data_ptr(), image.data_ptr(), M, N, 2,
+                  T_thresh, gs.data_ptr(), gf.data_ptr())
+        gy = torch.empty((M, 16), dtype=mdt, device=dev)
+        _hip.call("lnh_ragged_color_output_backward" + sfx, gf.data_ptr(), rgb.data_ptr(), M, gy.data_ptr())
+        gx = torch.empty((M, 96), dtype=mdt, device=dev)
+        n_col, n_sig = wcol16.numel(), wsig16.numel()
+        zeros = torch.zeros(n_col + n_sig, dtype=torch.float32, device=dev)
+        g_wcol, g_wsig = zeros[:n_col], zeros[n_col:]
+        _hip.call("lnh_mlp_backward" + sfx, gy.data_ptr(), cin.data_ptr(), wcol16.data_ptr(), M, 96, 16, 64, 1, 0, 6,
+                  gx.data_ptr(), g_wcol.data_ptr())
+        g_h16 = torch.empty((M, 16), dtype=mdt, device=dev)
+        _hip.call("lnh_ragged_grad_rows" + sfx, gs.data_ptr(), ds, h16.data_ptr(), gx.data_ptr(), (kd - 3) // 6, M,
+                  g_h16.data_ptr())
+        g_feat = torch.empty((L, M, 2), dtype=torch.half, device=dev)
+        _hip.call("lnh_density_mlp_backward" + sfx, g_h16.data_ptr(), feat.data_ptr(), wsig16.data_ptr(), M, M, M, 0,
+                  g_feat.data_ptr(), g_wsig.data_ptr())
+        g_table16 = torch.zeros((int(enc._offsets_host[-1]), 2), dtype=torch.half, device=dev)
+        world = parallel.world_size()
+        if world > 1:
+            for handle in _grid_bwd_overlapped(g_feat, x01, g_table16, enc, M, table_param):
+                handle.wait()
+        else:
+            _grid_bwd(g_feat, x01, g_table16, enc, M)
+        if getattr(table_param, "_lnh_keep_grad16", False):
+            table_param._lnh_grad16, table_param._lnh_grad16_div = g_table16, world
+            g_table = None
+        else:
+            g_table = g_table16.to(dts[0])
+            if world > 1:
+                g_table.div_(world)
+        g_wc0 = g_wcol[:64 * 96].view(64, 96)[:, :kd + 15]
+        g_wc1 = g_wcol[64 * 96:64 * 96 + 64 * 64].view(64, 64)
+        g_wc2 = g_wcol[64 * 96 + 64 * 64:].view(16, 64)[:2]
+        return (None, None, None, None, None, None, g_table, g_wsig[:64 * 32].view(64, 32).to(dts[1]),
+                g_wsig[64 * 32:].view(16, 64).to(dts[2]), g_wc0.to(dts[3]), g_wc1.to(dts[4]), g_wc2.to(dts[5]),
+                None, None, None, None)
+
+
+def ragged_supported(model):
+    """The occupancy-grid chain needs the same field shapes as the dense chain (and the in-kernel frequency encoder)."""
+    try:
+        sp = model.fused_spec()
+    except AttributeError:
+        return False
+    return supported(model, True, 16, 16) and getattr(sp, "dir_freq_degree", None) is not None \
+        and 3 + 6 * sp.dir_freq_degree == sp.n_dir and sp.n_dir + 15 <= 96
+
+
+def render_lidar_ragged(model, xyzs, dirs, deltas, rays, rays_o, rays_d, T_thresh):
+    """Field + compositing of renderer.run_cuda on the marcher's samples -> (weights_sum [N], depth [N], image [N, 2])."""
+    from ..ffmlp.ffmlp import mlp_dtype
+    sp = model.fused_spec()
+    return FusedLidarRagged.apply(xyzs.contiguous(), dirs.contiguous(), deltas.contiguous(), rays.contiguous(),
+                                  rays_o.contiguous(), rays_d.contiguous(), sp.table, sp.ws0, sp.ws1, sp.wc0, sp.wc1, sp.wc2,
+                                  model, sp, mlp_dtype(), T_thresh)

@@ -258,7 +258,12 @@ class NeRFRenderer(nn.Module):
         rays_d = rays_d.contiguous().view(-1, 3).float()
         N = rays_o.shape[0]
         nears = torch.full((N,), float(self.min_near_lidar), dtype=torch.float32, device=rays_o.device)
-        fars = nears * 81.0
+        # 1 m .. 81 m, cut at the ray's exit from the box: the marcher clamps sample POSITIONS to the box, and the compositing
+        # kernel recovers a sample's depth from its position ((xyz - o) . d) — a sample marched past the box would enter
+        # the depth sum with a shortened z (the dense path keeps the true z next to the clamped position, renderer.py:164-167)
+        aabb = self.aabb_train if self.training else self.aabb_infer
+        _, far_box = raymarching.near_far_from_aabb(rays_o, rays_d, aabb, float(self.min_near_lidar))
+        fars = torch.minimum(nears * 81.0, far_box)
         if self.training:
             counter = self.step_counter[self.local_step % 16]
             counter.zero_()
@@ -273,6 +278,13 @@ class NeRFRenderer(nn.Module):
             z = torch.zeros(N, device=rays_o.device)
             return {"depth_lidar": z.view(*prefix), "image_lidar": torch.zeros(*prefix, self.out_dim, device=z.device),
                     "weights_sum_lidar": z}
+        from . import fused
+        if (getattr(self, "fused_lidar", False) and xyzs.is_cuda and torch.is_autocast_enabled()
+                and fused.ragged_supported(self)):
+            # one autograd node over the ragged samples (encode -> sigma net -> colour head -> compositing)
+            ws, depth, image = fused.render_lidar_ragged(self, xyzs, dirs, deltas, rays, rays_o, rays_d, T_thresh)
+            return {"depth_lidar": depth.view(*prefix), "image_lidar": image.view(*prefix, self.out_dim),
+                    "weights_sum_lidar": ws}
         dens = self.density(xyzs)
         sigmas = dens["sigma"].float() * self.density_scale
         # every marched sample lies in an occupied cell: the colour head runs on all of them (no weight mask)

@@ -91,10 +91,10 @@ class LidarTrainer:
         self.epoch, self.stats = 0, {"loss": [], "valid_loss": [], "results": [], "checkpoints": [], "best_result": None}
         on_gpu = all(p.is_cuda for g in params for p in g["params"])
         self.table, self.sharded = None, False
-        # occupancy-grid sampling renders through the modular density()/color() path: the table gradient is a normal .grad
         self.occupancy = bool(getattr(model, "cuda_ray", False))
         self.update_extra_interval, self.global_step = 16, 0
-        if fused_table_optimizer and fp16 and on_gpu and hasattr(model, "fused_spec") and not self.occupancy:
+        if fused_table_optimizer and fp16 and on_gpu and hasattr(model, "fused_spec") and \
+                (not self.occupancy or self._ragged_chain(model)):
             try:
                 tp = model.fused_spec().table_param
             except AttributeError:
@@ -126,6 +126,14 @@ class LidarTrainer:
         self.scheduler = torch.optim.lr_scheduler.LambdaLR(self.optimizer, lambda it: 0.1 ** min(it / iters, 1))
         self.scaler = torch.amp.GradScaler("cuda", enabled=fp16)
         self.params = [p for g in self.optimizer.param_groups for p in g["params"]]
+
+    @staticmethod
+    def _ragged_chain(model):
+        """Occupancy-grid sampling renders through the fused ragged chain (nerf/fused.py) when the field has the shapes it is
+        built for: the table gradient then arrives in fp16 like the dense chain's; otherwise through the modular density() /
+        color() path, where it is a normal .grad and the table stays in torch.optim.Adam."""
+        from . import fused
+        return bool(getattr(model, "fused_lidar", False)) and fused.ragged_supported(model)
 
     def loss(self, rays_o, rays_d, images_lidar, patch=(1, 1)):
         out = self.model.render(rays_o, rays_d, cal_lidar_color=True, staged=False, perturb=True,
