@@ -422,7 +422,8 @@ def main():
     # HIP events around the encoder entry points only (the roofline candidates): every timed call costs two event
     # records on the stream, and timing all ~25 calls of a step inflates the step by ~4 % (--kernel-timers for all)
     grid_calls = ["lnh_grid_encode_forward", "lnh_grid_encode_forward_mapped", "lnh_grid_encode_backward",
-                  "lnh_grid_encode_backward_ws", "lnh_grid_encode_backward_ws_levels"]
+                  "lnh_grid_encode_backward_ws", "lnh_grid_encode_backward_ws_levels", "lnh_grid_encode_backward_ws_begin",
+                  "lnh_grid_encode_backward_ws_finish"]
     sfx = "_bf16" if args.mlp_dtype == "bf16" else ""
     # (the colour head's forward runs inside the fused forward tail — merged weights + colour head + compositing sums of a
     #  ray in one kernel — whose whole time is charged to the MLPs here)
@@ -507,12 +508,14 @@ def main():
         return
     rays_total = args.rays * world * args.steps
     kernels = event_table(timers)
-    if "lnh_grid_encode_backward_ws_levels" in kernels:  # DP: the backward runs as 4 level windows -> one logical launch
-        kw = kernels.pop("lnh_grid_encode_backward_ws_levels")
-        kernels["lnh_grid_encode_backward_ws"] = {"calls": args.steps, "total_ms": kw["total_ms"],
-                                                  "avg_us": round(1e3 * kw["total_ms"] / args.steps, 2),
+    if "lnh_grid_encode_backward_ws_begin" in kernels:  # DP: one scatter (begin) + 4 window reduces (finish) = one logical launch
+        kb, kf = kernels.pop("lnh_grid_encode_backward_ws_begin"), kernels.pop("lnh_grid_encode_backward_ws_finish")
+        tot = kb["total_ms"] + kf["total_ms"]
+        kernels["lnh_grid_encode_backward_ws"] = {"calls": args.steps, "total_ms": round(tot, 3),
+                                                  "avg_us": round(1e3 * tot / args.steps, 2),
                                                   "points": args.rays * (NUM_STEPS + UPSAMPLE) * args.steps,
-                                                  "note": "sum of 4 level-window calls per step"}
+                                                  "note": "begin (scatter pass) + 4 level-window finish calls (reduce pass) per step",
+                                                  "begin_avg_us": kb["avg_us"], "finish_avg_us": kf["avg_us"]}
     fwd_names = ("lnh_grid_encode_forward", "lnh_grid_encode_forward_mapped")
     bwd_names = ("lnh_grid_encode_backward", "lnh_grid_encode_backward_ws")
     dom = max(fwd_names + bwd_names, key=lambda k: kernels.get(k, {}).get("total_ms", 0))

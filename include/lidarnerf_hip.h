@@ -100,6 +100,21 @@ LNH_API int lnh_grid_encode_backward_ws_levels(const void *grad, const float *in
                                                float S, uint32_t H, uint32_t gridtype, int align_corners,
                                                uint32_t interp, int dtype, void *workspace, uint64_t workspace_bytes,
                                                uint32_t level_begin, uint32_t level_end, lnh_stream_t stream);
+/* The same backward in two steps for a data-parallel caller (bit-identical result): `_begin` runs everything except the
+ * reduce pass of the (last) chunk; `_finish` runs that reduce pass for the levels [level_begin, level_end), after which
+ * their rows of grad_embeddings are final.  Call `_begin` once, then `_finish` for consecutive level windows covering
+ * [0, L), with the same arguments and the same workspace on the same stream: the gradient of a finished window can go to
+ * the all-reduce while the next window is being reduced, and the scatter pass is NOT cut into windows (which costs it a
+ * quarter of its speed). */
+LNH_API int lnh_grid_encode_backward_ws_begin(const void *grad, const float *inputs, const int32_t *offsets_host,
+                                              void *grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                                              float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
+                                              int dtype, void *workspace, uint64_t workspace_bytes, lnh_stream_t stream);
+LNH_API int lnh_grid_encode_backward_ws_finish(const void *grad, const float *inputs, const int32_t *offsets_host,
+                                               void *grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                                               float S, uint32_t H, uint32_t gridtype, int align_corners,
+                                               uint32_t interp, int dtype, void *workspace, uint64_t workspace_bytes,
+                                               uint32_t level_begin, uint32_t level_end, lnh_stream_t stream);
 /*
  * Replaces grad_total_variation  gridencoder.h:43-55 (gridencoder.cu:695-910): adds the TV-regulariser gradient
  * of the cells visited by `inputs` into `grad` (same layout as embeddings).

@@ -1247,19 +1247,35 @@ template <typename T>
 int launch_backward_bucketed_chunk(const T *grad, const float *inputs, T *ge, uint32_t B, uint32_t L, const GridMeta &m,
                                    uint32_t align, uint32_t interp, void *workspace, uint64_t workspace_bytes,
                                    hipStream_t s, uint32_t level_begin, uint32_t level_end, uint32_t b_begin,
-                                   uint32_t B_all, uint32_t B_plan);
+                                   uint32_t B_all, uint32_t B_plan, int phase = 0);
 
+// split = 0: the whole backward of the levels [level_begin, level_end).
+// split = 1 ("begin"): every chunk but the last completely (all levels), then the SCATTER pass of the last chunk.
+// split = 2 ("finish"): the REDUCE pass of the last chunk for the levels [level_begin, level_end) — after it the gradient of
+//           those levels is final.  A data-parallel caller runs begin once and finish per level window, handing each window
+//           to the all-reduce while the next is being reduced: the scatter pass stays in one piece (cut into level windows it
+//           loses its level-fastest interleave: 2 windows cost 444 + 453 us against 707 us, profiles/r03_bwd_pipeline.txt).
 template <typename T>
 int launch_backward_bucketed(const T *grad, const float *inputs, T *ge, uint32_t B, uint32_t L, const GridMeta &m,
                              uint32_t align, uint32_t interp, void *workspace, uint64_t workspace_bytes,
-                             hipStream_t s, uint32_t level_begin = 0, uint32_t level_end = 0xffffffffu) {
+                             hipStream_t s, uint32_t level_begin = 0, uint32_t level_end = 0xffffffffu, int split = 0) {
     if (level_end > L) level_end = L;
     if (level_begin >= level_end) return LNH_OK;
     const uint32_t step = chunk_points(B, align == 0 && interp == 0);
     for (uint32_t b0 = 0; b0 < B; b0 += step) {
+        const bool last = b0 + step >= B;
+        int phase = 0;
+        uint32_t l0 = level_begin, l1 = level_end;
+        if (split == 1) {
+            l0 = 0;
+            l1 = L;
+            phase = last ? 1 : 0;
+        } else if (split == 2) {
+            if (!last) continue;
+            phase = 2;
+        }
         const int rc = launch_backward_bucketed_chunk<T>(grad, inputs, ge, std::min(step, B - b0), L, m, align, interp,
-                                                         workspace, workspace_bytes, s, level_begin, level_end, b0, B,
-                                                         step);
+                                                         workspace, workspace_bytes, s, l0, l1, b0, B, step, phase);
         if (rc) return rc;
     }
     return LNH_OK;
@@ -1269,7 +1285,8 @@ template <typename T>
 int launch_backward_bucketed_chunk(const T *grad, const float *inputs, T *ge, uint32_t B, uint32_t L, const GridMeta &m,
                                    uint32_t align, uint32_t interp, void *workspace, uint64_t workspace_bytes,
                                    hipStream_t s, uint32_t level_begin, uint32_t level_end, uint32_t b_begin,
-                                   uint32_t B_all, uint32_t B_plan) {
+                                   uint32_t B_all, uint32_t B_plan, int phase) {
+    // phase 0: scatter + reduce; 1: (zeroed cursors +) scatter only; 2: reduce only, of a scatter an earlier call has run
     BucketPlan plan;
     uint32_t nbt = 0;
     const bool plain = align == 0 && interp == 0;
@@ -1298,7 +1315,7 @@ int launch_backward_bucketed_chunk(const T *grad, const float *inputs, T *ge, ui
     uint32_t *spill_cursor = cursor + nbt, *done = spill_cursor + L;
     char *pool = reinterpret_cast<char *>(workspace) + cursor_bytes;
     (void)hipGetLastError();
-    if (hipMemsetAsync(cursor, 0, cursor_bytes, s) != hipSuccess) {
+    if (phase != 2 && hipMemsetAsync(cursor, 0, cursor_bytes, s) != hipSuccess) {
         lnh_set_error("grid backward: hipMemsetAsync failed");
         return LNH_ERR_LAUNCH;
     }
@@ -1309,14 +1326,15 @@ int launch_backward_bucketed_chunk(const T *grad, const float *inputs, T *ge, ui
     const uint32_t n_win = level_end - level_begin;
     bool generic = false;
     for (uint32_t l = level_begin; l < level_end; l++) generic |= level_is_generic(m.lv[l], 3, plain);
-    if (generic)
+    if (phase == 2) {
+    } else if (generic)
         LNH_LAUNCH((k_grid_bwd_scatter<T, 3, 6144>), dim3(div_up(B, 1024) * n_win), dim3(1024), 0, s, grad, inputs, B, m,
                    plan, pool, cursor, spill_cursor, align, interp, n_win, level_begin, b_begin, B_all, ge);
     else
         LNH_LAUNCH((k_grid_bwd_scatter<T, 3, 5120>), dim3(div_up(B, 1024) * n_win), dim3(1024), 0, s, grad, inputs, B, m,
                    plan, pool, cursor, spill_cursor, align, interp, n_win, level_begin, b_begin, B_all, ge);
     int rc = lnh_check_launch("lnh_grid_encode_backward_ws(scatter)");
-    if (rc) return rc;
+    if (rc || phase == 1) return rc;
     auto k = k_grid_bwd_reduce<T>;
     const size_t lds = (size_t)kBucketRows * 2 * sizeof(unsigned long long);
     allow_big_lds(k, lds);
@@ -1715,6 +1733,48 @@ int lnh_grid_encode_backward_ws_levels(const void *grad, const float *inputs, co
     return launch_backward_bucketed<half_t>((const half_t *)grad, inputs, (half_t *)grad_embeddings, B, L, m,
                                             align_corners != 0, interp, workspace, workspace_bytes, s, level_begin,
                                             level_end);
+}
+
+static int backward_ws_split(const void *grad, const float *inputs, const int32_t *offsets_host, void *grad_embeddings,
+                             uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype,
+                             int align_corners, uint32_t interp, int dtype, void *workspace, uint64_t workspace_bytes,
+                             uint32_t level_begin, uint32_t level_end, int split, lnh_stream_t stream) {
+    int rc = check_common(inputs, offsets_host, B, D, C, L, dtype);
+    if (rc) return rc;
+    LNH_REQUIRE(grad && grad_embeddings, LNH_ERR_INVALID_ARG, "grid backward: null grad/grad_embeddings");
+    LNH_REQUIRE(D == 3 && C == 2, LNH_ERR_UNSUPPORTED,
+                "grid backward (bucketed): only D == 3, C == 2 (use lnh_grid_encode_backward otherwise)");
+    LNH_REQUIRE(level_begin <= level_end && level_end <= L, LNH_ERR_INVALID_ARG,
+                "grid backward: need level_begin <= level_end <= L");
+    if (B == 0) return LNH_OK;
+    GridMeta m;
+    LNH_REQUIRE(build_meta(m, offsets_host, D, L, S, H, gridtype, align_corners != 0) == 0, LNH_ERR_INVALID_ARG,
+                "grid: offsets must be increasing and non-negative");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == LNH_F32)
+        return launch_backward_bucketed<float>((const float *)grad, inputs, (float *)grad_embeddings, B, L, m,
+                                               align_corners != 0, interp, workspace, workspace_bytes, s, level_begin,
+                                               level_end, split);
+    return launch_backward_bucketed<half_t>((const half_t *)grad, inputs, (half_t *)grad_embeddings, B, L, m,
+                                            align_corners != 0, interp, workspace, workspace_bytes, s, level_begin,
+                                            level_end, split);
+}
+
+int lnh_grid_encode_backward_ws_begin(const void *grad, const float *inputs, const int32_t *offsets_host,
+                                      void *grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                      uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, int dtype,
+                                      void *workspace, uint64_t workspace_bytes, lnh_stream_t stream) {
+    return backward_ws_split(grad, inputs, offsets_host, grad_embeddings, B, D, C, L, S, H, gridtype, align_corners, interp,
+                             dtype, workspace, workspace_bytes, 0, L, 1, stream);
+}
+
+int lnh_grid_encode_backward_ws_finish(const void *grad, const float *inputs, const int32_t *offsets_host,
+                                       void *grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                       uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, int dtype,
+                                       void *workspace, uint64_t workspace_bytes, uint32_t level_begin, uint32_t level_end,
+                                       lnh_stream_t stream) {
+    return backward_ws_split(grad, inputs, offsets_host, grad_embeddings, B, D, C, L, S, H, gridtype, align_corners, interp,
+                             dtype, workspace, workspace_bytes, level_begin, level_end, 2, stream);
 }
 
 int lnh_grad_total_variation(const void *inputs, const void *embeddings, void *grad, const int32_t *offsets_host,

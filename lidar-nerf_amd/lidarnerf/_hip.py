@@ -21,6 +21,9 @@ _SIGS = {
     "lnh_grid_encode_backward_ws": [P, P, P, P, U32, U32, U32, U32, F32, U32, U32, I32, U32, I32, P, C.c_uint64],
     "lnh_grid_encode_backward_ws_levels": [P, P, P, P, U32, U32, U32, U32, F32, U32, U32, I32, U32, I32, P, C.c_uint64,
                                            U32, U32],
+    "lnh_grid_encode_backward_ws_begin": [P, P, P, P, U32, U32, U32, U32, F32, U32, U32, I32, U32, I32, P, C.c_uint64],
+    "lnh_grid_encode_backward_ws_finish": [P, P, P, P, U32, U32, U32, U32, F32, U32, U32, I32, U32, I32, P, C.c_uint64,
+                                           U32, U32],
     "lnh_grad_total_variation": [P, P, P, P, F32, U32, U32, U32, U32, F32, U32, U32, I32, I32],
     "lnh_grid_corner_indices": [P, P, P, U32, U32, U32, U32, F32, U32, U32, I32],
     "lnh_freq_encode_forward": [P, U32, U32, U32, U32, P],

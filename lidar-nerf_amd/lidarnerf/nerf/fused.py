@@ -96,23 +96,37 @@ def _grid_bwd(g_feat, x01, g_table16, enc, B):
 # Data parallel: level windows of the table gradient.  The gradient of a window is final as soon as its scatter + reduce
 # pair has run, so its all-reduce (fp16, RCCL's own stream) overlaps with the kernels of the following windows; only the
 # last window's ~23 % of the 27 MB stays exposed.  Windows are cut so that each holds a similar number of pool entries.
+import os as _os
 _DP_LEVEL_WINDOWS = ((0, 7), (7, 10), (10, 13), (13, 16))
+if _os.environ.get("LNH_DP_WINDOWS"):  # developer override for A/B runs: "0,10,16" = two windows
+    _c = [int(v) for v in _os.environ["LNH_DP_WINDOWS"].split(",")]
+    _DP_LEVEL_WINDOWS = tuple(zip(_c[:-1], _c[1:]))
 FORCE_DP_WINDOWS = False  # bench.py --dp-windows: take the windowed backward on one GPU too (the exchange is a no-op)
 
 
-def _grid_bwd_overlapped(g_feat, x01, g_table16, enc, B, table_param):
-    """_grid_bwd + parallel.allreduce_half_table, pipelined over level windows.  Returns the handles to wait on."""
+def _grid_bwd_windows(g_feat, x01, g_table16, enc, B):
+    """The table-gradient backward as a generator over level windows: `lnh_grid_encode_backward_ws_begin` once (everything
+    but the last reduce pass: the scatter pass stays in ONE piece — cut into level windows it costs 0.33 ms more per 3.4 M
+    points, profiles/r03_bench_dpwindows*.json of the first cut), then `..._finish` per window; yields (l0, l1) when the rows
+    of that window are final, so that the caller can hand them to a collective while the next window is being reduced."""
     L = enc.num_levels
     off = enc._offsets_host
     need = _hip.lib().lnh_grid_backward_workspace_size(off.data_ptr(), B, 3, 2, L, enc.log2_scale,
                                                        enc.base_resolution, 0, 0, _hip.LNH_F16)
     ws = _workspace(g_feat.device, need)
-    windows = _DP_LEVEL_WINDOWS if L == 16 else ((0, L),)
+    args = (g_feat.data_ptr(), x01.data_ptr(), off.data_ptr(), g_table16.data_ptr(), B, 3, 2, L, enc.log2_scale,
+            enc.base_resolution, 0, 0, 0, _hip.LNH_F16, ws.data_ptr(), ws.numel())
+    _hip.call("lnh_grid_encode_backward_ws_begin", *args, tag=B)
+    for l0, l1 in (_DP_LEVEL_WINDOWS if L == 16 else ((0, L),)):
+        _hip.call("lnh_grid_encode_backward_ws_finish", *args, l0, l1)
+        yield l0, l1
+
+
+def _grid_bwd_overlapped(g_feat, x01, g_table16, enc, B, table_param):
+    """_grid_bwd + parallel.allreduce_half_table, pipelined over level windows.  Returns the handles to wait on."""
+    off = enc._offsets_host
     handles = []
-    for l0, l1 in windows:
-        _hip.call("lnh_grid_encode_backward_ws_levels", g_feat.data_ptr(), x01.data_ptr(), off.data_ptr(),
-                  g_table16.data_ptr(), B, 3, 2, L, enc.log2_scale, enc.base_resolution, 0, 0, 0, _hip.LNH_F16,
-                  ws.data_ptr(), ws.numel(), l0, l1)
+    for l0, l1 in _grid_bwd_windows(g_feat, x01, g_table16, enc, B):
         h = parallel.allreduce_half_table(g_table16[int(off[l0]):int(off[l1])], table_param)
         if h is not None:
             handles.append(h)
@@ -120,28 +134,21 @@ def _grid_bwd_overlapped(g_feat, x01, g_table16, enc, B, table_param):
 
 
 def _grid_bwd_sharded(g_feat, x01, enc, B, table_param):
-    """Data parallel, sharded table optimizer (parallel.py "second cut"): per level window, the table gradient is computed
-    into a window buffer padded to world * shard rows and REDUCE-SCATTERED (fp16, SUM) — each rank keeps only its rows.
+    """Data parallel, sharded table optimizer (parallel.py "second cut"): per level window, the finished rows are copied
+    into a buffer padded to world * shard rows and REDUCE-SCATTERED (fp16, SUM) — each rank keeps only its rows.
     Returns [(r0, r1, shard tensor [s, 2] fp16, handle, padded buffer)] per window of table rows [r0, r1): this rank's shard
     holds rows [r0 + rank * s, r0 + (rank + 1) * s) (cut at r1).  Pipelined like the all-reduce: the collective of a window
-    runs behind the kernels of the following windows."""
+    runs behind the reduce pass of the following windows."""
     import torch.distributed as dist
-    L = enc.num_levels
     off = enc._offsets_host
-    need = _hip.lib().lnh_grid_backward_workspace_size(off.data_ptr(), B, 3, 2, L, enc.log2_scale,
-                                                       enc.base_resolution, 0, 0, _hip.LNH_F16)
-    ws = _workspace(g_feat.device, need)
     world = dist.get_world_size()
-    windows = _DP_LEVEL_WINDOWS if L == 16 else ((0, L),)
+    g_table16 = torch.zeros((int(off[-1]), 2), dtype=torch.half, device=g_feat.device)
     shards = []
-    for l0, l1 in windows:
+    for l0, l1 in _grid_bwd_windows(g_feat, x01, g_table16, enc, B):
         r0, r1 = int(off[l0]), int(off[l1])
         s = parallel.shard_rows(r1 - r0, world)
         padded = torch.zeros((world * s, 2), dtype=torch.half, device=g_feat.device)
-        # the kernels address level l at `base + offsets[l] * 2`: shift the base so that this window lands at row 0
-        _hip.call("lnh_grid_encode_backward_ws_levels", g_feat.data_ptr(), x01.data_ptr(), off.data_ptr(),
-                  padded.data_ptr() - r0 * 2 * 2, B, 3, 2, L, enc.log2_scale, enc.base_resolution, 0, 0, 0, _hip.LNH_F16,
-                  ws.data_ptr(), ws.numel(), l0, l1)
+        padded[:r1 - r0] = g_table16[r0:r1]
         mine = torch.empty((s, 2), dtype=torch.half, device=g_feat.device)
         h = parallel.reduce_scatter_half(padded, mine)
         shards.append((r0, r1, mine, h, padded))

@@ -50,6 +50,16 @@ def test_backward_bucketed_level_windows(dt):
         assert torch.equal(part[:done], full[:done])
         assert float(part[done:].abs().max()) == 0.0 if done < rows else True
     assert torch.equal(part, full)
+    # begin + finish per window (what the data-parallel backward calls: ONE scatter pass, the reduce pass per window)
+    split = torch.zeros_like(full)
+    ws.random_(0, 255)
+    call("lnh_grid_encode_backward_ws_begin", gd, xd, offh, split, B, 3, CH, L, S, H, 0, 0, 0, code, ws, need)
+    for l0, l1 in ((0, 7), (7, 10), (10, 13), (13, L)):
+        before = split.clone()
+        call("lnh_grid_encode_backward_ws_finish", gd, xd, offh, split, B, 3, CH, L, S, H, 0, 0, 0, code, ws, need, l0, l1)
+        changed = (split != before).any(1).nonzero()
+        assert changed.numel() and int(changed.min()) >= int(OFF[l0]) and int(changed.max()) < int(OFF[l1])
+    assert torch.equal(split, full)
     call("lnh_grid_encode_backward_ws_levels", gd, xd, offh, part, B, 3, CH, L, S, H, 0, 0, 0, code, ws, need, 5, 5)  # empty
     assert torch.equal(part, full)
     with pytest.raises(RuntimeError, match="level_begin"):
