@@ -352,7 +352,7 @@ def main():
     ap.add_argument("--patch", default="1x1", help="rays drawn as PXxPY pixel patches; 2x8 = the reference's patch epochs "
                                                    "(structural-gradient loss term, utils.py:760-876)")
     ap.add_argument("--dp-windows", action="store_true",
-                    help="1 GPU: run the table-gradient backward the way data parallel does (4 level windows, the exchange a "
+                    help="1 GPU: run the table-gradient backward the way data parallel does (one scatter pass + the reduce pass per level window, the exchange a "
                          "no-op) to price the compute side of the DP pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="BASELINE.md 3 protocol in full: 10 warm-up + 30 timed steps per leg")
@@ -501,20 +501,20 @@ def main():
         comm = {"ms_per_step_inclusive": round(1e3 * elapsed / args.steps, 3),
                 "ms_per_step_without_allreduce": round(1e3 * t_nc, 3),
                 "allreduce_exposed_ms": round(1e3 * (elapsed / args.steps - t_nc), 3),
-                "payload": "hash-table gradient 27.4 MB fp16 (4 level windows, overlapped with the backward kernels) + "
+                "payload": "hash-table gradient 27.4 MB fp16 (2 level windows: the first one's all-reduce runs behind the second one's reduce pass) + "
                            "21.5 k MLP gradients fp32 (one flat buffer), sum over ranks, RCCL"}
 
     if rank != 0:
         return
     rays_total = args.rays * world * args.steps
     kernels = event_table(timers)
-    if "lnh_grid_encode_backward_ws_begin" in kernels:  # DP: one scatter (begin) + 4 window reduces (finish) = one logical launch
+    if "lnh_grid_encode_backward_ws_begin" in kernels:  # DP: one scatter (begin) + the window reduces (finish) = one logical launch
         kb, kf = kernels.pop("lnh_grid_encode_backward_ws_begin"), kernels.pop("lnh_grid_encode_backward_ws_finish")
         tot = kb["total_ms"] + kf["total_ms"]
         kernels["lnh_grid_encode_backward_ws"] = {"calls": args.steps, "total_ms": round(tot, 3),
                                                   "avg_us": round(1e3 * tot / args.steps, 2),
                                                   "points": args.rays * (NUM_STEPS + UPSAMPLE) * args.steps,
-                                                  "note": "begin (scatter pass) + 4 level-window finish calls (reduce pass) per step",
+                                                  "note": "begin (scatter pass) + one finish call (reduce pass) per level window, per step",
                                                   "begin_avg_us": kb["avg_us"], "finish_avg_us": kf["avg_us"]}
     fwd_names = ("lnh_grid_encode_forward", "lnh_grid_encode_forward_mapped")
     bwd_names = ("lnh_grid_encode_backward", "lnh_grid_encode_backward_ws")

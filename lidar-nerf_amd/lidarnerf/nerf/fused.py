@@ -93,11 +93,17 @@ def _grid_bwd(g_feat, x01, g_table16, enc, B):
               B, 3, 2, L, enc.log2_scale, enc.base_resolution, 0, 0, 0, _hip.LNH_F16, ws.data_ptr(), ws.numel(), tag=B)
 
 
-# Data parallel: level windows of the table gradient.  The gradient of a window is final as soon as its scatter + reduce
-# pair has run, so its all-reduce (fp16, RCCL's own stream) overlaps with the kernels of the following windows; only the
-# last window's ~23 % of the 27 MB stays exposed.  Windows are cut so that each holds a similar number of pool entries.
+# Data parallel: level windows of the table gradient.  The scatter pass of the backward runs once for all levels
+# (lnh_grid_encode_backward_ws_begin); the reduce pass runs per window (_finish), and a window's rows are final as soon as its
+# reduce has run, so its collective (fp16, RCCL's own stream) overlaps with the reduce of the next window.  Two windows:
+# a reduce launch is as slow as its slowest bucket (one workgroup per bucket, ~150 .. 250 us), so every extra window costs
+# compute — measured on one MI355X with the exchange a no-op (bench.py --dp-windows, 4096 rays, ms per step / backward us):
+#   1 window 2.309 / 1013    2 windows (0,10,16) 2.498 / 1196    3 (0,8,12,16) 2.529 / 1221    4 (0,7,10,13,16) 2.603 / 1291
+# (round 2 cut the SCATTER pass into 4 windows as well: 2.683 / 1362).  With two windows 54 % of the 27 MB hide behind the
+# second reduce for +0.19 ms of compute; which count wins depends on the all-reduce time, which no box of this build could
+# measure (LNH_DP_WINDOWS overrides the cut for such a measurement).
 import os as _os
-_DP_LEVEL_WINDOWS = ((0, 7), (7, 10), (10, 13), (13, 16))
+_DP_LEVEL_WINDOWS = ((0, 10), (10, 16))
 if _os.environ.get("LNH_DP_WINDOWS"):  # developer override for A/B runs: "0,10,16" = two windows
     _c = [int(v) for v in _os.environ["LNH_DP_WINDOWS"].split(",")]
     _DP_LEVEL_WINDOWS = tuple(zip(_c[:-1], _c[1:]))

@@ -11,8 +11,8 @@ out=gpurun_out/profiles; mkdir -p $out
 STEPS=10; WARM=3
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -o r -- python bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-eval > /dev/null 2>&1
 find /tmp/prof_kt -name "*kernel_stats.csv" -exec cp {} $out/${tag}_kernel_stats.csv \;
-# (+5 steps: the MFMA pass bench.py runs after the timed region)
-python - $out/${tag}_kernel_stats.csv $((STEPS+WARM+5)) > $out/${tag}_kernel_summary.txt <<'PY'
+# (+5 steps: the MFMA pass bench.py runs after the timed region; + 2 x STEPS: the two repeats of the timed region it lists as spread)
+python - $out/${tag}_kernel_stats.csv $((3*STEPS+WARM+5)) > $out/${tag}_kernel_summary.txt <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1]))); n = float(sys.argv[2])
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
