@@ -532,7 +532,13 @@ def main():
         # bench.py itself cannot run rocprofv3.  Scaled to this call's points (the PMC pass profiles whole launches).
         traffic, src = None, None
         parts = [pmc.get(n, {}).get("hbm_bytes_per_launch") for n in pmc_names.get(name, ())]
-        if pmc_file and parts and all(p is not None for p in parts) and args.rays == 4096:
+        if not (pmc_file and parts and all(p is not None for p in parts)):
+            src = "no committed PMC pass (profiles/r*_pmc.json) covers this entry point: traffic not reported"
+        elif args.rays != 4096 or args.table != "init" or args.patch.lower() != "1x1" or args.dp_windows:
+            # the PMC passes profile the default command (4096 rays, fresh table): bytes per launch of another workload
+            # are not that number scaled — say so instead of quoting it
+            src = f"{pmc_file} was collected on the default workload (4096 rays, fresh table, 1x1 rays): not quoted for this one"
+        else:
             traffic, src = int(sum(parts)), f"{pmc_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes: " + \
                 " + ".join(pmc_names[name]) + ")"
         return {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
