@@ -643,8 +643,8 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
     __shared__ uint32_t lsp[kMaxBucketsPerLevel];         // per bucket: spill slot - staging slot of the entries that do not
     __shared__ uint32_t lcnt[kMaxBucketsPerLevel];
     __shared__ uint32_t lstart[kMaxBucketsPerLevel + 1];  // first staging slot per bucket (workgroup-local)
-    __shared__ uint32_t skey[CAP];                        // staged entries, bucket-sorted: row | code << 29
-    __shared__ V2 sa[CAP], sb[CAP];
+    __shared__ __attribute__((aligned(16))) uint32_t skey[CAP];  // staged entries, bucket-sorted: row | code << 29
+    __shared__ __attribute__((aligned(16))) V2 sa[CAP], sb[CAP];
     // level-fastest workgroup order: concurrently resident workgroups work on the same points at different levels
     // (the coordinates stay in L2, the cursor atomics spread over all levels' counters instead of 64 hot words).
     // (A persistent-workgroup variant of this kernel was measured 1.5x SLOWER: the hardware dispatcher overlaps the
@@ -875,9 +875,13 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
                 put(row[2 * p + 1], kCodeSingle, val[2 * p + 1], make_v2<T>(0.0f, 0.0f), rank_x[p]);
     }
     __syncthreads();
-    const uint32_t total = min(lstart[kMaxBucketsPerLevel], (uint32_t)CAP);
+    // (workgroup-uniform, made scalar: the rounds below stop at it without touching LDS for slots nobody filled — on
+    //  average a workgroup stages 2.1 entries per thread of the 5 it has room for)
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(lstart[kMaxBucketsPerLevel], (uint32_t)CAP));
     // every thread moves up to CAP / 1024 staged entries: all their LDS reads (entry, then the bucket's slot map) are
-    // issued before the first use — one round trip for the batch instead of two dependent ones per entry
+    // issued before the first use — one round trip for the batch instead of two dependent ones per entry.  (Moving PAIRS of
+    // neighbouring entries per thread — 8-byte LDS reads, one 16-byte value store + one 4-byte row store per pair where both
+    // sit in one bucket — was measured slower: 709 vs 677 us; the wide stores land on 8- / 2-byte boundaries.)
     constexpr int NW = CAP / NTHREADS;
     static_assert(CAP % NTHREADS == 0, "staging slots are dealt to the threads in rounds");
     uint32_t ks[NW];
@@ -885,18 +889,22 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
     uint2 os[NW];
 #pragma unroll
     for (int i = 0; i < NW; i++) {
+        if ((uint32_t)i * NTHREADS >= total) break;  // scalar branch
         const uint32_t pos = threadIdx.x + (uint32_t)i * NTHREADS, pc = pos < total ? pos : 0u;
         ks[i] = skey[pc];
         as[i] = sa[pc];
         bs[i] = sb[pc];
     }
 #pragma unroll
-    for (int i = 0; i < NW; i++) os[i] = lout[((ks[i] & 0x7ffffu) >> kBucketRowsLog2) & (kMaxBucketsPerLevel - 1)];
+    for (int i = 0; i < NW; i++) {
+        if ((uint32_t)i * NTHREADS >= total) break;
+        os[i] = lout[((ks[i] & 0x7ffffu) >> kBucketRowsLog2) & (kMaxBucketsPerLevel - 1)];
+    }
 #pragma unroll
     for (int i = 0; i < NW; i++) {
+        if ((uint32_t)i * NTHREADS >= total) break;
         const uint32_t pos = threadIdx.x + (uint32_t)i * NTHREADS;
-        if (pos >= total) break;
-        to_global(pos, ks[i], as[i], bs[i], os[i]);
+        if (pos < total) to_global(pos, ks[i], as[i], bs[i], os[i]);
     }
     };
     const bool plain = align_rt == 0 && interp_rt == 0;
