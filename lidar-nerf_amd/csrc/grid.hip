@@ -881,7 +881,8 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
     // every thread moves up to CAP / 1024 staged entries: all their LDS reads (entry, then the bucket's slot map) are
     // issued before the first use — one round trip for the batch instead of two dependent ones per entry.  (Moving PAIRS of
     // neighbouring entries per thread — 8-byte LDS reads, one 16-byte value store + one 4-byte row store per pair where both
-    // sit in one bucket — was measured slower: 709 vs 677 us; the wide stores land on 8- / 2-byte boundaries.)
+    // sit in one bucket — was measured slower: 709 vs 677 us; the wide stores land on 8- / 2-byte boundaries.  So was ONE 16-byte
+    // LDS record per staged entry instead of three 4-byte arrays: 755 vs 675 us.)
     constexpr int NW = CAP / NTHREADS;
     static_assert(CAP % NTHREADS == 0, "staging slots are dealt to the threads in rounds");
     uint32_t ks[NW];
