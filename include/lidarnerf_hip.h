@@ -374,6 +374,12 @@ LNH_API int lnh_lidar_pack_weights(const float *ws0, uint32_t ld_s0, const float
 LNH_API int lnh_lidar_loss(const float *depth, const float *image, const float *gt, uint32_t N, float alpha_d,
                            float alpha_r, float alpha_i, float *loss, float *grad_depth, float *grad_image,
                            lnh_stream_t stream);
+/* The same with the structural-gradient term of the reference's patch epochs (nerf/utils.py:760-876, non-sobel grad_loss):
+ * rays come as N / (px * py) patches of px x py pixels, row-major; + alpha_grad * mean_{patch, row, j < py-1} |
+ * |pd_j - pd_j+1| m_j - (gd_j - gd_j+1) m_j |, depths in metres (value / scale), m_j = raydrop_j * (|gd_j - gd_j+1| < 0.01). */
+LNH_API int lnh_lidar_loss_patch(const float *depth, const float *image, const float *gt, uint32_t N, uint32_t px,
+                                 uint32_t py, float scale, float alpha_d, float alpha_r, float alpha_i, float alpha_grad,
+                                 float *loss, float *grad_depth, float *grad_image, lnh_stream_t stream);
 /*
  * Element-wise stages of the occupancy-grid render chain over the marcher's flat sample list [M] (BASELINE config 4; the
  * reference kept torch-ngp's kernels, raymarching.cu:331-772, and dropped this caller — what runs between them are the

@@ -173,6 +173,63 @@ k_lidar_loss(const float *__restrict__ depth, const float *__restrict__ image, c
     if (threadIdx.x == 0) unsafeAtomicAdd(loss, (part[0] + part[1] + part[2] + part[3]) / (float)N);
 }
 
+// The same loss on the reference's PATCH epochs (nerf/utils.py:760-876, grad_loss, non-sobel): rays arrive as patches of
+// px x py neighbouring pixels ([P, px, py] row-major), and the structural-gradient term
+//   a_g * mean over (P, px, py-1) of | |pd_j - pd_j+1| * m_j - (gd_j - gd_j+1) * m_j |,   m_j = gr_j * (|gd_j - gd_j+1| < 0.01)
+// (depths in metres: divided by `scale`; only the x term enters the loss) is added, with its gradient, in the same pass:
+// thread n = ray n handles the per-ray loss and the pair (n, n + 1) of its patch row.
+__global__ void __launch_bounds__(256)
+k_lidar_loss_patch(const float *__restrict__ depth, const float *__restrict__ image, const float *__restrict__ gt,
+                   uint32_t N, uint32_t py, float inv_scale, float a_d, float a_r, float a_i, float a_g,
+                   float *__restrict__ loss, float *__restrict__ g_depth, float *__restrict__ g_image) {
+    __shared__ float part[4];
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    float l = 0.0f;
+    if (n < N) {
+        const float gr = gt[n * 3], gi = gt[n * 3 + 1] * gr, gd = gt[n * 3 + 2] * gr;
+        const float pr = image[n * 2], pi = image[n * 2 + 1] * gr, pd = depth[n] * gr;
+        const float dd = pd - gd, dr = pr - gr, di = pi - gi;
+        const float inv = 1.0f / (float)N;
+        l = (a_d * fabsf(dd) + a_r * dr * dr + a_i * di * di) * inv;
+        const float sgn = dd > 0.0f ? 1.0f : (dd < 0.0f ? -1.0f : 0.0f);
+        float gdep = a_d * sgn * gr * inv;
+        g_image[n * 2] = 2.0f * a_r * dr * inv;
+        g_image[n * 2 + 1] = 2.0f * a_i * di * gr * inv;
+        // pairs (n, n + 1) and (n - 1, n) of this ray's patch row; N / py rows of py - 1 pairs each
+        const uint32_t c = n % py;
+        const float inv_pairs = a_g / ((float)(N / py) * (float)(py - 1));
+        auto pair_term = [&](uint32_t j, float &dj, float &dj1) {  // pair (j, j + 1): value, d/d pred_j, d/d pred_j+1
+            const float rj = gt[j * 3], rj1 = gt[(j + 1) * 3];
+            const float pj = depth[j] * rj * inv_scale, pj1 = depth[j + 1] * rj1 * inv_scale;
+            const float gj = gt[j * 3 + 2] * rj * inv_scale, gj1 = gt[(j + 1) * 3 + 2] * rj1 * inv_scale;
+            const float gg = gj - gj1, dp = pj - pj1, pg = fabsf(dp);
+            const float m = fabsf(gg) < 0.01f ? rj : 0.0f;
+            const float e = pg * m - gg * m;
+            const float se = e > 0.0f ? 1.0f : (e < 0.0f ? -1.0f : 0.0f), sp = dp > 0.0f ? 1.0f : (dp < 0.0f ? -1.0f : 0.0f);
+            dj = se * m * sp;
+            dj1 = -dj;
+            return fabsf(e);
+        };
+        float acc = 0.0f;
+        if (c + 1 < py) {  // this thread owns the pair (n, n + 1): its value and d/d pred_n
+            float dj, dj1;
+            l += pair_term(n, dj, dj1) * inv_pairs;
+            acc += dj;
+        }
+        if (c > 0) {       // d/d pred_n of the pair (n - 1, n)
+            float dj, dj1;
+            (void)pair_term(n - 1, dj, dj1);
+            acc += dj1;
+        }
+        g_depth[n] = gdep + acc * inv_pairs * gr * inv_scale;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = l;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(loss, part[0] + part[1] + part[2] + part[3]);
+}
+
 }  // namespace
 
 template <typename E>
@@ -276,6 +333,22 @@ int lnh_lidar_loss(const float *depth, const float *image, const float *gt, uint
     LNH_LAUNCH(k_lidar_loss, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, depth, image, gt, N, alpha_d,
                alpha_r, alpha_i, loss, grad_depth, grad_image);
     return lnh_check_launch("lnh_lidar_loss");
+}
+
+int lnh_lidar_loss_patch(const float *depth, const float *image, const float *gt, uint32_t N, uint32_t px, uint32_t py,
+                         float scale, float alpha_d, float alpha_r, float alpha_i, float alpha_grad, float *loss,
+                         float *grad_depth, float *grad_image, lnh_stream_t stream) {
+    LNH_REQUIRE(depth && image && gt && loss && grad_depth && grad_image, LNH_ERR_INVALID_ARG,
+                "lidar_loss_patch: null pointer");
+    LNH_REQUIRE(px >= 1 && py >= 2 && scale > 0.0f && N % (px * py) == 0, LNH_ERR_INVALID_ARG,
+                "lidar_loss_patch: need py >= 2, scale > 0 and N a multiple of px * py");
+    (void)hipGetLastError();
+    LNH_REQUIRE(hipMemsetAsync(loss, 0, sizeof(float), (hipStream_t)stream) == hipSuccess, LNH_ERR_LAUNCH,
+                "lidar_loss_patch: hipMemsetAsync failed");
+    if (N == 0) return LNH_OK;
+    LNH_LAUNCH(k_lidar_loss_patch, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, depth, image, gt, N, py,
+               1.0f / scale, alpha_d, alpha_r, alpha_i, alpha_grad, loss, grad_depth, grad_image);
+    return lnh_check_launch("lnh_lidar_loss_patch");
 }
 
 }  // extern "C"

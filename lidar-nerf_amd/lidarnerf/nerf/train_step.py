@@ -25,15 +25,22 @@ class _FusedLidarLoss(torch.autograd.Function):
     """lidar_loss as ONE kernel that also emits d loss / d (depth, image); backward only scales by the upstream scalar."""
 
     @staticmethod
-    def forward(ctx, depth, image, gt, ad, ar, ai):
+    def forward(ctx, depth, image, gt, ad, ar, ai, patch=None):
+        # patch = (px, py, scale, alpha_grad): the reference's patch epochs, structural-gradient term included
         from .. import _hip
         n = depth.numel()
         depth, image, gt = depth.reshape(n).float().contiguous(), image.reshape(n, 2).float().contiguous(), \
             gt.reshape(n, 3).float().contiguous()
         loss = torch.empty((), dtype=torch.float32, device=depth.device)
         grads = torch.empty(3 * n, dtype=torch.float32, device=depth.device)  # [d/d depth (n) | d/d image (n, 2)]
-        _hip.call("lnh_lidar_loss", depth.data_ptr(), image.data_ptr(), gt.data_ptr(), n, float(ad), float(ar), float(ai),
-                  loss.data_ptr(), grads.data_ptr(), grads.data_ptr() + 4 * n)
+        if patch is None:
+            _hip.call("lnh_lidar_loss", depth.data_ptr(), image.data_ptr(), gt.data_ptr(), n, float(ad), float(ar), float(ai),
+                      loss.data_ptr(), grads.data_ptr(), grads.data_ptr() + 4 * n)
+        else:
+            px, py, scale, ag = patch
+            _hip.call("lnh_lidar_loss_patch", depth.data_ptr(), image.data_ptr(), gt.data_ptr(), n, int(px), int(py),
+                      float(scale), float(ad), float(ar), float(ai), float(ag), loss.data_ptr(), grads.data_ptr(),
+                      grads.data_ptr() + 4 * n)
         ctx.save_for_backward(grads)
         ctx.n = n
         return loss
@@ -42,13 +49,14 @@ class _FusedLidarLoss(torch.autograd.Function):
     def backward(ctx, g):
         (grads,) = ctx.saved_tensors
         scaled = grads * g  # one launch for both
-        return scaled[:ctx.n], scaled[ctx.n:].view(ctx.n, 2), None, None, None, None
+        return scaled[:ctx.n], scaled[ctx.n:].view(ctx.n, 2), None, None, None, None, None
 
 
-def fused_lidar_loss(outputs, images_lidar, alpha_d=1000.0, alpha_r=1.0, alpha_i=10.0):
-    """lidar_loss through the single-launch kernel (GPU tensors only); same value and gradients."""
+def fused_lidar_loss(outputs, images_lidar, alpha_d=1000.0, alpha_r=1.0, alpha_i=10.0, patch=None):
+    """lidar_loss (+ patch_gradient_loss when patch = (px, py, scale, alpha_grad)) through the single-launch kernel (GPU
+    tensors only); same value and gradients."""
     depth, image = outputs["depth_lidar"], outputs["image_lidar"]
-    loss = _FusedLidarLoss.apply(depth.reshape(-1), image.reshape(-1, 2), images_lidar, alpha_d, alpha_r, alpha_i)
+    loss = _FusedLidarLoss.apply(depth.reshape(-1), image.reshape(-1, 2), images_lidar, alpha_d, alpha_r, alpha_i, patch)
     return loss
 
 
@@ -139,8 +147,10 @@ class LidarTrainer:
         out = self.model.render(rays_o, rays_d, cal_lidar_color=True, staged=False, perturb=True,
                                 **self.render_kwargs)
         ad, ar, ai, ag = self.alpha
-        if patch[0] <= 1 and out["depth_lidar"].is_cuda:
-            return fused_lidar_loss(out, images_lidar, ad, ar, ai)
+        if out["depth_lidar"].is_cuda and (patch[0] <= 1 or (patch[1] >= 2 and out["depth_lidar"].numel() %
+                                                               (patch[0] * patch[1]) == 0)):
+            return fused_lidar_loss(out, images_lidar, ad, ar, ai,
+                                    None if patch[0] <= 1 else (patch[0], patch[1], self.scale, ag))
         loss, pred_depth, gt_depth = lidar_loss(out, images_lidar, ad, ar, ai)
         if patch[0] > 1:
             loss = loss + patch_gradient_loss(pred_depth, gt_depth, images_lidar[..., 0], patch[0], patch[1],

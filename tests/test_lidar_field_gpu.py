@@ -338,6 +338,35 @@ def test_fused_lidar_loss_matches_train_step_loss():
     torch.testing.assert_close(image.grad, gi, rtol=1e-5, atol=1e-9)
 
 
+def test_fused_patch_loss_matches_the_restatement():
+    """lnh_lidar_loss_patch (per-ray LiDAR loss + the structural-gradient term of the patch epochs, one launch) against the
+    CPU restatement of nerf/utils.py:712-746 + 760-876 (oracle/render_ref.py lidar_loss + patch_grad_loss, autograd for the
+    gradients): 256 patches of 2 x 8 rays, ground truth smooth inside a patch (so the 0.01 m gate passes), dropped rays,
+    exact ties."""
+    from lidarnerf.nerf.train_step import fused_lidar_loss
+    from oracle import render_ref
+    g = torch.Generator().manual_seed(3)
+    scale = 0.010784853507573345
+    n = 256 * 16
+    base = (torch.rand(256, 1, generator=g) * 0.6).expand(256, 16).reshape(n)
+    gt_depth = base + 0.003 * scale * torch.randn(n, generator=g)
+    gt_depth[16:32] = base[16:32] + 0.05 * scale * torch.randn(16, generator=g)       # a patch the gate rejects
+    depth0 = gt_depth + 0.05 * scale * torch.randn(n, generator=g)
+    depth0[40] = depth0[41]                                                              # |dx| = 0: sign(0) = 0
+    gt = torch.stack([(torch.rand(n, generator=g) > 0.15).float(), torch.rand(n, generator=g), gt_depth], -1)
+    image0 = torch.rand(n, 2, generator=g)
+    dc, ic = depth0.clone().requires_grad_(True), image0.clone().requires_grad_(True)
+    want = render_ref.lidar_loss(dc, ic, gt) + render_ref.patch_grad_loss(dc, gt, 2, 8, scale)
+    (want * 5.0).backward()
+    dg, ig = depth0.cuda().requires_grad_(True), image0.cuda().requires_grad_(True)
+    got = fused_lidar_loss({"depth_lidar": dg[None], "image_lidar": ig[None]}, gt.cuda()[None], patch=(2, 8, scale, 100.0))
+    (got * 5.0).backward()
+    torch.testing.assert_close(got.cpu(), want.detach(), rtol=2e-5, atol=1e-6)
+    torch.testing.assert_close(dg.grad.cpu(), dc.grad, rtol=2e-5, atol=1e-6 * float(dc.grad.abs().max()))
+    torch.testing.assert_close(ig.grad.cpu(), ic.grad, rtol=2e-5, atol=1e-9)
+    assert float(render_ref.patch_grad_loss(dc.detach(), gt, 2, 8, scale)) > 1.0                 # the term is active in this test
+
+
 def test_dir_term_backward():
     from lidarnerf import _hip
     torch.manual_seed(2)
