@@ -174,7 +174,12 @@ def table16_of(param, embeddings=None, training=True):
     shadow = getattr(param, "_lnh_table16", None)
     if shadow is not None and getattr(param, "_lnh_shard_optimizer", False):
         # sharded table optimizer: the fp32 master of this rank is current on its own rows only; the all-gathered shadow
-        # IS the table (LidarTrainer.gather_table_state() completes the master for checkpoints)
+        # IS the table (LidarTrainer.gather_table_state() completes the master for checkpoints).  A write to the parameter
+        # through torch (load_state_dict, broadcast) moves its version counter — the optimizer kernel and the gather do not —
+        # and then the parameter is whole and newer: re-cast.
+        if getattr(param, "_lnh_table16_version", None) != param._version:
+            shadow.copy_(param.detach().reshape(shadow.shape))
+            param._lnh_table16_version = param._version
         return shadow
     if shadow is None or not training:
         return src.detach().to(torch.half).contiguous()
