@@ -1,0 +1,99 @@
+"""The element-wise stages of the occupancy-grid render chain (csrc/lidar_ragged.hip, lnh_ragged_*), each against the tensor
+expression of the reference's network code it replaces (network.py:162-237 on flat sample lists; activation.py:17-19;
+gridencoder/grid.py:213), fp16 and bf16 builds, called through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import encoders_ref
+
+pytestmark = pytest.mark.gpu
+M = 3001  # not a multiple of anything
+
+
+def _dt(sfx):
+    return torch.bfloat16 if sfx else torch.float16
+
+
+def test_ragged_points():
+    from gpu_util import call
+    xyz = (torch.rand(M, 3, device="cuda") * 2 - 1) * 2.0
+    out = torch.empty_like(xyz)
+    call("lnh_ragged_points", xyz, 2.0, M, out)
+    assert torch.equal(out, (xyz + 2.0) / (2 * 2.0))
+
+
+@pytest.mark.parametrize("sfx", ["", "_bf16"])
+def test_ragged_pack_weights(sfx):
+    from gpu_util import call
+    dt = _dt(sfx)
+    g = torch.Generator().manual_seed(1)
+    ws0, ws1 = torch.randn(64, 32, generator=g).cuda(), torch.randn(16, 64, generator=g).cuda()
+    big = torch.randn(64, 100, generator=g).cuda()
+    wc0 = big[:, 5:95]                                         # a strided view: leading dimension 100, 90 used columns
+    wc1, wc2 = torch.randn(64, 64, generator=g).cuda(), torch.randn(2, 64, generator=g).cuda()
+    wsig = torch.empty(64 * 32 + 16 * 64, dtype=dt, device="cuda")
+    wcol = torch.empty(64 * 96 + 64 * 64 + 16 * 64, dtype=dt, device="cuda")
+    call("lnh_ragged_pack_weights" + sfx, ws0, 32, ws1, 64, wc0, 100, 90, wc1, 64, wc2, 64, wsig, wcol)
+    assert torch.equal(wsig, torch.cat([ws0.reshape(-1), ws1.reshape(-1)]).to(dt))
+    w0 = torch.zeros(64, 96, device="cuda")
+    w0[:, :90] = wc0
+    w2 = torch.zeros(16, 64, device="cuda")
+    w2[:2] = wc2
+    assert torch.equal(wcol, torch.cat([w0.reshape(-1), wc1.reshape(-1), w2.reshape(-1)]).to(dt))
+
+
+@pytest.mark.parametrize("sfx", ["", "_bf16"])
+def test_ragged_color_input(sfx):
+    from gpu_util import call
+    dt = _dt(sfx)
+    g = torch.Generator().manual_seed(2)
+    d = torch.nn.functional.normalize(torch.randn(M, 3, generator=g), dim=-1)
+    h16 = torch.randn(M, 16, generator=g).to(dt)
+    cin = torch.full((M, 96), 7.0, dtype=dt, device="cuda")
+    call("lnh_ragged_color_input" + sfx, d.cuda(), h16.cuda(), M, 12, cin)
+    got = cin.float().cpu()
+    want = torch.from_numpy(encoders_ref.freq_forward(d.numpy(), 12)).to(dt).float()   # freqencoder.cu:34-63 layout
+    # frequency features: the kernel's sinf against NumPy's, then one rounding to the element type
+    np.testing.assert_allclose(got[:, :75].numpy(), want.numpy(), rtol=0, atol=2e-3 if sfx == "" else 1.6e-2)
+    assert torch.equal(got[:, 75:90], h16[:, 1:].float()) and float(got[:, 90:].abs().max()) == 0.0
+    # bit-identical to the product's own frequency encoder followed by the cast
+    enc = torch.empty(M, 75, device="cuda")
+    call("lnh_freq_encode_forward", d.cuda(), M, 3, 12, 75, enc)
+    assert torch.equal(cin[:, :75], enc.to(dt))
+
+
+@pytest.mark.parametrize("sfx", ["", "_bf16"])
+def test_ragged_color_output_and_backward(sfx):
+    from gpu_util import call
+    dt = _dt(sfx)
+    g = torch.Generator().manual_seed(3)
+    y = (torch.randn(M, 16, generator=g) * 3).to(dt).cuda()
+    rgb = torch.empty(M, 2, device="cuda")
+    call("lnh_ragged_color_output" + sfx, y, M, rgb)
+    torch.testing.assert_close(rgb, torch.sigmoid(y[:, :2].float()), rtol=2e-6, atol=1e-7)
+    grad = torch.randn(M, 2, generator=g).cuda()
+    gy = torch.full((M, 16), 9.0, dtype=dt, device="cuda")
+    call("lnh_ragged_color_output_backward" + sfx, grad, rgb, M, gy)
+    want = torch.zeros(M, 16, device="cuda")
+    want[:, :2] = grad * rgb * (1 - rgb)
+    assert torch.equal(gy, want.to(dt))
+
+
+@pytest.mark.parametrize("sfx", ["", "_bf16"])
+def test_ragged_grad_rows(sfx):
+    from gpu_util import call
+    from lidarnerf.activation import trunc_exp
+    dt = _dt(sfx)
+    g = torch.Generator().manual_seed(4)
+    h16 = (torch.randn(M, 16, generator=g) * 8).to(dt).cuda()     # |h0| beyond 15 on some rows: the clamp of trunc_exp's backward
+    h16[:4, 0] = torch.tensor([20.0, -20.0, 15.0, -15.0]).to(dt)
+    gs = torch.randn(M, generator=g).cuda()
+    gx = torch.randn(M, 96, generator=g).to(dt).cuda()
+    out = torch.empty(M, 16, dtype=dt, device="cuda")
+    call("lnh_ragged_grad_rows" + sfx, gs, 1.5, h16, gx, 12, M, out)
+    # column 0 through the product's own trunc_exp autograd (activation.py:6-20): d sigma / d h0 = exp(clamp(h0, -15, 15))
+    h0 = h16[:, 0].float().clone().requires_grad_(True)
+    (trunc_exp(h0) * 1.5 * gs).sum().backward()
+    torch.testing.assert_close(out[:, 0].float(), h0.grad.to(dt).float(), rtol=2e-3 if sfx == "" else 1.6e-2, atol=0)
+    assert torch.equal(out[:, 1:], gx[:, 75:90])
