@@ -164,29 +164,31 @@ def test_color_head_forward_backward(N, T, pattern):
     torch.testing.assert_close(S.cpu().double(), want_gcd, rtol=1e-2, atol=5e-3 * want_gcd.abs().max().item())
 
 
-def test_color_backward_from_image_gradient_equals_explicit_rgb_gradient():
+@pytest.mark.parametrize("sfx", ["", "_bf16"])
+def test_color_backward_from_image_gradient_equals_explicit_rgb_gradient(sfx):
     """lnh_lidar_color_backward_image(grad_image) == lnh_lidar_color_backward(grad_rgb = weights (x) grad_image), bit for bit
-    (the product the compositing backward would have written is formed in the kernel)."""
+    (the product the compositing backward would have written is formed in the kernel); fp16 and bf16 builds."""
     from gpu_util import call
+    dt16 = torch.bfloat16 if sfx else torch.float16
     N, T = 37, 832
     g = torch.Generator().manual_seed(99)
-    h16 = (torch.randn(N * T, 16, generator=g) * 0.5).half().cuda()
+    h16 = (torch.randn(N * T, 16, generator=g) * 0.5).to(dt16).cuda()
     perm = torch.stack([torch.randperm(T, generator=g) for _ in range(N)]).int().cuda()
     weights = (torch.rand(N, T, generator=g) * 2.5e-4).cuda()
     cdir = torch.randn(N, 64, generator=g).cuda()
-    w16 = (torch.randn(64 * 16 + 64 * 64 + 16 * 64, generator=g) * 0.2).half().cuda()
+    w16 = (torch.randn(64 * 16 + 64 * 64 + 16 * 64, generator=g) * 0.2).to(dt16).cuda()
     g_image = torch.randn(N, 2, generator=g).cuda()
     g_sigma = torch.randn(N, T, generator=g).cuda()
     g_rgb = (weights[..., None] * g_image[:, None, :]).contiguous()
     outs = []
     for mode in ("rgb", "image"):
-        g_h16 = torch.full((N * T, 16), float("nan"), dtype=torch.float16, device="cuda")
+        g_h16 = torch.full((N * T, 16), float("nan"), dtype=dt16, device="cuda")
         g_w = torch.zeros(w16.numel(), device="cuda")
         S = torch.empty((N, 64), device="cuda")
         if mode == "rgb":
-            call("lnh_lidar_color_backward", g_rgb, g_sigma, h16, perm, weights, cdir, w16, N, T, g_h16, g_w, S)
+            call("lnh_lidar_color_backward" + sfx, g_rgb, g_sigma, h16, perm, weights, cdir, w16, N, T, g_h16, g_w, S)
         else:
-            call("lnh_lidar_color_backward_image", g_image, g_sigma, h16, perm, weights, cdir, w16, N, T, g_h16, g_w, S)
+            call("lnh_lidar_color_backward_image" + sfx, g_image, g_sigma, h16, perm, weights, cdir, w16, N, T, g_h16, g_w, S)
         outs.append((g_h16, S, g_w))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     # (the weight gradient is flushed with float atomics from several workgroups: same values, order-dependent last bits)
