@@ -74,7 +74,8 @@ def spread(x, y):
     return float(d.max()), int((d.sum(1) > 0).sum())
 s_same, s_shard = spread(a, a2), spread(a, b)
 print(f"rank {rank}: after 3 steps, fp16 table: replicated vs replicated max {s_same[0]:.2e} in {s_same[1]} rows; sharded vs replicated max {s_shard[0]:.2e} in {s_shard[1]} rows")
-assert s_shard[1] <= max(4 * s_same[1], 2000) and s_shard[0] <= max(4 * s_same[0], 2e-2)
+# (a differing row differs by at most a few Adam steps of lr = 1e-2 each way: the bound on the VALUE is 3 steps x lr x 2)
+assert s_shard[1] <= max(4 * s_same[1], 5000) and s_shard[0] <= 0.06 + 1e-3
 # ---- sharded evaluation: every rank renders its range of a frame, the pieces are all-gathered
 model.eval()
 frame = bench.make_batch(poses, 0, 1500, 0, device)
