@@ -197,24 +197,25 @@ def test_fused_ragged_chain_vs_oracle_and_modular_path():
                                                             True, 0, 1024)
     M = xyzs.shape[0]
     assert 1000 < M < N * 1024
+    ref.storage = torch.float16  # the CPU side models WHERE 16-bit values are stored (oracle/render_ref.py RefLidarField)
     sigma, geo = ref.density(xyzs.cpu())
     feats = ref.color(xyzs.cpu(), dirs.cpu(), torch.ones(M, dtype=torch.bool), geo)
     ws, dep, img = render_ref.composite_ragged(sigma, feats, deltas.cpu(), xyzs.cpu(), o, d, rays.cpu())
     lw = render_ref.lidar_loss(dep, img, gt)
-    lw.backward()
+    (lw * scale).backward()  # the same loss scale: 16-bit gradient rows round at the same magnitudes
     out, loss, net = res["fused"]
-    # fp16 storage of features / activations: measured ~2e-4 on the outputs
-    for got, want, tol in ((out["depth_lidar"][0], dep, 2e-3), (out["image_lidar"][0], img, 3e-3),
-                           (out["weights_sum_lidar"], ws, 2e-3)):
+    # measured on MI355X against the storage model: outputs 1.5e-6 .. 3.5e-6 of the largest entry, hash-table gradient
+    # 2.4e-4, MLP weight gradients <= 3.1e-5 (against the fp32 restatement without the model: 2e-4 / 1e-2 / 5e-3)
+    for got, want in ((out["depth_lidar"][0], dep), (out["image_lidar"][0], img), (out["weights_sum_lidar"], ws)):
         err = (got.detach().float().cpu() - want.detach().float()).abs().max().item() / (want.detach().abs().max().item() + 1e-12)
-        assert err < tol, err
-    assert abs(loss - float(lw.detach())) <= 2e-3 * abs(float(lw.detach()))
+        assert err < 2e-5, err
+    assert abs(loss - float(lw.detach())) <= 2e-5 * abs(float(lw.detach()))
     ge = net.encoder.embeddings.grad.detach().float().cpu().double() / scale
-    gr = ref.embeddings.grad.double()
-    assert ((ge - gr).norm() / gr.norm()).item() < 2e-2
+    gr = ref.embeddings.grad.double() / scale
+    assert ((ge - gr).norm() / gr.norm()).item() < 8e-4
     for a, b in list(zip(net.sigma_net, ref.sigma_net)) + list(zip(net.lidar_color_net, ref.lidar_color_net)):
-        ga, gb = a.weight.grad.detach().float().cpu().double() / scale, b.weight.grad.double()
-        assert ((ga - gb).norm() / gb.norm()).item() < 1.5e-2
+        ga, gb = a.weight.grad.detach().float().cpu().double() / scale, b.weight.grad.double() / scale
+        assert ((ga - gb).norm() / gb.norm()).item() < 2e-4
     # (b) the modular path computes the same step through other kernels / autograd nodes
     outm, lossm, netm = res["modular"]
     for k in ("depth_lidar", "image_lidar", "weights_sum_lidar"):
