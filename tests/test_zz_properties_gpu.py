@@ -165,6 +165,13 @@ def test_backward_bucketed_chunked_matches_atomic_path():
     torch.cuda.synchronize()
     scale = float(b.abs().max())
     assert float((a - b).abs().max()) <= 2e-4 * scale
+    # the data-parallel form of the same call on a chunked batch: begin (all chunks but the last in full + the last chunk's
+    # scatter pass), then the last chunk's reduce pass window by window — bit-identical to the one-shot call
+    c = torch.zeros((rows, CH), device="cuda")
+    call("lnh_grid_encode_backward_ws_begin", g, x, offh, c, B, 3, CH, L, S, H, 0, 0, 0, 0, ws, need)
+    for l0, l1 in ((0, 10), (10, L)):
+        call("lnh_grid_encode_backward_ws_finish", g, x, offh, c, B, 3, CH, L, S, H, 0, 0, 0, 0, ws, need, l0, l1)
+    assert torch.equal(c, a)
     offs = torch.from_numpy(OFF.astype(np.int64))
     for l in range(L):
         s_tab = a[offs[l]:offs[l + 1]].double().sum(0)
