@@ -464,6 +464,9 @@ def main():
         trainer.step(*batches[(args.warmup + args.steps + s) % len(batches)], **step_kw)
     sync()
     mlp_timers = event_table(_hip.disable_timers())
+    # (the mask fraction belongs to the steps the MLP kernels were timed in: close the collection before anything else runs)
+    mask_frac = float(torch.stack(fused.MASK_STATS).mean().item()) if fused.MASK_STATS else 1.0
+    fused.MASK_STATS = None
     # ---- spread: the timed region is short (K x ~2.3 ms); repeat it twice more (outside the reported number) and list all
     spread = [round(1e3 * elapsed / args.steps, 3)]
     for rep in range(2):
@@ -478,8 +481,6 @@ def main():
         fw = [k for k in mlp_timers if role in k and (role != "color_" or "forward" in k)]
         if not fw:
             raise RuntimeError(f"bench: no '{role}' entry point was timed in the MFMA pass (got {sorted(mlp_timers)})")
-    mask_frac = float(torch.stack(fused.MASK_STATS).mean().item()) if fused.MASK_STATS else 1.0
-    fused.MASK_STATS = None
 
     # ---- data parallel: the same step with the gradient exchange switched off (every rank keeps its own gradient;
     #      timing only, the replicas are not used afterwards) -> all-reduce cost = inclusive - exclusive
