@@ -9,6 +9,7 @@ import math
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 from torch.autograd import Function
 
 from .. import _hip
@@ -156,11 +157,28 @@ class FFMLP(nn.Module):
         std = math.sqrt(3 / self.hidden_dim)
         self.weights.data.uniform_(-std, std)
 
+    def _weights_padded_to_32(self):
+        """hidden_dim = 16 on the hidden-32 MFMA kernels: every matrix zero-padded to 32 hidden units (a padded unit has
+        zero weights in AND out: it contributes nothing forward, receives a zero gradient, and autograd drops the padding's
+        gradient on the way back to `weights`).  Same flat layout, [32*in | 32*32*(layers-1) | 16*32]."""
+        h, i, n = self.hidden_dim, self.input_dim, self.num_layers - 1
+        w = self.weights
+        parts = [F.pad(w[:h * i].view(h, i), (0, 0, 0, 32 - h)).reshape(-1)]
+        o = h * i
+        for _ in range(n):
+            parts.append(F.pad(w[o:o + h * h].view(h, h), (0, 32 - h, 0, 32 - h)).reshape(-1))
+            o += h * h
+        parts.append(F.pad(w[o:o + self.padded_output_dim * h].view(self.padded_output_dim, h), (0, 32 - h)).reshape(-1))
+        return torch.cat(parts)
+
     def forward(self, inputs):
-        if kernel_supported(self.input_dim, self.hidden_dim, self.num_layers - 1):
+        if self.hidden_dim == 16 and kernel_supported(self.input_dim, 32, self.num_layers - 1):
+            y = _FusedMLP.apply(inputs, self._weights_padded_to_32(), self.input_dim, 32, self.num_layers - 1,
+                                self.activation, self.output_activation, not self.training)
+        elif kernel_supported(self.input_dim, self.hidden_dim, self.num_layers - 1):
             y = _FusedMLP.apply(inputs, self.weights, self.input_dim, self.hidden_dim, self.num_layers - 1,
                                 self.activation, self.output_activation, not self.training)
-        else:  # hidden 16 / 128 / 256, deeper or wider-input nets: library GEMM chain, same semantics
+        else:  # hidden 128 / 256, deeper or wider-input nets: library GEMM chain, same semantics
             if not inputs.is_cuda:
                 raise RuntimeError("lidarnerf_hip: tensor must live on the GPU (no CPU path in this library)")
             y = gemm_mlp(inputs, self.weights, self.input_dim, self.hidden_dim, self.num_layers - 1, self.activation,
