@@ -50,7 +50,9 @@ def test_dense_path_learns_the_analytic_scene():
     # run to run (0.45 m at step 300, 0.10 at 400, 0.09 at 600, 0.07 at 800, 0.14 at 1200 in one run: the MLP gradients meet
     # in float atomics, so two runs differ) — the bound leaves an order of magnitude
     assert e0 > 5.0 and e1 < 1.0 and e1 < e0 / 10, (e0, e1)
-    assert float(tr.loss_scale) >= 1024.0  # the dynamic loss scale did not collapse
+    # the dynamic loss scale settles where the fp16 table gradient just fits (a 6000-step run: 32 .. 128 — the depth term
+    # carries a factor 1000), it must not collapse towards zero
+    assert float(tr.loss_scale) >= 4.0
 
 
 def test_patch_mode_step_learns_too():
