@@ -16,6 +16,13 @@ typedef float float4_t __attribute__((ext_vector_type(4)));
 
 #define LNH_WAVE 64
 
+// Section marks for tools/isa_sections.py (an assembly comment per mark in -DLNH_ISA_MARKS builds, nothing otherwise)
+#ifdef LNH_ISA_MARKS
+#define LNH_MARK(name) asm volatile("; MARK " name)
+#else
+#define LNH_MARK(name) do { } while (0)
+#endif
+
 // thread-local last-error string (lnh_last_error)
 void lnh_set_error(const char *fmt, ...);
 int lnh_cu_count();  // compute units of the current device (cached per device); 256 on MI355X
@@ -157,6 +164,29 @@ __device__ __forceinline__ void cross_segscan_add_n(float (&v)[N], const SegScan
 #pragma unroll
     for (int i = 0; i < N; i++)
         asm volatile("v_fmac_f32_dpp %0, %0, %1 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v[i]) : "v"(k.m[5]));
+}
+// ONE step of the segmented scan over N values (v_fmac_f32_dpp, value-interleaved like row_segscan_add_n): S = 0..3 are the
+// row_shr:1/2/4/8 steps, 4 / 5 the row_bcast:15 / :31 steps.  `take` = 1.0f where the lane adds the shifted value, else 0.0f.
+// Callers run only the steps the longest run of the wave needs.
+template <int S, int N>
+__device__ __forceinline__ void segscan_step_n(float (&v)[N], float take) {
+    static_assert(N >= 3, "needs >= 2 independent instructions between the steps of one value");
+    asm volatile("s_nop 1");
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        if constexpr (S == 0)
+            asm volatile("v_fmac_f32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(v[i]) : "v"(take));
+        else if constexpr (S == 1)
+            asm volatile("v_fmac_f32_dpp %0, %0, %1 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(v[i]) : "v"(take));
+        else if constexpr (S == 2)
+            asm volatile("v_fmac_f32_dpp %0, %0, %1 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(v[i]) : "v"(take));
+        else if constexpr (S == 3)
+            asm volatile("v_fmac_f32_dpp %0, %0, %1 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(v[i]) : "v"(take));
+        else if constexpr (S == 4)
+            asm volatile("v_fmac_f32_dpp %0, %0, %1 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v[i]) : "v"(take));
+        else
+            asm volatile("v_fmac_f32_dpp %0, %0, %1 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v[i]) : "v"(take));
+    }
 }
 // the two cross-row steps that complete row_segscan_add to the full-wave scan
 __device__ __forceinline__ float cross_segscan_add(float v, const SegScanMask &k) {

@@ -908,17 +908,407 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
         if (pos < total) to_global(pos, ks[i], as[i], bs[i], os[i]);
     }
     };
+    // the two plain classes (hashed power-of-two table / dense level, linear interpolation, align_corners off) are
+    // k_grid_bwd_scatter_plain's levels: this kernel serves the generic classes of a window (8 singles per point)
     const bool plain = align_rt == 0 && interp_rt == 0;
-    if (plain && (lv_rt.flags & (LV_HASH | LV_POW2)) == (LV_HASH | LV_POW2)) body(std::integral_constant<int, 1>{});
-    else if (plain && !(lv_rt.flags & LV_HASH) && (lv_rt.flags & LV_NOWRAP) && (lv_rt.flags & 15u) == (uint32_t)D)
-        body(std::integral_constant<int, 2>{});
-    else body(std::integral_constant<int, 0>{});
+    if (plain && (lv_rt.flags & (LV_HASH | LV_POW2)) == (LV_HASH | LV_POW2)) return;
+    if (plain && !(lv_rt.flags & LV_HASH) && (lv_rt.flags & LV_NOWRAP) && (lv_rt.flags & 15u) == (uint32_t)D) return;
+    body(std::integral_constant<int, 0>{});
 }
 // true when every corner of the level travels as a single (generic class): 8 entries per point
 __host__ __device__ inline bool level_is_generic(const LevelParams &lv, uint32_t D, bool plain) {
     if (plain && (lv.flags & (LV_HASH | LV_POW2)) == (LV_HASH | LV_POW2)) return false;
     if (plain && !(lv.flags & LV_HASH) && (lv.flags & LV_NOWRAP) && (lv.flags & 15u) == D) return false;
     return true;
+}
+
+// ---- scatter pass for the two PLAIN level classes (hashed power-of-two tables / dense levels, linear interpolation,
+// align_corners off — every level of the usual configuration).  Same contract as k_grid_bwd_scatter (which keeps the
+// generic classes): same pool format, same cursors, same spill rules; what differs is the instruction budget.  The scatter
+// pass is issue-bound (profiles/r03_grid_counters.json: 324 VALU + 168 SALU per wave), so this kernel is written to the
+// instruction:
+//   * every lane predicate that is a function of wave-wide facts (who continues a run, who emits, the six "take" masks of
+//     the segmented scan) lives in SGPR PAIRS: built from two ballots with scalar shifts / ands and handed to the VALU as a
+//     v_cndmask source or an exec mask (__builtin_amdgcn_inverse_ballot_w64) — no 64-bit lane arithmetic, no run_start;
+//   * the scan executes only the steps the LONGEST run of the wave needs (scalar test on the masks): runs of 2 — the usual
+//     case on the middle levels — cost one step instead of four;
+//   * the range test is two min3 / max3 + two compares; locate() without its own second range test;
+//   * a workgroup whose entries all fit their staging and pool slots (flag from the reserving wave; always, short of
+//     adversarial inputs) stages and writes out WITHOUT per-entry tests: the staged key carries the bucket's LDS address
+//     pre-shifted (key >> 16) and the pool's 16-bit (row | code << 13) in its low half, so the write-out of an entry is
+//     one shift, one LDS read, one add, two shifts and two stores; LDS addresses of the staging reads are immediates;
+//   * level / chunk come from a 2-D grid (x = level: the level-fastest order), not from a division.
+// (amdgpu_num_sgpr: two 1024-thread workgroups per CU need 8 waves per SIMD, and gfx950 admits 8 only up to 80 SGPRs
+//  including VCC / flat-scratch / XNACK — at the 84 the unconstrained allocation took, ONE workgroup per CU ran and the
+//  pass took 959 us instead of 682; see profiles/r04_scatter_rewrite.txt)
+template <typename T, int CAP>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(72)))
+k_grid_bwd_scatter_plain(const T *__restrict__ grad, const float *__restrict__ inputs, uint32_t B, GridMeta meta,
+                         BucketPlan plan, char *__restrict__ pool_bytes, uint32_t *__restrict__ cursor,
+                         uint32_t *__restrict__ spill_cursor, uint32_t level0, uint32_t b_begin, uint32_t B_all,
+                         T *__restrict__ grad_table) {
+    constexpr int NP = 4, NTHREADS = 1024;
+    typedef v2_t<T> V2;
+    struct Pair { V2 a, b; };
+    __shared__ uint32_t lcnt[kMaxBucketsPerLevel];
+    __shared__ uint32_t lstart[kMaxBucketsPerLevel + 1];  // first staging slot per bucket; [64] = staged entries in all
+    __shared__ uint32_t lox[kMaxBucketsPerLevel];          // pool slot - staging slot
+    __shared__ uint32_t lofit[kMaxBucketsPerLevel];        // first staging slot of the bucket that does NOT fit its pool
+    __shared__ uint32_t lsp[kMaxBucketsPerLevel];          // spill slot - staging slot of those
+    __shared__ uint32_t lflag;                             // 1: everything fits staging and pool (the fast path)
+    // staged key: bits 0-12 bucket-local row | 13-15 code | 16-23 bucket * 4
+    __shared__ __attribute__((aligned(16))) uint32_t skey[CAP];
+    __shared__ __attribute__((aligned(16))) V2 sa[CAP], sb[CAP];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t level = level0 + blockIdx.x, chunk = blockIdx.y;
+    const LevelParams lv = meta.lv[level];
+    const bool cls_hash = (lv.flags & (LV_HASH | LV_POW2)) == (LV_HASH | LV_POW2);
+    const bool cls_dense = !(lv.flags & LV_HASH) && (lv.flags & LV_NOWRAP) && (lv.flags & 15u) == 3u;
+    if (!cls_hash && !cls_dense) return;  // generic class: k_grid_bwd_scatter's level
+    const uint32_t fb = plan.first_bucket[level], nb = plan.first_bucket[level + 1] - fb, cap = plan.cap[level];
+    auto lds_at = [](uint32_t *base, uint32_t byte_off) -> uint32_t & {
+        return *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(base) + byte_off);
+    };
+    auto body = [&](auto mode_c) {
+    constexpr int MODE = decltype(mode_c)::value;  // 1 hashed, 2 dense
+    LNH_MARK("A load+locate");
+    if (tid < kMaxBucketsPerLevel) lcnt[tid] = 0;
+    // ---- load (unconditional, clamped index), range test, cell
+    const uint32_t bl = chunk * (uint32_t)NTHREADS + tid;
+    const bool in_range = bl < B;
+    const uint32_t bc = b_begin + (in_range ? bl : 0u);
+    const float *px = inputs + (size_t)bc * 3;
+    float x0 = px[0], x1 = px[1], x2 = px[2];
+    const Vec<T, 2> gv = load_vec<T, 2>(grad + ((size_t)level * B_all + bc) * 2);
+    // !(x < 0 || x > 1) per coordinate (gridencoder.cu:158-163), as max3 / min3: a NaN coordinate drops out of both
+    bool ok = in_range & !(__builtin_fmaxf(__builtin_fmaxf(x0, x1), x2) > 1.0f) &
+              !(__builtin_fminf(__builtin_fminf(x0, x1), x2) < 0.0f);
+    const float g0 = (float)gv.v[0], g1 = (float)gv.v[1];
+    // a sample whose upstream gradient is exactly zero contributes nothing: dropped here, not moved through the pool
+    if constexpr (sizeof(T) == 2) {
+        uint32_t raw;
+        __builtin_memcpy(&raw, &gv, 4);
+        ok = ok & ((raw & 0x7fff7fffu) != 0u);
+    } else {
+        ok = ok & ((g0 != 0.0f) | (g1 != 0.0f));
+    }
+    // Lanes that are not `ok` never emit and never join a run (masks below); they only must stay FINITE, because the scan
+    // multiplies foreign lanes by 0: out-of-range coordinates are replaced by the cube centre.
+    x0 = ok ? x0 : 0.5f;
+    x1 = ok ? x1 : 0.5f;
+    x2 = ok ? x2 : 0.5f;
+    const float sc = lv.scale;
+    const float p0 = fmaf(x0, sc, 0.5f), p1 = fmaf(x1, sc, 0.5f), p2 = fmaf(x2, sc, 0.5f);
+    const float f0 = floorf(p0), f1 = floorf(p1), f2 = floorf(p2);
+    const uint32_t c0 = (uint32_t)f0, c1 = (uint32_t)f1, c2 = (uint32_t)f2;
+    const float fr0 = p0 - f0, fr1 = p1 - f1, fr2 = p2 - f2;
+    LNH_MARK("B rows");
+    // ---- rows of the four even corners (pair p = y + 2 z holds corners 2p, 2p + 1)
+    uint32_t r0[NP];
+    uint32_t xm = 0;       // hashed: r1 = r0 ^ xm
+    bool single[NP];       // the pair travels as two singles
+    uint32_t codesh;       // hashed: code << 13 of all four pairs
+    if constexpr (MODE == 1) {
+        const uint32_t m = lv.hashmap_size - 1u;
+        const uint32_t ty0 = c1 * prime_of(1), ty1 = ty0 + prime_of(1), tz0 = c2 * prime_of(2), tz1 = tz0 + prime_of(2);
+        r0[0] = ((ty0 ^ tz0) ^ c0) & m;
+        r0[1] = ((ty1 ^ tz0) ^ c0) & m;
+        r0[2] = ((ty0 ^ tz1) ^ c0) & m;
+        r0[3] = ((ty1 ^ tz1) ^ c0) & m;
+        xm = (c0 ^ (c0 + 1u)) & m;  // 2^(t+1) - 1, t = trailing ones of x
+        const uint32_t t_hash = (uint32_t)__builtin_popcount(xm) - 1u;
+        const bool sg = t_hash >= kCodeSingle;
+#pragma unroll
+        for (int p = 0; p < NP; p++) single[p] = sg;
+        codesh = (sg ? kCodeSingle : t_hash) << kBucketRowsLog2;
+    } else {
+        const uint32_t R = lv.resolution + 1u, RR = R * R;
+        const uint32_t base = c0 + c1 * R + c2 * RR;
+        r0[0] = base;
+        r0[1] = base + R;
+        r0[2] = base + RR;
+        r0[3] = base + R + RR;
+#pragma unroll
+        for (int p = 0; p < NP; p++) single[p] = (r0[p] & (kBucketRows - 1)) == kBucketRows - 1;  // r0 + 1 opens the next bucket
+        codesh = 0;
+    }
+    LNH_MARK("C masks");
+    // ---- run-merge masks (SGPR pairs).  A lane CONTINUES the run of its lower neighbour when both are ok and lie in the
+    //      same cell; hashed levels cut runs at 16-lane row starts (row-local scan), dense levels scan the whole wave.
+    const bool same = ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)c0, 0x138, 0xf, 0xf, false) == c0) &
+                      ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)c1, 0x138, 0xf, 0xf, false) == c1) &
+                      ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)c2, 0x138, 0xf, 0xf, false) == c2);
+    const unsigned long long ok_m = __builtin_amdgcn_ballot_w64(ok);
+    constexpr unsigned long long kRowStarts = MODE == 1 ? 0x0001000100010001ull : 1ull;
+    unsigned long long cont = __builtin_amdgcn_ballot_w64(same) & ok_m & (ok_m << 1) & ~kRowStarts;
+    constexpr int kMinMerges = 8;  // a wave with fewer mergeable lanes skips the scan (4 / 16 / 24 measured within noise)
+    if (__builtin_popcountll(cont) < kMinMerges) cont = 0ull;
+    const unsigned long long emit_m = ok_m & ~(cont >> 1);  // run tails
+    const bool emit = __builtin_amdgcn_inverse_ballot_w64(emit_m);
+    LNH_MARK("D values");
+    // ---- w * (g0, g1) per corner: float product, then the per-contribution rounding to the table type (gridencoder.cu:350)
+    V2 val[8];
+    {
+        const float wx0 = 1.0f - fr0, wy0 = 1.0f - fr1, wz0 = 1.0f - fr2;
+        const float wxy[4] = {wx0 * wy0, fr0 * wy0, wx0 * fr1, fr0 * fr1};
+        const f32x2_t gg = {g0, g1};
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const float w = wxy[c & 3] * ((c & 4) ? fr2 : wz0);
+            const f32x2_t p = gg * w;
+            val[c] = __builtin_convertvector(p, V2);
+        }
+    }
+    LNH_MARK("E scan");
+    if (cont != 0ull) {  // wave-uniform: sum the runs in fp32 (one rounding of the sum when it is stored again)
+        // take masks of the scan steps: step s adds the value 2^s lanes below iff the lanes (lane - 2^s, lane] all continue
+        const unsigned long long k0 = cont, k1 = k0 & (k0 << 1), k2 = k1 & (k1 << 2), k3 = k2 & (k2 << 4);
+        float vv[16];
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            vv[2 * c] = (float)val[c][0];
+            vv[2 * c + 1] = (float)val[c][1];
+        }
+        {
+            const float m0 = __builtin_amdgcn_inverse_ballot_w64(k0) ? 1.0f : 0.0f;
+            segscan_step_n<0>(vv, m0);
+        }
+        if (k1 != 0ull) {  // a run of 3 or more somewhere in the wave
+            const float m1 = __builtin_amdgcn_inverse_ballot_w64(k1) ? 1.0f : 0.0f;
+            segscan_step_n<1>(vv, m1);
+            if (k2 != 0ull) {
+                const float m2 = __builtin_amdgcn_inverse_ballot_w64(k2) ? 1.0f : 0.0f;
+                segscan_step_n<2>(vv, m2);
+                if (k3 != 0ull) {
+                    const float m3 = __builtin_amdgcn_inverse_ballot_w64(k3) ? 1.0f : 0.0f;
+                    segscan_step_n<3>(vv, m3);
+                }
+            }
+        }
+        if constexpr (MODE == 2) {
+            // cross-row steps: lanes of rows 1, 3 (then 2, 3) whose run began before their row (before lane 32) take the
+            // sum the last lane of the preceding row (lane 31) holds.  pre = lanes whose whole row prefix continues.
+            unsigned long long pre = cont;
+            pre &= (pre << 1) | 0x0001000100010001ull;
+            pre &= (pre << 2) | 0x0003000300030003ull;
+            pre &= (pre << 4) | 0x000f000f000f000full;
+            pre &= (pre << 8) | 0x00ff00ff00ff00ffull;
+            const unsigned long long k4 = pre & 0xffff0000ffff0000ull;
+            const unsigned long long k5 = (pre & 0x0000ffff00000000ull) | (((pre >> 47) & 1ull) ? (pre & 0xffff000000000000ull) : 0ull);
+            if (k4 != 0ull) {
+                const float m4 = __builtin_amdgcn_inverse_ballot_w64(k4) ? 1.0f : 0.0f;
+                segscan_step_n<4>(vv, m4);
+            }
+            if (k5 != 0ull) {  // (not nested: a run may cross the lane 31 | 32 boundary only)
+                const float m5 = __builtin_amdgcn_inverse_ballot_w64(k5) ? 1.0f : 0.0f;
+                segscan_step_n<5>(vv, m5);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 8; c++) val[c] = make_v2<T>(vv[2 * c], vv[2 * c + 1]);
+    }
+    LNH_MARK("F rank");
+    // ---- rank inside the workgroup's (bucket) counters
+    uint32_t bk4[NP], rank[NP], rank_x[NP];
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+        bk4[p] = (r0[p] >> (kBucketRowsLog2 - 2)) & 0xfcu;  // bucket * 4 = LDS byte offset of its counter
+        rank[p] = 0;
+        rank_x[p] = 0;
+    }
+    bool any_single = false;
+#pragma unroll
+    for (int p = 0; p < NP; p++) any_single |= single[p];
+    const bool wave_singles = __builtin_amdgcn_ballot_w64(emit && any_single) != 0ull;  // wave-uniform, rare
+    __syncthreads();
+    if constexpr (MODE == 1) {
+        // buckets are mixed: per-lane returning atomics
+        if (emit) {
+#pragma unroll
+            for (int p = 0; p < NP; p++) rank[p] = atomicAdd(&lds_at(lcnt, bk4[p]), 1u);
+        }
+    } else {
+        // every emitting lane of a wave usually targets the SAME bucket: 64 returning atomics on one counter serialise, so
+        // aggregate — one lane adds the population count, the others take their rank from the lane mask
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            if (emit_m == 0ull) continue;  // wave-uniform
+            const int leader = __builtin_ctzll(emit_m);
+            const uint32_t bk0 = (uint32_t)__builtin_amdgcn_readlane((int)bk4[p], leader);
+            const bool uniform = __ballot(emit && bk4[p] != bk0) == 0ull;
+            if (uniform) {
+                uint32_t base = 0;
+                if ((int)lane == leader) base = atomicAdd(&lds_at(lcnt, bk0), (uint32_t)__builtin_popcountll(emit_m));
+                base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+                rank[p] = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(emit_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)emit_m, 0u));
+            } else if (emit) {
+                rank[p] = atomicAdd(&lds_at(lcnt, bk4[p]), 1u);
+            }
+        }
+    }
+    if (wave_singles) {  // the second corners of pairs that travel as two singles
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            const uint32_t r1 = MODE == 1 ? (r0[p] ^ xm) : r0[p] + 1u;
+            if (emit && single[p]) rank_x[p] = atomicAdd(&lcnt[r1 >> kBucketRowsLog2], 1u);
+        }
+    }
+    __syncthreads();
+    LNH_MARK("G reserve");
+    // ---- global reservation + exclusive scan of the workgroup's bucket counts (first wave: one counter per lane)
+    if (tid < 64) {
+        static_assert(kMaxBucketsPerLevel == 64, "one bucket counter per lane of the first wave");
+        const uint32_t n0 = lcnt[lane];
+        uint32_t base = 0;
+        if (lane < nb && n0) base = atomicAdd(&cursor[fb + lane], n0);
+        const uint32_t incl = wave_scan_add_u32(n0);  // DPP network: no LDS round trips while the atomics are in flight
+        const uint32_t st = incl - n0;
+        lstart[lane] = st;
+        // staging slot pos of bucket bk goes to pool slot bk * cap + base + (pos - st) while base + (pos - st) < cap; the
+        // `over` entries behind those go to consecutive slots of the level's spill list, reserved with ONE atomic per
+        // workgroup (and none at all in the usual case of no overflow)
+        const uint32_t fit = base < cap ? min(cap - base, n0) : 0u, over = n0 - fit;
+        const uint32_t oincl = wave_scan_add_u32(over);
+        uint32_t sp0 = 0;
+        if (lane == 63 && oincl) sp0 = atomicAdd(&spill_cursor[level], oincl);
+        sp0 = (uint32_t)__builtin_amdgcn_readlane((int)sp0, 63);
+        lox[lane] = lane * cap + base - st;
+        lofit[lane] = st + fit;
+        lsp[lane] = sp0 + (oincl - over) - (st + fit);
+        if (lane == 63) {
+            lstart[kMaxBucketsPerLevel] = incl;
+            lflag = (incl <= (uint32_t)CAP && oincl == 0u) ? 1u : 0u;
+        }
+    }
+    __syncthreads();
+    LNH_MARK("H stage");
+    // pool streams of this level: values [slot][2] | rows [slot] | spill list; byte offsets inside a level fit 32 bits
+    // (<= 4 M points per launch), so every store is base (scalar) + 32-bit lane offset
+    char *pvals = pool_bytes + plan.pool_off[level];
+    char *prows = pool_bytes + plan.rows_off[level];
+    const bool fast = __builtin_amdgcn_readfirstlane((int)lflag) != 0;
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(lstart[kMaxBucketsPerLevel], (uint32_t)CAP));
+    auto key_of = [&](uint32_t r, uint32_t csh) {  // staged key of level-local row r, code << 13
+        return (r & (kBucketRows - 1)) | csh | ((r >> kBucketRowsLog2) << 18);
+    };
+    constexpr int NW = CAP / NTHREADS;
+    static_assert(CAP % NTHREADS == 0, "staging slots are dealt to the threads in rounds");
+    if (fast) {
+        // ---- stage (bucket order), no per-entry tests
+        if (emit) {
+            uint32_t st[NP];
+#pragma unroll
+            for (int p = 0; p < NP; p++) st[p] = lds_at(lstart, bk4[p]);
+#pragma unroll
+            for (int p = 0; p < NP; p++) {
+                const uint32_t pos = st[p] + rank[p];
+                const uint32_t csh = MODE == 1 ? codesh : (single[p] ? kCodeSingle << kBucketRowsLog2 : 0u);
+                skey[pos] = (r0[p] & (kBucketRows - 1)) | (csh | (bk4[p] << 16));
+                sa[pos] = val[2 * p];
+                sb[pos] = val[2 * p + 1];
+            }
+        }
+        if (wave_singles && emit) {
+#pragma unroll
+            for (int p = 0; p < NP; p++)
+                if (single[p]) {
+                    const uint32_t r1 = MODE == 1 ? (r0[p] ^ xm) : r0[p] + 1u;
+                    const uint32_t pos = lstart[r1 >> kBucketRowsLog2] + rank_x[p];
+                    skey[pos] = key_of(r1, kCodeSingle << kBucketRowsLog2);
+                    sa[pos] = val[2 * p + 1];
+                    sb[pos] = make_v2<T>(0.0f, 0.0f);
+                }
+        }
+        __syncthreads();
+        LNH_MARK("I writeout");
+        // ---- write out: consecutive lanes write consecutive pool slots; all LDS reads of a thread before the first use
+        uint32_t ks[NW], dl[NW];
+        V2 as[NW], bs[NW];
+#pragma unroll
+        for (int i = 0; i < NW; i++) {
+            if ((uint32_t)i * NTHREADS >= total) break;  // scalar branch
+            // (slots at and beyond `total` hold stale bytes: read, never stored; their 8-bit bucket field stays inside lox)
+            const uint32_t pos = tid + (uint32_t)i * NTHREADS;
+            ks[i] = skey[pos];
+            as[i] = sa[pos];
+            bs[i] = sb[pos];
+        }
+#pragma unroll
+        for (int i = 0; i < NW; i++) {
+            if ((uint32_t)i * NTHREADS >= total) break;
+            dl[i] = lds_at(lox, (ks[i] >> 16) & 0xffu);
+        }
+#pragma unroll
+        for (int i = 0; i < NW; i++) {
+            if ((uint32_t)i * NTHREADS >= total) break;
+            const uint32_t pos = tid + (uint32_t)i * NTHREADS;
+            if (pos < total) {
+                const uint32_t slot = dl[i] + pos;
+                Pair pr = {as[i], bs[i]};
+                *reinterpret_cast<Pair *>(pvals + slot * (uint32_t)sizeof(Pair)) = pr;
+                *reinterpret_cast<unsigned short *>(prows + slot * 2u) = (unsigned short)ks[i];
+            }
+        }
+        return;
+    }
+    LNH_MARK("J general");
+    // ---- the general path: entries beyond the staging area, a bucket beyond its pool share, a full spill list
+    char *spill = pool_bytes + plan.spill_off[level];
+    auto to_global = [&](uint32_t pos, uint32_t k, V2 a, V2 b) {
+        const uint32_t bo = k >> 16;  // bucket * 4
+        if (pos < lds_at(lofit, bo)) {
+            const uint32_t slot = lds_at(lox, bo) + pos;
+            Pair pr = {a, b};
+            *reinterpret_cast<Pair *>(pvals + slot * (uint32_t)sizeof(Pair)) = pr;
+            *reinterpret_cast<unsigned short *>(prows + slot * 2u) = (unsigned short)k;
+        } else {
+            const uint32_t sp = lds_at(lsp, bo) + pos;
+            const uint32_t rr = (k & (kBucketRows - 1)) | ((k >> 18) << kBucketRowsLog2), cd = (k >> kBucketRowsLog2) & 7u;
+            if (sp < plan.spill_cap) {
+                SpillEntry<T> e = {rr | (cd << 29), a, b};
+                *reinterpret_cast<SpillEntry<T> *>(spill + sp * (uint32_t)sizeof(SpillEntry<T>)) = e;
+            } else {
+                // The spill list is full too (it holds 1/16 of a level's worst case): these entries go straight into the
+                // table with device atomics — always correct, slow, and the one place where a sum depends on arrival order.
+                T *gt = grad_table + (size_t)lv.offset * 2;
+                atomic_add_pair(gt + (size_t)rr * 2, (float)a[0], (float)a[1]);
+                if (cd != kCodeSingle)
+                    atomic_add_pair(gt + (size_t)pair_row(rr, cd, MODE == 1) * 2, (float)b[0], (float)b[1]);
+            }
+        }
+    };
+    auto put = [&](uint32_t r, uint32_t csh, V2 a, V2 b, uint32_t rk) {
+        const uint32_t pos = lstart[r >> kBucketRowsLog2] + rk, k = key_of(r, csh);
+        if (pos < (uint32_t)CAP) {
+            skey[pos] = k;
+            sa[pos] = a;
+            sb[pos] = b;
+        } else {
+            to_global(pos, k, a, b);
+        }
+    };
+    if (emit) {
+#pragma unroll
+        for (int p = 0; p < NP; p++)
+            put(r0[p], MODE == 1 ? codesh : (single[p] ? kCodeSingle << kBucketRowsLog2 : 0u), val[2 * p], val[2 * p + 1],
+                rank[p]);
+    }
+    if (wave_singles && emit) {
+#pragma unroll
+        for (int p = 0; p < NP; p++)
+            if (single[p])
+                put(MODE == 1 ? (r0[p] ^ xm) : r0[p] + 1u, kCodeSingle << kBucketRowsLog2, val[2 * p + 1],
+                    make_v2<T>(0.0f, 0.0f), rank_x[p]);
+    }
+    __syncthreads();
+    for (uint32_t pos = tid; pos < total; pos += NTHREADS) to_global(pos, skey[pos], sa[pos], sb[pos]);
+    };
+#ifdef LNH_ONLY_MODE  // tools/isa_sections.py: one body per census
+    body(std::integral_constant<int, LNH_ONLY_MODE>{});
+#else
+    if (cls_hash) body(std::integral_constant<int, 1>{});
+    else body(std::integral_constant<int, 2>{});
+#endif
 }
 
 // A bucket with many entries (coarse dense levels: every ray passes the same few cells; very large batches) is split
@@ -1333,15 +1723,22 @@ int launch_backward_bucketed_chunk(const T *grad, const float *inputs, T *ge, ui
     // the LDS staging at 60 KiB (two workgroups per CU).  A window with a generic-class level (8 singles per point)
     // takes the instantiation with the larger staging area.
     const uint32_t n_win = level_end - level_begin;
-    bool generic = false;
-    for (uint32_t l = level_begin; l < level_end; l++) generic |= level_is_generic(m.lv[l], 3, plain);
-    if (phase == 2) {
-    } else if (generic)
-        LNH_LAUNCH((k_grid_bwd_scatter<T, 3, 6144>), dim3(div_up(B, 1024) * n_win), dim3(1024), 0, s, grad, inputs, B, m,
-                   plan, pool, cursor, spill_cursor, align, interp, n_win, level_begin, b_begin, B_all, ge);
-    else
-        LNH_LAUNCH((k_grid_bwd_scatter<T, 3, 5120>), dim3(div_up(B, 1024) * n_win), dim3(1024), 0, s, grad, inputs, B, m,
-                   plan, pool, cursor, spill_cursor, align, interp, n_win, level_begin, b_begin, B_all, ge);
+    bool generic = false, any_plain = false;
+    for (uint32_t l = level_begin; l < level_end; l++) {
+        const bool g = level_is_generic(m.lv[l], 3, plain);
+        generic |= g;
+        any_plain |= !g;
+    }
+    if (phase != 2) {
+        // the plain classes' levels and the generic ones are served by their own kernel (a workgroup of the other kernel's
+        // level exits at once); the usual configuration has plain levels only
+        if (any_plain)
+            LNH_LAUNCH((k_grid_bwd_scatter_plain<T, 5120>), dim3(n_win, div_up(B, 1024)), dim3(1024), 0, s, grad, inputs, B,
+                       m, plan, pool, cursor, spill_cursor, level_begin, b_begin, B_all, ge);
+        if (generic)
+            LNH_LAUNCH((k_grid_bwd_scatter<T, 3, 6144>), dim3(div_up(B, 1024) * n_win), dim3(1024), 0, s, grad, inputs, B,
+                       m, plan, pool, cursor, spill_cursor, align, interp, n_win, level_begin, b_begin, B_all, ge);
+    }
     int rc = lnh_check_launch("lnh_grid_encode_backward_ws(scatter)");
     if (rc || phase == 1) return rc;
     auto k = k_grid_bwd_reduce<T>;

@@ -22,6 +22,12 @@ Vectors:
                        eval and train (replayed draws); plus the two bias-free Linear stacks evaluated directly on
                        2048 points (inputs, outputs, weight and input gradients) — reference-produced pins for the
                        MFMA MLP kernels (lnh_mlp_forward / lnh_mlp_backward) and the HIP frequency encoder
+  G8 Trainer.train_step  lidarnerf/nerf/utils.py:697-884     the reference's OWN method, called unbound on a stub `self`
+                       (opt = configs/kitti360_1908.txt's loss settings, criterion = main_lidarnerf.py:330-342,
+                       model.render returning fixed leaf tensors): loss + d loss / d (depth, image) for
+                       patch_size_lidar = 1, [2, 8] (the configured patch epochs) and [4, 4].  The module's unused
+                       third-party imports (cv2, lpips, mcubes, ... — none is touched by train_step) resolve to empty
+                       placeholder modules exactly as `trimesh` does above
 """
 import os
 import sys
@@ -311,8 +317,74 @@ def g7():
     return out
 
 
+def _reference_trainer():
+    """lidarnerf.nerf.utils.Trainer with the module-level imports train_step never touches resolved to empty modules
+    (nerf/utils.py:1-27: image IO, LPIPS, marching cubes, tensorboard, SSIM, EMA, the chamfer CUDA extension)."""
+    def stub(name, **attrs):
+        m = sys.modules.get(name)
+        if m is None:
+            m = types.ModuleType(name)
+            sys.modules[name] = m
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        return m
+    for name in ("cv2", "imageio", "lpips", "mcubes", "tensorboardX"):
+        stub(name)
+    stub("skimage").metrics = stub("skimage.metrics", structural_similarity=None)
+    stub("torch_ema", ExponentialMovingAverage=None)
+    stub("extern")
+    stub("extern.chamfer3D")
+    stub("extern.chamfer3D.dist_chamfer_3D", chamfer_3DDist=None)
+    stub("extern.fscore", fscore=None)
+    from lidarnerf.nerf.utils import Trainer
+    return Trainer
+
+
+def g8():
+    import argparse
+    Trainer = _reference_trainer()
+    # main_lidarnerf.py:330-342 with the default criteria (depth l1, raydrop mse, intensity mse, grad l1)
+    loss_dict = {"mse": torch.nn.MSELoss(reduction="none"), "l1": torch.nn.L1Loss(reduction="none")}
+    criterion = {"depth": loss_dict["l1"], "raydrop": loss_dict["mse"], "intensity": loss_dict["mse"], "grad": loss_dict["l1"]}
+    out = {}
+    N = 512
+    g = torch.Generator().manual_seed(88)
+    raydrop = (torch.rand(N, generator=g) < 0.8).float()
+    intensity = torch.rand(N, generator=g)
+    # ground-truth depth in scene units: smooth inside a patch row (neighbours closer than the 0.01 m mask threshold on
+    # about half of the pixel pairs), with jumps in between
+    metres = 5.0 + 60.0 * torch.rand(N // 8, 1, generator=g) + 0.012 * torch.randn(N // 8, 8, generator=g).cumsum(-1)
+    gt = torch.stack([raydrop, intensity, SCALE * metres.reshape(N)], -1)[None]               # images_lidar [1, N, 3]
+    depth0 = gt[0, :, 2] * (1 + 0.05 * torch.randn(N, generator=g)) + 0.003 * torch.rand(N, generator=g)
+    image0 = torch.rand(N, 2, generator=g)
+    out.update(gt=gt.numpy(), depth=depth0.numpy(), image=image0.numpy(), scale=np.float32(SCALE),
+               alphas=np.array([1000.0, 1.0, 10.0, 100.0], dtype=np.float32))               # configs/kitti360_1908.txt:2-5
+    for tag, patch in (("p1", 1), ("p2x8", [2, 8]), ("p4x4", [4, 4])):
+        depth = depth0.clone()[None].requires_grad_(True)                                      # depth_lidar [1, N]
+        image = image0.clone()[None].requires_grad_(True)                                      # image_lidar [1, N, 2]
+
+        class _Model:
+            def render(self, rays_o, rays_d, **kw):
+                assert kw["cal_lidar_color"] and kw["perturb"] and not kw["staged"]
+                return {"image_lidar": image, "depth_lidar": depth}
+
+        opt = argparse.Namespace(enable_lidar=True, patch_size=1, patch_size_lidar=patch, scale=SCALE, alpha_d=1000.0,
+                                 alpha_r=1, alpha_i=10.0, alpha_grad=100.0, grad_loss=True, sobel_grad=False,
+                                 grad_norm_smooth=False, spatial_smooth=False, tv_loss=False, depth_grad_loss="l1")
+        me = types.SimpleNamespace(opt=opt, model=_Model(), criterion=criterion, device=torch.device("cpu"))
+        data = {"rays_o_lidar": torch.zeros(1, N, 3), "rays_d_lidar": torch.zeros(1, N, 3), "images_lidar": gt}
+        pred_i, gt_i, pred_d, gt_d, loss = Trainer.train_step(me, data)
+        loss.backward()
+        out[f"{tag}_loss"] = loss.detach().numpy()
+        out[f"{tag}_grad_depth"] = depth.grad[0].numpy().copy()
+        out[f"{tag}_grad_image"] = image.grad[0].numpy().copy()
+        out[f"{tag}_pred_depth_ret"] = pred_d.detach().numpy().reshape(-1)   # what train_step hands back (patch: metres)
+    np.savez_compressed(os.path.join(OUT, "g8_train_step.npz"), **{k: np.asarray(v, dtype=np.float32) for k, v in out.items()})
+    return out
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     for name in which:
         globals()[name]()
     for f in sorted(os.listdir(OUT)):
