@@ -980,6 +980,7 @@ k_grid_bwd_scatter_plain(const T *__restrict__ grad, const float *__restrict__ i
     const float *px = inputs + (size_t)bc * 3;
     float x0 = px[0], x1 = px[1], x2 = px[2];
     const Vec<T, 2> gv = load_vec<T, 2>(grad + ((size_t)level * B_all + bc) * 2);
+    __syncthreads();  // (the zeroed counters; the loads above stay in flight across it)
     // !(x < 0 || x > 1) per coordinate (gridencoder.cu:158-163), as max3 / min3: a NaN coordinate drops out of both
     bool ok = in_range & !(__builtin_fmaxf(__builtin_fmaxf(x0, x1), x2) > 1.0f) &
               !(__builtin_fminf(__builtin_fminf(x0, x1), x2) < 0.0f);
@@ -1045,6 +1046,54 @@ k_grid_bwd_scatter_plain(const T *__restrict__ grad, const float *__restrict__ i
     if (__builtin_popcountll(cont) < kMinMerges) cont = 0ull;
     const unsigned long long emit_m = ok_m & ~(cont >> 1);  // run tails
     const bool emit = __builtin_amdgcn_inverse_ballot_w64(emit_m);
+    LNH_MARK("F rank");
+    // ---- rank inside the workgroup's (bucket) counters
+    uint32_t bk4[NP], rank[NP], rank_x[NP];
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+        bk4[p] = (r0[p] >> (kBucketRowsLog2 - 2)) & 0xfcu;  // bucket * 4 = LDS byte offset of its counter
+        rank[p] = 0;
+        rank_x[p] = 0;
+    }
+    bool any_single = false;
+#pragma unroll
+    for (int p = 0; p < NP; p++) any_single |= single[p];
+    const bool wave_singles = __builtin_amdgcn_ballot_w64(emit && any_single) != 0ull;  // wave-uniform, rare
+    // The returning LDS atomics are issued BEFORE the value arithmetic: the LDS atomic unit retires ~3 lanes per clock and
+    // CU (29 cycles per wave instruction here), the two resident workgroups of a CU run phase-locked, so nobody else hides
+    // that time — the wave's own ~100 VALU instructions of weights / products / scan do (profiles/r04_scatter_phases.txt).
+    if constexpr (MODE == 1) {
+        // buckets are mixed: per-lane returning atomics
+        if (emit) {
+#pragma unroll
+            for (int p = 0; p < NP; p++) rank[p] = atomicAdd(&lds_at(lcnt, bk4[p]), 1u);
+        }
+    } else {
+        // every emitting lane of a wave usually targets the SAME bucket: 64 returning atomics on one counter serialise, so
+        // aggregate — one lane adds the population count, the others take their rank from the lane mask
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            if (emit_m == 0ull) continue;  // wave-uniform
+            const int leader = __builtin_ctzll(emit_m);
+            const uint32_t bk0 = (uint32_t)__builtin_amdgcn_readlane((int)bk4[p], leader);
+            const bool uniform = __ballot(emit && bk4[p] != bk0) == 0ull;
+            if (uniform) {
+                uint32_t base = 0;
+                if ((int)lane == leader) base = atomicAdd(&lds_at(lcnt, bk0), (uint32_t)__builtin_popcountll(emit_m));
+                base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+                rank[p] = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(emit_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)emit_m, 0u));
+            } else if (emit) {
+                rank[p] = atomicAdd(&lds_at(lcnt, bk4[p]), 1u);
+            }
+        }
+    }
+    if (wave_singles) {  // the second corners of pairs that travel as two singles
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            const uint32_t r1 = MODE == 1 ? (r0[p] ^ xm) : r0[p] + 1u;
+            if (emit && single[p]) rank_x[p] = atomicAdd(&lcnt[r1 >> kBucketRowsLog2], 1u);
+        }
+    }
     LNH_MARK("D values");
     // ---- w * (g0, g1) per corner: float product, then the per-contribution rounding to the table type (gridencoder.cu:350)
     V2 val[8];
@@ -1107,78 +1156,21 @@ k_grid_bwd_scatter_plain(const T *__restrict__ grad, const float *__restrict__ i
 #pragma unroll
         for (int c = 0; c < 8; c++) val[c] = make_v2<T>(vv[2 * c], vv[2 * c + 1]);
     }
-    LNH_MARK("F rank");
-    // ---- rank inside the workgroup's (bucket) counters
-    uint32_t bk4[NP], rank[NP], rank_x[NP];
-#pragma unroll
-    for (int p = 0; p < NP; p++) {
-        bk4[p] = (r0[p] >> (kBucketRowsLog2 - 2)) & 0xfcu;  // bucket * 4 = LDS byte offset of its counter
-        rank[p] = 0;
-        rank_x[p] = 0;
-    }
-    bool any_single = false;
-#pragma unroll
-    for (int p = 0; p < NP; p++) any_single |= single[p];
-    const bool wave_singles = __builtin_amdgcn_ballot_w64(emit && any_single) != 0ull;  // wave-uniform, rare
-    __syncthreads();
-    if constexpr (MODE == 1) {
-        // buckets are mixed: per-lane returning atomics
-        if (emit) {
-#pragma unroll
-            for (int p = 0; p < NP; p++) rank[p] = atomicAdd(&lds_at(lcnt, bk4[p]), 1u);
-        }
-    } else {
-        // every emitting lane of a wave usually targets the SAME bucket: 64 returning atomics on one counter serialise, so
-        // aggregate — one lane adds the population count, the others take their rank from the lane mask
-#pragma unroll
-        for (int p = 0; p < NP; p++) {
-            if (emit_m == 0ull) continue;  // wave-uniform
-            const int leader = __builtin_ctzll(emit_m);
-            const uint32_t bk0 = (uint32_t)__builtin_amdgcn_readlane((int)bk4[p], leader);
-            const bool uniform = __ballot(emit && bk4[p] != bk0) == 0ull;
-            if (uniform) {
-                uint32_t base = 0;
-                if ((int)lane == leader) base = atomicAdd(&lds_at(lcnt, bk0), (uint32_t)__builtin_popcountll(emit_m));
-                base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-                rank[p] = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(emit_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)emit_m, 0u));
-            } else if (emit) {
-                rank[p] = atomicAdd(&lds_at(lcnt, bk4[p]), 1u);
-            }
-        }
-    }
-    if (wave_singles) {  // the second corners of pairs that travel as two singles
-#pragma unroll
-        for (int p = 0; p < NP; p++) {
-            const uint32_t r1 = MODE == 1 ? (r0[p] ^ xm) : r0[p] + 1u;
-            if (emit && single[p]) rank_x[p] = atomicAdd(&lcnt[r1 >> kBucketRowsLog2], 1u);
-        }
-    }
     __syncthreads();
     LNH_MARK("G reserve");
-    // ---- global reservation + exclusive scan of the workgroup's bucket counts (first wave: one counter per lane)
+    // ---- global reservation, in two halves around the staging pass: the first wave ISSUES one returning global atomic per
+    //      touched bucket and publishes the workgroup-local exclusive scan of the counts (all the staging needs); the
+    //      atomics' round trip (~66 us of the pass when it was waited for here) runs under the staging of all 16 waves, and
+    //      the first wave turns the returned bases into pool / spill offsets only afterwards.
+    uint32_t rs_n0 = 0, rs_base = 0, rs_st = 0, rs_incl = 0;
     if (tid < 64) {
         static_assert(kMaxBucketsPerLevel == 64, "one bucket counter per lane of the first wave");
-        const uint32_t n0 = lcnt[lane];
-        uint32_t base = 0;
-        if (lane < nb && n0) base = atomicAdd(&cursor[fb + lane], n0);
-        const uint32_t incl = wave_scan_add_u32(n0);  // DPP network: no LDS round trips while the atomics are in flight
-        const uint32_t st = incl - n0;
-        lstart[lane] = st;
-        // staging slot pos of bucket bk goes to pool slot bk * cap + base + (pos - st) while base + (pos - st) < cap; the
-        // `over` entries behind those go to consecutive slots of the level's spill list, reserved with ONE atomic per
-        // workgroup (and none at all in the usual case of no overflow)
-        const uint32_t fit = base < cap ? min(cap - base, n0) : 0u, over = n0 - fit;
-        const uint32_t oincl = wave_scan_add_u32(over);
-        uint32_t sp0 = 0;
-        if (lane == 63 && oincl) sp0 = atomicAdd(&spill_cursor[level], oincl);
-        sp0 = (uint32_t)__builtin_amdgcn_readlane((int)sp0, 63);
-        lox[lane] = lane * cap + base - st;
-        lofit[lane] = st + fit;
-        lsp[lane] = sp0 + (oincl - over) - (st + fit);
-        if (lane == 63) {
-            lstart[kMaxBucketsPerLevel] = incl;
-            lflag = (incl <= (uint32_t)CAP && oincl == 0u) ? 1u : 0u;
-        }
+        rs_n0 = lcnt[lane];
+        if (lane < nb && rs_n0) rs_base = atomicAdd(&cursor[fb + lane], rs_n0);
+        rs_incl = wave_scan_add_u32(rs_n0);  // DPP network: no LDS round trips while the atomics are in flight
+        rs_st = rs_incl - rs_n0;
+        lstart[lane] = rs_st;
+        if (lane == 63) lstart[kMaxBucketsPerLevel] = rs_incl;
     }
     __syncthreads();
     LNH_MARK("H stage");
@@ -1186,41 +1178,70 @@ k_grid_bwd_scatter_plain(const T *__restrict__ grad, const float *__restrict__ i
     // (<= 4 M points per launch), so every store is base (scalar) + 32-bit lane offset
     char *pvals = pool_bytes + plan.pool_off[level];
     char *prows = pool_bytes + plan.rows_off[level];
-    const bool fast = __builtin_amdgcn_readfirstlane((int)lflag) != 0;
-    const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(lstart[kMaxBucketsPerLevel], (uint32_t)CAP));
+    const uint32_t total_all = (uint32_t)__builtin_amdgcn_readfirstlane((int)lstart[kMaxBucketsPerLevel]);
+    const uint32_t total = min(total_all, (uint32_t)CAP);
+    const bool all_staged = total_all <= (uint32_t)CAP;  // workgroup-uniform; false only for adversarial inputs
     auto key_of = [&](uint32_t r, uint32_t csh) {  // staged key of level-local row r, code << 13
         return (r & (kBucketRows - 1)) | csh | ((r >> kBucketRowsLog2) << 18);
     };
     constexpr int NW = CAP / NTHREADS;
     static_assert(CAP % NTHREADS == 0, "staging slots are dealt to the threads in rounds");
-    if (fast) {
-        // ---- stage (bucket order), no per-entry tests
-        if (emit) {
-            uint32_t st[NP];
+    // ---- stage in bucket order.  Needs the workgroup-local scan only.  An entry whose position lies beyond the staging
+    //      area (more than CAP entries in the workgroup: every x coordinate = 127 mod 128, ...) stays in its thread's
+    //      registers and is written to its global slot by that thread after the bases have arrived.
+    uint32_t pos[NP], pos_x[NP];
 #pragma unroll
-            for (int p = 0; p < NP; p++) st[p] = lds_at(lstart, bk4[p]);
+    for (int p = 0; p < NP; p++) pos[p] = pos_x[p] = 0;
+    auto stage = [&](auto checked_c) {  // (unswitched by hand: the usual, unchecked copy has no per-entry test)
+        constexpr bool CHECKED = decltype(checked_c)::value;
+        if (emit) {
+#pragma unroll
+            for (int p = 0; p < NP; p++) pos[p] = lds_at(lstart, bk4[p]);
 #pragma unroll
             for (int p = 0; p < NP; p++) {
-                const uint32_t pos = st[p] + rank[p];
+                pos[p] += rank[p];
                 const uint32_t csh = MODE == 1 ? codesh : (single[p] ? kCodeSingle << kBucketRowsLog2 : 0u);
-                skey[pos] = (r0[p] & (kBucketRows - 1)) | (csh | (bk4[p] << 16));
-                sa[pos] = val[2 * p];
-                sb[pos] = val[2 * p + 1];
+                if (!CHECKED || pos[p] < (uint32_t)CAP) {
+                    skey[pos[p]] = (r0[p] & (kBucketRows - 1)) | (csh | (bk4[p] << 16));
+                    sa[pos[p]] = val[2 * p];
+                    sb[pos[p]] = val[2 * p + 1];
+                }
             }
         }
-        if (wave_singles && emit) {
+        if (wave_singles && emit) {  // the second corners of pairs that travel as two singles
 #pragma unroll
             for (int p = 0; p < NP; p++)
                 if (single[p]) {
                     const uint32_t r1 = MODE == 1 ? (r0[p] ^ xm) : r0[p] + 1u;
-                    const uint32_t pos = lstart[r1 >> kBucketRowsLog2] + rank_x[p];
-                    skey[pos] = key_of(r1, kCodeSingle << kBucketRowsLog2);
-                    sa[pos] = val[2 * p + 1];
-                    sb[pos] = make_v2<T>(0.0f, 0.0f);
+                    pos_x[p] = lstart[r1 >> kBucketRowsLog2] + rank_x[p];
+                    if (!CHECKED || pos_x[p] < (uint32_t)CAP) {
+                        skey[pos_x[p]] = key_of(r1, kCodeSingle << kBucketRowsLog2);
+                        sa[pos_x[p]] = val[2 * p + 1];
+                        sb[pos_x[p]] = make_v2<T>(0.0f, 0.0f);
+                    }
                 }
         }
-        __syncthreads();
-        LNH_MARK("I writeout");
+    };
+    if (all_staged) stage(std::false_type{});
+    else stage(std::true_type{});
+    // ---- second half of the reservation (first wave): staging slot pos of bucket bk goes to pool slot bk * cap + base +
+    //      (pos - st) while base + (pos - st) < cap; the `over` entries behind those go to consecutive slots of the level's
+    //      spill list, reserved with ONE atomic per workgroup (and none at all in the usual case of no overflow)
+    if (tid < 64) {
+        const uint32_t fit = rs_base < cap ? min(cap - rs_base, rs_n0) : 0u, over = rs_n0 - fit;
+        const uint32_t oincl = wave_scan_add_u32(over);
+        uint32_t sp0 = 0;
+        if (lane == 63 && oincl) sp0 = atomicAdd(&spill_cursor[level], oincl);
+        sp0 = (uint32_t)__builtin_amdgcn_readlane((int)sp0, 63);
+        lox[lane] = lane * cap + rs_base - rs_st;
+        lofit[lane] = rs_st + fit;
+        lsp[lane] = sp0 + (oincl - over) - (rs_st + fit);
+        if (lane == 63) lflag = oincl == 0u ? 1u : 0u;  // 1: every entry of the workgroup has a pool slot
+    }
+    __syncthreads();
+    LNH_MARK("I writeout");
+    const bool fits = __builtin_amdgcn_readfirstlane((int)lflag) != 0;
+    if (fits) {
         // ---- write out: consecutive lanes write consecutive pool slots; all LDS reads of a thread before the first use
         uint32_t ks[NW], dl[NW];
         V2 as[NW], bs[NW];
@@ -1228,10 +1249,10 @@ k_grid_bwd_scatter_plain(const T *__restrict__ grad, const float *__restrict__ i
         for (int i = 0; i < NW; i++) {
             if ((uint32_t)i * NTHREADS >= total) break;  // scalar branch
             // (slots at and beyond `total` hold stale bytes: read, never stored; their 8-bit bucket field stays inside lox)
-            const uint32_t pos = tid + (uint32_t)i * NTHREADS;
-            ks[i] = skey[pos];
-            as[i] = sa[pos];
-            bs[i] = sb[pos];
+            const uint32_t q = tid + (uint32_t)i * NTHREADS;
+            ks[i] = skey[q];
+            as[i] = sa[q];
+            bs[i] = sb[q];
         }
 #pragma unroll
         for (int i = 0; i < NW; i++) {
@@ -1241,31 +1262,31 @@ k_grid_bwd_scatter_plain(const T *__restrict__ grad, const float *__restrict__ i
 #pragma unroll
         for (int i = 0; i < NW; i++) {
             if ((uint32_t)i * NTHREADS >= total) break;
-            const uint32_t pos = tid + (uint32_t)i * NTHREADS;
-            if (pos < total) {
-                const uint32_t slot = dl[i] + pos;
+            const uint32_t q = tid + (uint32_t)i * NTHREADS;
+            if (q < total) {
+                const uint32_t slot = dl[i] + q;
                 Pair pr = {as[i], bs[i]};
                 *reinterpret_cast<Pair *>(pvals + slot * (uint32_t)sizeof(Pair)) = pr;
                 *reinterpret_cast<unsigned short *>(prows + slot * 2u) = (unsigned short)ks[i];
             }
         }
-        return;
+        if (all_staged) return;
     }
     LNH_MARK("J general");
-    // ---- the general path: entries beyond the staging area, a bucket beyond its pool share, a full spill list
+    // ---- the general path: a bucket beyond its pool share (spill list, then atomics), entries beyond the staging area
     char *spill = pool_bytes + plan.spill_off[level];
-    auto to_global = [&](uint32_t pos, uint32_t k, V2 a, V2 b) {
+    auto to_global = [&](uint32_t q, uint32_t k, V2 a, V2 b2) {
         const uint32_t bo = k >> 16;  // bucket * 4
-        if (pos < lds_at(lofit, bo)) {
-            const uint32_t slot = lds_at(lox, bo) + pos;
-            Pair pr = {a, b};
+        if (q < lds_at(lofit, bo)) {
+            const uint32_t slot = lds_at(lox, bo) + q;
+            Pair pr = {a, b2};
             *reinterpret_cast<Pair *>(pvals + slot * (uint32_t)sizeof(Pair)) = pr;
             *reinterpret_cast<unsigned short *>(prows + slot * 2u) = (unsigned short)k;
         } else {
-            const uint32_t sp = lds_at(lsp, bo) + pos;
+            const uint32_t sp = lds_at(lsp, bo) + q;
             const uint32_t rr = (k & (kBucketRows - 1)) | ((k >> 18) << kBucketRowsLog2), cd = (k >> kBucketRowsLog2) & 7u;
             if (sp < plan.spill_cap) {
-                SpillEntry<T> e = {rr | (cd << 29), a, b};
+                SpillEntry<T> e = {rr | (cd << 29), a, b2};
                 *reinterpret_cast<SpillEntry<T> *>(spill + sp * (uint32_t)sizeof(SpillEntry<T>)) = e;
             } else {
                 // The spill list is full too (it holds 1/16 of a level's worst case): these entries go straight into the
@@ -1273,35 +1294,28 @@ k_grid_bwd_scatter_plain(const T *__restrict__ grad, const float *__restrict__ i
                 T *gt = grad_table + (size_t)lv.offset * 2;
                 atomic_add_pair(gt + (size_t)rr * 2, (float)a[0], (float)a[1]);
                 if (cd != kCodeSingle)
-                    atomic_add_pair(gt + (size_t)pair_row(rr, cd, MODE == 1) * 2, (float)b[0], (float)b[1]);
+                    atomic_add_pair(gt + (size_t)pair_row(rr, cd, MODE == 1) * 2, (float)b2[0], (float)b2[1]);
             }
         }
     };
-    auto put = [&](uint32_t r, uint32_t csh, V2 a, V2 b, uint32_t rk) {
-        const uint32_t pos = lstart[r >> kBucketRowsLog2] + rk, k = key_of(r, csh);
-        if (pos < (uint32_t)CAP) {
-            skey[pos] = k;
-            sa[pos] = a;
-            sb[pos] = b;
-        } else {
-            to_global(pos, k, a, b);
+    if (!fits)
+        for (uint32_t q = tid; q < total; q += NTHREADS) to_global(q, skey[q], sa[q], sb[q]);
+    if (!all_staged) {
+        if (emit) {
+#pragma unroll
+            for (int p = 0; p < NP; p++)
+                if (pos[p] >= (uint32_t)CAP)
+                    to_global(pos[p], key_of(r0[p], MODE == 1 ? codesh : (single[p] ? kCodeSingle << kBucketRowsLog2 : 0u)),
+                              val[2 * p], val[2 * p + 1]);
         }
-    };
-    if (emit) {
+        if (wave_singles && emit) {
 #pragma unroll
-        for (int p = 0; p < NP; p++)
-            put(r0[p], MODE == 1 ? codesh : (single[p] ? kCodeSingle << kBucketRowsLog2 : 0u), val[2 * p], val[2 * p + 1],
-                rank[p]);
+            for (int p = 0; p < NP; p++)
+                if (single[p] && pos_x[p] >= (uint32_t)CAP)
+                    to_global(pos_x[p], key_of(MODE == 1 ? (r0[p] ^ xm) : r0[p] + 1u, kCodeSingle << kBucketRowsLog2),
+                              val[2 * p + 1], make_v2<T>(0.0f, 0.0f));
+        }
     }
-    if (wave_singles && emit) {
-#pragma unroll
-        for (int p = 0; p < NP; p++)
-            if (single[p])
-                put(MODE == 1 ? (r0[p] ^ xm) : r0[p] + 1u, kCodeSingle << kBucketRowsLog2, val[2 * p + 1],
-                    make_v2<T>(0.0f, 0.0f), rank_x[p]);
-    }
-    __syncthreads();
-    for (uint32_t pos = tid; pos < total; pos += NTHREADS) to_global(pos, skey[pos], sa[pos], sb[pos]);
     };
 #ifdef LNH_ONLY_MODE  // tools/isa_sections.py: one body per census
     body(std::integral_constant<int, LNH_ONLY_MODE>{});
