@@ -45,6 +45,9 @@ LNH_API int lnh_version(void);
 LNH_API const char *lnh_last_error(void);
 /* "gfx950" — the only architecture this library carries code for */
 LNH_API const char *lnh_arch(void);
+/* "product" for the shipped library; timing-probe builds (tools/probe_variants.py) report their own name here and the
+ * Python side refuses to load them unless LNH_ALLOW_VARIANT=1 — results of such builds are wrong by construction. */
+LNH_API const char *lnh_build_variant(void);
 
 /* ------------------------------------------------------------------ hash / tiled grid encoder --------------- */
 /*
@@ -86,6 +89,11 @@ LNH_API uint64_t lnh_grid_backward_workspace_size(const int32_t *offsets_host, u
  * out[3] = entries per reduce slice (a bucket with more is reduced by several workgroups).  The sum the call produces
  * never depends on these numbers — integer accumulation (see grid.hip) — the tests use them to build inputs that
  * overflow a bucket by a few entries or split one.  Returns LNH_ERR_UNSUPPORTED where workspace_size returns 0. */
+/* Testing knob, process-wide: entries per reduce slice (0 restores the default, 512 K; clamped to [1024, 512 K]) — with the
+ * default only a concentrated batch of more than half a million entries per bucket is reduced in slices; a small value
+ * lets the tests reach that path with small inputs.  Set it BEFORE lnh_grid_backward_workspace_size (more slices need
+ * more image slots).  Never changes a result. */
+LNH_API void lnh_grid_backward_set_slice_entries(uint32_t entries);
 LNH_API int lnh_grid_backward_plan_info(const int32_t *offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
                                         float S, uint32_t H, uint32_t gridtype, int align_corners, int dtype,
                                         uint32_t level, uint32_t *out4);

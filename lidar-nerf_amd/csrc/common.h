@@ -16,6 +16,10 @@ typedef float float4_t __attribute__((ext_vector_type(4)));
 
 #define LNH_WAVE 64
 
+// Name of this build (lnh_build_variant): tools/probe_variants.py compiles its timing probes with -DLNH_VARIANT_TAG="<name>"
+#ifndef LNH_VARIANT_TAG
+#define LNH_VARIANT_TAG "product"
+#endif
 // Section marks for tools/isa_sections.py (an assembly comment per mark in -DLNH_ISA_MARKS builds, nothing otherwise)
 #ifdef LNH_ISA_MARKS
 #define LNH_MARK(name) asm volatile("; MARK " name)

@@ -26,4 +26,5 @@ extern "C" {
 int lnh_version(void) { return 100; }
 const char *lnh_last_error(void) { return g_err; }
 const char *lnh_arch(void) { return "gfx950"; }
+const char *lnh_build_variant(void) { return LNH_VARIANT_TAG; }
 }

@@ -558,6 +558,7 @@ struct BucketPlan {
     uint64_t partial_off;                       // byte offset of the slice images (kBucketRows * 2 int64 each)
     uint32_t spill_cap;                         // entries per spill list (= worst case of a level: B * 2^D)
     uint32_t partial_slots;
+    uint32_t interleaved;                       // bit l: level l maps rows to buckets in 128-row groups (see bucket_of_row)
 };
 
 // ---- pool entries.  One entry carries the contributions of an x-NEIGHBOUR PAIR of corners (c0 = even corner index,
@@ -571,6 +572,26 @@ struct BucketPlan {
 // Pool streams per level: values (two channel pairs: 8 bytes for fp16 tables, 16 for fp32) | 2-byte (row | code << 13):
 // 10 bytes per PAIR of corners through HBM instead of 12, and half the LDS rank / stage / row-decode work per corner.
 constexpr uint32_t kCodeSingle = 7;
+
+// Rows -> buckets.  Hashed (and generic) levels: bucket = 8192 CONSECUTIVE rows — the hash spreads every batch evenly.
+// Dense plain levels: rows are positions in space, every LiDAR ray leaves the same few cells around the sensor, and with
+// consecutive rows level 0 is ONE bucket: one workgroup of the reduce pass worked 240 us on its 350 K entries, most of them
+// on a handful of rows, while the 64 buckets of a hashed level took 85 us side by side — the whole pass waited for it
+// (profiles/r04_reduce_levels.txt).  There the rows are dealt to up to 64 buckets in GROUPS OF 128: bucket = (row >> 7) & 63,
+// position inside the bucket's image = (row >> 13) * 128 + (row & 127).  The eight corner rows of a cell differ by 1, R and
+// R^2 (R = resolution + 1 >= 17), so the y / z neighbours of a hot cell land in other groups, i.e. other buckets; an x pair
+// (r, r + 1) stays inside its group unless r & 127 == 127 (then it travels as two singles, one pair in 128).
+constexpr uint32_t kGroupRowsLog2 = 7;
+__host__ __device__ inline uint32_t bucket_of_row(uint32_t r, bool il) {
+    return il ? (r >> kGroupRowsLog2) & (kMaxBucketsPerLevel - 1) : r >> kBucketRowsLog2;
+}
+__host__ __device__ inline uint32_t local_of_row(uint32_t r, bool il) {
+    return il ? ((r >> kBucketRowsLog2) << kGroupRowsLog2) | (r & ((1u << kGroupRowsLog2) - 1)) : r & (kBucketRows - 1);
+}
+__host__ __device__ inline uint32_t row_of_local(uint32_t loc, uint32_t bk, bool il) {
+    return il ? ((loc >> kGroupRowsLog2) << kBucketRowsLog2) | (bk << kGroupRowsLog2) | (loc & ((1u << kGroupRowsLog2) - 1))
+              : (bk << kBucketRowsLog2) | loc;
+}
 
 template <typename T>
 struct V2Of;
@@ -922,6 +943,10 @@ __host__ __device__ inline bool level_is_generic(const LevelParams &lv, uint32_t
     return true;
 }
 
+#ifndef LNH_SCATTER_THREADS
+#define LNH_SCATTER_THREADS 1024
+#endif
+constexpr int kScatterThreads = LNH_SCATTER_THREADS;  // points (= threads) of a scatter workgroup; 5 staging slots each
 // ---- scatter pass for the two PLAIN level classes (hashed power-of-two tables / dense levels, linear interpolation,
 // align_corners off — every level of the usual configuration).  Same contract as k_grid_bwd_scatter (which keeps the
 // generic classes): same pool format, same cursors, same spill rules; what differs is the instruction budget.  The scatter
@@ -940,14 +965,15 @@ __host__ __device__ inline bool level_is_generic(const LevelParams &lv, uint32_t
 //   * level / chunk come from a 2-D grid (x = level: the level-fastest order), not from a division.
 // (amdgpu_num_sgpr: two 1024-thread workgroups per CU need 8 waves per SIMD, and gfx950 admits 8 only up to 80 SGPRs
 //  including VCC / flat-scratch / XNACK — at the 84 the unconstrained allocation took, ONE workgroup per CU ran and the
-//  pass took 959 us instead of 682; see profiles/r04_scatter_rewrite.txt)
-template <typename T, int CAP>
-__global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(72)))
+//  pass took 959 us instead of 682; amdgpu_waves_per_eu: the same for the VGPR side, 64 at most — fp16 tables; fp32 tables
+//  stage 100 KB and run one workgroup per CU anyway; profiles/r04_scatter_phases.txt)
+template <typename T, int NTHREADS, int CAP>
+__global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(72), amdgpu_waves_per_eu(sizeof(T) == 2 ? 8 : 4)))
 k_grid_bwd_scatter_plain(const T *__restrict__ grad, const float *__restrict__ inputs, uint32_t B, GridMeta meta,
                          BucketPlan plan, char *__restrict__ pool_bytes, uint32_t *__restrict__ cursor,
                          uint32_t *__restrict__ spill_cursor, uint32_t level0, uint32_t b_begin, uint32_t B_all,
                          T *__restrict__ grad_table) {
-    constexpr int NP = 4, NTHREADS = 1024;
+    constexpr int NP = 4;
     typedef v2_t<T> V2;
     struct Pair { V2 a, b; };
     __shared__ uint32_t lcnt[kMaxBucketsPerLevel];
@@ -1030,7 +1056,8 @@ k_grid_bwd_scatter_plain(const T *__restrict__ grad, const float *__restrict__ i
         r0[2] = base + RR;
         r0[3] = base + R + RR;
 #pragma unroll
-        for (int p = 0; p < NP; p++) single[p] = (r0[p] & (kBucketRows - 1)) == kBucketRows - 1;  // r0 + 1 opens the next bucket
+        for (int p = 0; p < NP; p++)  // r0 + 1 opens the next 128-row group, i.e. another bucket (bucket_of_row)
+            single[p] = (r0[p] & ((1u << kGroupRowsLog2) - 1)) == (1u << kGroupRowsLog2) - 1;
         codesh = 0;
     }
     LNH_MARK("C masks");
@@ -1051,7 +1078,8 @@ k_grid_bwd_scatter_plain(const T *__restrict__ grad, const float *__restrict__ i
     uint32_t bk4[NP], rank[NP], rank_x[NP];
 #pragma unroll
     for (int p = 0; p < NP; p++) {
-        bk4[p] = (r0[p] >> (kBucketRowsLog2 - 2)) & 0xfcu;  // bucket * 4 = LDS byte offset of its counter
+        // bucket * 4 = LDS byte offset of its counter (hashed: 8192 consecutive rows; dense: 128-row groups dealt to 64)
+        bk4[p] = (r0[p] >> ((MODE == 1 ? kBucketRowsLog2 : kGroupRowsLog2) - 2)) & 0xfcu;
         rank[p] = 0;
         rank_x[p] = 0;
     }
@@ -1091,7 +1119,7 @@ k_grid_bwd_scatter_plain(const T *__restrict__ grad, const float *__restrict__ i
 #pragma unroll
         for (int p = 0; p < NP; p++) {
             const uint32_t r1 = MODE == 1 ? (r0[p] ^ xm) : r0[p] + 1u;
-            if (emit && single[p]) rank_x[p] = atomicAdd(&lcnt[r1 >> kBucketRowsLog2], 1u);
+            if (emit && single[p]) rank_x[p] = atomicAdd(&lcnt[bucket_of_row(r1, MODE == 2)], 1u);
         }
     }
     LNH_MARK("D values");
@@ -1182,7 +1210,7 @@ k_grid_bwd_scatter_plain(const T *__restrict__ grad, const float *__restrict__ i
     const uint32_t total = min(total_all, (uint32_t)CAP);
     const bool all_staged = total_all <= (uint32_t)CAP;  // workgroup-uniform; false only for adversarial inputs
     auto key_of = [&](uint32_t r, uint32_t csh) {  // staged key of level-local row r, code << 13
-        return (r & (kBucketRows - 1)) | csh | ((r >> kBucketRowsLog2) << 18);
+        return local_of_row(r, MODE == 2) | csh | (bucket_of_row(r, MODE == 2) << 18);
     };
     constexpr int NW = CAP / NTHREADS;
     static_assert(CAP % NTHREADS == 0, "staging slots are dealt to the threads in rounds");
@@ -1202,7 +1230,7 @@ k_grid_bwd_scatter_plain(const T *__restrict__ grad, const float *__restrict__ i
                 pos[p] += rank[p];
                 const uint32_t csh = MODE == 1 ? codesh : (single[p] ? kCodeSingle << kBucketRowsLog2 : 0u);
                 if (!CHECKED || pos[p] < (uint32_t)CAP) {
-                    skey[pos[p]] = (r0[p] & (kBucketRows - 1)) | (csh | (bk4[p] << 16));
+                    skey[pos[p]] = local_of_row(r0[p], MODE == 2) | (csh | (bk4[p] << 16));
                     sa[pos[p]] = val[2 * p];
                     sb[pos[p]] = val[2 * p + 1];
                 }
@@ -1213,7 +1241,7 @@ k_grid_bwd_scatter_plain(const T *__restrict__ grad, const float *__restrict__ i
             for (int p = 0; p < NP; p++)
                 if (single[p]) {
                     const uint32_t r1 = MODE == 1 ? (r0[p] ^ xm) : r0[p] + 1u;
-                    pos_x[p] = lstart[r1 >> kBucketRowsLog2] + rank_x[p];
+                    pos_x[p] = lstart[bucket_of_row(r1, MODE == 2)] + rank_x[p];
                     if (!CHECKED || pos_x[p] < (uint32_t)CAP) {
                         skey[pos_x[p]] = key_of(r1, kCodeSingle << kBucketRowsLog2);
                         sa[pos_x[p]] = val[2 * p + 1];
@@ -1284,7 +1312,7 @@ k_grid_bwd_scatter_plain(const T *__restrict__ grad, const float *__restrict__ i
             *reinterpret_cast<unsigned short *>(prows + slot * 2u) = (unsigned short)k;
         } else {
             const uint32_t sp = lds_at(lsp, bo) + q;
-            const uint32_t rr = (k & (kBucketRows - 1)) | ((k >> 18) << kBucketRowsLog2), cd = (k >> kBucketRowsLog2) & 7u;
+            const uint32_t rr = row_of_local(k & (kBucketRows - 1), k >> 18, MODE == 2), cd = (k >> kBucketRowsLog2) & 7u;
             if (sp < plan.spill_cap) {
                 SpillEntry<T> e = {rr | (cd << 29), a, b2};
                 *reinterpret_cast<SpillEntry<T> *>(spill + sp * (uint32_t)sizeof(SpillEntry<T>)) = e;
@@ -1329,11 +1357,16 @@ k_grid_bwd_scatter_plain(const T *__restrict__ grad, const float *__restrict__ i
 // over up to kMaxSlices workgroups (blockIdx.y).  An unsplit bucket owns its rows and adds its image into the table with
 // plain stores; the slices of a split bucket write their 64-bit integer images to the workspace and the slice that
 // arrives last adds them up — integers, so the sum does not depend on the order.
-constexpr uint32_t kSliceEntries = 512 * 1024;  // measured: 96 K -> 445 us, 192 K -> 425, 384 K -> 415, unsliced 418
+// Entries per slice: 512 K keeps every hashed bucket whole up to 4 M points (a chunk).  Measured in round 4 with everything
+// else as it is: 384 K the same, 256 K +4 %, 192 K and below 3.5 x (every hashed bucket split, its images through HBM).
+// With the dense levels' rows dealt to 64 buckets, slices occur for concentrated batches only; lnh_grid_backward_set_slice_
+// entries lowers the length so that tests reach this path with small inputs.
+constexpr uint32_t kSliceEntries = 512 * 1024;
 constexpr uint32_t kMaxSlices = 16;
+uint32_t g_slice_entries = kSliceEntries;  // process-wide (set before sizing the workspace)
 
-__device__ __forceinline__ uint32_t slices_of(uint32_t n_tot) {
-    const uint32_t s = (n_tot + kSliceEntries - 1) / kSliceEntries;
+__device__ __forceinline__ uint32_t slices_of(uint32_t n_tot, uint32_t per) {
+    const uint32_t s = (n_tot + per - 1) / per;
     return s > kMaxSlices ? kMaxSlices : s;
 }
 // Work items of pass 2 in dispatch order (blockIdx.x): first the EXTRA slices (slice 1.. of every split bucket — known
@@ -1348,6 +1381,7 @@ struct ReduceOrder {
     uint32_t level[LNH_MAX_LEVELS];      // levels of the window in processing order
     uint32_t first[LNH_MAX_LEVELS + 1];  // prefix sum of their bucket counts
     uint32_t n_levels, n_extra, bucket0, n_buckets;  // window: buckets [bucket0, bucket0 + n_buckets)
+    uint32_t slice_entries;
 };
 
 template <typename T>
@@ -1370,11 +1404,11 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
             if (j >= ord.first[q]) k = q;
         bid = plan.first_bucket[ord.level[k]] + (j - ord.first[k]);
     }
-    if (is_extra || slices_of(cursor[bid]) > 1) {  // workgroup-uniform
+    if (is_extra || slices_of(cursor[bid], ord.slice_entries) > 1) {  // workgroup-uniform
         // block-wide exclusive scan over the window's buckets: extra slices before a bucket (-> which bucket an extra
         // workgroup serves) and image slots before it (-> where a split bucket keeps its slice images)
         const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
-        const uint32_t sl = t < ord.n_buckets ? slices_of(cursor[ord.bucket0 + t]) : 0u;
+        const uint32_t sl = t < ord.n_buckets ? slices_of(cursor[ord.bucket0 + t], ord.slice_entries) : 0u;
         const uint32_t ex = sl > 1 ? sl - 1 : 0u, im = sl > 1 ? sl : 0u;
         const uint32_t in_ex = wave_scan_add_u32(ex), in_im = wave_scan_add_u32(im);
         if (lane == 63) {
@@ -1408,48 +1442,81 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
     const uint32_t bk = bid - plan.first_bucket[level], cap = plan.cap[level];
     const uint32_t n_tot = cursor[bid];          // every entry reserved for this bucket, pool + spill
     const uint32_t n_all = min(n_tot, cap);      // ... of which in the pool
-    const uint32_t slices = slices_of(n_tot);
+    const uint32_t slices = slices_of(n_tot, ord.slice_entries);
     if (slice >= slices) return;  // workgroup-uniform (n_tot == 0: nothing to add)
     const uint32_t i_begin = (uint32_t)((uint64_t)n_all * slice / slices);
     const uint32_t i_end = (uint32_t)((uint64_t)n_all * (slice + 1) / slices);
     const uint32_t n = i_end - i_begin;
-    const uint32_t rows = min(kBucketRows, lv.hashmap_size - bk * kBucketRows);
+    const bool il = (plan.interleaved >> level) & 1u;  // rows dealt to the buckets in 128-row groups (bucket_of_row)
+    // table row of position r of this bucket's image (>= hashmap_size: no such row)
+    auto table_row = [&](uint32_t r) { return row_of_local(r, bk, il); };
     // channel-planar image: acc[row] | acc[kBucketRows + row].  With the two channels of a row interleaved, each
-    // ds_add_u64 instruction of a wave would touch only every other pair of banks and pay twice the conflicts; planar,
-    // the 64 random rows of an instruction spread over all banks.
+    // 64-bit LDS add of a wave would touch only every other pair of banks and pay twice the conflicts; planar, the 64
+    // random rows of an instruction spread over all banks.
+    //
+    // Element of the image: 64-bit FIXED POINT (ds_add_u64).  fp16 contributions are multiples of 2^-24 and enter exactly
+    // (half_to_fixed24); fp32 ones are truncated to 2^-40 each.  Integer sums do not depend on the order of arrival.
+    // (Measured and rejected in round 4: a DOUBLE image for fp16 tables — exact as well up to partial sums of 2^29, two
+    // conversions per value instead of five VALU operations — runs the pass at 447 us against 330: ds_add_f64 is the slower
+    // LDS atomic.  profiles/r04_reduce_variants.txt)
+    typedef unsigned long long acc_t;
+    acc_t *img = reinterpret_cast<acc_t *>(smem_raw);
     for (uint32_t i = threadIdx.x; i < kBucketRows * 2; i += blockDim.x) acc[i] = 0ull;
     __syncthreads();
-    auto add_entry = [&](uint32_t row0, uint32_t code, const V2 &a, const V2 &b) {
-        long long qa, qb;
-        to_fixed<T>(a, qa, qb);
-        atomicAdd(&acc[row0], (unsigned long long)qa);  // ds_add_u64
-        atomicAdd(&acc[kBucketRows + row0], (unsigned long long)qb);
-        if (code != kCodeSingle) {
-            const uint32_t row1 = pair_row(row0, code, hashed) & (kBucketRows - 1);
-            to_fixed<T>(b, qa, qb);
-            atomicAdd(&acc[row1], (unsigned long long)qa);
-            atomicAdd(&acc[kBucketRows + row1], (unsigned long long)qb);
-        }
+    auto acc_add = [&](uint32_t idx, T v) {
+        if constexpr (sizeof(T) == 2) atomicAdd(&img[idx], (unsigned long long)half_to_fixed24(v));
+        else atomicAdd(&img[idx], (unsigned long long)(long long)ldexp((double)v, 40));
     };
-    // One workgroup streams its whole slice; every lane keeps UNROLL independent QUADS of entries outstanding
-    // (unconditional, non-temporal loads from clamped indices: a predicated load would be branched around and waited
-    // for one by one; the pool is written once and read once).  A quad = 4 entries = 4 * sizeof(2 V2) bytes of values
-    // (aligned 16-byte loads) + 8 bytes of rows; slots outside [a_begin, a_end) are masked.
-    {
+    // No branch around the LDS adds: a single (code 7) adds ZERO for its absent second corner, to whatever row of the bucket
+    // the pair rule yields.  (Per-entry `if`s cost an exec-mask round trip and a wait each; singles are one entry in 128.)
+    auto add_entry = [&](auto hashed_c, uint32_t row0, uint32_t code, V2 a, V2 b) {
+        constexpr bool HASHED = decltype(hashed_c)::value;
+        const bool sgl = code == kCodeSingle;
+        if constexpr (sizeof(T) == 2) {
+            uint32_t wb = __builtin_bit_cast(uint32_t, b);
+            wb = sgl ? 0u : wb;
+            b = __builtin_bit_cast(V2, wb);
+        } else {
+            b[0] = sgl ? (T)0.0f : b[0];
+            b[1] = sgl ? (T)0.0f : b[1];
+        }
+        const uint32_t row1 = (HASHED ? row0 ^ ((2u << code) - 1u) : row0 + 1u) & (kBucketRows - 1);
+        acc_add(row0, a[0]);
+        acc_add(kBucketRows + row0, a[1]);
+        acc_add(row1, b[0]);
+        acc_add(kBucketRows + row1, b[1]);
+    };
+    // One workgroup streams its whole slice [a_begin, a_end) of the level's slots.  The aligned QUADS inside it (4 entries =
+    // 4 * sizeof(2 V2) bytes of values in 16-byte loads + 8 bytes of rows) take the main loop, with no per-entry range test;
+    // the up to 3 + 3 entries in front of the first and behind the last full quad are added by the first threads, one each.
+    auto stream = [&](auto hashed_c) {
         constexpr uint32_t UNROLL = sizeof(T) == 2 ? 2 : 1;  // (fp16: 1 / 2 / 4 quads in flight per lane measure the same)
-        constexpr uint32_t VQ = sizeof(V2) * 2 * 4 / 16;  // 16-byte loads per quad: 2 (fp16) / 4 (fp32)
-        const uint4_t *vals4 = reinterpret_cast<const uint4_t *>(pool_bytes + plan.pool_off[level]);
-        const uint2_t *rows4 = reinterpret_cast<const uint2_t *>(pool_bytes + plan.rows_off[level]);
+        constexpr uint32_t VQ = sizeof(V2) * 2 * 4 / 16;     // 16-byte loads per quad: 2 (fp16) / 4 (fp32)
+        const char *vbytes = pool_bytes + plan.pool_off[level], *rbytes = pool_bytes + plan.rows_off[level];
+        const uint4_t *vals4 = reinterpret_cast<const uint4_t *>(vbytes);
+        const uint2_t *rows4 = reinterpret_cast<const uint2_t *>(rbytes);
         const uint32_t a_begin = bk * cap + i_begin, a_end = a_begin + n;  // level-relative slots (< 2^32, checked)
-        const uint32_t q_begin = a_begin >> 2, q_end = (a_end + 3) >> 2;
-        const uint32_t nquads = n ? q_end - q_begin : 0u, stride = blockDim.x * UNROLL;
-        // double-buffered: the loads of batch i+1 are in flight while the LDS adds of batch i execute
+        const uint32_t qf_begin = (a_begin + 3) >> 2, qf_end = a_end >> 2;
+        const uint32_t nfull = qf_end > qf_begin ? qf_end - qf_begin : 0u;
+        {
+            const uint32_t lo_end = nfull ? qf_begin * 4 : a_end, hi_begin = nfull ? qf_end * 4 : a_end;
+            const uint32_t n_lo = lo_end - a_begin, n_hi = a_end - hi_begin;
+            if (threadIdx.x < n_lo + n_hi) {
+                const uint32_t slot = threadIdx.x < n_lo ? a_begin + threadIdx.x : hi_begin + (threadIdx.x - n_lo);
+                const V2 *pv = reinterpret_cast<const V2 *>(vbytes + (size_t)slot * (2 * sizeof(V2)));
+                const uint32_t key = *reinterpret_cast<const unsigned short *>(rbytes + (size_t)slot * 2);
+                add_entry(hashed_c, key & (kBucketRows - 1), key >> kBucketRowsLog2, pv[0], pv[1]);
+            }
+        }
+        // every lane keeps UNROLL independent quads outstanding (non-temporal loads: the pool is written once and read
+        // once), double-buffered: the loads of batch i+1 are in flight while the LDS adds of batch i execute
+        const uint32_t stride = blockDim.x * UNROLL;
         uint4_t rv[2][UNROLL][VQ];
         uint2_t rr[2][UNROLL];
         auto fetch = [&](uint32_t j0, uint4_t (&v)[UNROLL][VQ], uint2_t (&r)[UNROLL]) {
 #pragma unroll
             for (uint32_t u = 0; u < UNROLL; u++) {
-                const uint32_t j = j0 + u * blockDim.x, q = q_begin + (j < nquads ? j : nquads - 1);
+                const uint32_t j = j0 + u * blockDim.x, q = qf_begin + (j < nfull ? j : nfull - 1);  // clamped, unconditional
 #pragma unroll
                 for (uint32_t w = 0; w < VQ; w++) v[u][w] = __builtin_nontemporal_load(vals4 + (size_t)q * VQ + w);
                 r[u] = __builtin_nontemporal_load(rows4 + q);
@@ -1458,8 +1525,7 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
         auto consume = [&](uint32_t j0, const uint4_t (&v)[UNROLL][VQ], const uint2_t (&r)[UNROLL]) {
 #pragma unroll
             for (uint32_t u = 0; u < UNROLL; u++) {
-                const uint32_t j = j0 + u * blockDim.x;
-                const uint32_t e0 = (q_begin + j) * 4;
+                if (j0 + u * blockDim.x >= nfull) continue;  // (only in the last round of a lane: one test per quad)
                 uint32_t words[VQ * 4];
 #pragma unroll
                 for (uint32_t w = 0; w < VQ; w++) {
@@ -1469,79 +1535,81 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
                 const uint32_t rw[2] = {r[u].x, r[u].y};
 #pragma unroll
                 for (int h = 0; h < 4; h++) {
-                    if (j < nquads && e0 + h >= a_begin && e0 + h < a_end) {
-                        constexpr uint32_t EW = VQ;  // dwords per entry: 2 (fp16: a | b) / 4 (fp32: a0 a1 | b0 b1)
-                        V2 a, b;
-                        __builtin_memcpy(&a, &words[h * EW], sizeof(V2));
-                        __builtin_memcpy(&b, &words[h * EW + EW / 2], sizeof(V2));
-                        const uint32_t key = (rw[h >> 1] >> (16 * (h & 1))) & 0xffffu;
-                        add_entry(key & (kBucketRows - 1), key >> kBucketRowsLog2, a, b);
-                    }
+                    constexpr uint32_t EW = VQ;  // dwords per entry: 2 (fp16: a | b) / 4 (fp32: a0 a1 | b0 b1)
+                    V2 a, b;
+                    __builtin_memcpy(&a, &words[h * EW], sizeof(V2));
+                    __builtin_memcpy(&b, &words[h * EW + EW / 2], sizeof(V2));
+                    const uint32_t key = (rw[h >> 1] >> (16 * (h & 1))) & 0xffffu;
+                    add_entry(hashed_c, key & (kBucketRows - 1), key >> kBucketRowsLog2, a, b);
                 }
             }
         };
-        if (nquads) fetch(threadIdx.x, rv[0], rr[0]);
+        if (nfull) fetch(threadIdx.x, rv[0], rr[0]);
         uint32_t j0 = threadIdx.x;
-        while (j0 < nquads) {  // unrolled by two so that the buffer index is a compile-time constant
+        while (j0 < nfull) {  // unrolled by two so that the buffer index is a compile-time constant
             const uint32_t j1 = j0 + stride;
-            if (j1 < nquads) fetch(j1, rv[1], rr[1]);
+            if (j1 < nfull) fetch(j1, rv[1], rr[1]);
             consume(j0, rv[0], rr[0]);
-            if (j1 >= nquads) break;
+            if (j1 >= nfull) break;
             const uint32_t j2 = j1 + stride;
-            if (j2 < nquads) fetch(j2, rv[0], rr[0]);
+            if (j2 < nfull) fetch(j2, rv[0], rr[0]);
             consume(j1, rv[1], rr[1]);
             j0 = j2;
         }
-    }
-    // ---- this bucket overflowed its pool: its remaining entries sit somewhere in the level's spill list (among those
-    //      of the level's other overflowing buckets).  Each slice filters its share of the list.
-    if (n_tot > cap) {  // workgroup-uniform
-        const SpillEntry<T> *spill = reinterpret_cast<const SpillEntry<T> *>(pool_bytes + plan.spill_off[level]);
-        const uint32_t s_all = min(spill_cursor[level], plan.spill_cap);
-        const uint32_t s_begin = (uint32_t)((uint64_t)s_all * slice / slices);
-        const uint32_t s_end = (uint32_t)((uint64_t)s_all * (slice + 1) / slices);
-        constexpr uint32_t UNROLL = 4;
-        for (uint32_t i0 = s_begin + threadIdx.x; i0 < s_end; i0 += blockDim.x * UNROLL) {
-            SpillEntry<T> e[UNROLL];
+        // ---- this bucket overflowed its pool: its remaining entries sit somewhere in the level's spill list (among those
+        //      of the level's other overflowing buckets).  Each slice filters its share of the list.
+        if (n_tot > cap) {  // workgroup-uniform
+            const SpillEntry<T> *spill = reinterpret_cast<const SpillEntry<T> *>(pool_bytes + plan.spill_off[level]);
+            const uint32_t s_all = min(spill_cursor[level], plan.spill_cap);
+            const uint32_t s_begin = (uint32_t)((uint64_t)s_all * slice / slices);
+            const uint32_t s_end = (uint32_t)((uint64_t)s_all * (slice + 1) / slices);
+            constexpr uint32_t SU = 4;
+            for (uint32_t i0 = s_begin + threadIdx.x; i0 < s_end; i0 += blockDim.x * SU) {
+                SpillEntry<T> e[SU];
 #pragma unroll
-            for (uint32_t u = 0; u < UNROLL; u++) {
-                const uint32_t i = i0 + u * blockDim.x;
-                e[u] = spill[i < s_end ? i : s_end - 1];
-            }
+                for (uint32_t u = 0; u < SU; u++) {
+                    const uint32_t i = i0 + u * blockDim.x;
+                    e[u] = spill[i < s_end ? i : s_end - 1];
+                }
 #pragma unroll
-            for (uint32_t u = 0; u < UNROLL; u++) {
-                const uint32_t i = i0 + u * blockDim.x;
-                const uint32_t r = e[u].key & 0x7ffffu;
-                if (i < s_end && (r >> kBucketRowsLog2) == bk) add_entry(r & (kBucketRows - 1), e[u].key >> 29, e[u].a, e[u].b);
+                for (uint32_t u = 0; u < SU; u++) {
+                    const uint32_t i = i0 + u * blockDim.x;
+                    const uint32_t r = e[u].key & 0x7ffffu;
+                    if (i < s_end && bucket_of_row(r, il) == bk)
+                        add_entry(hashed_c, local_of_row(r, il), e[u].key >> 29, e[u].a, e[u].b);
+                }
             }
         }
-    }
+    };
+    if (hashed) stream(std::true_type{});
+    else stream(std::false_type{});
     __syncthreads();
+    // image element -> float: the exact integer sum * 2^-K, rounded once
+    auto to_float = [&](acc_t q) -> float { return (float)ldexp((double)(long long)q, -K); };
     if (slices == 1) {
         // this workgroup owns the bucket's rows: table += image.  All row loads of a thread are issued before the first
         // use (a load -> add -> store chain per row would cost a memory round trip per row: 8 in a row per thread)
-        T *gt = grad_table + ((size_t)lv.offset + (size_t)bk * kBucketRows) * 2;
+        T *gt = grad_table + (size_t)lv.offset * 2;
         constexpr uint32_t RPT = kBucketRows / 1024;
         Vec<T, 2> cur[RPT];
 #pragma unroll
         for (uint32_t i = 0; i < RPT; i++) {
-            const uint32_t r = threadIdx.x + i * 1024u;
-            cur[i] = load_vec<T, 2>(gt + 2 * (r < rows ? r : 0u));
+            const uint32_t row = table_row(threadIdx.x + i * 1024u);
+            cur[i] = load_vec<T, 2>(gt + 2 * (size_t)(row < lv.hashmap_size ? row : 0u));
         }
 #pragma unroll
         for (uint32_t i = 0; i < RPT; i++) {
-            const uint32_t r = threadIdx.x + i * 1024u;
-            const long long qa = (long long)acc[r], qb = (long long)acc[kBucketRows + r];
-            if (r < rows && (qa != 0 || qb != 0)) {
-                const float a = (float)ldexp((double)qa, -K), b = (float)ldexp((double)qb, -K);
-                cur[i].v[0] = (T)((float)cur[i].v[0] + a);
-                cur[i].v[1] = (T)((float)cur[i].v[1] + b);
-                store_vec<T, 2>(gt + 2 * r, cur[i]);
+            const uint32_t r = threadIdx.x + i * 1024u, row = table_row(r);
+            const acc_t qa = img[r], qb = img[kBucketRows + r];
+            if (row < lv.hashmap_size && (qa != (acc_t)0 || qb != (acc_t)0)) {
+                cur[i].v[0] = (T)((float)cur[i].v[0] + to_float(qa));
+                cur[i].v[1] = (T)((float)cur[i].v[1] + to_float(qb));
+                store_vec<T, 2>(gt + 2 * (size_t)row, cur[i]);
             }
         }
     } else {
         // slice image -> workspace (coalesced 16-byte stores of the whole image); the slice that finishes LAST adds the
-        // images up (integers: the sum does not depend on which slice that is) and adds the rows into the table
+        // images up (exact sums: the result does not depend on which slice that is) and adds the rows into the table
         if (slot0 + slices > plan.partial_slots) return;  // (never: plan_buckets sizes the region for the worst case)
         char *images = const_cast<char *>(pool_bytes) + plan.partial_off;
         uint4 *dst = reinterpret_cast<uint4 *>(images) + (size_t)(slot0 + slice) * kBucketRows;
@@ -1553,21 +1621,21 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
         __syncthreads();
         if (sh_sum != slices - 1) return;  // workgroup-uniform
         __threadfence();  // acquire: the other slices' images (written by other CUs / XCDs) are read from memory
-        const unsigned long long *img = reinterpret_cast<const unsigned long long *>(images) +
-                                        (size_t)slot0 * kBucketRows * 2;
-        T *gt = grad_table + ((size_t)lv.offset + (size_t)bk * kBucketRows) * 2;
-        for (uint32_t r = threadIdx.x; r < rows; r += blockDim.x) {
-            long long qa = 0, qb = 0;
+        const acc_t *simg = reinterpret_cast<const acc_t *>(images) + (size_t)slot0 * kBucketRows * 2;
+        T *gt = grad_table + (size_t)lv.offset * 2;
+        for (uint32_t r = threadIdx.x; r < kBucketRows; r += blockDim.x) {
+            const uint32_t row = table_row(r);
+            if (row >= lv.hashmap_size) continue;
+            acc_t qa = (acc_t)0, qb = (acc_t)0;
             for (uint32_t sl = 0; sl < slices; sl++) {
-                qa += (long long)img[(size_t)sl * kBucketRows * 2 + r];
-                qb += (long long)img[(size_t)sl * kBucketRows * 2 + kBucketRows + r];
+                qa += simg[(size_t)sl * kBucketRows * 2 + r];
+                qb += simg[(size_t)sl * kBucketRows * 2 + kBucketRows + r];
             }
-            if (qa != 0 || qb != 0) {
-                const float a = (float)ldexp((double)qa, -K), b = (float)ldexp((double)qb, -K);
-                Vec<T, 2> cur = load_vec<T, 2>(gt + 2 * r);
-                cur.v[0] = (T)((float)cur.v[0] + a);
-                cur.v[1] = (T)((float)cur.v[1] + b);
-                store_vec<T, 2>(gt + 2 * r, cur);
+            if (qa != (acc_t)0 || qb != (acc_t)0) {
+                Vec<T, 2> cur = load_vec<T, 2>(gt + 2 * (size_t)row);
+                cur.v[0] = (T)((float)cur.v[0] + to_float(qa));
+                cur.v[1] = (T)((float)cur.v[1] + to_float(qb));
+                store_vec<T, 2>(gt + 2 * (size_t)row, cur);
             }
         }
     }
@@ -1589,8 +1657,14 @@ uint64_t plan_buckets(BucketPlan &plan, const GridMeta &m, uint32_t L, uint32_t 
     const uint64_t worst = (uint64_t)B << D;  // worst-case entries of one level (all singles)
     uint64_t bytes = 0;
     uint32_t nbt = 0;
+    plan.interleaved = 0;
     for (uint32_t l = 0; l < L; l++) {
-        const uint32_t nb = (m.lv[l].hashmap_size + kBucketRows - 1) / kBucketRows;
+        // dense plain levels (k_grid_bwd_scatter_plain's MODE 2): 128-row groups dealt to up to 64 buckets
+        const bool il = plain && !(m.lv[l].flags & LV_HASH) && (m.lv[l].flags & LV_NOWRAP) && (m.lv[l].flags & 15u) == D;
+        if (il) plan.interleaved |= 1u << l;
+        const uint32_t groups = (m.lv[l].hashmap_size + (1u << kGroupRowsLog2) - 1) >> kGroupRowsLog2;
+        const uint32_t nb = il ? std::min<uint32_t>(groups, kMaxBucketsPerLevel)
+                               : (m.lv[l].hashmap_size + kBucketRows - 1) / kBucketRows;
         plan.first_bucket[l] = nbt;
         const uint64_t expect = level_is_generic(m.lv[l], D, plain) ? worst : worst / 2 + worst / 128;
         const uint64_t mean = (expect + nb - 1) / nb;
@@ -1617,9 +1691,9 @@ uint64_t plan_buckets(BucketPlan &plan, const GridMeta &m, uint32_t L, uint32_t 
         plan.spill_off[l] = bytes;
         bytes += ((uint64_t)plan.spill_cap * sizeof(SpillEntry<T>) + 15) / 16 * 16;
     }
-    // slice images: a split bucket has n > kSliceEntries entries and ceil(n / kSliceEntries) < 2 n / kSliceEntries
-    // slices, so all split buckets together have fewer than 2 * (entries of all levels) / kSliceEntries of them
-    uint64_t slots = 2 * (worst * L) / kSliceEntries + 1;
+    // slice images: a split bucket has n > S entries (S = slice length of its level) and ceil(n / S) < 2 n / S slices, so
+    // the split buckets of a level together have fewer than 2 * (entries of the level) / S of them
+    uint64_t slots = 2 * (worst * L) / g_slice_entries + 1;
     if (slots > (uint64_t)nbt * kMaxSlices) slots = (uint64_t)nbt * kMaxSlices;
     plan.partial_slots = (uint32_t)slots;
     plan.partial_off = bytes;
@@ -1747,8 +1821,9 @@ int launch_backward_bucketed_chunk(const T *grad, const float *inputs, T *ge, ui
         // the plain classes' levels and the generic ones are served by their own kernel (a workgroup of the other kernel's
         // level exits at once); the usual configuration has plain levels only
         if (any_plain)
-            LNH_LAUNCH((k_grid_bwd_scatter_plain<T, 5120>), dim3(n_win, div_up(B, 1024)), dim3(1024), 0, s, grad, inputs, B,
-                       m, plan, pool, cursor, spill_cursor, level_begin, b_begin, B_all, ge);
+            LNH_LAUNCH((k_grid_bwd_scatter_plain<T, kScatterThreads, 5 * kScatterThreads>), dim3(n_win, div_up(B, kScatterThreads)),
+                       dim3(kScatterThreads), 0, s, grad, inputs, B, m, plan, pool, cursor, spill_cursor, level_begin, b_begin,
+                       B_all, ge);
         if (generic)
             LNH_LAUNCH((k_grid_bwd_scatter<T, 3, 6144>), dim3(div_up(B, 1024) * n_win), dim3(1024), 0, s, grad, inputs, B,
                        m, plan, pool, cursor, spill_cursor, align, interp, n_win, level_begin, b_begin, B_all, ge);
@@ -1774,8 +1849,9 @@ int launch_backward_bucketed_chunk(const T *grad, const float *inputs, T *ge, ui
         if (m.lv[l].flags & LV_HASH) push(l);
     // slices beyond the first: sum over buckets of ceil(n / kSliceEntries) - 1 <= (entries of the window) / kSliceEntries
     const uint64_t extra = std::min<uint64_t>((uint64_t)ord.n_buckets * (kMaxSlices - 1),
-                                              (((uint64_t)B << 3) * n_win) / kSliceEntries);
+                                              (((uint64_t)B << 3) * n_win) / g_slice_entries);
     ord.n_extra = (uint32_t)extra;
+    ord.slice_entries = g_slice_entries;
     LNH_LAUNCH(k, dim3(ord.n_extra + ord.n_buckets), dim3(1024), lds, s, ge, m, plan, pool, cursor, spill_cursor, done, L,
                ord);
     return lnh_check_launch("lnh_grid_encode_backward_ws(reduce)");
@@ -2089,6 +2165,10 @@ uint64_t lnh_grid_backward_workspace_size(const int32_t *offsets_host, uint32_t 
     return need;
 }
 
+void lnh_grid_backward_set_slice_entries(uint32_t entries) {
+    g_slice_entries = entries == 0 ? kSliceEntries : std::min(std::max(entries, 1024u), kSliceEntries);
+}
+
 int lnh_grid_backward_plan_info(const int32_t *offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
                                 uint32_t H, uint32_t gridtype, int align_corners, int dtype, uint32_t level,
                                 uint32_t *out4) {
@@ -2104,7 +2184,7 @@ int lnh_grid_backward_plan_info(const int32_t *offsets_host, uint32_t B, uint32_
     out4[0] = plan.first_bucket[level + 1] - plan.first_bucket[level];
     out4[1] = plan.cap[level];
     out4[2] = kBucketRows;
-    out4[3] = kSliceEntries;
+    out4[3] = g_slice_entries;
     return LNH_OK;
 }
 

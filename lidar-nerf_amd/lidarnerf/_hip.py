@@ -86,8 +86,9 @@ for _n in ("lnh_mlp_forward", "lnh_mlp_backward", "lnh_density_mlp_forward", "ln
            "lnh_ragged_pack_weights", "lnh_ragged_color_input", "lnh_ragged_color_output",
            "lnh_ragged_color_output_backward", "lnh_ragged_grad_rows"):
     _SIGS[_n + "_bf16"] = _SIGS[_n]  # bf16-operand build of the MLP kernels (include/lidarnerf_hip.h, last section)
-EXPORTS = sorted(list(_SIGS) + ["lnh_version", "lnh_last_error", "lnh_arch", "lnh_grid_backward_workspace_size",
-                                 "lnh_grid_backward_plan_info"])
+EXPORTS = sorted(list(_SIGS) + ["lnh_version", "lnh_last_error", "lnh_arch", "lnh_build_variant",
+                                 "lnh_grid_backward_workspace_size", "lnh_grid_backward_plan_info",
+                                 "lnh_grid_backward_set_slice_entries"])
 
 LNH_F32, LNH_F16 = 0, 1
 
@@ -115,9 +116,18 @@ def lib():
         L.lnh_grid_backward_workspace_size.restype = C.c_uint64
         L.lnh_grid_backward_plan_info.argtypes = [P, U32, U32, U32, U32, F32, U32, U32, I32, I32, U32, P]
         L.lnh_grid_backward_plan_info.restype = C.c_int
+        L.lnh_grid_backward_set_slice_entries.argtypes = [U32]
+        L.lnh_grid_backward_set_slice_entries.restype = None
         L.lnh_last_error.restype = C.c_char_p
         L.lnh_arch.restype = C.c_char_p
+        L.lnh_build_variant.restype = C.c_char_p
         L.lnh_version.restype = C.c_int
+        # A library that is not the product build (tools/probe_variants.py: phases compiled out, fake cursors, ...) gives
+        # WRONG results by construction; LNH_LIB_PATH may point at one only together with LNH_ALLOW_VARIANT=1.
+        tag = L.lnh_build_variant().decode()
+        if tag != "product" and os.environ.get("LNH_ALLOW_VARIANT") != "1":
+            raise RuntimeError(f"{_LIB_PATH} is the timing-probe build '{tag}', not the product library "
+                               "(set LNH_ALLOW_VARIANT=1 to time it; its results are wrong by construction)")
         _lib = L
     return _lib
 

@@ -268,23 +268,32 @@ def test_backward_bucketed_overflow_by_a_few(dt):
 @pytest.mark.parametrize("dt", [torch.float32, torch.float16])
 def test_backward_bucketed_sliced_and_spilled(dt):
     """One cell receives every 16th point of 320 K (its neighbours in the batch are random points, so nothing merges), the
-    rest is uniform: level 0 (one bucket, 1.3 M pair entries) is reduced in slices; on the hashed levels the buckets holding
-    that cell's corner rows receive 20 K entries on top of their even share and overflow into the spill list (which holds 1/16
-    of a level's worst case: 164 K entries).  Against the oracle, repeated for bit equality."""
+    rest is uniform, and the slice length of the reduce pass is lowered to 8 K entries (lnh_grid_backward_set_slice_entries;
+    default 512 K — with the dense levels' rows dealt to 64 buckets only a concentrated batch of millions of points gets
+    there): every bucket of every level is reduced in slices whose images the last slice to arrive adds up; on the hashed
+    levels the buckets holding that cell's corner rows receive 20 K entries on top of their even share and overflow into the
+    spill list (which holds 1/16 of a level's worst case: 164 K entries), which every slice filters.  Against the oracle,
+    repeated for bit equality."""
+    from lidarnerf import _hip
     code = 0 if dt == torch.float32 else 1
     B = 320 * 1024
     r = np.random.default_rng(1)
     x = r.random((B, 3), dtype=np.float32)
     x[0::16] = np.float32(0.3) + r.random((B // 16, 3), dtype=np.float32) * np.float32(1e-6)
-    nb0, cap0, _, slice_entries = _plan(B, 0, code)
-    nb9, cap9, _, _ = _plan(B, 9, code)
-    assert nb0 == 1 and B * 4 > 2 * slice_entries                   # level 0 is cut into slices (4 pair entries per point)
-    mean9 = B * 4 / nb9
-    assert mean9 + B // 16 > cap9 + 1000                             # a hashed bucket holding one corner row overflows
-    assert 4 * (mean9 + B // 16 - cap9) < B * 8 // 16                # ... and the level's spill list holds the excess
-    nd = np.float32 if dt == torch.float32 else np.float16
-    g = (np.random.default_rng(8).standard_normal((L, B, CH)) * 0.1).astype(nd)
-    got = _run_bucketed(x, g, dt, times=2)
+    _hip.lib().lnh_grid_backward_set_slice_entries(8192)
+    try:
+        nb0, cap0, _, slice_entries = _plan(B, 0, code)
+        nb9, cap9, _, _ = _plan(B, 9, code)
+        assert slice_entries == 8192 and B * 4 / nb0 > 2 * slice_entries and B * 4 / nb9 > 2 * slice_entries
+        mean9 = B * 4 / nb9
+        assert mean9 + B // 16 > cap9 + 1000                         # a hashed bucket holding one corner row overflows
+        assert 4 * (mean9 + B // 16 - cap9) < B * 8 // 16            # ... and the level's spill list holds the excess
+        nd = np.float32 if dt == torch.float32 else np.float16
+        g = (np.random.default_rng(8).standard_normal((L, B, CH)) * 0.1).astype(nd)
+        got = _run_bucketed(x, g, dt, times=2)
+    finally:
+        _hip.lib().lnh_grid_backward_set_slice_entries(0)
+    assert _plan(B, 0, code)[3] == 512 * 1024
     want = c_oracle.grid_backward(g, x, OFF, int(OFF[-1]), S, H)
     if dt == torch.float32:
         # up to 20 K addends per row, each truncated to 2^-40 before the integer sum: one fp32 rounding on top
@@ -292,6 +301,19 @@ def test_backward_bucketed_sliced_and_spilled(dt):
     else:
         np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-3)
     assert np.all(got[want == 0] == 0)
+    # the same batch with the default slice length (no bucket is split): bit-identical — slicing never changes a sum
+    again = _run_bucketed(x, g, dt, times=1)
+    assert np.array_equal(got, again)
+
+
+def test_dense_levels_are_dealt_to_64_buckets():
+    """Plan of the dense plain levels (grid.hip bucket_of_row): rows go to min(64, ceil(rows / 128)) buckets in groups of
+    128, so the few cells around the sensor that every LiDAR ray leaves are reduced by many workgroups, not one."""
+    for level, rows in ((0, 17 ** 3), (1, 28 ** 3), (2, 45 ** 3), (3, 75 ** 3)):
+        assert int(OFF[level + 1] - OFF[level]) >= rows
+        nb = _plan(4096 * 832, level, 1)[0]
+        assert nb == min(64, -(-int(OFF[level + 1] - OFF[level]) // 128)), (level, nb)
+    assert _plan(4096 * 832, 4, 1)[0] == 64      # first hashed level: 2^19 rows, 8192 consecutive rows per bucket
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.float16])
@@ -320,10 +342,8 @@ def test_backward_bucketed_spill_list_full_falls_back_to_atomics(dt):
     assert np.isfinite(got).all() and np.all(got[want == 0] == 0)
     rel = np.linalg.norm(got - want) / np.linalg.norm(want)
     assert rel < (1e-4 if dt == torch.float32 else 0.25), rel
-    # the levels that never overflow (level 0: one bucket, its pool holds the level's worst case) stay exact
-    lvl0 = slice(0, int(OFF[1]))
-    np.testing.assert_allclose(got[lvl0], want[lvl0], rtol=1e-5 if dt == torch.float32 else 2e-3,
-                               atol=1e-6 if dt == torch.float32 else 2e-3)
+    # rows no point of the batch touches stay exactly zero; every other level's hot rows went the same way (level 0 too: its
+    # rows are dealt to 38 buckets, the four holding the cell's even corners overflow like the hashed ones)
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.float16])

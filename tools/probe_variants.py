@@ -30,23 +30,80 @@ def _keep(exprs):
 VAL_WORDS = [f"__builtin_bit_cast(uint32_t, (float)val[{c}][0]) ^ __builtin_bit_cast(uint32_t, (float)val[{c}][1])" for c in range(8)]
 # ---- scatter pass of the table-gradient backward cut after each of its phases (profiles/r04_scatter_phases.txt)
 SCATTER_CUTS = {
-    "cutA": ("grid.hip", [("    // ---- rank inside the workgroup's (bucket) counters",
-                           "    " + _keep(VAL_WORDS + ["r0[0] ^ r0[1] ^ r0[2] ^ r0[3]", "emit", "codesh"]) + "    if (B != 0xffffffffu) return;\n"
-                           "    // ---- rank inside the workgroup's (bucket) counters")]),
-    "cutB": ("grid.hip", [("    // ---- global reservation + exclusive scan of the workgroup's bucket counts (first wave: one counter per lane)\n    if (tid < 64) {\n        static_assert",
-                           "    " + _keep(VAL_WORDS + ["rank[0] ^ rank[1] ^ rank[2] ^ rank[3] ^ rank_x[0] ^ rank_x[1] ^ rank_x[2] ^ rank_x[3]", "lcnt[lane]"]) + "    if (B != 0xffffffffu) return;\n"
-                           "    // ---- global reservation + exclusive scan of the workgroup's bucket counts (first wave: one counter per lane)\n    if (tid < 64) {\n        static_assert")]),
-    "cutC": ("grid.hip", [("    const bool fast = __builtin_amdgcn_readfirstlane((int)lflag) != 0;",
-                           "    " + _keep(VAL_WORDS + ["rank[0] ^ rank[1] ^ rank[2] ^ rank[3]", "lox[lane] ^ lstart[lane]"]) + "    if (B != 0xffffffffu) return;\n"
-                           "    const bool fast = __builtin_amdgcn_readfirstlane((int)lflag) != 0;")]),
-    "cutD": ("grid.hip", [("        // ---- write out: consecutive lanes write consecutive pool slots; all LDS reads",
-                           "        " + _keep(["skey[tid] ^ skey[tid + 1024]"]) + "        if (B != 0xffffffffu) return;\n"
-                           "        // ---- write out: consecutive lanes write consecutive pool slots; all LDS reads")]),
-    "noatomic": ("grid.hip", [("        if (lane < nb && n0) base = atomicAdd(&cursor[fb + lane], n0);\n        const uint32_t incl = wave_scan_add_u32(n0);  // DPP network: no LDS round trips while the atomics are in flight\n        const uint32_t st = incl - n0;\n        lstart[lane] = st;\n        // staging slot pos of bucket bk goes",
-                               "        if (lane < nb && n0) base = (blockIdx.y * 97u) % (cap - n0);\n        const uint32_t incl = wave_scan_add_u32(n0);  // DPP network: no LDS round trips while the atomics are in flight\n        const uint32_t st = incl - n0;\n        lstart[lane] = st;\n        // staging slot pos of bucket bk goes")]),
+    # A: load, locate, rows, merge masks.  B: + rank atomics, values, scan, barrier.  C: + cursor atomics issued, local scan,
+    # barrier.  D: + staging, reservation completed, barrier.  full: + write-out.
+    "cutA": ("grid.hip", [('    LNH_MARK("F rank");', "    " + _keep(["r0[0] ^ r0[1] ^ r0[2] ^ r0[3]", "emit", "codesh", "__builtin_bit_cast(uint32_t, fr0 + fr1 + fr2 + g0 + g1)"]) + "    if (B != 0xffffffffu) return;\n")]),
+    "cutB": ("grid.hip", [('    LNH_MARK("G reserve");', "    " + _keep(VAL_WORDS + ["rank[0] ^ rank[1] ^ rank[2] ^ rank[3] ^ rank_x[0] ^ rank_x[1] ^ rank_x[2] ^ rank_x[3]", "lcnt[lane]"]) + "    if (B != 0xffffffffu) return;\n")]),
+    "cutC": ("grid.hip", [('    LNH_MARK("H stage");', "    " + _keep(VAL_WORDS + ["rank[0] ^ rank[1] ^ rank[2] ^ rank[3]", "rs_base ^ lstart[lane]"]) + "    if (B != 0xffffffffu) return;\n")]),
+    "cutD": ("grid.hip", [('    LNH_MARK("I writeout");', "    " + _keep(["skey[tid] ^ skey[tid + 1024] ^ lox[lane]"]) + "    if (B != 0xffffffffu) return;\n")]),
+    "noatomic": ("grid.hip", [("        if (lane < nb && rs_n0) rs_base = atomicAdd(&cursor[fb + lane], rs_n0);",
+                               "        if (lane < nb && rs_n0) rs_base = (blockIdx.y * 97u) % (cap - rs_n0);")]),
     "full": ("grid.hip", []),
 }
-SETS = {"scatter": SCATTER_CUTS}
+
+# ---- phase-lock breakers: the second workgroup of every CU starts late once (the offset then persists)
+def _stagger(n):
+    return ("grid.hip", [("    if (!cls_hash && !cls_dense) return;  // generic class: k_grid_bwd_scatter's level\n",
+                          "    if (!cls_hash && !cls_dense) return;  // generic class: k_grid_bwd_scatter's level\n"
+                          "    { const uint32_t lin = blockIdx.y * gridDim.x + blockIdx.x;\n"
+                          "      if (lin >= 256u && lin < 512u) __builtin_amdgcn_s_sleep(%d); }\n" % n)])
+
+
+STAGGER = {"stag40": _stagger(40), "stag80": _stagger(80), "stag120": _stagger(120), "full": ("grid.hip", [])}
+
+# ---- a workgroup walks N consecutive chunks of the same level (the stores of one chunk drain under the next chunk's work)
+def _iters(n):
+    return ("grid.hip", [
+        ("    const uint32_t level = level0 + blockIdx.x, chunk = blockIdx.y;",
+         "    const uint32_t level = level0 + blockIdx.x; uint32_t chunk = 0;"),
+        ("    if (cls_hash) body(std::integral_constant<int, 1>{});\n    else body(std::integral_constant<int, 2>{});\n#endif\n}\n\n// A bucket with many entries",
+         "    for (uint32_t it = 0; it < %du; it++) {\n        chunk = blockIdx.y * %du + it;\n        if (chunk * (uint32_t)NTHREADS >= B) break;\n"
+         "        if (it) __syncthreads();\n"
+         "        if (cls_hash) body(std::integral_constant<int, 1>{});\n        else body(std::integral_constant<int, 2>{});\n    }\n#endif\n}\n\n// A bucket with many entries" % (n, n)),
+        ("dim3(n_win, div_up(B, kScatterThreads)),", "dim3(n_win, div_up(div_up(B, kScatterThreads), %d))," % n)])
+
+
+ITERS = {"it2": _iters(2), "it4": _iters(4), "it13": _iters(13), "full": ("grid.hip", [])}
+
+# ---- scatter workgroups of 512 / 256 threads (4 / 8 per CU instead of 2; the cursor atomics double / quadruple)
+def _threads(n):
+    return ("grid.hip", [("#define LNH_SCATTER_THREADS 1024", "#define LNH_SCATTER_THREADS %d" % n)])
+
+
+WGSIZE = {"t512": _threads(512), "t256": _threads(256), "full": ("grid.hip", [])}
+
+# ---- reduce pass with one ingredient removed at a time (profiles/r04_reduce_variants.txt)
+REDUCE = {
+    # the pool stream and the conversions, no LDS add (the values are folded into one word per lane instead)
+    "r_noadd": ("grid.hip", [("        if constexpr (sizeof(T) == 2) atomicAdd(&img[idx], (unsigned long long)half_to_fixed24(v));",
+                              "        if constexpr (sizeof(T) == 2) { probe_acc ^= (unsigned long long)half_to_fixed24(v) + idx; }"),
+                             ("    auto acc_add = [&](uint32_t idx, T v) {", "    unsigned long long probe_acc = 0;\n    auto acc_add = [&](uint32_t idx, T v) {"),
+                             ("    if (hashed) stream(std::true_type{});\n    else stream(std::false_type{});\n",
+                              "    if (hashed) stream(std::true_type{});\n    else stream(std::false_type{});\n    if (probe_acc == 0x123456789abcull) img[threadIdx.x] = probe_acc;\n")]),
+    # the pool stream and the LDS adds, no conversion (the raw half bits are added)
+    "r_noconv": ("grid.hip", [("        if constexpr (sizeof(T) == 2) atomicAdd(&img[idx], (unsigned long long)half_to_fixed24(v));",
+                               "        if constexpr (sizeof(T) == 2) atomicAdd(&img[idx], (unsigned long long)__builtin_bit_cast(unsigned short, v));")]),
+    # conversions and LDS adds on the first quad of the slice over and over, no pool stream
+    "r_noload": ("grid.hip", [("                const uint32_t j = j0 + u * blockDim.x, q = qf_begin + (j < nfull ? j : nfull - 1);  // clamped, unconditional",
+                               "                const uint32_t j = j0 + u * blockDim.x, q = qf_begin + ((j < nfull ? j : nfull - 1) & 1023u);")]),
+    "full": ("grid.hip", []),
+}
+
+# ---- reduce slices: entries per slice (the makespan of the pass is its longest slice)
+def _slice(n):
+    return ("grid.hip", [("constexpr uint32_t kSliceEntries = 512 * 1024;", "constexpr uint32_t kSliceEntries = %d * 1024;" % n)])
+
+
+SLICES = {"s384": _slice(384), "s256": _slice(256), "s192": _slice(192), "s128": _slice(128), "s96": _slice(96), "full": ("grid.hip", [])}
+
+# ---- work-queue reduce: order of the dense levels' slices and their length
+def _dense(first, kb):
+    return ("grid.hip", [("#define LNH_REDUCE_DENSE_FIRST 1", "#define LNH_REDUCE_DENSE_FIRST %d" % first),
+                         ("constexpr uint32_t kSliceEntriesDense = 64 * 1024;", "constexpr uint32_t kSliceEntriesDense = %d * 1024;" % kb)])
+
+
+DENSE = {"df64": _dense(1, 64), "df32": _dense(1, 32), "df16": _dense(1, 16), "dl64": _dense(0, 64), "dl16": _dense(0, 16), "df512": _dense(1, 512)}
+SETS = {"dense": DENSE, "slices": SLICES, "reduce": REDUCE, "scatter": SCATTER_CUTS, "stagger": STAGGER, "iters": ITERS, "wgsize": WGSIZE}
 
 
 def build_variant(name, fname, subs):
@@ -70,9 +127,15 @@ def build_variant(name, fname, subs):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode:
             raise SystemExit(f"variant {name}: hipcc failed\n{r.stderr[-3000:]}")
+        core = os.path.join(tmp, "core.o")  # (lnh_build_variant lives there)
+        r = subprocess.run([product_build.HIPCC] + product_build.FLAGS + [f'-DLNH_VARIANT_TAG="{name}"', "-c",
+                                                                          os.path.join(dst, "core.hip"), "-o", core],
+                           capture_output=True, text=True)
+        if r.returncode:
+            raise SystemExit(f"variant {name}: hipcc failed (core.hip)\n{r.stderr[-3000:]}")
         product_build.build(verbose=False)
         objs = [o for o in sorted(glob.glob(os.path.join(PKG, "lib", "obj", "*.o")))
-                if os.path.basename(o) != os.path.basename(obj)] + [obj]
+                if os.path.basename(o) not in (os.path.basename(obj), "core.o")] + [obj, core]
         lib = os.path.join(PKG, "lib", f"liblidarnerf_hip_{name}.so")
         r = subprocess.run([product_build.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs,
                            capture_output=True, text=True)
