@@ -63,8 +63,10 @@ def test_patch_mode_step_learns_too():
 
 
 def test_patch_gradient_term_matches_the_restatement():
-    """The GPU-side torch ops of the patch term (train_step.patch_gradient_loss) against oracle/render_ref.patch_grad_loss on
-    the same depths (the term enters the step above through the non-fused loss path)."""
+    """The GPU-side torch ops of the patch term (train_step.patch_gradient_loss: the fallback for tensors the one-launch
+    kernel does not take; the step above goes through lnh_lidar_loss_patch, tests/test_lidar_field_gpu.py and
+    tests/test_g8_train_step_gpu.py) against oracle/render_ref.patch_grad_loss on the same depths; both are pinned to the
+    reference's own Trainer.train_step by G8 (tests/test_oracle_golden.py)."""
     from lidarnerf.nerf.train_step import patch_gradient_loss
     from oracle import render_ref
     g = torch.Generator().manual_seed(1)

@@ -344,7 +344,9 @@ def test_fused_patch_loss_matches_the_restatement():
     """lnh_lidar_loss_patch (per-ray LiDAR loss + the structural-gradient term of the patch epochs, one launch) against the
     CPU restatement of nerf/utils.py:712-746 + 760-876 (oracle/render_ref.py lidar_loss + patch_grad_loss, autograd for the
     gradients): 256 patches of 2 x 8 rays, ground truth smooth inside a patch (so the 0.01 m gate passes), dropped rays,
-    exact ties."""
+    exact ties.  The restatement itself is pinned by G8 — the reference's own Trainer.train_step run on fixed inputs
+    (tests/test_oracle_golden.py::test_g8_train_step_loss_restatements) — and the kernel meets G8 directly in
+    tests/test_g8_train_step_gpu.py; this test adds the shapes G8 does not hold (4096 rays, a rejected patch, |dx| = 0)."""
     from lidarnerf.nerf.train_step import fused_lidar_loss
     from oracle import render_ref
     g = torch.Generator().manual_seed(3)

@@ -179,3 +179,43 @@ def test_g7_config1_restatement_end_to_end(golden_dir, tag):
         for n, p in f.named_parameters():
             w = g[f"{tag}_{loss_name}_grad_{n}"]
             np.testing.assert_allclose(p.grad.numpy(), w, rtol=0, atol=2e-6 * np.abs(w).max(), err_msg=n)
+
+
+@pytest.mark.parametrize("tag,patch", [("p1", None), ("p2x8", (2, 8)), ("p4x4", (4, 4))])
+def test_g8_train_step_loss_restatements(golden_dir, tag, patch):
+    """G8 = loss and d loss / d (depth, image) produced by the reference's OWN Trainer.train_step (nerf/utils.py:697-884,
+    called unbound on a stub self; tests/golden/make_golden.py g8) for patch_size_lidar 1, [2, 8] and [4, 4].  Pins the two
+    restatements of it: oracle/render_ref.py (lidar_loss + patch_grad_loss — the checker of the HIP loss kernels) and the
+    product's own torch expressions (lidarnerf/nerf/train_step.py lidar_loss + patch_gradient_loss: what LidarTrainer runs
+    on tensors the kernels do not cover).  fp32-tight: the same torch ops in a different grouping."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "lidar-nerf_amd"))
+    from lidarnerf.nerf import train_step
+    g = _load(golden_dir, "g8_train_step.npz")
+    ad, ar, ai, ag = (float(v) for v in g["alphas"])
+    scale = float(g["scale"])
+    gt = torch.from_numpy(g["gt"])                                           # [1, N, 3]
+    want_loss, want_gd, want_gi = float(g[f"{tag}_loss"]), g[f"{tag}_grad_depth"], g[f"{tag}_grad_image"]
+
+    def check(loss, d, im):
+        loss.backward()
+        assert abs(float(loss) - want_loss) <= 2e-6 * abs(want_loss)
+        np.testing.assert_allclose(d.grad.reshape(-1).numpy(), want_gd, rtol=1e-5, atol=1e-6 * np.abs(want_gd).max())
+        np.testing.assert_allclose(im.grad.reshape(-1, 2).numpy(), want_gi, rtol=1e-5, atol=1e-9)
+
+    # the oracle's restatement
+    d = torch.from_numpy(g["depth"]).clone().requires_grad_(True)
+    im = torch.from_numpy(g["image"]).clone().requires_grad_(True)
+    loss = render_ref.lidar_loss(d, im, gt[0], ad, ar, ai)
+    if patch:
+        loss = loss + render_ref.patch_grad_loss(d, gt[0], patch[0], patch[1], scale, ag)
+    check(loss, d, im)
+    # the product's torch expressions
+    d = torch.from_numpy(g["depth"])[None].clone().requires_grad_(True)
+    im = torch.from_numpy(g["image"])[None].clone().requires_grad_(True)
+    loss, pd, gd = train_step.lidar_loss({"depth_lidar": d, "image_lidar": im}, gt, ad, ar, ai)
+    if patch:
+        loss = loss + train_step.patch_gradient_loss(pd, gd, gt[..., 0], patch[0], patch[1], scale, ag)
+    check(loss, d, im)
+    assert np.abs(want_gd).max() > 1.0 and (np.abs(want_gd) > 0).mean() > 0.5   # the fixture exercises the terms
