@@ -1090,30 +1090,12 @@ k_grid_bwd_scatter_plain(const T *__restrict__ grad, const float *__restrict__ i
     // The returning LDS atomics are issued BEFORE the value arithmetic: the LDS atomic unit retires ~3 lanes per clock and
     // CU (29 cycles per wave instruction here), the two resident workgroups of a CU run phase-locked, so nobody else hides
     // that time — the wave's own ~100 VALU instructions of weights / products / scan do (profiles/r04_scatter_phases.txt).
-    if constexpr (MODE == 1) {
-        // buckets are mixed: per-lane returning atomics
-        if (emit) {
+    // per-lane returning atomics.  (Dense levels: a wave emits a few run tails, and with the rows dealt to 64 buckets in
+    // 128-row groups their four pairs go to four buckets — the wave-aggregated rank of round 3, one atomic for a whole
+    // wave on the level's single bucket, has nothing left to aggregate and cost ~50 VALU instructions per wave.)
+    if (emit) {
 #pragma unroll
-            for (int p = 0; p < NP; p++) rank[p] = atomicAdd(&lds_at(lcnt, bk4[p]), 1u);
-        }
-    } else {
-        // every emitting lane of a wave usually targets the SAME bucket: 64 returning atomics on one counter serialise, so
-        // aggregate — one lane adds the population count, the others take their rank from the lane mask
-#pragma unroll
-        for (int p = 0; p < NP; p++) {
-            if (emit_m == 0ull) continue;  // wave-uniform
-            const int leader = __builtin_ctzll(emit_m);
-            const uint32_t bk0 = (uint32_t)__builtin_amdgcn_readlane((int)bk4[p], leader);
-            const bool uniform = __ballot(emit && bk4[p] != bk0) == 0ull;
-            if (uniform) {
-                uint32_t base = 0;
-                if ((int)lane == leader) base = atomicAdd(&lds_at(lcnt, bk0), (uint32_t)__builtin_popcountll(emit_m));
-                base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-                rank[p] = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(emit_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)emit_m, 0u));
-            } else if (emit) {
-                rank[p] = atomicAdd(&lds_at(lcnt, bk4[p]), 1u);
-            }
-        }
+        for (int p = 0; p < NP; p++) rank[p] = atomicAdd(&lds_at(lcnt, bk4[p]), 1u);
     }
     if (wave_singles) {  // the second corners of pairs that travel as two singles
 #pragma unroll
@@ -1123,7 +1105,10 @@ k_grid_bwd_scatter_plain(const T *__restrict__ grad, const float *__restrict__ i
         }
     }
     LNH_MARK("D values");
-    // ---- w * (g0, g1) per corner: float product, then the per-contribution rounding to the table type (gridencoder.cu:350)
+    // ---- w * (g0, g1) per corner: float product, then the per-contribution rounding to the table type (gridencoder.cu:350).
+    //      (Summing the fp32 PRODUCTS of a merged run and rounding once — 24 conversions less per scanning lane — was built
+    //      in round 4 and dropped: 844 us against 838 for the backward, i.e. nothing, and rows whose every addend underflows
+    //      in fp16 then hold a tiny sum where the reference and the oracle hold 0.)
     V2 val[8];
     {
         const float wx0 = 1.0f - fr0, wy0 = 1.0f - fr1, wz0 = 1.0f - fr2;

@@ -153,7 +153,16 @@ class GridEncoder(nn.Module):
     def log2_scale(self):
         return float(np.log2(self.per_level_scale))
 
+    def _require_whole_table(self, what):
+        # Sharded table optimizer (LidarTrainer(shard_table_optimizer=True)): between steps the fp32 parameter of a rank is
+        # current on ITS rows only (the fused chain reads the all-gathered fp16 shadow instead).  Reading the parameter
+        # here would silently use other ranks' stale rows.
+        if getattr(self.embeddings, "_lnh_master_stale", False):
+            raise RuntimeError(f"GridEncoder.{what}: the fp32 table is sharded over the ranks (sharded table optimizer); "
+                               "call LidarTrainer.gather_table_state() on every rank first")
+
     def forward(self, inputs, bound=1):
+        self._require_whole_table("forward")
         inputs = (inputs + bound) / (2 * bound)  # [-bound, bound] -> [0, 1]
         lead = list(inputs.shape[:-1])
         flat = inputs.reshape(-1, self.input_dim)
@@ -164,6 +173,7 @@ class GridEncoder(nn.Module):
     @torch.autocast("cuda", enabled=False)
     def grad_total_variation(self, weight=1e-7, inputs=None, bound=1, B=1000000):
         """Adds the TV-regulariser gradient into embeddings.grad (grid.py:237-277)."""
+        self._require_whole_table("grad_total_variation")
         if self.embeddings.grad is None:
             raise ValueError("grad is None, should be called after loss.backward() and before optimizer.step()!")
         if inputs is None:

@@ -106,6 +106,10 @@ import os as _os
 _DP_LEVEL_WINDOWS = ((0, 10), (10, 16))
 if _os.environ.get("LNH_DP_WINDOWS"):  # developer override for A/B runs: "0,10,16" = two windows
     _c = [int(v) for v in _os.environ["LNH_DP_WINDOWS"].split(",")]
+    # (must be the same on every rank: the shard layout follows the windows)
+    if len(_c) < 2 or _c[0] != 0 or _c[-1] != 16 or any(b <= a for a, b in zip(_c[:-1], _c[1:])):
+        raise ValueError(f"LNH_DP_WINDOWS={_os.environ['LNH_DP_WINDOWS']!r}: need increasing level cuts from 0 to 16, "
+                         "e.g. '0,10,16'")
     _DP_LEVEL_WINDOWS = tuple(zip(_c[:-1], _c[1:]))
 FORCE_DP_WINDOWS = False  # bench.py --dp-windows: take the windowed backward on one GPU too (the exchange is a no-op)
 
@@ -178,6 +182,12 @@ def table16_of(param, embeddings=None, training=True):
         # through torch (load_state_dict, broadcast) moves its version counter — the optimizer kernel and the gather do not —
         # and then the parameter is whole and newer: re-cast.
         if getattr(param, "_lnh_table16_version", None) != param._version:
+            if getattr(param, "_lnh_master_stale", False):
+                # an in-place write that moved the version counter while only this rank's rows of the master are current:
+                # re-casting would overwrite the other ranks' rows of the shadow with stale values
+                raise RuntimeError("the fp32 hash table was written through torch while the sharded table optimizer holds "
+                                   "only this rank's rows of it: call LidarTrainer.gather_table_state() (every rank) "
+                                   "before modifying `embeddings`, or load through LidarTrainer.load_checkpoint")
             shadow.copy_(param.detach().reshape(shadow.shape))
             param._lnh_table16_version = param._version
         return shadow
@@ -384,8 +394,15 @@ class FusedLidarRender(Function):
         if parallel.world_size() > 1 or FORCE_DP_WINDOWS:
             # data parallel: the table gradient goes on the wire as fp16, window by window, behind the kernels of the
             # following windows
-            for handle in _grid_bwd_overlapped(g_feat, x01, g_table16, enc, B_all, ctx.table_param):
-                handle.wait()
+            handles = _grid_bwd_overlapped(g_feat, x01, g_table16, enc, B_all, ctx.table_param)
+            if getattr(ctx.table_param, "_lnh_keep_grad16", False):
+                # the fused table optimizer is the only consumer: it waits right before its kernels (train_step.py), so the
+                # last window's bytes travel under the MLP gradients' all-reduce and the loss-scale bookkeeping instead of
+                # being waited for here, inside backward
+                ctx.table_param._lnh_grad16_handles = handles
+            else:
+                for handle in handles:
+                    handle.wait()
         else:
             _grid_bwd(g_feat, x01, g_table16, enc, B_all)
         dts = ctx.param_dtypes
@@ -470,6 +487,18 @@ class FusedLidarRagged(Function):
         dev = xyzs.device
         M, N, L = xyzs.shape[0], rays.shape[0], enc.num_levels
         bound, ds = float(model.bound), float(model.density_scale)
+        if M == 0:
+            # The marcher found no sample (every ray misses the occupied cells).  The node still exists: its outputs are
+            # zeros CONNECTED to the graph, and its backward hands out zero gradients and takes part in the gradient
+            # exchange — under data parallel a rank that skipped the table all-reduce would leave the others waiting.
+            ctx.meta = (model, enc, spec.table_param, mdt, float(T_thresh), spec.n_dir, ds,
+                        (embeddings.dtype, ws0.dtype, ws1.dtype, wc0.dtype, wc1.dtype, wc2.dtype))
+            ctx.empty = True
+            ctx.shapes = (ws0.shape, ws1.shape, wc0.shape, wc1.shape, wc2.shape)
+            ctx.set_materialize_grads(False)
+            z = torch.zeros(N, dtype=torch.float32, device=dev)
+            return z, z.clone(), torch.zeros((N, 2), dtype=torch.float32, device=dev)
+        ctx.empty = False
         table16 = table16_of(spec.table_param, embeddings, model.training)
         kd, deg = spec.n_dir, int(spec.dir_freq_degree)  # 75, 12
         mats = [m.detach() if m.dtype == torch.float32 and m.stride(-1) == 1 else m.detach().float().contiguous()
@@ -512,9 +541,29 @@ class FusedLidarRagged(Function):
     @staticmethod
     @_no_autocast
     def backward(ctx, g_ws, g_depth, g_image):
+        model, enc, table_param, mdt, T_thresh, kd, ds, dts = ctx.meta
+        if ctx.empty:  # no sample: zero gradients, but the same collectives as every other rank
+            dev = table_param.device
+            g_table16 = torch.zeros((int(enc._offsets_host[-1]), 2), dtype=torch.half, device=dev)
+            world = parallel.world_size()
+            if world > 1:
+                off = enc._offsets_host
+                handles = []
+                for l0, l1 in (_DP_LEVEL_WINDOWS if enc.num_levels == 16 else ((0, enc.num_levels),)):
+                    h = parallel.allreduce_half_table(g_table16[int(off[l0]):int(off[l1])], table_param)
+                    if h is not None:
+                        handles.append(h)
+                for h in handles:
+                    h.wait()
+            if getattr(table_param, "_lnh_keep_grad16", False):
+                table_param._lnh_grad16, table_param._lnh_grad16_div = g_table16, world
+                g_table = None
+            else:
+                g_table = g_table16.to(dts[0])
+            zw = [torch.zeros(sh, dtype=dt, device=dev) for sh, dt in zip(ctx.shapes, dts[1:])]
+            return (None, None, None, None, None, None, g_table, zw[0], zw[1], zw[2], zw[3], zw[4], None, None, None, None)
         (x01, feat, h16, sig_s, cin, rgb, deltas, xyzs, rays_o, rays_d, rays, ws, depth, image, wsig16,
          wcol16) = ctx.saved_tensors
-        model, enc, table_param, mdt, T_thresh, kd, ds, dts = ctx.meta
         sfx = _hip.mlp_suffix(mdt)
         dev = x01.device
         M, N, L = x01.shape[0], rays.shape[0], enc.num_levels

@@ -274,13 +274,17 @@ class NeRFRenderer(nn.Module):
         xyzs, dirs, deltas, rays = raymarching.march_rays_train(
             rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size, nears, fars, counter,
             mean_count, perturb, 128, force_all_rays, dt_gamma, max_steps)
-        if xyzs.shape[0] == 0:
+        from . import fused
+        use_fused = (getattr(self, "fused_lidar", False) and xyzs.is_cuda and torch.is_autocast_enabled()
+                     and fused.ragged_supported(self))
+        if xyzs.shape[0] == 0 and not (use_fused and torch.is_grad_enabled()):
+            # no sample on any ray (evaluation, or the modular path): plain zeros.  The fused training chain below runs its
+            # node on zero samples instead — zeros connected to the graph, zero gradients, and under data parallel the same
+            # collectives as the other ranks (a rank that skipped the table all-reduce would leave them waiting)
             z = torch.zeros(N, device=rays_o.device)
             return {"depth_lidar": z.view(*prefix), "image_lidar": torch.zeros(*prefix, self.out_dim, device=z.device),
                     "weights_sum_lidar": z}
-        from . import fused
-        if (getattr(self, "fused_lidar", False) and xyzs.is_cuda and torch.is_autocast_enabled()
-                and fused.ragged_supported(self)):
+        if use_fused:
             # one autograd node over the ragged samples (encode -> sigma net -> colour head -> compositing)
             ws, depth, image = fused.render_lidar_ragged(self, xyzs, dirs, deltas, rays, rays_o, rays_d, T_thresh)
             return {"depth_lidar": depth.view(*prefix), "image_lidar": image.view(*prefix, self.out_dim),

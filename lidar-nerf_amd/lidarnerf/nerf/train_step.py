@@ -86,6 +86,11 @@ class LidarTrainer:
                  mlp_dtype=torch.float16, shard_table_optimizer=False):
         # mlp_dtype: the autocast dtype — torch.float16 (the reference's --fp16) or torch.bfloat16 (BASELINE config 5:
         # bf16 MFMA MLPs; the hash table and its gradient stay fp16, so the dynamic loss scale is kept either way)
+        # (the backward picks reduce-scatter or all-reduce from the process group, parallel.world_size(): a world_size
+        #  argument that disagrees with it would silently run without the exchange and fail later, in gather_table_state)
+        if world_size > 1 and parallel.world_size() != world_size:
+            raise RuntimeError(f"LidarTrainer(world_size={world_size}) but the initialised process group has "
+                               f"{parallel.world_size()} rank(s): call torch.distributed.init_process_group first")
         self.model, self.fp16, self.world, self.amp_dtype = model, fp16, world_size, mlp_dtype
         self.alpha = (alpha_d, alpha_r, alpha_i, alpha_grad)
         self.scale = scale
@@ -123,6 +128,7 @@ class LidarTrainer:
                 # then current on ITS rows only: gather_table_state() completes them (checkpoints call it).
                 self.sharded = bool(shard_table_optimizer and world_size > 1)
                 tp._lnh_shard_optimizer = self.sharded
+                tp._lnh_master_stale = False
         params = [g for g in params if len(g["params"])]
         # the reference's groups differ in nothing but their parameter lists (network.py get_params: every group at `lr`):
         # step them as ONE group — torch launches its fused Adam once per group — and keep the reference's grouping for
@@ -164,6 +170,7 @@ class LidarTrainer:
         self.optimizer.zero_grad(set_to_none=True)
         tp._lnh_grad16 = None
         tp._lnh_grad_reduced = False
+        tp._lnh_grad16_handles = None
         with torch.autocast("cuda", dtype=self.amp_dtype):
             loss = self.loss(rays_o, rays_d, images_lidar, patch)
         loss.backward(gradient=self.loss_scale.to(loss.dtype))  # = (loss * scale).backward() without the product and its ones_like
@@ -194,6 +201,9 @@ class LidarTrainer:
             # every rank has looked at its own rows only: the skip / back-off decision must be the same everywhere
             dist.all_reduce(found_inf, op=dist.ReduceOp.MAX)
         else:
+            for handle in getattr(tp, "_lnh_grad16_handles", None) or ():
+                handle.wait()  # the table windows' all-reduce (left in flight by the backward pass)
+            tp._lnh_grad16_handles = None
             _hip.call("lnh_grad_check_f16", g16.data_ptr(), g16.numel(), found_inf.data_ptr())
         self.optimizer.grad_scale, self.optimizer.found_inf = None, found_inf
         try:
@@ -246,6 +256,9 @@ class LidarTrainer:
             handle.wait()
             table16[r0:r1] = out[:r1 - r0]  # the shards back to back; what lies beyond r1 is padding
         tp._lnh_grad16_shards = None
+        # from here on the fp32 master (and the moments) of this rank are current on ITS rows only: whoever reads
+        # `embeddings` itself (GridEncoder.forward, grad_total_variation, a state_dict) must gather_table_state() first
+        tp._lnh_master_stale = True
 
     def gather_table_state(self):
         """Sharded table optimizer: complete the fp32 master table and the Adam moments on every rank from their owners
@@ -270,6 +283,7 @@ class LidarTrainer:
                 full = torch.empty((world * s, 2), dtype=t.dtype, device=t.device)
                 dist.all_gather_into_tensor(full, mine)
                 rows[r0:r1] = full[:r1 - r0]
+        self.table._lnh_master_stale = False
 
     # ---- what lives outside torch.optim / GradScaler when the table is stepped by the fused kernel
     def table_grad(self):
@@ -279,13 +293,16 @@ class LidarTrainer:
         g16 = getattr(self.table, "_lnh_grad16", None) if self.table is not None else None
         if g16 is None:
             return None
+        for handle in getattr(self.table, "_lnh_grad16_handles", None) or ():
+            handle.wait()
         div = float(getattr(self.table, "_lnh_grad16_div", 1))
         # (the scale the backward ran with — _amp_update_scale_ has already moved self.loss_scale on growth / backoff steps)
         return g16.float().reshape(self.table.shape) / (getattr(self, "_last_scale", self.loss_scale) * div)
 
     def state_dict(self):
         """Everything a resume needs: torch optimizer / scheduler / scaler state plus — fused table optimizer — the
-        table's Adam moments, its device-side step counter and the dynamic loss scale (99.8 % of the optimizer state)."""
+        table's Adam moments, its device-side step counter and the dynamic loss scale (99.8 % of the optimizer state).
+        Sharded table optimizer: COLLECTIVE (gather_table_state) — call it on every rank."""
         self.gather_table_state()
         sd = {"optimizer": self.optimizer.state_dict(), "scheduler": self.scheduler.state_dict(),
               "scaler": self.scaler.state_dict(), "fused_table": None}
@@ -394,11 +411,30 @@ class LidarTrainer:
             sd[key] = [first.get(i, vals[0]) for i in range(n_own)]
         self.scheduler.load_state_dict(sd)
 
-    def save_checkpoint(self, path, full=True):
+    def save_checkpoint(self, path, full=True, gather=True):
         """Same dictionary as Trainer.save_checkpoint (utils.py:1449-1480): epoch, global_step, stats, model and — `full`
         — optimizer / lr_scheduler / scaler in the layout the reference's Trainer.load_checkpoint restores (a reference
-        run can resume from it and vice versa: the state dict keys of the model are the reference's, see network.py)."""
-        self.gather_table_state()  # (sharded table optimizer: every rank completes master table + moments first)
+        run can resume from it and vice versa: the state dict keys of the model are the reference's, see network.py).
+
+        Sharded table optimizer (shard_table_optimizer=True): the master table and the moments live in pieces on the
+        ranks, so completing them is a COLLECTIVE.  Two ways to write a checkpoint:
+          * call save_checkpoint(path) on EVERY rank — all of them gather, rank 0 alone writes the file (the others
+            return the path without touching it); a call on rank 0 only would wait for the others forever;
+          * the reference's convention, save on local_rank 0 only (utils.py:1069-1074): call gather_table_state() on every
+            rank first, then save_checkpoint(path, gather=False) where the reference saves.  Without the gather that
+            raises instead of writing a table with other ranks' stale rows."""
+        write = True
+        if self.sharded:
+            import torch.distributed as dist
+            if gather:
+                self.gather_table_state()
+                write = dist.get_rank() == 0
+            elif getattr(self.table, "_lnh_master_stale", False):
+                raise RuntimeError("save_checkpoint(gather=False) with the sharded table optimizer: call "
+                                   "gather_table_state() on every rank first (this rank holds only its own rows of the "
+                                   "table and the Adam moments)")
+        if not write:
+            return path
         state = {"epoch": self.epoch, "global_step": self.global_step, "stats": self.stats}
         if full:
             state["optimizer"] = self._optimizer_state_ref_layout()
@@ -426,6 +462,8 @@ class LidarTrainer:
             for key in ("mean_count", "mean_density", "iter_density", "local_step"):
                 if key in ck:  # without them the next 16 grid updates are full sweeps and sample buffers are N * 1024
                     setattr(self.model, key, ck[key])
+        if self.table is not None:
+            self.table._lnh_master_stale = False  # a loaded table is whole
         if model_only:
             return missing, unexpected
         self.stats, self.epoch, self.global_step = ck["stats"], ck["epoch"], ck["global_step"]

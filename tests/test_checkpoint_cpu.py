@@ -118,3 +118,39 @@ def test_occupancy_bookkeeping_in_checkpoint(tmp_path):
     tr2 = LidarTrainer(m2, lr=1e-2, fp16=False)
     tr2.load_checkpoint(path)
     assert (m2.mean_count, m2.mean_density, m2.iter_density, m2.local_step) == (345678, 0.0123, 40, 7)
+
+
+def test_sharded_table_guards(tmp_path):
+    """Sharded table optimizer: between steps the fp32 master table of a rank is current on its own rows only.  Everything
+    that would read (or persist) the parameter itself refuses until gather_table_state() has completed it, and a trainer
+    told about more ranks than the process group has says so at construction."""
+    import pytest
+    from lidarnerf.nerf import fused
+    from lidarnerf.nerf.train_step import LidarTrainer
+    m = _model()
+    with pytest.raises(RuntimeError, match="process group"):
+        LidarTrainer(m, lr=1e-2, fp16=False, world_size=2)
+    emb = m.encoder.embeddings
+    emb._lnh_master_stale = True
+    with pytest.raises(RuntimeError, match="gather_table_state"):
+        m.encoder(torch.zeros(4, 3))
+    emb.grad = torch.zeros_like(emb)
+    with pytest.raises(RuntimeError, match="gather_table_state"):
+        m.encoder.grad_total_variation()
+    # the fp16 shadow of a sharded table is never re-cast from a stale master
+    emb._lnh_table16 = emb.detach().half().reshape(-1, 2).contiguous()
+    emb._lnh_shard_optimizer, emb._lnh_table16_version = True, emb._version
+    assert fused.table16_of(emb) is emb._lnh_table16
+    with torch.no_grad():
+        emb.mul_(1.0)                                  # an in-place write through torch: the version counter moves
+    with pytest.raises(RuntimeError, match="sharded table optimizer"):
+        fused.table16_of(emb)
+    emb._lnh_master_stale = False                      # gather_table_state() / load_checkpoint: the master is whole again
+    assert fused.table16_of(emb) is emb._lnh_table16
+    # save_checkpoint(gather=False) on a rank whose master is stale must not write a file
+    tr = LidarTrainer(m, lr=1e-2, fp16=False)
+    tr.table, tr.sharded = emb, True
+    emb._lnh_master_stale = True
+    with pytest.raises(RuntimeError, match="gather_table_state"):
+        tr.save_checkpoint(os.path.join(tmp_path, "x.pth"), gather=False)
+    assert not os.path.exists(os.path.join(tmp_path, "x.pth"))

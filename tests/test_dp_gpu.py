@@ -1,4 +1,4 @@
-"""Data-parallel path on real kernels: 2 ranks (gloo) sharing GPU 0 — see tests/dp_worker.py.  The collective backend
+"""Data-parallel path on real kernels: 2 and 4 ranks (gloo) sharing GPU 0 — see tests/dp_worker.py.  The collective backend
 differs from production (RCCL needs one GPU per rank), the code path above it does not."""
 import os
 import subprocess
@@ -9,15 +9,17 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_two_rank_training_step_matches_single_process():
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_data_parallel_training_step_matches_single_process(ranks):
+    """2 and 4 ranks (4: shard boundaries inside levels, three or more addends per table row in the exchange)."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, LNH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29541", os.path.join(root, "tests", "dp_worker.py")]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
+           "127.0.0.1", "--master-port", str(29541 + ranks), os.path.join(root, "tests", "dp_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     out = r.stdout + r.stderr
     assert r.returncode == 0, out[-3000:]
-    assert out.count("DP-OK") == 2, out[-3000:]
+    assert out.count("DP-OK") == ranks, out[-3000:]
 
 
 def test_bench_launches_its_own_ranks_and_reports_the_exchange():

@@ -222,3 +222,31 @@ def test_fused_ragged_chain_vs_oracle_and_modular_path():
         torch.testing.assert_close(out[k].float(), outm[k].float(), rtol=3e-3, atol=3e-4)
     gm = netm.encoder.embeddings.grad.detach().float().cpu().double() / scale
     assert ((ge - gm).norm() / gm.norm()).item() < 2e-2
+
+
+def test_training_step_with_no_marched_sample():
+    """Every ray misses the occupied cells (empty bitfield): the fused ragged node runs on ZERO samples — outputs are zeros
+    connected to the graph, the step goes through with zero gradients (the table and the MLP weights do not move: Adam on a
+    zero gradient from zero moments), and nothing raises.  (Before: run_cuda returned graph-less zeros and the step failed
+    in backward, or with 'produced no fp16 table gradient'; under data parallel that rank skipped the table all-reduce.)"""
+    from lidarnerf.nerf.train_step import LidarTrainer
+    net = _net(seed=3).train()
+    tr = LidarTrainer(net, lr=1e-2, fp16=True, scale=SCALE, render_kwargs={})
+    assert tr.occupancy and tr.table is not None
+    tr.update_extra_interval = 10 ** 9            # keep the (emptied) occupancy grid as it is
+    tr.global_step = 1
+    net.density_bitfield.zero_()
+    before = net.encoder.embeddings.detach().clone()
+    w_before = net.sigma_net[0].weight.detach().clone()
+    o, d = _object_rays(256, 5)
+    gt = torch.rand(1, 256, 3, device="cuda")
+    loss = tr.step(o.cuda()[None], d.cuda()[None], gt)
+    assert torch.isfinite(loss) and float(loss) > 0                     # |0 - gt| terms
+    assert torch.equal(net.encoder.embeddings.detach(), before)
+    assert torch.equal(net.sigma_net[0].weight.detach(), w_before)
+    g16 = tr.table._lnh_grad16
+    assert g16 is not None and float(g16.abs().max()) == 0.0
+    # and the next step, with samples again, trains normally
+    net.density_bitfield.fill_(255)
+    loss2 = tr.step(o.cuda()[None], d.cuda()[None], gt)
+    assert torch.isfinite(loss2) and not torch.equal(net.encoder.embeddings.detach(), before)

@@ -94,3 +94,66 @@ def test_dp_gradient_allreduce_world2():
         p.join(120)
         assert p.exitcode == 0
     assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1]
+
+
+def _worker_layout8(rank, world, port, out):
+    """The sharded table optimizer's exchange on the REAL table layout (BASELINE configs 2/3/5: 16 levels, 6 837 544 rows,
+    level windows 0-9 / 10-15) with 8 ranks: reduce-scatter of the padded fp16 windows, a stand-in for the shard step,
+    all-gather of the compute copy (train_step.LidarTrainer._step_table_shards / fused._grid_bwd_sharded, minus the kernels)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import numpy as np
+    from lidarnerf import parallel
+    from lidarnerf.gridencoder.grid import level_offsets
+    from lidarnerf.nerf.fused import _DP_LEVEL_WINDOWS
+    parallel.init_from_env(backend="gloo")
+    torch.set_num_threads(1)
+    pls = np.exp2(np.log2(32768 / 16) / 15)
+    off = level_offsets(3, 16, pls, 16, 19, False)
+    rows = int(off[-1])
+    assert rows == 6837544 and _DP_LEVEL_WINDOWS == ((0, 10), (10, 16))
+    idx = torch.arange(rows, dtype=torch.int64)
+
+    def grad_of(r):  # small integers: every partial sum is exact in fp16
+        return torch.stack([(idx * 7 + r) % 13 - 6, (idx * 7 + 3 + r) % 13 - 6], -1).to(torch.float16)
+    g = grad_of(rank)
+    total = sum(grad_of(r).float() for r in range(world))                      # what the SUM over ranks must be
+    table16 = torch.zeros((rows, 2), dtype=torch.float16)
+    covered = 0
+    for l0, l1 in _DP_LEVEL_WINDOWS:
+        r0, r1 = int(off[l0]), int(off[l1])
+        s = parallel.shard_rows(r1 - r0, world)
+        assert s % 4 == 0 and world * s >= r1 - r0 and world * (s - 4) < r1 - r0   # 4-row aligned, minimal padding
+        padded = torch.zeros((world * s, 2), dtype=torch.float16)
+        padded[:r1 - r0] = g[r0:r1]
+        mine = torch.empty((s, 2), dtype=torch.float16)
+        parallel.reduce_scatter_half(padded, mine).wait()
+        a = r0 + rank * s
+        n = max(0, min(s, r1 - a))
+        torch.testing.assert_close(mine[:n].float(), total[a:a + n], rtol=0, atol=0)
+        assert float(mine[n:].abs().max()) == 0.0 if n < s else True            # beyond the window: padding
+        covered += n
+        stepped = (mine.float() * 0.25).to(torch.float16)                        # stand-in for lnh_adam_table_step on [a, a + n)
+        full = torch.empty((world * s, 2), dtype=torch.float16)
+        parallel.all_gather_half(full, stepped).wait()
+        table16[r0:r1] = full[:r1 - r0]
+    torch.testing.assert_close(table16.float(), (total * 0.25).to(torch.float16).float(), rtol=0, atol=0)
+    cov = torch.tensor([covered], dtype=torch.int64)
+    dist.all_reduce(cov)
+    assert int(cov) == rows                                                       # every row has exactly one owner
+    dist.barrier()
+    dist.destroy_process_group()
+    out.put(rank)
+
+
+def test_sharded_table_exchange_on_the_real_layout_world8():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_layout8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(8)) == list(range(8))
