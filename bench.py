@@ -158,9 +158,9 @@ def _cpu_config1(n_rays, threads, warmup, steps, budget_s):
 def cpu_baseline(full=False):
     """config 1, N = 1024 rays x 832 samples, forward + loss + backward, fp32, median step time on k = 1 and
     k = ALL usable host cores (see usable_cores(): os.cpu_count() capped by affinity and cgroup quota — both stated).
-    `full` runs the protocol as written there (10 warm-up + 30 timed steps per leg, ~2 min of CPU time); the default is a
-    bounded sample of it (1 + up to 10 steps per leg inside ~12 s each, at least 3 timed) so that the default bench run stays
-    within its few minutes.  `value` / `cores` = the k = all leg.  Validated against the imported reference in the build
+    `full` (the default of bench.py) runs the protocol as written there (10 warm-up + 30 timed steps per leg, ~2 min of CPU
+    time); --cpu-baseline-quick takes a bounded sample of it (1 + up to 10 steps per leg inside ~12 s each, at least 3
+    timed).  `value` / `cores` = the FASTER leg; both legs are listed.  Validated against the imported reference in the build
     container (tests/test_config1_cpu.py, golden vector G7) and pinned on the GPU box by golden vectors G2 / G4 / G7."""
     import platform
     k_all, quota = usable_cores()
@@ -179,12 +179,13 @@ def cpu_baseline(full=False):
         model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
         model = platform.processor()
-    top = legs[-1]
+    top = max(legs, key=lambda l: l["value"])  # the FASTEST leg is the baseline (on some hosts k = 1 beats k = all)
     return {"value": top["value"], "unit": "rays/s", "cores": top["cores"], "kind": "port",
             "sample": f"BASELINE config 1 (pure-torch freq encoder + nn.Linear 39->64->16 / 90->64->64->2, fp32), 1024 rays x "
                       f"{NUM_STEPS + UPSAMPLE} samples, fwd+loss+bwd; median of {top['steps']} timed steps after "
-                      f"{top['warmup']} warm-up, torch.set_num_threads({top['cores']}) = all usable cores"
-                      + ("" if full else " (bounded sample of BASELINE.md §3's 10 + 30 protocol: --cpu-baseline-full runs it whole)")
+                      f"{top['warmup']} warm-up, torch.set_num_threads({top['cores']}) = the faster of k = 1 and k = all usable cores "
+                      f"({k_all}); " + ("BASELINE.md §3's protocol (10 warm-up + 30 timed steps per leg)" if full else
+                                         "bounded sample of BASELINE.md §3's 10 + 30 protocol (--cpu-baseline-quick)")
                       + "; oracle/render_ref.py RefFreqField",
             "legs": legs,
             "host": {"cpu": model, "os_cpu_count": os.cpu_count(), "cgroup_cpu_quota": quota, "usable_cores": k_all,
@@ -206,16 +207,28 @@ def _relaunch_distributed(n):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def lib_sha16():
+    """First 16 hex digits of the SHA-256 of the loaded liblidarnerf_hip.so: ties a PMC file to the library it profiled."""
+    import hashlib
+    from lidarnerf import _hip
+    try:
+        return hashlib.sha256(open(_hip.lib_path(), "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
 def _latest_pmc():
     """HBM bytes per launch of the grid kernels from the newest committed PMC pass (profiles/r*_pmc.json, written by
-    profiles/collect.sh from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command)."""
+    profiles/collect.sh from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command), and the hash of
+    the library that pass profiled (None for files written before round 4)."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
         try:
-            return os.path.relpath(path, ROOT), json.load(open(path)).get("kernels", {})
+            d = json.load(open(path))
+            return os.path.relpath(path, ROOT), d.get("kernels", {}), d.get("lib_sha16")
         except Exception:
             continue
-    return None, {}
+    return None, {}, None
 
 
 def run_nerfmvl(args):
@@ -355,7 +368,9 @@ def main():
                     help="1 GPU: run the table-gradient backward the way data parallel does (one scatter pass + the reduce pass per level window, the exchange a "
                          "no-op) to price the compute side of the DP pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-full", action="store_true", help="BASELINE.md 3 protocol in full: 10 warm-up + 30 timed steps per leg")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="(default since round 4) BASELINE.md 3 protocol in full: 10 warm-up + 30 timed steps per leg")
+    ap.add_argument("--cpu-baseline-quick", action="store_true", help="bounded sample of that protocol (1 + up to 10 steps per leg, ~12 s each)")
+    ap.add_argument("--no-mfma-states", action="store_true", help="skip the two fixed-state MFMA measurements (fresh table with a frozen optimizer; 600-step trained table)")
     ap.add_argument("--no-eval", action="store_true", help="skip the secondary full-frame evaluation measurement")
     ap.add_argument("--kernel-timers", action="store_true", help="HIP-event timing of every C-ABI call (adds ~4 %)")
     args = ap.parse_args()
@@ -467,6 +482,46 @@ def main():
     # (the mask fraction belongs to the steps the MLP kernels were timed in: close the collection before anything else runs)
     mask_frac = float(torch.stack(fused.MASK_STATS).mean().item()) if fused.MASK_STATS else 1.0
     fused.MASK_STATS = None
+    # ---- the same MFMA measurement at two FIXED states (the fraction of samples above the colour mask moves with the
+    #      training trajectory, so the as-run figure above depends on --steps / --warmup): (a) a fresh table with the
+    #      optimizer frozen (lr = 0: every step sees the initial field, mask ~ 1.0), (b) the 'trained-like' table (the field
+    #      first learns the analytic scene for --pretrain-steps untimed steps, mask ~ 0.15).  One GPU only.
+    def mfma_pass(tr, bats, n):
+        fused.MASK_STATS = []
+        _hip.enable_timers(mlp_calls)
+        for s in range(n):
+            tr.step(*bats[s % len(bats)], **step_kw)
+        sync()
+        tm = event_table(_hip.disable_timers())
+        mf = float(torch.stack(fused.MASK_STATS).mean().item()) if fused.MASK_STATS else 1.0
+        fused.MASK_STATS = None
+        return tm, mf, n
+
+    mfma_states = {}
+    if world == 1 and not args.no_mfma_states:
+        mk = dict(iters=30000, fp16=True, scale=SCALE, world_size=1,
+                  render_kwargs=dict(num_steps=NUM_STEPS, upsample_steps=UPSAMPLE),
+                  mlp_dtype=torch.bfloat16 if args.mlp_dtype == "bf16" else torch.float16)
+        torch.manual_seed(0)
+        m2 = build_model(device)
+        t2 = LidarTrainer(m2, lr=0.0, **mk)
+        bats_r = [make_batch(poses, s, args.rays, rank, device, patch, "random") for s in range(8)]
+        for s in range(2):
+            t2.step(*bats_r[s], **step_kw)
+        mfma_states["fresh_frozen"] = mfma_pass(t2, bats_r, 5)
+        del m2, t2
+        if args.table == "trained":
+            mfma_states["trained"] = (mlp_timers, mask_frac, n_prof)  # the run itself IS that state
+        else:
+            torch.manual_seed(0)
+            m3 = build_model(device)
+            t3 = LidarTrainer(m3, lr=1e-2, **mk)
+            bats_a = [make_batch(poses, s, args.rays, rank, device, patch, "analytic") for s in range(60)]
+            for s in range(args.pretrain_steps):
+                t3.step(*bats_a[s % 60], **step_kw)
+            mfma_states["trained"] = mfma_pass(t3, bats_a, 5)
+            del m3, t3
+        torch.cuda.empty_cache()
     # ---- spread: the timed region is short (K x ~2.3 ms); repeat it twice more (outside the reported number) and list all
     spread = [round(1e3 * elapsed / args.steps, 3)]
     for rep in range(2):
@@ -499,11 +554,26 @@ def main():
         t_nc = parallel_max = time.perf_counter() - t0
         parallel.world_size, trainer.world = saved_ws, world
         t_nc = parallel.max_over_ranks(parallel_max, device) / n_nc
+        # the exchange in numbers: bytes per rank and step, and the level windows they travel in (fused._DP_LEVEL_WINDOWS)
+        from lidarnerf.nerf.fused import _DP_LEVEL_WINDOWS
+        enc = model.encoder
+        off = enc._offsets_host
+        wins = _DP_LEVEL_WINDOWS if enc.num_levels == 16 else ((0, enc.num_levels),)
+        plan = [{"levels": [int(l0), int(l1)], "rows": int(off[l1] - off[l0]), "bytes_fp16": int(off[l1] - off[l0]) * 2 * 2,
+                 "overlaps": "the reduce pass of the following window(s)" if i + 1 < len(wins) else
+                             "the MLP gradients' all-reduce and the loss-scale bookkeeping (waited for at the table optimizer)"}
+                for i, (l0, l1) in enumerate(wins)]
+        mlp_bytes = sum(p.numel() for p in trainer.params) * 4
         comm = {"ms_per_step_inclusive": round(1e3 * elapsed / args.steps, 3),
                 "ms_per_step_without_allreduce": round(1e3 * t_nc, 3),
                 "allreduce_exposed_ms": round(1e3 * (elapsed / args.steps - t_nc), 3),
-                "payload": "hash-table gradient 27.4 MB fp16 (2 level windows: the first one's all-reduce runs behind the second one's reduce pass) + "
-                           "21.5 k MLP gradients fp32 (one flat buffer), sum over ranks, RCCL"}
+                "payload_bytes": {"table_gradient_fp16": sum(w["bytes_fp16"] for w in plan), "mlp_gradients_fp32": mlp_bytes,
+                                  "per_rank_on_the_wire_ring_allreduce": int(2 * (world - 1) / world *
+                                                                           (sum(w["bytes_fp16"] for w in plan) + mlp_bytes))},
+                "window_plan": plan,
+                "backend": os.environ.get("LNH_DIST_BACKEND", "nccl (RCCL)"),
+                "payload": "hash-table gradient fp16, SUM over ranks, one all-reduce per level window (the scatter pass runs once, "
+                           "the reduce pass per window) + the MLP gradients fp32 in one flat buffer"}
 
     if rank != 0:
         return
@@ -520,8 +590,11 @@ def main():
     fwd_names = ("lnh_grid_encode_forward", "lnh_grid_encode_forward_mapped")
     bwd_names = ("lnh_grid_encode_backward", "lnh_grid_encode_backward_ws")
     dom = max(fwd_names + bwd_names, key=lambda k: kernels.get(k, {}).get("total_ms", 0))
-    pmc_file, pmc = _latest_pmc()
-    pmc_names = {"lnh_grid_encode_backward_ws": ("k_grid_bwd_scatter", "k_grid_bwd_reduce"),
+    pmc_file, pmc, pmc_lib = _latest_pmc()
+    this_lib = lib_sha16()
+    # (round 4: the plain level classes have their own scatter kernel; older PMC files know k_grid_bwd_scatter only)
+    scatter_name = "k_grid_bwd_scatter_plain" if "k_grid_bwd_scatter_plain" in pmc else "k_grid_bwd_scatter"
+    pmc_names = {"lnh_grid_encode_backward_ws": (scatter_name, "k_grid_bwd_reduce"),
                  "lnh_grid_encode_forward_mapped": ("k_grid_forward",), "lnh_grid_encode_forward": ("k_grid_forward",)}
 
     def hbm_roofline(name):
@@ -542,28 +615,48 @@ def main():
         else:
             traffic, src = int(sum(parts)), f"{pmc_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes: " + \
                 " + ".join(pmc_names[name]) + ")"
+            if pmc_lib is None:
+                src += "; that file does not record which library it profiled"
+            elif pmc_lib != this_lib:
+                src += f"; COLLECTED ON ANOTHER BUILD of the library (sha256 {pmc_lib} there, {this_lib} running now): " \
+                       "re-run profiles/collect.sh"
+            else:
+                src += f"; same library as the one running now (sha256 {this_lib})"
         return {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
+                "traffic_lib_matches": (pmc_lib == this_lib) if (traffic is not None and pmc_lib is not None) else None,
                 "algorithmic_bytes_per_launch": int(per_pt * avg_points), "bytes_per_point": per_pt,
                 "points_per_launch": int(avg_points), "avg_launch_us": k["avg_us"]}
 
     # MFMA utilisation of the MLP kernels: BASELINE.md §4 flops (6 144 sigma + 22 528 * mask fraction colour per sample
     # forward, backward = 2x) over the summed HIP-event time of the four MLP entry points, against the dense fp16 peak
     pts = args.rays * (NUM_STEPS + UPSAMPLE)
-    mlp_ms = sum(v["total_ms"] for v in mlp_timers.values()) / max(n_prof, 1)
-    flops_step = 3 * pts * (SIGMA_FLOPS + COLOR_FLOPS * mask_frac)
-    flops_exec = 3 * pts * (SIGMA_FLOPS + COLOR_FLOPS_EXECUTED * mask_frac)
-    tf = flops_step / (mlp_ms * 1e-3) / 1e12 if mlp_ms else 0.0
-    roofline_mfma = {"bound": "mfma", "kernel": "+".join(sorted(mlp_timers)), "achieved": round(tf, 1),
-                     "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
-                     "flops_per_step": int(flops_step), "mask_fraction": round(mask_frac, 4),
-                     "mlp_kernel_ms_per_step": round(mlp_ms, 4),
-                     "executed_tflops": round(flops_exec / (mlp_ms * 1e-3) / 1e12, 1) if mlp_ms else 0.0,
-                     "note": "flops per SURVEY 8(d): 3 x points x (6144 + 22528 x mask fraction); 'executed' counts the "
-                             "colour head at K = 16 per sample (direction columns folded into a per-ray term); the MLP "
-                             "kernels also read the encoder output and write activations: at 61 flop/B the sigma net is "
-                             "HBM-bound by construction (DESIGN.md)",
-                     "per_kernel_us": {k: v["avg_us"] for k, v in mlp_timers.items()}}
+
+    def mfma_entry(tm, mf, n):
+        ms = sum(v["total_ms"] for v in tm.values()) / max(n, 1)
+        fl = 3 * pts * (SIGMA_FLOPS + COLOR_FLOPS * mf)
+        fl_exec = 3 * pts * (SIGMA_FLOPS + COLOR_FLOPS_EXECUTED * mf)
+        tf_ = fl / (ms * 1e-3) / 1e12 if ms else 0.0
+        return {"achieved": round(tf_, 1), "frac": round(tf_ / MFMA_PEAK_TFLOPS, 4), "flops_per_step": int(fl),
+                "mask_fraction": round(mf, 4), "mlp_kernel_ms_per_step": round(ms, 4),
+                "executed_tflops": round(fl_exec / (ms * 1e-3) / 1e12, 1) if ms else 0.0,
+                "per_kernel_us": {k: v["avg_us"] for k, v in tm.items()}}
+
+    as_run = mfma_entry(mlp_timers, mask_frac, n_prof)
+    head_state = "fresh_frozen" if "fresh_frozen" in mfma_states else "as_run"
+    head = mfma_entry(*mfma_states["fresh_frozen"]) if head_state == "fresh_frozen" else as_run
+    roofline_mfma = dict({"bound": "mfma", "kernel": "+".join(sorted(mlp_timers)), "peak": MFMA_PEAK_TFLOPS,
+                          "unit": "TFLOP/s", "state": head_state}, **head)
+    roofline_mfma["states"] = dict({"as_run": dict(as_run, note=f"the {n_prof} steps after the timed region of THIS run "
+                                                                   f"(--warmup {args.warmup} --steps {args.steps}): the mask "
+                                                                   "fraction depends on how far training got")},
+                                   **{k: mfma_entry(*v) for k, v in mfma_states.items()})
+    roofline_mfma["note"] = ("flops per SURVEY 8(d): 3 x points x (6144 + 22528 x mask fraction); the headline figures are those "
+                             "of state '" + head_state + "' (fresh table, optimizer frozen at lr = 0: every step sees the initial "
+                             "field, mask ~ 1.0; 'trained' = after --pretrain-steps untimed steps on the analytic scene, mask "
+                             "~ 0.15); 'executed' counts the colour head at K = 16 per sample (direction columns folded into a "
+                             "per-ray term); the MLP kernels also read the encoder output and write activations: at 61 flop/B "
+                             "the sigma net is HBM-bound by construction (DESIGN.md)")
     result = {
         "metric": "train rays/sec (encode+MLP+composite+bwd), KITTI-360 66x1030",
         "value": round(rays_total / elapsed, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps,
@@ -610,7 +703,7 @@ def main():
                           "unit": "rays/s", "ms_per_frame": round(1e3 * dt, 3)}
         model.train()
     if world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(full=args.cpu_baseline_full)
+        result["cpu_baseline"] = cpu_baseline(full=not args.cpu_baseline_quick)
     print(json.dumps(result))
 
 

@@ -15,19 +15,12 @@
 //     scan and only the run tail issues the atomic.
 #include "common.h"
 
-#ifndef LNH_FWD_LEVEL_LOOP
-#define LNH_FWD_LEVEL_LOOP 0  // 1: timing probe, see k_grid_forward
-#endif
 typedef uint32_t uint4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t uint2_t __attribute__((ext_vector_type(2)));
 #include <type_traits>
 
 #include <algorithm>
 #include <cmath>
-
-#ifndef LNH_GATHER_PROBE
-#define LNH_GATHER_PROBE 0  // see k_grid_forward: timing probes of the gather cost model, 0 = the product
-#endif
 
 namespace {
 
@@ -210,16 +203,8 @@ k_grid_forward(const float *__restrict__ inputs, const T *__restrict__ table, T 
                RowMap map) {
     const uint32_t b0 = blockIdx.x * blockDim.x + threadIdx.x;
     if (b0 >= B) return;
-#if LNH_FWD_LEVEL_LOOP
-    // A/B probe of the encode -> sigma-net fusion question (tools/probe_fusion.sh, profiles/r03_fusion_probe.txt): a fused
-    // kernel has to walk a point tile through ALL levels inside one workgroup.  This build does exactly that to the encode
-    // alone (same gathers, same outputs, grid.y = 1, the workgroups start together and drift apart as they please) and so
-    // prices what the fusion would give up: the level-major launch order that keeps ONE level's ~2 MB table in each XCD's L2.
-    for (uint32_t level = 0; level < L; level++) {
-#else
-    {
+    {  // (tools/probe_variants.py "fusion" turns this block into a loop over the levels: the encode -> MLP fusion probe)
     const uint32_t level = blockIdx.y;
-#endif
     const LevelParams lv_rt = meta.lv[level];
     // optional row map: launch index b0 = r*T_cur + j addresses row r*T_tot + slot_off + j of buffers holding
     // B_all rows (coarse and fine samples of a ray side by side); identity when T_cur == 0
@@ -282,23 +267,7 @@ k_grid_forward(const float *__restrict__ inputs, const T *__restrict__ table, T 
                     r0s[yz] = r0;
                     r1s[yz] = r1;
                     blk[yz] = load_vec<T, 8>(tab + (size_t)(r0 & ~3u) * C);
-#if LNH_GATHER_PROBE == 0
-                    solo[yz] = load_vec<T, C>(tab + (size_t)(far ? r1 : 0u) * C);
-#else
-                    // Timing probes behind the gather cost model of DESIGN.md §3b (tools/probe_gather.sh builds one
-                    // library per value; results are WRONG by construction).  The second load of every lane goes to:
-                    //   1 row 0 (one line for the whole wave)   2 nowhere (no instruction)
-                    //   3 the other 16-byte half of the 32-byte block it already fetched
-                    //   4 r1 itself (same 128-byte line for 31 lanes in 32, any 64-byte half)   5 another random line
-                    {
-                        const uint32_t far_row = LNH_GATHER_PROBE == 1 ? 0u
-                                               : LNH_GATHER_PROBE == 3 ? ((r0 & ~3u) ^ 4u)
-                                               : LNH_GATHER_PROBE == 4 ? r1
-                                               : ((r1 * 2654435761u) & (lv.hashmap_size - 1));
-                        if (LNH_GATHER_PROBE == 2) solo[yz] = Vec<T, C>{};
-                        else solo[yz] = load_vec<T, C>(tab + (size_t)far_row * C);
-                    }
-#endif
+                    solo[yz] = load_vec<T, C>(tab + (size_t)(far ? r1 : 0u) * C);  // (probe anchor: tools/probe_variants.py "gather")
                 }
 #pragma unroll
                 for (uint32_t yz = 0; yz < 4; yz++) {
@@ -309,11 +278,7 @@ k_grid_forward(const float *__restrict__ inputs, const T *__restrict__ table, T 
                     const uint32_t i0 = r0s[yz] & 3u, i1 = r1s[yz] & 3u;
                     const uint32_t a0 = (i0 & 2u) ? ((i0 & 1u) ? w[3] : w[2]) : ((i0 & 1u) ? w[1] : w[0]);
                     const uint32_t a1 = (i1 & 2u) ? ((i1 & 1u) ? w[3] : w[2]) : ((i1 & 1u) ? w[1] : w[0]);
-#if LNH_GATHER_PROBE == 0
                     const uint32_t b1 = far ? so : a1;
-#else
-                    const uint32_t b1 = (r0s[yz] & 64u) ? so : a1;  // (keeps the probe's second load alive)
-#endif
                     __builtin_memcpy(&g[c0], &a0, 4);
                     __builtin_memcpy(&g[c1], &b1, 4);
                 }
@@ -415,7 +380,7 @@ k_grid_forward(const float *__restrict__ inputs, const T *__restrict__ table, T 
     else if (plain && !(lv_rt.flags & LV_HASH) && (lv_rt.flags & LV_NOWRAP) && (lv_rt.flags & 15u) == (uint32_t)D)
         body(std::integral_constant<int, 2>{});
     else body(std::integral_constant<int, 0>{});
-    }  // level (loop in the LNH_FWD_LEVEL_LOOP probe build)
+    }  // level
 }
 
 // Debug kernel for the bit-exact index contract.
@@ -1945,7 +1910,7 @@ k_grad_tv(const T *__restrict__ inputs, const T *__restrict__ table, T *__restri
 template <typename T, int D>
 int launch_forward_c(const float *inputs, const T *emb, T *out, T *dy_dx, uint32_t B, uint32_t C, uint32_t L,
                      const GridMeta &m, uint32_t align, uint32_t interp, hipStream_t s, RowMap map = RowMap{0, 0, 0, 0}) {
-    dim3 grid(div_up(B, 256), LNH_FWD_LEVEL_LOOP ? 1 : L), block(256);
+    dim3 grid(div_up(B, 256), /* levels */ L), block(256);
 #define LNH_FWD(CC)                                                                                               \
     if (dy_dx)                                                                                                    \
         LNH_LAUNCH((k_grid_forward<T, D, CC, true>), grid, block, 0, s, inputs, emb, out, dy_dx, B, L, m, \

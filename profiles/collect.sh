@@ -5,11 +5,11 @@
 #   <tag>_pmc.json           FETCH_SIZE / WRITE_SIZE per launch of the grid kernels (separate --pmc passes, no other
 #                            trace domains; FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM": gfx950 tallies 128-B reads at 64 B)
 #   <tag>_bench.json         the default bench line (with cpu_baseline)
-tag=${1:-r03}
+tag=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 out=gpurun_out/profiles; mkdir -p $out
 STEPS=10; WARM=3
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -o r -- python bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-eval > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -o r -- python bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-eval --no-mfma-states > /dev/null 2>&1
 find /tmp/prof_kt -name "*kernel_stats.csv" -exec cp {} $out/${tag}_kernel_stats.csv \;
 # (+5 steps: the MFMA pass bench.py runs after the timed region; + 2 x STEPS: the two repeats of the timed region it lists as spread)
 python - $out/${tag}_kernel_stats.csv $((3*STEPS+WARM+5)) > $out/${tag}_kernel_summary.txt <<'PY'
@@ -22,7 +22,7 @@ for r in rows[:40]:
     print(f"{float(r['TotalDurationNs'])/n/1e6:8.3f} ms/step {int(r['Calls'])/n:6.1f} calls/step  avg {float(r['AverageNs'])/1e3:9.1f} us  {r['Name'][:110]}")
 PY
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/prof_$c -o r -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-eval > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/prof_$c -o r -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-eval --no-mfma-states > /dev/null 2>&1
 done
 python - $out/${tag}_pmc.json <<'PY'
 import csv, glob, json, sys, collections
@@ -36,7 +36,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         k = r["Kernel_Name"]
         agg[k] += float(r["Counter_Value"]); cnt[k] += 1
     for k in agg:
-        short = next((s for s in ("k_grid_bwd_scatter", "k_grid_bwd_reduce", "k_grid_forward", "k_color_backward_wi", "k_color_forward",
+        short = next((s for s in ("k_grid_bwd_scatter_plain", "k_grid_bwd_scatter", "k_grid_bwd_reduce", "k_grid_forward", "k_color_backward_wi", "k_color_forward",
                                   "k_mlp_backward_wi", "k_mlp_forward") if s in k), None)
         if short: res[short][c + "_KB_per_launch_raw"] = round(agg[k] / cnt[k], 1)
 for k, d in res.items():
@@ -46,11 +46,14 @@ for k, d in res.items():
         # 4-12 B/lane loads of the other kernels are calibrated on k_grid_bwd_scatter (raw FETCH_SIZE == known input bytes).
         d["fetch_scale"] = 2.0 if k == "k_grid_bwd_reduce" else 1.0
         d["hbm_bytes_per_launch"] = int((d["fetch_scale"] * f + w) * 1024)
-json.dump({"command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-eval",
+import hashlib, os
+lib = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "lidar-nerf_amd", "lib", "liblidarnerf_hip.so")
+json.dump({"command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-eval --no-mfma-states",
+           "lib_sha16": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16],   # bench.py compares it with the library it runs
            "note": "KB per launch, averaged over all launches. hbm_bytes_per_launch = fetch_scale*FETCH_SIZE + WRITE_SIZE "
                    "(fetch_scale 2 for the 16 B/lane streaming loads of k_grid_bwd_reduce, 1 elsewhere; see profiles/README.md)",
            "kernels": res},
           open(sys.argv[1], "w"), indent=1)
 PY
-timeout 400 python bench.py > $out/${tag}_bench.json 2> /dev/null
+timeout 900 python bench.py > $out/${tag}_bench.json 2> /dev/null
 tail -c 600 $out/${tag}_bench.json; echo; cat $out/${tag}_pmc.json | head -40

@@ -96,14 +96,33 @@ def _slice(n):
 
 SLICES = {"s384": _slice(384), "s256": _slice(256), "s192": _slice(192), "s128": _slice(128), "s96": _slice(96), "full": ("grid.hip", [])}
 
-# ---- work-queue reduce: order of the dense levels' slices and their length
-def _dense(first, kb):
-    return ("grid.hip", [("#define LNH_REDUCE_DENSE_FIRST 1", "#define LNH_REDUCE_DENSE_FIRST %d" % first),
-                         ("constexpr uint32_t kSliceEntriesDense = 64 * 1024;", "constexpr uint32_t kSliceEntriesDense = %d * 1024;" % kb)])
+# ---- encode forward: the two probes of rounds 2 / 3, formerly #if branches inside k_grid_forward
+# fusion (profiles/r03_fusion_probe.txt): the level loop INSIDE the workgroup (grid.y = 1) — what an encode -> MLP fusion
+# gives up: the level-major launch order that keeps ONE level's ~2 MB table in each XCD's L2.
+FUSION = {
+    "fwdloop": ("grid.hip", [
+        ('    {  // (tools/probe_variants.py "fusion" turns this block into a loop over the levels: the encode -> MLP fusion probe)\n    const uint32_t level = blockIdx.y;\n',
+         "    for (uint32_t level = 0; level < L; level++) {\n"),
+        ("    dim3 grid(div_up(B, 256), /* levels */ L), block(256);", "    dim3 grid(div_up(B, 256), 1), block(256);")]),
+    "product": ("grid.hip", []),
+}
 
 
-DENSE = {"df64": _dense(1, 64), "df32": _dense(1, 32), "df16": _dense(1, 16), "dl64": _dense(0, 64), "dl16": _dense(0, 16), "df512": _dense(1, 512)}
-SETS = {"dense": DENSE, "slices": SLICES, "reduce": REDUCE, "scatter": SCATTER_CUTS, "stagger": STAGGER, "iters": ITERS, "wgsize": WGSIZE}
+# gather cost model (profiles/r02_gather_probe.txt): the second load of every lane of a hashed level goes to
+#   1 row 0 (one line for the whole wave)   2 nowhere (no instruction)   3 the other 16-byte half of the 32-byte block it
+#   already fetched   4 r1 itself (same 128-byte line for 31 lanes in 32)   5 another random line.  Results are WRONG.
+def _gather(n):
+    far_row = {1: "0u", 3: "((r0 & ~3u) ^ 4u)", 4: "r1", 5: "((r1 * 2654435761u) & (lv.hashmap_size - 1))"}
+    load = "solo[yz] = Vec<T, C>{};" if n == 2 else f"solo[yz] = load_vec<T, C>(tab + (size_t){far_row[n]} * C);"
+    return ("grid.hip", [
+        ('                    solo[yz] = load_vec<T, C>(tab + (size_t)(far ? r1 : 0u) * C);  // (probe anchor: tools/probe_variants.py "gather")\n',
+         "                    " + load + "\n"),
+        ("                    const uint32_t b1 = far ? so : a1;\n",
+         "                    const uint32_t b1 = (r0s[yz] & 64u) ? so : a1;  // (keeps the probe's second load alive)\n")])
+
+
+GATHER = dict({"probe0": ("grid.hip", [])}, **{f"probe{n}": _gather(n) for n in (1, 2, 3, 4, 5)})
+SETS = {"fusion": FUSION, "gather": GATHER, "slices": SLICES, "reduce": REDUCE, "scatter": SCATTER_CUTS, "stagger": STAGGER, "iters": ITERS, "wgsize": WGSIZE}
 
 
 def build_variant(name, fname, subs):
