@@ -4,6 +4,7 @@
 // mlp_common.h for the register-resident layer chaining and the fp16 / bf16 element-type builds
 // (lidar_color_bf16.hip compiles this file again with bf16 MFMA operands: entry points lnh_lidar_color_*_bf16).
 #include "mlp_common.h"
+#include <type_traits>
 
 namespace LNH_MLP_NS {
 namespace {
@@ -294,8 +295,31 @@ k_color_forward_ray(ColorArgs a) {
 // fragment (the A and B operand layouts are mirror images: row/col = lane & 15, same k enumeration), which is exact.
 // Every wave owns all 24 gradient tiles (dW2 4, dW1 16, dW0g 4) in accumulators; the four waves of a workgroup are
 // combined through LDS once at the end and flushed with one atomic per weight.
-template <bool FROM_IMAGE>  // d loss / d rgb read from a.g_rgb, or formed as weights (x) a.g_image
-__global__ void __launch_bounds__(256)
+// LDS reads the compiler cannot hoist out of the loop (the weight table is loop-invariant: as plain loads the 28 fragments
+// come back as 112 live registers, which is what keeping them in LDS is meant to avoid).  lds_wait* ties the s_waitcnt to
+// the fragments it covers, so no consumer can be scheduled in front of it.
+__device__ __forceinline__ uint32_t lds_addr(const void *p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+}
+template <int OFF>
+__device__ __forceinline__ half8_t lds_read16(uint32_t addr) {
+    half8_t r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+__device__ __forceinline__ void lds_wait2(half8_t &a, half8_t &b) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void lds_wait4(half8_t &a, half8_t &b, half8_t &c, half8_t &d) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+
+// LDSW (round 4): the 28 weight fragments live in LDS, shared by the 8 waves of a 512-thread workgroup, and every wave
+// reads a fragment right before the MFMA that uses it — which frees 112 registers, so that TWO waves fit a SIMD (96 AGPR
+// accumulators + <= 160 VGPRs each).  A lone wave issues one VALU instruction per ~6 cycles (tools/valu_rate.hip); with a
+// second wave on the SIMD the issue rate doubles, which is what this VALU-issue-bound kernel needs.
+template <bool FROM_IMAGE, bool LDSW>  // d loss / d rgb read from a.g_rgb, or formed as weights (x) a.g_image
+__global__ void __launch_bounds__(LDSW ? 512 : 256) __attribute__((amdgpu_waves_per_eu(LDSW ? 2 : 1, LDSW ? 2 : 1)))
 k_color_backward_wi(ColorArgs a) {
     constexpr int HT = 4, HS = 2, NT = 2, NTILE = HT + HT * HT + HT;
     // The 28 weight fragments (112 registers) stay in registers for the whole kernel: the 24 gradient tiles live in
@@ -307,25 +331,37 @@ k_color_backward_wi(ColorArgs a) {
     const uint32_t wid = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
     const uint32_t nw = blockDim.x >> 6, nwaves = gridDim.x * nw;
     const uint32_t wave = blockIdx.x * nw + (uint32_t)__builtin_amdgcn_readfirstlane((int)wid);  // known wave-uniform
-    half8_t wreg[NFRAG];
-    {
-#pragma unroll
-        for (int t = 0; t < HT; t++) {
-            wreg[F_W0 + t] = load_a_natural(a.W + kW0g, 16, 16 * t + c, 0, g, 16);
-            wreg[F_W2T + t] = load_at_natural(a.W + kW2, 64, 16 * t + c, 0, g, 16);
-#pragma unroll
-            for (int s = 0; s < HS; s++) {
-                wreg[F_W1 + 2 * t + s] = load_a_nu(a.W + kW1, 64, 16 * t + c, s, g);
-                wreg[F_W1T + 2 * t + s] = load_at_nu(a.W + kW1, 64, 16 * t + c, s, g);
+    __shared__ half8_t wlds[LDSW ? NFRAG * 64 : 1];
+    half8_t wreg[LDSW ? 1 : NFRAG];
+    auto frag = [&](int i) -> half8_t {  // fragment i of this lane (see the F_* enumeration)
+        if (i < F_W1) return load_a_natural(a.W + kW0g, 16, 16 * (i - F_W0) + c, 0, g, 16);
+        if (i < F_W2) return load_a_nu(a.W + kW1, 64, 16 * ((i - F_W1) >> 1) + c, (i - F_W1) & 1, g);
+        if (i < F_W2T) return load_a_nu(a.W + kW2, 64, c, i - F_W2, g);
+        if (i < F_W1T) return load_at_natural(a.W + kW2, 64, 16 * (i - F_W2T) + c, 0, g, 16);
+        if (i < F_W0T) return load_at_nu(a.W + kW1, 64, 16 * ((i - F_W1T) >> 1) + c, (i - F_W1T) & 1, g);
+        return load_at_nu(a.W + kW0g, 16, c, i - F_W0T, g);
+    };
+    if constexpr (LDSW) {
+        // the 8 waves of the workgroup fill the table together, one fragment at a time (nothing of it stays in registers)
+        for (uint32_t i = wid; i < (uint32_t)NFRAG; i += nw) {
+            half8_t f;
+            switch (i) {  // (constant fragment numbers: the loaders pick their matrix at compile time)
+#define LNH_FRAG_CASE(k) case k: f = frag(k); break;
+                LNH_FRAG_CASE(0) LNH_FRAG_CASE(1) LNH_FRAG_CASE(2) LNH_FRAG_CASE(3) LNH_FRAG_CASE(4) LNH_FRAG_CASE(5) LNH_FRAG_CASE(6)
+                LNH_FRAG_CASE(7) LNH_FRAG_CASE(8) LNH_FRAG_CASE(9) LNH_FRAG_CASE(10) LNH_FRAG_CASE(11) LNH_FRAG_CASE(12)
+                LNH_FRAG_CASE(13) LNH_FRAG_CASE(14) LNH_FRAG_CASE(15) LNH_FRAG_CASE(16) LNH_FRAG_CASE(17) LNH_FRAG_CASE(18)
+                LNH_FRAG_CASE(19) LNH_FRAG_CASE(20) LNH_FRAG_CASE(21) LNH_FRAG_CASE(22) LNH_FRAG_CASE(23) LNH_FRAG_CASE(24)
+                LNH_FRAG_CASE(25) LNH_FRAG_CASE(26) default: f = frag(27); break;
+#undef LNH_FRAG_CASE
             }
+            wlds[i * 64 + lane] = f;
         }
+        __syncthreads();
+    } else {
 #pragma unroll
-        for (int s = 0; s < HS; s++) {
-            wreg[F_W2 + s] = load_a_nu(a.W + kW2, 64, c, s, g);
-            wreg[F_W0T + s] = load_at_nu(a.W + kW0g, 16, c, s, g);
-        }
+        for (int i = 0; i < NFRAG; i++) wreg[i] = frag(i);
     }
-#define WF(i) (wreg[(i)])
+#define WF(i) (LDSW ? wlds[(i) * 64 + lane] : wreg[(i)])
     // identity fragments: idn selects natural-k element c (k = 8g + j); idv[tt] selects nu-enumerated channel
     // 16 * (2s + tt) + c out of k-step s (element j of lane group g is channel 16 * (2s + (j >> 2)) + 4g + (j & 3))
     half8_t idn, idv[2];
@@ -472,7 +508,7 @@ k_color_backward_wi(ColorArgs a) {
             A.gs[n] = a.g_sigma[A.m[n]];
             if constexpr (!FROM_IMAGE) {
                 A.gr[n] = *reinterpret_cast<const float2 *>(a.g_rgb + (size_t)A.m[n] * 2);
-            } else {        // what lnh_lidar_composite_backward would have written: w * d loss / d image, same product
+            } else if constexpr (!LDSW) {  // what lnh_lidar_composite_backward would have written: w * d loss / d image
                 const float2 gi = *reinterpret_cast<const float2 *>(a.g_image + (size_t)(I.live ? I.ray : 0) * 2);
                 A.gr[n] = make_float2(A.wgt[n] * gi.x, A.wgt[n] * gi.y);
             }
@@ -505,8 +541,8 @@ k_color_backward_wi(ColorArgs a) {
     };
     StageA A0 = load_a(next_item()), A1 = load_a(next_item());
     StageB B0 = load_b(A0);
-    f32x4 cb[HT], cb_next[HT];
-    load_cb(A0.ray, cb_next);
+    f32x4 cb[HT], cb_next[LDSW ? 1 : HT];
+    if constexpr (!LDSW) load_cb(A0.ray, cb_next);
     float ssum[HT] = {0.0f, 0.0f, 0.0f, 0.0f};
     bool first_of_ray = true;
 
@@ -515,14 +551,16 @@ k_color_backward_wi(ColorArgs a) {
         const StageA A2 = load_a(next_item());
         const StageB B1 = load_b(A1);
         if (first_of_ray) {
+            if constexpr (LDSW) load_cb(ray, cb);  // (two waves per SIMD: the partner covers this round trip; 16 registers less)
 #pragma unroll
             for (int t = 0; t < HT; t++) {
-                cb[t] = cb_next[t];
+                if constexpr (!LDSW) cb[t] = cb_next[t];
                 ssum[t] = 0.0f;
             }
         }
         const bool last_of_ray = !A1.live || A1.ray != ray;
-        if (last_of_ray) load_cb(A1.ray, cb_next);   // the next item opens another ray: its direction term, one item ahead
+        if constexpr (!LDSW)
+            if (last_of_ray) load_cb(A1.ray, cb_next);   // the next item opens another ray: its direction term, one item ahead
         bool msk[NT];
         half8_t bx[NT];
 #pragma unroll
@@ -532,6 +570,106 @@ k_color_backward_wi(ColorArgs a) {
         }
         {
             half8_t by[NT], bh0[NT][HS], bh1[NT][HS], bd1[NT][HS], bd0[NT][HS];
+            if constexpr (LDSW) {
+                // weight fragments from LDS right before their MFMAs, four at a time, each used for BOTH 16-sample tiles
+                const uint32_t wb = lds_addr(wlds) + lane * 16;
+                float2 gimg = make_float2(0.0f, 0.0f);
+                if constexpr (FROM_IMAGE) gimg = *reinterpret_cast<const float2 *>(a.g_image + (size_t)ray * 2);
+#define LDF(i) lds_read16<(i) * 1024>(wb)
+                f32x4 acc[NT][HT];
+                {
+                    half8_t w[HT] = {LDF(F_W0 + 0), LDF(F_W0 + 1), LDF(F_W0 + 2), LDF(F_W0 + 3)};
+                    lds_wait4(w[0], w[1], w[2], w[3]);
+#pragma unroll
+                    for (int t = 0; t < HT; t++)
+#pragma unroll
+                        for (int n = 0; n < NT; n++) acc[n][t] = MFMA16(w[t], bx[n], cb[t]);
+                }
+#pragma unroll
+                for (int n = 0; n < NT; n++)
+#pragma unroll
+                    for (int s = 0; s < HS; s++) bh0[n][s] = pack_pair_relu(acc[n][2 * s], acc[n][2 * s + 1]);
+                auto layer1 = [&](auto tp_c) {
+                    constexpr int tp = decltype(tp_c)::value;
+                    half8_t w[4] = {LDF(F_W1 + 2 * tp + 0), LDF(F_W1 + 2 * tp + 1), LDF(F_W1 + 2 * tp + 2), LDF(F_W1 + 2 * tp + 3)};
+                    lds_wait4(w[0], w[1], w[2], w[3]);
+#pragma unroll
+                    for (int t = tp; t < tp + 2; t++)
+#pragma unroll
+                        for (int n = 0; n < NT; n++) {
+                            acc[n][t] = MFMA16(w[2 * (t - tp)], bh0[n][0], zero_f4());
+                            acc[n][t] = MFMA16(w[2 * (t - tp) + 1], bh0[n][1], acc[n][t]);
+                        }
+                };
+                layer1(std::integral_constant<int, 0>{});
+                layer1(std::integral_constant<int, 2>{});
+#pragma unroll
+                for (int n = 0; n < NT; n++)
+#pragma unroll
+                    for (int s = 0; s < HS; s++) bh1[n][s] = pack_pair_relu(acc[n][2 * s], acc[n][2 * s + 1]);
+                {
+                    half8_t w0 = LDF(F_W2 + 0), w1 = LDF(F_W2 + 1);
+                    lds_wait2(w0, w1);
+#pragma unroll
+                    for (int n = 0; n < NT; n++) {
+                        f32x4 o = MFMA16(w0, bh1[n][0], zero_f4());
+                        o = MFMA16(w1, bh1[n][1], o);
+                        by[n] = zero_h8();
+                        if (g == 0 && msk[n]) {
+                            const float r0 = sigmoidf((float)(half_t)o[0]), r1 = sigmoidf((float)(half_t)o[1]);
+                            float2 gr = A0.gr[n];
+                            if constexpr (FROM_IMAGE) gr = make_float2(A0.wgt[n] * gimg.x, A0.wgt[n] * gimg.y);
+                            by[n][0] = (half_t)(gr.x * r0 * (1.0f - r0));
+                            by[n][1] = (half_t)(gr.y * r1 * (1.0f - r1));
+                        }
+                    }
+                }
+                {
+                    half8_t w[HT] = {LDF(F_W2T + 0), LDF(F_W2T + 1), LDF(F_W2T + 2), LDF(F_W2T + 3)};
+                    lds_wait4(w[0], w[1], w[2], w[3]);
+#pragma unroll
+                    for (int t = 0; t < HT; t++)
+#pragma unroll
+                        for (int n = 0; n < NT; n++) acc[n][t] = MFMA16(w[t], by[n], zero_f4());
+                }
+#pragma unroll
+                for (int n = 0; n < NT; n++)
+#pragma unroll
+                    for (int s = 0; s < HS; s++) bd1[n][s] = pack_pair_relu_bwd(acc[n][2 * s], acc[n][2 * s + 1], bh1[n][s]);
+                auto layer1t = [&](auto tp_c) {
+                    constexpr int tp = decltype(tp_c)::value;
+                    half8_t w[4] = {LDF(F_W1T + 2 * tp + 0), LDF(F_W1T + 2 * tp + 1), LDF(F_W1T + 2 * tp + 2), LDF(F_W1T + 2 * tp + 3)};
+                    lds_wait4(w[0], w[1], w[2], w[3]);
+#pragma unroll
+                    for (int t = tp; t < tp + 2; t++)
+#pragma unroll
+                        for (int n = 0; n < NT; n++) {
+                            acc[n][t] = MFMA16(w[2 * (t - tp)], bd1[n][0], zero_f4());
+                            acc[n][t] = MFMA16(w[2 * (t - tp) + 1], bd1[n][1], acc[n][t]);
+                        }
+                };
+                layer1t(std::integral_constant<int, 0>{});
+                layer1t(std::integral_constant<int, 2>{});
+#pragma unroll
+                for (int n = 0; n < NT; n++)
+#pragma unroll
+                    for (int s = 0; s < HS; s++) bd0[n][s] = pack_pair_relu_bwd(acc[n][2 * s], acc[n][2 * s + 1], bh0[n][s]);
+                {
+                    half8_t w0 = LDF(F_W0T + 0), w1 = LDF(F_W0T + 1);
+                    lds_wait2(w0, w1);
+#pragma unroll
+                    for (int n = 0; n < NT; n++) {
+                        f32x4 dx = MFMA16(w0, bd0[n][0], zero_f4());
+                        dx = MFMA16(w1, bd0[n][1], dx);
+                        if (A0.valid[n]) {
+                            if (g == 0) dx[0] = A0.gs[n] * exp_clamped((float)bx[n][0]);
+                            half4_t v = {(half_t)dx[0], (half_t)dx[1], (half_t)dx[2], (half_t)dx[3]};
+                            *reinterpret_cast<half4_t *>(a.g_h16 + src_of(A0, n) * 16 + 4 * g) = v;
+                        }
+                    }
+                }
+#undef LDF
+            } else {
             // the two 16-sample tiles go through every layer side by side: one tile's MFMAs run while the other tile's
             // results are narrowed and activated (a single wave per SIMD has nothing else to hide MFMA latency with)
             f32x4 acc[NT][HT];
@@ -605,6 +743,7 @@ k_color_backward_wi(ColorArgs a) {
                     half4_t v = {(half_t)dx[0], (half_t)dx[1], (half_t)dx[2], (half_t)dx[3]};
                     *reinterpret_cast<half4_t *>(a.g_h16 + src_of(A0, n) * 16 + 4 * g) = v;
                 }
+            }
             }
             // ---- sample-major operands (exact transposes) and the weight gradients
             const half8_t fy = pack2(MFMA16(by[0], idn, zero_f4()), MFMA16(by[1], idn, zero_f4()));
@@ -729,11 +868,20 @@ static int color_backward_launch(const float *grad_rgb, const float *grad_image,
     a.N = N; a.T = T;
     // persistent workgroups: each flushes 6144 weight-gradient partials with device atomics (~20 G/s chip-wide), so
     // keep the workgroup count near the CU count rather than one per ray
-    const uint32_t wgs = (N + 3) / 4;
+    // LDSW = 1 (two waves per SIMD, weights in LDS) is correct and measured: 434 us against 217 at 60 % active samples, 653
+    // against 275 at 100 % (profiles/r04_color_backward_2wave.txt) — at 256 registers per wave hipcc splits the file 128 / 128
+    // and spills 66 registers of the chain to scratch.  The product stays on the one-wave kernel.
+#ifndef LNH_COLOR_BWD_LDSW
+#define LNH_COLOR_BWD_LDSW 0
+#endif
+    constexpr bool kLdsw = LNH_COLOR_BWD_LDSW != 0;
+    const uint32_t per_wg = kLdsw ? 8 : 4, nwg = (N + per_wg - 1) / per_wg;
     if (grad_rgb) {
-        LNH_LAUNCH(k_color_backward_wi<false>, dim3(wgs < 256 ? wgs : 256), dim3(256), 0, (hipStream_t)stream, a);
+        LNH_LAUNCH((k_color_backward_wi<false, kLdsw>), dim3(nwg < 256 ? nwg : 256), dim3(kLdsw ? 512 : 256), 0,
+                   (hipStream_t)stream, a);
     } else {
-        LNH_LAUNCH(k_color_backward_wi<true>, dim3(wgs < 256 ? wgs : 256), dim3(256), 0, (hipStream_t)stream, a);
+        LNH_LAUNCH((k_color_backward_wi<true, kLdsw>), dim3(nwg < 256 ? nwg : 256), dim3(kLdsw ? 512 : 256), 0,
+                   (hipStream_t)stream, a);
     }
     return lnh_check_launch("lnh_lidar_color_backward");
 }

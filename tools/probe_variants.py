@@ -122,7 +122,12 @@ def _gather(n):
 
 
 GATHER = dict({"probe0": ("grid.hip", [])}, **{f"probe{n}": _gather(n) for n in (1, 2, 3, 4, 5)})
-SETS = {"fusion": FUSION, "gather": GATHER, "slices": SLICES, "reduce": REDUCE, "scatter": SCATTER_CUTS, "stagger": STAGGER, "iters": ITERS, "wgsize": WGSIZE}
+
+# ---- colour-head backward: one wave per SIMD with the weights in registers (round 3) against two waves per SIMD with
+# the weights in LDS (round 4)
+COLOR = {"c1wave": ("lidar_color.hip", []),
+         "c2wave": ("lidar_color.hip", [("#define LNH_COLOR_BWD_LDSW 0", "#define LNH_COLOR_BWD_LDSW 1")])}
+SETS = {"color": COLOR, "fusion": FUSION, "gather": GATHER, "slices": SLICES, "reduce": REDUCE, "scatter": SCATTER_CUTS, "stagger": STAGGER, "iters": ITERS, "wgsize": WGSIZE}
 
 
 def build_variant(name, fname, subs):
