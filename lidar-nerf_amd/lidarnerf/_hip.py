@@ -139,7 +139,15 @@ def ptr(t):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """hipStream_t of torch's current stream on the current device.  (torch.cuda.current_stream() builds a Stream object
+    per call: 9 us of host time, ~45 times per training step — the occupancy-grid step of BASELINE config 4 was host-bound on
+    it; the raw-handle accessor torch itself uses costs a fraction of a microsecond.)"""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -165,7 +173,7 @@ _TIMED = None
 
 def call(name, *args, tag=None):
     """Invoke an entry point on the current stream; raise on any non-zero status."""
-    L = lib()
+    L = _lib if _lib is not None else lib()
     timed = TIMERS is not None and (_TIMED is None or name in _TIMED)
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

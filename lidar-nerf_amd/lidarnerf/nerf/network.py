@@ -76,14 +76,21 @@ class NeRFNetwork(NeRFRenderer):
         return out
 
     def fused_spec(self):
+        # (built once: a dozen nn.Module attribute look-ups, 20 us, three times per training step — the occupancy-grid step
+        #  of BASELINE config 4 is bound by the host's enqueue time.  Parameters keep their identity across load_state_dict
+        #  / optimizer steps; whoever REPLACES a sub-module deletes `_fused_spec_cache`.)
+        cached = self.__dict__.get("_fused_spec_cache")
+        if cached is not None:
+            return cached
         if self.encoder.__class__.__name__ != "GridEncoder" or len(self.sigma_net) != 2 \
                 or self.encoder_lidar_dir.__class__.__name__ != "FreqEncoder" or self.encoder_lidar_dir.degree != 12:
             raise AttributeError("field is not fusable")
         c = self.lidar_color_net
-        return fused.FieldSpec(grid=self.encoder, table=self.encoder.embeddings, ws0=self.sigma_net[0].weight,
+        spec = self.__dict__["_fused_spec_cache"] = fused.FieldSpec(grid=self.encoder, table=self.encoder.embeddings, ws0=self.sigma_net[0].weight,
                                ws1=self.sigma_net[1].weight, wc0=c[0].weight,
                                wc1=c[1].weight if len(c) == 3 else None, wc2=c[-1].weight, n_dir=75,
                                dir_features=self._lidar_dir_features, dir_freq_degree=12, n_color_mats=len(c))
+        return spec
 
     def run(self, rays_o, rays_d, cal_lidar_color=False, num_steps=128, upsample_steps=128, bg_color=None,
             perturb=False, **kwargs):
