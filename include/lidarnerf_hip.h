@@ -84,6 +84,13 @@ LNH_API int lnh_grid_encode_backward(const void *grad, const float *inputs, cons
 LNH_API uint64_t lnh_grid_backward_workspace_size(const int32_t *offsets_host, uint32_t B, uint32_t D, uint32_t C,
                                                   uint32_t L, float S, uint32_t H, uint32_t gridtype,
                                                   int align_corners, int dtype);
+/* The workspace serves one chunk of the batch at a time: any size between lnh_grid_backward_workspace_size_min(...) and
+ * lnh_grid_backward_workspace_size(...) is accepted — a smaller workspace means shorter chunks (more launches: 3.09 / 1.60 /
+ * 0.91 GB cost 897 / 922 / 992 us at 4096 rays x 832 samples), never another result class.  Below the minimum the call
+ * returns LNH_ERR_INVALID_ARG and lnh_last_error() names the minimum. */
+LNH_API uint64_t lnh_grid_backward_workspace_size_min(const int32_t *offsets_host, uint32_t B, uint32_t D, uint32_t C,
+                                                      uint32_t L, float S, uint32_t H, uint32_t gridtype,
+                                                      int align_corners, int dtype);
 /* Host-side description of that workspace's bucket plan for `level` (no device work): out[0] = table buckets of the
  * level, out[1] = pool slots per bucket (what exceeds them goes to the level's spill list), out[2] = rows per bucket,
  * out[3] = entries per reduce slice (a bucket with more is reduced by several workgroups).  The sum the call produces

@@ -1408,7 +1408,7 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
     // (half_to_fixed24); fp32 ones are truncated to 2^-40 each.  Integer sums do not depend on the order of arrival.
     // (Measured and rejected in round 4: a DOUBLE image for fp16 tables — exact as well up to partial sums of 2^29, two
     // conversions per value instead of five VALU operations — runs the pass at 447 us against 330: ds_add_f64 is the slower
-    // LDS atomic.  profiles/r04_reduce_variants.txt)
+    // LDS atomic.  profiles/r04_reduce_levels.txt)
     typedef unsigned long long acc_t;
     acc_t *img = reinterpret_cast<acc_t *>(smem_raw);
     for (uint32_t i = threadIdx.x; i < kBucketRows * 2; i += blockDim.x) acc[i] = 0ull;
@@ -1686,6 +1686,27 @@ int launch_backward_bucketed_chunk(const T *grad, const float *inputs, T *ge, ui
                                    hipStream_t s, uint32_t level_begin, uint32_t level_end, uint32_t b_begin,
                                    uint32_t B_all, uint32_t B_plan, int phase = 0);
 
+// Shortest chunk the call will use for a batch (256 K points, or the batch itself), and the longest chunk whose plan fits
+// `workspace_bytes` (0: not even the shortest does).
+constexpr uint32_t kMinChunkPoints = 256u << 10;
+__host__ inline uint32_t halve_chunk(uint32_t B, uint32_t step) {
+    return div_up(div_up(B, div_up(B, step) * 2), 1024) * 1024;
+}
+__host__ inline uint32_t min_chunk_points(uint32_t B, bool plain) {
+    uint32_t step = chunk_points(B, plain);
+    while (step > kMinChunkPoints) step = halve_chunk(B, step);
+    return step;
+}
+template <typename T>
+uint32_t fit_chunk(uint32_t B, const GridMeta &m, uint32_t L, bool plain, uint64_t workspace_bytes) {
+    BucketPlan plan;
+    uint32_t nbt = 0;
+    for (uint32_t step = chunk_points(B, plain);; step = halve_chunk(B, step)) {
+        if (plan_buckets<T>(plan, m, L, step, 3, plain, nbt) <= workspace_bytes) return step;
+        if (step <= kMinChunkPoints) return 0;
+    }
+}
+
 // split = 0: the whole backward of the levels [level_begin, level_end).
 // split = 1 ("begin"): every chunk but the last completely (all levels), then the SCATTER pass of the last chunk.
 // split = 2 ("finish"): the REDUCE pass of the last chunk for the levels [level_begin, level_end) — after it the gradient of
@@ -1698,7 +1719,21 @@ int launch_backward_bucketed(const T *grad, const float *inputs, T *ge, uint32_t
                              hipStream_t s, uint32_t level_begin = 0, uint32_t level_end = 0xffffffffu, int split = 0) {
     if (level_end > L) level_end = L;
     if (level_begin >= level_end) return LNH_OK;
-    const uint32_t step = chunk_points(B, align == 0 && interp == 0);
+    // The workspace serves one chunk at a time, so a SMALLER workspace than lnh_grid_backward_workspace_size() asks for is
+    // not an error: the batch is walked in shorter chunks (fit_chunk halves the chunk until its plan fits; 3.09 GB / 1.60 /
+    // 0.91 GB at 4096 rays x 832 cost 897 / 922 / 992 us, profiles/r04_workspace_chunks.txt).  Below the plan of the
+    // shortest chunk the call fails and names that size.
+    const uint32_t step = fit_chunk<T>(B, m, L, align == 0 && interp == 0, workspace_bytes);
+    if (step == 0) {
+        BucketPlan plan;
+        uint32_t nbt = 0;
+        const uint64_t least = plan_buckets<T>(plan, m, L, min_chunk_points(B, align == 0 && interp == 0), 3,
+                                               align == 0 && interp == 0, nbt);
+        lnh_set_error("grid backward: workspace too small (%llu bytes; this batch needs at least %llu — "
+                      "lnh_grid_backward_workspace_size_min — and runs fastest with lnh_grid_backward_workspace_size)",
+                      (unsigned long long)workspace_bytes, (unsigned long long)least);
+        return LNH_ERR_INVALID_ARG;
+    }
     for (uint32_t b0 = 0; b0 < B; b0 += step) {
         const bool last = b0 + step >= B;
         int phase = 0;
@@ -2108,6 +2143,23 @@ uint64_t lnh_grid_backward_workspace_size(const int32_t *offsets_host, uint32_t 
     uint64_t need = 0;
     for (int plain = 0; plain <= (align_corners ? 0 : 1); plain++) {
         const uint32_t Bc = chunk_points(B, plain != 0);
+        const uint64_t n = dtype == LNH_F16 ? plan_buckets<half_t>(plan, m, L, Bc, D, plain != 0, nbt)
+                                            : plan_buckets<float>(plan, m, L, Bc, D, plain != 0, nbt);
+        need = n > need ? n : need;
+    }
+    return need;
+}
+
+uint64_t lnh_grid_backward_workspace_size_min(const int32_t *offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                                              float S, uint32_t H, uint32_t gridtype, int align_corners, int dtype) {
+    if (lnh_grid_backward_workspace_size(offsets_host, B, D, C, L, S, H, gridtype, align_corners, dtype) == 0) return 0;
+    GridMeta m;
+    (void)build_meta(m, offsets_host, D, L, S, H, gridtype, align_corners != 0);
+    BucketPlan plan;
+    uint32_t nbt = 0;
+    uint64_t need = 0;
+    for (int plain = 0; plain <= (align_corners ? 0 : 1); plain++) {
+        const uint32_t Bc = min_chunk_points(B, plain != 0);
         const uint64_t n = dtype == LNH_F16 ? plan_buckets<half_t>(plan, m, L, Bc, D, plain != 0, nbt)
                                             : plan_buckets<float>(plan, m, L, Bc, D, plain != 0, nbt);
         need = n > need ? n : need;

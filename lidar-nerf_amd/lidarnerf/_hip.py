@@ -87,7 +87,8 @@ for _n in ("lnh_mlp_forward", "lnh_mlp_backward", "lnh_density_mlp_forward", "ln
            "lnh_ragged_color_output_backward", "lnh_ragged_grad_rows"):
     _SIGS[_n + "_bf16"] = _SIGS[_n]  # bf16-operand build of the MLP kernels (include/lidarnerf_hip.h, last section)
 EXPORTS = sorted(list(_SIGS) + ["lnh_version", "lnh_last_error", "lnh_arch", "lnh_build_variant",
-                                 "lnh_grid_backward_workspace_size", "lnh_grid_backward_plan_info",
+                                 "lnh_grid_backward_workspace_size", "lnh_grid_backward_workspace_size_min",
+                                 "lnh_grid_backward_plan_info",
                                  "lnh_grid_backward_set_slice_entries"])
 
 LNH_F32, LNH_F16 = 0, 1
@@ -114,6 +115,8 @@ def lib():
             fn.restype = C.c_int
         L.lnh_grid_backward_workspace_size.argtypes = [P, U32, U32, U32, U32, F32, U32, U32, I32, I32]
         L.lnh_grid_backward_workspace_size.restype = C.c_uint64
+        L.lnh_grid_backward_workspace_size_min.argtypes = [P, U32, U32, U32, U32, F32, U32, U32, I32, I32]
+        L.lnh_grid_backward_workspace_size_min.restype = C.c_uint64
         L.lnh_grid_backward_plan_info.argtypes = [P, U32, U32, U32, U32, F32, U32, U32, I32, I32, U32, P]
         L.lnh_grid_backward_plan_info.restype = C.c_int
         L.lnh_grid_backward_set_slice_entries.argtypes = [U32]

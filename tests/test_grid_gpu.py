@@ -207,12 +207,18 @@ def _run_bucketed(x, g, dt, times=1):
     return host(outs[0]).astype(np.float64)
 
 
-def _check_table(got, want, dt):
+def _check_table(got, want, dt, untouched=None):
+    """`untouched`: the rows no point reaches, when the caller knows them.  Without it the oracle's exact zeros stand in — which
+    is only right while no contribution is small enough for the oracle's per-contribution fp16 rounding (the reference's
+    __half2 atomicAdd operand) to flush it to zero: the bucketed path keeps such a contribution in its 2^-24 fixed-point
+    sum and may round the row to the smallest subnormals instead (seen at 700 K points: 2.4e-7 against 0)."""
     if dt == torch.float32:
         np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5)
     else:
         np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-3 * max(1.0, np.abs(want).max() / 10))
-    assert np.all(got[want == 0] == 0)
+    if untouched is None:
+        untouched = want == 0
+    assert np.all(got[untouched] == 0)
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.float16])
@@ -304,6 +310,45 @@ def test_backward_bucketed_sliced_and_spilled(dt):
     # the same batch with the default slice length (no bucket is split): bit-identical — slicing never changes a sum
     again = _run_bucketed(x, g, dt, times=1)
     assert np.array_equal(got, again)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16])
+def test_backward_bucketed_smaller_workspace_means_shorter_chunks(dt):
+    """Any workspace between lnh_grid_backward_workspace_size_min and lnh_grid_backward_workspace_size is accepted: the batch
+    is walked in shorter chunks (one scatter + reduce pair each, the table accumulates).  Same table as the oracle; against
+    the one-chunk result only the fp16 roundings move (one per row and chunk)."""
+    from gpu_util import call, dev, host
+    from lidarnerf import _hip
+    B = 700 * 1024                                         # > 2 x 256 K points: the minimum plan walks it in 4 chunks
+    x = np.concatenate([_ray_points(B // 512, 256, 21), _points(B - (B // 512) * 256, 22)])
+    assert x.shape[0] == B
+    nd = np.float32 if dt == torch.float32 else np.float16
+    g = (np.random.default_rng(23).standard_normal((L, B, CH)) * 0.05).astype(nd)
+    rows, code = int(OFF[-1]), (0 if dt == torch.float32 else 1)
+    offh = torch.from_numpy(OFF)
+    full = _hip.lib().lnh_grid_backward_workspace_size(offh.data_ptr(), B, 3, CH, L, S, H, 0, 0, code)
+    least = _hip.lib().lnh_grid_backward_workspace_size_min(offh.data_ptr(), B, 3, CH, L, S, H, 0, 0, code)
+    assert 0 < least < 0.75 * full                         # (spill lists and slice images have floors that do not shrink)
+    gd, xd = dev(g), dev(x)
+    outs = {}
+    for name, nbytes in (("full", full), ("least", least), ("between", (full + least) // 2)):
+        ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        ge = torch.zeros((rows, CH), dtype=dt, device="cuda")
+        call("lnh_grid_encode_backward_ws", gd, xd, offh, ge, B, 3, CH, L, S, H, 0, 0, 0, code, ws, nbytes)
+        outs[name] = host(ge).astype(np.float64)
+        del ws
+    want = c_oracle.grid_backward(g, x, OFF, rows, S, H)
+    reach = c_oracle.grid_backward(np.ones((L, B, CH), dtype=np.float32), x, OFF, rows, S, H)
+    for name, got in outs.items():
+        _check_table(got, want, dt, untouched=(reach == 0))
+    scale = np.abs(outs["full"]).max()
+    assert np.abs(outs["least"] - outs["full"]).max() <= (1e-6 if dt == torch.float32 else 2e-3) * scale
+    # far below the minimum (lnh_grid_backward_workspace_size_min covers every interpolation mode; this linear-interpolation
+    # call gets by with somewhat less): refused, and the message names the size it needs at least
+    ws = torch.empty(least // 4, dtype=torch.uint8, device="cuda")
+    ge = torch.zeros((rows, CH), dtype=dt, device="cuda")
+    with pytest.raises(RuntimeError, match=r"workspace too small.*at least \d+"):
+        call("lnh_grid_encode_backward_ws", gd, xd, offh, ge, B, 3, CH, L, S, H, 0, 0, 0, code, ws, least // 4)
 
 
 def test_dense_levels_are_dealt_to_64_buckets():

@@ -127,7 +127,12 @@ GATHER = dict({"probe0": ("grid.hip", [])}, **{f"probe{n}": _gather(n) for n in 
 # the weights in LDS (round 4)
 COLOR = {"c1wave": ("lidar_color.hip", []),
          "c2wave": ("lidar_color.hip", [("#define LNH_COLOR_BWD_LDSW 0", "#define LNH_COLOR_BWD_LDSW 1")])}
-SETS = {"color": COLOR, "fusion": FUSION, "gather": GATHER, "slices": SLICES, "reduce": REDUCE, "scatter": SCATTER_CUTS, "stagger": STAGGER, "iters": ITERS, "wgsize": WGSIZE}
+
+# ---- chunk length of the bucketed backward (workspace size against per-chunk launch costs)
+CHUNK = {"ch2m": ("grid.hip", [("constexpr uint32_t kChunkPoints = 4u << 20;", "constexpr uint32_t kChunkPoints = 2u << 20;")]),
+         "ch1m": ("grid.hip", [("constexpr uint32_t kChunkPoints = 4u << 20;", "constexpr uint32_t kChunkPoints = 1u << 20;")]),
+         "full": ("grid.hip", [])}
+SETS = {"chunk": CHUNK, "color": COLOR, "fusion": FUSION, "gather": GATHER, "slices": SLICES, "reduce": REDUCE, "scatter": SCATTER_CUTS, "stagger": STAGGER, "iters": ITERS, "wgsize": WGSIZE}
 
 
 def build_variant(name, fname, subs):
