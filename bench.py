@@ -252,7 +252,9 @@ def run_nerfmvl(args):
     model = NeRFNetwork(encoding="hashgrid", desired_resolution=32768, log2_hashmap_size=19, num_layers=2, hidden_dim=64,
                         geo_feat_dim=15, bound=1, density_scale=1, min_near=scale, min_near_lidar=scale,
                         density_thresh=10, bg_radius=-1, cuda_ray=True).to(device).train()
-    trainer = LidarTrainer(model, lr=1e-2, iters=30000, fp16=True, scale=scale)
+    # the whole step captured in a hipGraph and replayed (LidarTrainer graph mode); --no-graph = one launch at a time
+    use_graph = not args.no_graph
+    trainer = LidarTrainer(model, lr=1e-2, iters=30000, fp16=True, scale=scale, graph=use_graph)
 
     def frame(k):
         th = 2 * np.pi * k / 60
@@ -287,16 +289,18 @@ def run_nerfmvl(args):
         trainer.step(*batches[s])
     torch.cuda.synchronize()
     grid_calls = ["lnh_grid_encode_forward", "lnh_grid_encode_backward_ws", "lnh_grid_encode_backward"]
-    _hip.enable_timers(grid_calls)
+    if not use_graph:  # (a replayed graph makes no library calls to put events around: the eager pass below times them)
+        _hip.enable_timers(grid_calls)
     t0 = time.perf_counter()
     counts = []
     for s in range(args.steps):
         loss = trainer.step(*batches[n_pre + args.warmup + s])
-        counts.append(model.step_counter[(model.local_step - 1) % 16, 0])
+        counts.append(model.step_counter[(model.local_step - 1) % 16, 0].clone())  # (the ring slot is reused 16 steps on)
     host_ms = (time.perf_counter() - t0) * 1e3 / args.steps
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    timers = _hip.disable_timers()
+    timers = _hip.disable_timers() if not use_graph else {}
+    graphs_captured = len(trainer._graphs)
     n_rays = sum(b[0].shape[1] for b in batches[n_pre + args.warmup:n_pre + args.warmup + args.steps])
     samples_total = float(torch.stack(counts).float().sum())
     samples = samples_total / n_rays
@@ -312,10 +316,15 @@ def run_nerfmvl(args):
     kernels = event_table(timers)
     # every entry point of a few more steps (outside the timed region: the events cost ~4 %)
     _hip.enable_timers(None)
+    trainer.graph = False  # launch by launch (same kernels, same device-side learning rate)
     for s in range(n_prof):
         trainer.step(*batches[n_pre + args.warmup + args.steps + s])
     torch.cuda.synchronize()
-    per_call = {k: v["avg_us"] for k, v in event_table(_hip.disable_timers()).items()}
+    trainer.graph = use_graph
+    eager_tab = event_table(_hip.disable_timers())
+    per_call = {k: v["avg_us"] for k, v in eager_tab.items()}
+    if use_graph:
+        kernels = {k: v for k, v in eager_tab.items() if k in grid_calls}
 
     def roof(name, per_pt):
         k = kernels.get(name)
@@ -341,7 +350,10 @@ def run_nerfmvl(args):
                    "dense_samples_per_ray": NUM_STEPS + UPSAMPLE, "occupied_cell_fraction": round(occ, 5),
                    "pretrain_steps": n_pre, "final_loss": round(float(loss.detach()), 5),
                    "render_path": "fused ragged chain (nerf/fused.py FusedLidarRagged) + fused table optimizer"
-                   if trainer.table is not None else "modular density()/color() path"},
+                   if trainer.table is not None else "modular density()/color() path",
+                   "launch": (f"hipGraph replay of the whole step (march .. optimizers; {graphs_captured} graph(s) captured, "
+                              "one per sample capacity; steps at a new capacity run launch by launch once, then capture)")
+                   if use_graph else "launch by launch from Python"},
         "samples_per_s": round(samples_total / elapsed, 1), "host_enqueue_ms_per_step": round(host_ms, 3),
         "roofline": roof(bwd_name, GRID_BWD_BYTES), "roofline_fwd": roof("lnh_grid_encode_forward", GRID_FWD_BYTES),
         "kernels": kernels, "entry_points_avg_us": per_call}))
@@ -355,6 +367,8 @@ def main():
     ap.add_argument("--rays", type=int, default=4096, help="rays per step per GPU")
     ap.add_argument("--mlp-dtype", choices=("fp16", "bf16"), default="fp16",
                     help="MFMA operand type of the MLP kernels (bf16 = BASELINE config 5; hash features stay fp16)")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="nerfmvl workload: issue the step launch by launch instead of replaying the captured hipGraph")
     ap.add_argument("--workload", choices=("kitti360", "nerfmvl"), default="kitti360",
                     help="kitti360 = the headline benchmark (BASELINE configs[1]); nerfmvl = configs[3], occupancy-grid path")
     ap.add_argument("--table", choices=("init", "trained"), default="init",

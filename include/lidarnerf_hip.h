@@ -483,12 +483,19 @@ LNH_API int lnh_chamfer_nn(const float *xyz1, uint32_t n, const float *xyz2, uin
  * lnh_adam_table_step: torch.optim.Adam (no weight decay / amsgrad) on fp32 param / exp_avg / exp_avg_sq with the
  *   fp16 gradient scaled by *inv_scale; also writes the fp16 copy of the updated parameters.  *found_inf != 0 skips
  *   the whole update.  The step counter t lives on the device, double-buffered: reads *step_in, writes *step_out.
+ * lnh_adam_table_step_dlr: the same with the learning rate read from device memory (*lr, f32) — for a training step
+ *   captured in a hipGraph, whose kernel arguments are frozen at capture while the schedule moves lr every step
+ *   (main_lidarnerf.py:408-410: LambdaLR).
  */
 LNH_API int lnh_grad_check_f16(const void *grad16, uint64_t n, float *found_inf, lnh_stream_t stream);
 LNH_API int lnh_adam_table_step(float *param, float *exp_avg, float *exp_avg_sq, const void *grad16, void *param16,
                                 uint64_t n, double lr, double beta1, double beta2, double eps,
                                 const float *inv_scale, const float *found_inf, const float *step_in,
                                 float *step_out, lnh_stream_t stream);
+LNH_API int lnh_adam_table_step_dlr(float *param, float *exp_avg, float *exp_avg_sq, const void *grad16, void *param16,
+                                    uint64_t n, const float *lr, double beta1, double beta2, double eps,
+                                    const float *inv_scale, const float *found_inf, const float *step_in,
+                                    float *step_out, lnh_stream_t stream);
 
 
 /* ------------------------------------------------------------------ bf16 MLP operands (BASELINE config 5) ---- */

@@ -58,6 +58,25 @@ static inline int lnh_check_launch(const char *what) {
 
 static inline uint32_t div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
+// Zero fill as a KERNEL, not hipMemsetAsync.  A training step captured in a hipGraph (LidarTrainer graph mode) turns every
+// hipMemsetAsync into a memset node, and on this runtime (ROCm 7.2) such nodes were seen to replay with a wrong fill byte:
+// the 4-byte clear of the loss accumulator came back as 0xF0F0F0F0 / 0x70707070 / 0xD0D0D0D0 plus the sum, in one captured
+// graph out of a few, every replay of that graph (tests/test_occupancy_gpu.py caught it).  A kernel node has no such field.
+static __global__ void __launch_bounds__(256) k_lnh_zero_words(uint32_t *__restrict__ p, uint64_t n_words) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * 256) p[i] = 0u;
+}
+static inline int lnh_zero_async(void *p, uint64_t bytes, hipStream_t s, const char *what) {
+    if (bytes == 0) return LNH_OK;
+    if ((bytes & 3) || ((uintptr_t)p & 3)) {
+        lnh_set_error("%s: zero fill needs 4-byte alignment", what);
+        return LNH_ERR_INVALID_ARG;
+    }
+    const uint64_t n = bytes / 4;
+    const uint32_t blocks = (uint32_t)(n / 256 < 1024 ? n / 256 + 1 : 1024);
+    LNH_LAUNCH(k_lnh_zero_words, dim3(blocks), dim3(256), 0, s, (uint32_t *)p, n);
+    return lnh_check_launch(what);
+}
+
 // ---- wave-level primitives (64 lanes) ------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -1786,10 +1786,9 @@ int launch_backward_bucketed_chunk(const T *grad, const float *inputs, T *ge, ui
     uint32_t *cursor = reinterpret_cast<uint32_t *>(workspace);
     uint32_t *spill_cursor = cursor + nbt, *done = spill_cursor + L;
     char *pool = reinterpret_cast<char *>(workspace) + cursor_bytes;
-    (void)hipGetLastError();
-    if (phase != 2 && hipMemsetAsync(cursor, 0, cursor_bytes, s) != hipSuccess) {
-        lnh_set_error("grid backward: hipMemsetAsync failed");
-        return LNH_ERR_LAUNCH;
+    if (phase != 2) {
+        const int zrc = lnh_zero_async(cursor, cursor_bytes, s, "grid backward (cursor clear)");
+        if (zrc != LNH_OK) return zrc;
     }
     // 1024 threads x 1 point: the per-workgroup cost that matters is the one returning device atomic per touched
     // bucket (measured: 256- and 512-thread workgroups are 2.3x / 1.5x slower); 5 staged pair entries per thread keep

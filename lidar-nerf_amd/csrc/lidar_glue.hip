@@ -326,9 +326,7 @@ int lnh_lidar_loss(const float *depth, const float *image, const float *gt, uint
                    float alpha_i, float *loss, float *grad_depth, float *grad_image, lnh_stream_t stream) {
     LNH_REQUIRE(depth && image && gt && loss && grad_depth && grad_image, LNH_ERR_INVALID_ARG,
                 "lidar_loss: null pointer");
-    (void)hipGetLastError();
-    LNH_REQUIRE(hipMemsetAsync(loss, 0, sizeof(float), (hipStream_t)stream) == hipSuccess, LNH_ERR_LAUNCH,
-                "lidar_loss: hipMemsetAsync failed");
+    if (int zrc = lnh_zero_async(loss, sizeof(float), (hipStream_t)stream, "lidar_loss (accumulator clear)")) return zrc;
     if (N == 0) return LNH_OK;
     LNH_LAUNCH(k_lidar_loss, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, depth, image, gt, N, alpha_d,
                alpha_r, alpha_i, loss, grad_depth, grad_image);
@@ -342,9 +340,7 @@ int lnh_lidar_loss_patch(const float *depth, const float *image, const float *gt
                 "lidar_loss_patch: null pointer");
     LNH_REQUIRE(px >= 1 && py >= 2 && scale > 0.0f && N % (px * py) == 0, LNH_ERR_INVALID_ARG,
                 "lidar_loss_patch: need py >= 2, scale > 0 and N a multiple of px * py");
-    (void)hipGetLastError();
-    LNH_REQUIRE(hipMemsetAsync(loss, 0, sizeof(float), (hipStream_t)stream) == hipSuccess, LNH_ERR_LAUNCH,
-                "lidar_loss_patch: hipMemsetAsync failed");
+    if (int zrc = lnh_zero_async(loss, sizeof(float), (hipStream_t)stream, "lidar_loss_patch (accumulator clear)")) return zrc;
     if (N == 0) return LNH_OK;
     LNH_LAUNCH(k_lidar_loss_patch, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, depth, image, gt, N, py,
                1.0f / scale, alpha_d, alpha_r, alpha_i, alpha_grad, loss, grad_depth, grad_image);

@@ -35,6 +35,7 @@ struct AdamArgs {
     double lr, beta1, beta2, eps;
     const float *inv_scale, *found_inf, *step_in;
     float *step_out;
+    const float *lr_dev;  // non-null: the learning rate is read from device memory (a step captured in a hipGraph)
 };
 
 __global__ void __launch_bounds__(256)
@@ -50,7 +51,8 @@ k_adam_table(AdamArgs a) {
     // the kernel's memory time) and differs from torch's by an ulp of the parameter.
     const double bc1 = 1.0 - pow(a.beta1, (double)t), bc2 = 1.0 - pow(a.beta2, (double)t);
     const double w1 = 1.0 - a.beta1, w2 = 1.0 - a.beta2;
-    const float step_size = (float)(a.lr / bc1), bc2_sqrt = (float)sqrt(bc2), eps = (float)a.eps;
+    const double lr = a.lr_dev ? (double)*a.lr_dev : a.lr;
+    const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2), eps = (float)a.eps;
     auto update = [&](float &p, float &m, float &v, half_t gh) {
         const float g = (float)gh * inv;
         m = (float)((double)m + w1 * ((double)g - (double)m));  // lerp(m, g, 1 - beta1), |weight| < 0.5 branch
@@ -93,9 +95,9 @@ int lnh_grad_check_f16(const void *grad16, uint64_t n, float *found_inf, lnh_str
     return lnh_check_launch("lnh_grad_check_f16");
 }
 
-int lnh_adam_table_step(float *param, float *exp_avg, float *exp_avg_sq, const void *grad16, void *param16, uint64_t n,
-                        double lr, double beta1, double beta2, double eps, const float *inv_scale,
-                        const float *found_inf, const float *step_in, float *step_out, lnh_stream_t stream) {
+static int adam_table_step(float *param, float *exp_avg, float *exp_avg_sq, const void *grad16, void *param16, uint64_t n,
+                           double lr, const float *lr_dev, double beta1, double beta2, double eps, const float *inv_scale,
+                           const float *found_inf, const float *step_in, float *step_out, lnh_stream_t stream) {
     LNH_REQUIRE(param && exp_avg && exp_avg_sq && grad16 && param16 && inv_scale && found_inf && step_in && step_out,
                 LNH_ERR_INVALID_ARG, "adam_table_step: null pointer");
     LNH_REQUIRE(step_in != step_out, LNH_ERR_INVALID_ARG, "adam_table_step: the step counter is double-buffered");
@@ -104,11 +106,26 @@ int lnh_adam_table_step(float *param, float *exp_avg, float *exp_avg_sq, const v
                 LNH_ERR_INVALID_ARG, "adam_table_step: buffers must be 16-byte (fp32) / 8-byte (fp16) aligned");
     if (n == 0) return LNH_OK;
     AdamArgs a{param, exp_avg, exp_avg_sq, (const half_t *)grad16, (half_t *)param16, n, lr, beta1, beta2, eps,
-               inv_scale, found_inf, step_in, step_out};
+               inv_scale, found_inf, step_in, step_out, lr_dev};
     const uint64_t n4 = n / 4;
     const uint32_t blocks = (uint32_t)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 + 1 : 4096);
     LNH_LAUNCH(k_adam_table, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     return lnh_check_launch("lnh_adam_table_step");
+}
+
+int lnh_adam_table_step(float *param, float *exp_avg, float *exp_avg_sq, const void *grad16, void *param16, uint64_t n,
+                        double lr, double beta1, double beta2, double eps, const float *inv_scale,
+                        const float *found_inf, const float *step_in, float *step_out, lnh_stream_t stream) {
+    return adam_table_step(param, exp_avg, exp_avg_sq, grad16, param16, n, lr, nullptr, beta1, beta2, eps, inv_scale,
+                           found_inf, step_in, step_out, stream);
+}
+
+int lnh_adam_table_step_dlr(float *param, float *exp_avg, float *exp_avg_sq, const void *grad16, void *param16, uint64_t n,
+                            const float *lr, double beta1, double beta2, double eps, const float *inv_scale,
+                            const float *found_inf, const float *step_in, float *step_out, lnh_stream_t stream) {
+    LNH_REQUIRE(lr, LNH_ERR_INVALID_ARG, "adam_table_step_dlr: null learning-rate pointer");
+    return adam_table_step(param, exp_avg, exp_avg_sq, grad16, param16, n, 0.0, lr, beta1, beta2, eps, inv_scale,
+                           found_inf, step_in, step_out, stream);
 }
 
 }  // extern "C"

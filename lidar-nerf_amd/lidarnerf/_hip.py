@@ -69,6 +69,7 @@ _SIGS = {
     "lnh_chamfer_nn": [P, U32, P, U32, P, P],
     "lnh_grad_check_f16": [P, C.c_uint64, P],
     "lnh_adam_table_step": [P, P, P, P, P, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_double, P, P, P, P],
+    "lnh_adam_table_step_dlr": [P, P, P, P, P, C.c_uint64, P, C.c_double, C.c_double, C.c_double, P, P, P, P],
     "lnh_lidar_loss": [P, P, P, U32, F32, F32, F32, P, P, P],
     "lnh_lidar_loss_patch": [P, P, P, U32, U32, U32, F32, F32, F32, F32, F32, P, P, P],
     "lnh_lidar_color_backward": [P, P, P, P, P, P, P, U32, U32, P, P, P],

@@ -53,6 +53,10 @@ def _workspace(device, nbytes):
     cap = os.environ.get("LNH_BWD_WORKSPACE_MB")
     if cap:
         nbytes = min(int(nbytes), int(float(cap) * (1 << 20)))
+    if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+        # a step being captured in a hipGraph (LidarTrainer graph mode): the graph keeps the POINTER — a scratch from the
+        # grow-only cache below would be freed under it the day a larger batch replaces it.  Take it from the graph's pool.
+        return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
     ws = _WORKSPACE.get(device)
     if ws is None or ws.numel() < nbytes:
         ws = None

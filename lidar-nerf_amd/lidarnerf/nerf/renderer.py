@@ -264,7 +264,13 @@ class NeRFRenderer(nn.Module):
         aabb = self.aabb_train if self.training else self.aabb_infer
         _, far_box = raymarching.near_far_from_aabb(rays_o, rays_d, aabb, float(self.min_near_lidar))
         fars = torch.minimum(nears * 81.0, far_box)
-        if self.training:
+        static = getattr(self, "_static_march", None)
+        if self.training and static is not None:
+            # LidarTrainer's captured step (train_step.py, graph=True): a fixed counter buffer and a fixed sample capacity —
+            # this Python runs at capture only; the trainer copies the counter into the ring and advances local_step per replay
+            counter, mean_count = static
+            counter.zero_()
+        elif self.training:
             counter = self.step_counter[self.local_step % 16]
             counter.zero_()
             self.local_step += 1

@@ -83,7 +83,7 @@ class LidarTrainer:
 
     def __init__(self, model, lr=1e-2, iters=30000, fp16=True, alpha_d=1000.0, alpha_r=1.0, alpha_i=10.0,
                  alpha_grad=100.0, scale=1.0, world_size=1, render_kwargs=None, fused_table_optimizer=True,
-                 mlp_dtype=torch.float16, shard_table_optimizer=False):
+                 mlp_dtype=torch.float16, shard_table_optimizer=False, graph=False):
         # mlp_dtype: the autocast dtype — torch.float16 (the reference's --fp16) or torch.bfloat16 (BASELINE config 5:
         # bf16 MFMA MLPs; the hash table and its gradient stay fp16, so the dynamic loss scale is kept either way)
         # (the backward picks reduce-scatter or all-reduce from the process group, parallel.world_size(): a world_size
@@ -136,7 +136,25 @@ class LidarTrainer:
         if len(params) > 1 and all({k: v for k, v in g.items() if k != "params"} ==
                                    {k: v for k, v in params[0].items() if k != "params"} for g in params):
             params = [dict(params[0], params=[p for g in params for p in g["params"]])]
-        self.optimizer = torch.optim.Adam(params, betas=(0.9, 0.99), eps=1e-15, fused=on_gpu)
+        # graph=True (occupancy-grid sampling + fused table optimizer, one GPU): the whole step — march, ragged chain, loss,
+        # backward, both optimizers, loss-scale update — is captured in a hipGraph per (batch shape, sample capacity) and
+        # replayed (_step_graphed).  The step is ~45 launches over ~0.4 M samples: eager, the host cannot issue them as fast
+        # as the GPU retires them (profiles/r04_bench_nerfmvl.json: 1.0 ms of host time per 0.7 ms of kernels).  What a
+        # capture freezes — kernel arguments — must not change between replays, so the learning rate becomes a device
+        # scalar (torch's capturable Adam, lnh_adam_table_step_dlr) and the marcher's sample capacity comes from a ladder
+        # of sizes (_graph_capacity; the reference sizes it to the running mean rounded to 128, raymarching.py:223-229: a
+        # larger buffer drops fewer rays on overflow, nothing else changes).
+        self.graph = bool(graph and self.table is not None and self.occupancy and world_size == 1 and on_gpu)
+        if graph and not self.graph:
+            raise RuntimeError("LidarTrainer(graph=True): the captured step exists for occupancy-grid sampling (cuda_ray) "
+                               "through the fused ragged chain with the fused table optimizer, on one GPU")
+        self._graphs, self._graph_warm, self._graph_pool = {}, set(), None
+        if self.graph:
+            dev0 = self.table.device
+            params = [dict(g, lr=torch.tensor(float(g["lr"]), dtype=torch.float32, device=dev0)) for g in params]
+            self.optimizer = torch.optim.Adam(params, betas=(0.9, 0.99), eps=1e-15, fused=True, capturable=True)
+        else:
+            self.optimizer = torch.optim.Adam(params, betas=(0.9, 0.99), eps=1e-15, fused=on_gpu)
         self.scheduler = torch.optim.lr_scheduler.LambdaLR(self.optimizer, lambda it: 0.1 ** min(it / iters, 1))
         self.scaler = torch.amp.GradScaler("cuda", enabled=fp16)
         self.params = [p for g in self.optimizer.param_groups for p in g["params"]]
@@ -210,20 +228,87 @@ class LidarTrainer:
             self.optimizer.step()
         finally:
             del self.optimizer.grad_scale, self.optimizer.found_inf
-        lr = float(self.optimizer.param_groups[0]["lr"])
+        lr = self.optimizer.param_groups[0]["lr"]
         s_in, s_out = self.t_steps[self.t_flip], self.t_steps[1 - self.t_flip]
         shadow = table16_of(tp)  # (re-cast first if somebody wrote the parameter since the last step)
         if shards:
-            self._step_table_shards(shards, shadow, lr, inv_scale_table, found_inf, s_in, s_out)
+            self._step_table_shards(shards, shadow, float(lr), inv_scale_table, found_inf, s_in, s_out)
+        elif torch.is_tensor(lr):
+            # graph mode: lr is a device scalar the scheduler fills; the step counter is copied back instead of flipped
+            # (a captured step always reads and writes the same two buffers)
+            _hip.call("lnh_adam_table_step_dlr", tp.data_ptr(), self.t_m.data_ptr(), self.t_v.data_ptr(), g16.data_ptr(),
+                      shadow.data_ptr(), tp.numel(), lr.data_ptr(), 0.9, 0.99, 1e-15, inv_scale_table.data_ptr(),
+                      found_inf.data_ptr(), s_in.data_ptr(), s_out.data_ptr())
+            s_in.copy_(s_out)
         else:
             _hip.call("lnh_adam_table_step", tp.data_ptr(), self.t_m.data_ptr(), self.t_v.data_ptr(), g16.data_ptr(),
-                      shadow.data_ptr(), tp.numel(), lr, 0.9, 0.99, 1e-15, inv_scale_table.data_ptr(),
+                      shadow.data_ptr(), tp.numel(), float(lr), 0.9, 0.99, 1e-15, inv_scale_table.data_ptr(),
                       found_inf.data_ptr(), s_in.data_ptr(), s_out.data_ptr())
-        self.t_flip = 1 - self.t_flip
+            self.t_flip = 1 - self.t_flip
         self._last_scale = self.loss_scale.clone()  # the scale this step's gradient carries (table_grad divides by it)
         torch._amp_update_scale_(self.loss_scale, self.growth_tracker, found_inf, 2.0, 0.5, 2000)
-        self.scheduler.step()
+        if not torch.cuda.is_current_stream_capturing():
+            self.scheduler.step()  # (host arithmetic + a fill of the lr scalar: _step_graphed does it after each replay)
         return loss
+
+    # ---- the captured step (graph=True)
+    def _graph_capacity(self):
+        """Sample capacity of the marcher for a captured step: the running mean of the recent marches (renderer.py
+        update_extra_state) rounded UP to the next of a geometric ladder of capacities (ratio 2^(1/4), multiples of 1024):
+        while the occupancy grid is still settling the mean swings by tens of percent from one grid update to the next
+        (measured on the NeRF-MVL-shaped bench: 107 K .. 393 K over 300 steps), and every distinct capacity is one capture
+        (~10 ms) — a ladder has ~8 rungs over that range, each captured once and kept.  On average 9 % of the buffer is
+        padding (zero samples the chain runs over).  0 while there is no mean yet (the first 16 steps march into N x 1024
+        buffers and read the count back)."""
+        mc = int(self.model.mean_count)
+        if mc <= 0:
+            return 0
+        import math
+        rung = math.ceil(4 * math.log2(max(mc, 1024) / 1024.0) - 1e-9)
+        return int(math.ceil(1024 * 2 ** (rung / 4) / 1024.0)) * 1024
+
+    def _step_graphed(self, rays_o, rays_d, images_lidar, patch):
+        model = self.model
+        cap = self._graph_capacity()
+        if cap == 0 or not self._graph_warm:
+            # eager: no sample mean yet / the very first step (it takes every lazy initialisation — workspaces, kernel
+            # attributes, optimizer state — out of the captures that follow).
+            # (detached: a caller holding the loss would keep this step's autograd graph — and its AccumulateGrad nodes,
+            #  bound to the eager stream — alive into the capture that follows)
+            self._graph_warm.add("eager")
+            model._static_march = None
+            return self._step_fused_table(rays_o, rays_d, images_lidar, patch).detach()
+        key = (tuple(rays_o.shape), tuple(images_lidar.shape), tuple(patch), cap)
+        ent = self._graphs.get(key)
+        if ent is None:
+            dev = self.table.device
+            if self._graph_pool is None:
+                # one memory pool for all captured steps: they never run concurrently and none reads what another left
+                # behind, so a later capture may reuse what an earlier one freed (and no capture after the largest pays
+                # for fresh device allocations)
+                self._graph_pool = torch.cuda.graph_pool_handle()
+            ent = {"rays_o": torch.empty_like(rays_o), "rays_d": torch.empty_like(rays_d),
+                   "gt": torch.empty_like(images_lidar), "counter": torch.zeros(2, dtype=torch.int32, device=dev),
+                   "graph": torch.cuda.CUDAGraph()}
+            for k, src in (("rays_o", rays_o), ("rays_d", rays_d), ("gt", images_lidar)):
+                ent[k].copy_(src)
+            model._static_march = (ent["counter"], cap - 128)  # (march_rays_train adds its 128-alignment on top)
+            try:
+                torch.cuda.synchronize()
+                with torch.cuda.graph(ent["graph"], pool=self._graph_pool):
+                    ent["loss"] = self._step_fused_table(ent["rays_o"], ent["rays_d"], ent["gt"], patch).detach()
+            finally:
+                model._static_march = None
+            self._graphs[key] = ent
+        else:
+            ent["rays_o"].copy_(rays_o)
+            ent["rays_d"].copy_(rays_d)
+            ent["gt"].copy_(images_lidar)
+        ent["graph"].replay()
+        model.step_counter[model.local_step % 16].copy_(ent["counter"])
+        model.local_step += 1
+        self.scheduler.step()
+        return ent["loss"].clone()  # (the graphs share a pool: the next replay of another one may reuse this memory)
 
     def _step_table_shards(self, shards, shadow, lr, inv_scale_table, found_inf, s_in, s_out):
         """Sharded table optimizer: Adam on this rank's rows of every level window, then the all-gather of the fp16 compute
@@ -313,6 +398,7 @@ class LidarTrainer:
 
     def load_state_dict(self, sd):
         self.optimizer.load_state_dict(sd["optimizer"])
+        self._after_optimizer_load()
         self.scheduler.load_state_dict(sd["scheduler"])
         self.scaler.load_state_dict(sd["scaler"])
         ft = sd.get("fused_table")
@@ -332,6 +418,8 @@ class LidarTrainer:
         own = self.optimizer.state_dict()
         own_ids = {id(p): i for i, p in enumerate(p for g in self.optimizer.param_groups for p in g["params"])}
         template = {k: v for k, v in own["param_groups"][0].items() if k != "params"} if own["param_groups"] else {}
+        # (graph mode keeps lr in a device scalar: the file carries the number, as the reference's does)
+        template = {k: (float(v) if torch.is_tensor(v) and v.dim() == 0 else v) for k, v in template.items()}
         state, groups, idx = {}, [], 0
         for gi, group in enumerate(self._ref_layout):
             ids = []
@@ -373,6 +461,18 @@ class LidarTrainer:
             if lr is not None:
                 g["lr"] = lr
         self.optimizer.load_state_dict(own)
+        self._after_optimizer_load()
+
+    def _after_optimizer_load(self):
+        """Graph mode: the learning rate stays a device scalar whatever the loaded state held, and every captured step is
+        dropped (Optimizer.load_state_dict replaces the tensors a capture holds pointers to)."""
+        if not self.graph:
+            return
+        for g in self.optimizer.param_groups:
+            if not torch.is_tensor(g["lr"]) or not g["lr"].is_cuda:
+                g["lr"] = torch.tensor(float(g["lr"]), dtype=torch.float32, device=self.table.device)
+        self._graphs.clear()
+        self._graph_warm.clear()
 
     def _own_group_of_ref_group(self):
         """For every parameter group of the reference's optimizer: index of the group of self.optimizer that steps its
@@ -389,7 +489,7 @@ class LidarTrainer:
         m = self._own_group_of_ref_group()
         for key in ("base_lrs", "_last_lr"):
             if key in sd:
-                sd[key] = [sd[key][i] for i in m]
+                sd[key] = [float(sd[key][i]) if torch.is_tensor(sd[key][i]) else sd[key][i] for i in m]
         if "lr_lambdas" in sd:
             sd["lr_lambdas"] = [sd["lr_lambdas"][i] for i in m]
         return sd
@@ -484,6 +584,8 @@ class LidarTrainer:
             with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.fp16):
                 self.model.update_extra_state()  # refresh the occupancy grid the marcher reads (every 16 steps)
         self.global_step += 1
+        if self.graph:
+            return self._step_graphed(rays_o, rays_d, images_lidar, patch)
         if self.table is not None:
             return self._step_fused_table(rays_o, rays_d, images_lidar, patch)
         self.optimizer.zero_grad(set_to_none=True)

@@ -231,6 +231,23 @@ def test_adam_table_kernel_matches_torch_fused_adam():
         assert float(steps[1 - it % 2]) == float(st["step"])
         if it != 2:
             assert torch.equal(p16, p.half())
+    # lnh_adam_table_step_dlr: the same step with the learning rate read from device memory (captured steps) — bit-identical
+    pa, ma, va = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    pb, mb, vb = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    pa16, pb16 = torch.empty_like(p16), torch.empty_like(p16)
+    sa, sb = [torch.zeros((), device="cuda") for _ in range(2)], [torch.zeros((), device="cuda") for _ in range(2)]
+    lr_dev, found = torch.zeros((), device="cuda"), torch.zeros((), device="cuda")
+    for it, lr in enumerate((1e-2, 3.3e-3)):
+        g16 = torch.randn(n, device="cuda").half()
+        lr_dev.fill_(lr)
+        _hip.call("lnh_adam_table_step", pa.data_ptr(), ma.data_ptr(), va.data_ptr(), g16.data_ptr(), pa16.data_ptr(), n,
+                  float(lr_dev), 0.9, 0.99, 1e-15, inv.data_ptr(), found.data_ptr(), sa[it % 2].data_ptr(),
+                  sa[1 - it % 2].data_ptr())
+        _hip.call("lnh_adam_table_step_dlr", pb.data_ptr(), mb.data_ptr(), vb.data_ptr(), g16.data_ptr(), pb16.data_ptr(),
+                  n, lr_dev.data_ptr(), 0.9, 0.99, 1e-15, inv.data_ptr(), found.data_ptr(), sb[it % 2].data_ptr(),
+                  sb[1 - it % 2].data_ptr())
+        assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb) and torch.equal(pa16, pb16)
+        assert float((pa - p0).abs().max()) > 1e-3 and float(sb[1 - it % 2]) == it + 1
     # NaN, tail elements (n not a multiple of 8) and the never-clears contract of the check
     g = torch.zeros(11, dtype=torch.half, device="cuda")
     found = torch.zeros((), device="cuda")

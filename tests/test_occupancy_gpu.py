@@ -250,3 +250,77 @@ def test_training_step_with_no_marched_sample():
     net.density_bitfield.fill_(255)
     loss2 = tr.step(o.cuda()[None], d.cuda()[None], gt)
     assert torch.isfinite(loss2) and not torch.equal(net.encoder.embeddings.detach(), before)
+
+
+def _sphere_batch(n, seed, R=0.15):
+    o, d = _object_rays(n, seed)
+    b = (o * d).sum(-1)
+    disc = b * b - ((o * o).sum(-1) - R * R)
+    hit = disc > 0
+    depth = torch.where(hit, -b - torch.sqrt(disc.clamp(min=0)), torch.zeros_like(b))
+    gt = torch.stack([hit.float(), torch.full_like(b, 0.5), depth], -1)[None].cuda()
+    return o.cuda()[None], d.cuda()[None], gt
+
+
+def test_captured_step_trains_like_the_eager_step():
+    """LidarTrainer(graph=True): the occupancy-grid step (march .. both optimizers .. loss-scale update) captured in a
+    hipGraph per sample capacity and replayed.  Against an eager trainer on the same batches from the same initial state:
+    the same loss trajectory (not bit-equal: the jitter comes from the generator's graph-safe Philox stream, the marcher's
+    capacity is rounded up to a ladder of sizes, and the MLP weight gradients are float atomics), the learning rate
+    follows the schedule through the device scalar, the step counters of both optimizers advance once per replay, the
+    marcher's counters reach the ring update_extra_state reads, and a checkpoint taken in graph mode loads into an eager
+    trainer."""
+    import os
+    import tempfile
+    from lidarnerf.nerf.train_step import LidarTrainer
+    nets = [_net(seed=1).train(), _net(seed=1).train()]
+    for net in nets:
+        with torch.no_grad():
+            net.encoder.embeddings.uniform_(-1e-4, 1e-4)
+    nets[1].load_state_dict(nets[0].state_dict())
+    eager = LidarTrainer(nets[0], lr=1e-2, iters=200, fp16=True, scale=SCALE, render_kwargs={})
+    graph = LidarTrainer(nets[1], lr=1e-2, iters=200, fp16=True, scale=SCALE, render_kwargs={}, graph=True)
+    assert graph.graph and not eager.graph
+    le, lg = [], []
+    n_steps = 96
+    for step in range(n_steps):
+        batch = _sphere_batch(2048, 100 + step)
+        le.append(float(eager.step(*batch).detach()))
+        lg.append(float(graph.step(*batch).detach()))
+    assert len(graph._graphs) >= 1                        # captured (the first 16 steps ran launch by launch)
+    assert len(graph._graphs) <= 4, list(graph._graphs)   # ... and the capacity ladder keeps the number of graphs small
+    caps = sorted(k[-1] for k in graph._graphs)
+    assert all(c % 1024 == 0 for c in caps) and caps[-1] >= nets[1].mean_count
+    assert all(np.isfinite(lg))
+    # same training: start equal, both fall by the same factor, and the smoothed trajectories stay close
+    np.testing.assert_allclose(lg[0], le[0], rtol=1e-3)
+    se, sg = np.convolve(le, np.ones(8) / 8, "valid"), np.convolve(lg, np.ones(8) / 8, "valid")
+    assert sg[-1] < 0.35 * sg[0]
+    assert np.abs(sg - se).max() < 0.25 * se[0], (se[::8], sg[::8])
+    assert abs(sg[-1] - se[-1]) < 0.5 * se[-1] + 0.02 * se[0], (se[-1], sg[-1])
+    # learning rate: the schedule's value, in the device scalar both optimizers read
+    lr = graph.optimizer.param_groups[0]["lr"]
+    assert torch.is_tensor(lr) and lr.is_cuda
+    np.testing.assert_allclose(float(lr), 1e-2 * 0.1 ** (n_steps / 200), rtol=1e-5)
+    # step counters: the table's device-side counter and torch Adam's per-parameter counters moved once per step
+    skipped = n_steps - int(graph.t_steps[graph.t_flip])
+    assert 0 <= skipped <= 3                              # (the dynamic loss scale may back off a couple of times early on)
+    st = graph.optimizer.state[graph.params[0]]["step"]
+    assert int(st) == n_steps - skipped
+    # the marcher's counters reach the ring: update_extra_state derived a plausible mean from them
+    assert 0 < nets[1].mean_count < 2048 * 832 * 0.25
+    assert abs(nets[1].mean_count - nets[0].mean_count) < 0.3 * nets[0].mean_count
+    # a checkpoint written in graph mode carries plain numbers and loads into an eager trainer, which continues
+    with tempfile.TemporaryDirectory() as tmp:
+        path = graph.save_checkpoint(os.path.join(tmp, "g.pth"))
+        ck = torch.load(path, weights_only=False)
+        assert isinstance(ck["optimizer"]["param_groups"][0]["lr"], float)
+        third = LidarTrainer(_net(seed=7).train(), lr=1e-2, iters=200, fp16=True, scale=SCALE, render_kwargs={})
+        third.load_checkpoint(path)
+        l3 = float(third.step(*_sphere_batch(2048, 500)).detach())
+        # ... and back into a graph-mode trainer: the captured steps are dropped, lr stays a device scalar
+        graph.load_checkpoint(path)
+        assert not graph._graphs and torch.is_tensor(graph.optimizer.param_groups[0]["lr"])
+        l4 = float(graph.step(*_sphere_batch(2048, 500)).detach())
+        l5 = float(graph.step(*_sphere_batch(2048, 501)).detach())   # (recaptured)
+    assert np.isfinite([l3, l4, l5]).all() and abs(l3 - l4) < 0.3 * max(l3, l4) + 1e-3
