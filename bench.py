@@ -282,7 +282,8 @@ def run_nerfmvl(args):
         sel = torch.randperm(o.shape[0], generator=g)[:args.rays].to(device)
         return o[sel][None].contiguous(), d[sel][None].contiguous(), gt[sel][None].contiguous()
 
-    n_pre = 192  # let the occupancy grid settle (12 grid updates) before anything is timed
+    n_pre = 320  # let the occupancy grid settle before anything is timed: 20 grid updates — the first 16 are full 128^3 sweeps
+                 # (renderer.py update_extra_state: ~100 ms each), the steady state updates a quarter of the cells
     n_prof = min(args.steps, 5)
     batches = [batch(s) for s in range(n_pre + args.warmup + args.steps + n_prof)]
     for s in range(n_pre + args.warmup):
@@ -293,17 +294,23 @@ def run_nerfmvl(args):
         _hip.enable_timers(grid_calls)
     t0 = time.perf_counter()
     counts = []
+    covered = 0  # marches the ring reads below cover (the first block may reach a few steps back into the warm-up)
     for s in range(args.steps):
+        if trainer.global_step % trainer.update_extra_interval == 0 and model.local_step:
+            # the ring of the last 16 marches, before the grid update resets it: ONE tiny kernel per 16 steps
+            counts.append(model.step_counter[:model.local_step, 0].sum())
+            covered += model.local_step
         loss = trainer.step(*batches[n_pre + args.warmup + s])
-        counts.append(model.step_counter[(model.local_step - 1) % 16, 0].clone())  # (the ring slot is reused 16 steps on)
+    counts.append(model.step_counter[:model.local_step, 0].sum())
+    covered += model.local_step
     host_ms = (time.perf_counter() - t0) * 1e3 / args.steps
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timers = _hip.disable_timers() if not use_graph else {}
     graphs_captured = len(trainer._graphs)
     n_rays = sum(b[0].shape[1] for b in batches[n_pre + args.warmup:n_pre + args.warmup + args.steps])
-    samples_total = float(torch.stack(counts).float().sum())
-    samples = samples_total / n_rays
+    samples = float(torch.stack(counts).float().sum()) / (covered * (n_rays / args.steps))  # marched samples per ray
+    samples_total = samples * n_rays
     occ = float((model.density_grid > min(model.mean_density, model.density_thresh)).float().mean())
 
     def event_table(tm):

@@ -404,6 +404,10 @@ LNH_API int lnh_lidar_loss_patch(const float *depth, const float *image, const f
  *   64,64 | 16,64 (wc2 in rows 0..1)] — the flat vectors of lnh_density_mlp_* / lnh_mlp_*(input_dim 96, one hidden matrix).
  * lnh_ragged_color_input: cin [M,96] = [x | sin(2^f x), sin(2^f x + pi/2), f < degree (freqencoder.cu:34-63) of the
  *   sample's direction | geo_feat = h16[m, 1:16] | 0] (network.py:215-221), in the MLP element type.
+ * lnh_ragged_color_input_rays: the same rows written ray by ray from the marcher's rays [N,3] (id, offset, count): a
+ *   ray's samples share its direction (raymarching.cu:331-534), so the direction terms are evaluated once per ray from
+ *   dirs[offset]; rows no ray owns (deltas[m,0] == 0: the unused tail, the slots of a ray dropped for lack of room) are
+ *   set to zero.  Same values as lnh_ragged_color_input on the rows rays own.
  * lnh_ragged_color_output: rgb [M,2] f32 = sigmoid(y16[m, 0:2]) (network.py:224).  _backward: grad_y16 [M,16] =
  *   (grad_rgb * rgb * (1 - rgb) | 0).
  * lnh_ragged_grad_rows: grad_h16[m,0] = grad_sigma[m] * density_scale * exp(clamp(h16[m,0], -15, 15)) (trunc_exp backward,
@@ -415,6 +419,8 @@ LNH_API int lnh_ragged_pack_weights(const float *ws0, uint32_t ld_s0, const floa
                                     uint32_t ld_c2, void *wsig16, void *wcol16, lnh_stream_t stream);
 LNH_API int lnh_ragged_color_input(const float *dirs, const void *h16, uint32_t M, uint32_t degree, void *cin,
                                    lnh_stream_t stream);
+LNH_API int lnh_ragged_color_input_rays(const float *dirs, const void *h16, const int32_t *rays, const float *deltas,
+                                        uint32_t N, uint32_t M, uint32_t degree, void *cin, lnh_stream_t stream);
 LNH_API int lnh_ragged_color_output(const void *y16, uint32_t M, float *rgb, lnh_stream_t stream);
 LNH_API int lnh_ragged_color_output_backward(const float *grad_rgb, const float *rgb, uint32_t M, void *grad_y16,
                                              lnh_stream_t stream);
@@ -526,6 +532,8 @@ LNH_API int lnh_ragged_pack_weights_bf16(const float *ws0, uint32_t ld_s0, const
                                          uint32_t ld_c2, void *wsig16, void *wcol16, lnh_stream_t stream);
 LNH_API int lnh_ragged_color_input_bf16(const float *dirs, const void *h16, uint32_t M, uint32_t degree, void *cin,
                                         lnh_stream_t stream);
+LNH_API int lnh_ragged_color_input_rays_bf16(const float *dirs, const void *h16, const int32_t *rays, const float *deltas,
+                                             uint32_t N, uint32_t M, uint32_t degree, void *cin, lnh_stream_t stream);
 LNH_API int lnh_ragged_color_output_bf16(const void *y16, uint32_t M, float *rgb, lnh_stream_t stream);
 LNH_API int lnh_ragged_color_output_backward_bf16(const float *grad_rgb, const float *rgb, uint32_t M, void *grad_y16,
                                                   lnh_stream_t stream);

@@ -5,11 +5,13 @@
 //   lnh_ragged_points           x01 = (xyz + bound) / (2 bound)                      (gridencoder/grid.py:213)
 //   lnh_ragged_pack_weights     fp32 master matrices -> flat 16-bit vectors: [ws0 | ws1], [wc0 padded to 96 cols | wc1 | wc2 padded to 16 rows]
 //   lnh_ragged_color_input      [freq(d) (3 + 6 deg) | geo_feat = h16[:, 1:16] | 0] -> [M, 96]   (network.py:215-221)
+//   lnh_ragged_color_input_rays the same rows written ray by ray (the direction terms once per ray)
 //   lnh_ragged_color_output     rgb = sigmoid(y[:, :2])                                (network.py:224-231)
 //   lnh_ragged_color_output_backward   d/dy of the above into a zero-padded [M, 16] row
 //   lnh_ragged_grad_rows        gradient row of the sigma-net output: col 0 = g_sigma * density_scale * exp(clamp(h0, -15, 15))
 //                               (trunc_exp backward, activation.py:17-19), cols 1..15 = colour head's d/d geo_feat
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -69,6 +71,63 @@ k_ragged_color_input(const float *__restrict__ dirs, const E *__restrict__ h16, 
     }
     cin[(size_t)m * 96 + c2] = out[0];
     cin[(size_t)m * 96 + c2 + 1] = out[1];
+}
+
+// The same rows, ONE WAVE PER RAY: every marched sample of a ray carries the ray's direction (raymarching.cu:331-534 writes
+// dirs = the ray's d for each of its samples), so the 2 * 6 * degree sines are evaluated once per ray instead of once per
+// sample (the per-sample kernel above spends its 49 us per step of the NeRF-MVL-shaped bench on 312 K x 72 sinf).  48 lanes
+// hold one column pair each; the wave walks the ray's rows writing 192 contiguous bytes per row.  Rows no ray owns — the
+// unused tail of the sample buffer, and the slots of a ray the marcher dropped for lack of room — still enter the weight
+// gradient GEMM (with a zero output gradient), so they must hold finite numbers: the blocks behind the ray blocks find them
+// by their delta == 0 (the marcher never wrote them; a marched sample has dt > 0) and zero them.
+template <typename E>
+__global__ void __launch_bounds__(256)
+k_ragged_color_input_rays(const float *__restrict__ dirs, const E *__restrict__ h16, const int32_t *__restrict__ rays,
+                          const float *__restrict__ deltas, uint32_t N, uint32_t M, uint32_t kd, uint32_t ray_blocks,
+                          E *__restrict__ cin) {
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    struct alignas(4) Pair { E a, b; };
+    if (blockIdx.x < ray_blocks) {
+        const uint32_t n = blockIdx.x * 4 + wv;
+        if (n >= N || lane >= 48) return;
+        const uint32_t offset = (uint32_t)rays[n * 3 + 1], count = (uint32_t)rays[n * 3 + 2];
+        if (count == 0 || offset + count > M) return;  // (a dropped ray's slots: zeroed by the scanning blocks)
+        const uint32_t c2 = lane * 2;
+        float fv[2] = {0.0f, 0.0f};
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const uint32_t k = c2 + u;
+            if (k < kd) {  // frequency features, same operations in the same order as encoders.hip k_freq_forward
+                const uint32_t q = k < 3 ? 0u : k - 3u, d = k < 3 ? k : q % 3u, f = q / 6u, c = (q / 3u) & 1u;
+                const float x = dirs[(size_t)offset * 3 + d];
+                const float a = scalbnf(x, (int)f);
+                fv[u] = k < 3 ? x : sinf(c ? a + 1.5707963267948966f : a);
+            }
+        }
+        const bool g0 = c2 >= kd && c2 < kd + 15, g1 = c2 + 1 >= kd && c2 + 1 < kd + 15;
+        const uint32_t h0 = 1 + (c2 - kd), h1 = 1 + (c2 + 1 - kd);
+        Pair fixed{(E)fv[0], (E)fv[1]};
+#pragma unroll 8  // (independent rows: the loads of several in flight)
+        for (uint32_t j = 0; j < count; j++) {
+            const size_t row = (size_t)offset + j;
+            Pair o = fixed;
+            if (g0) o.a = h16[row * 16 + h0];
+            if (g1) o.b = h16[row * 16 + h1];
+            *reinterpret_cast<Pair *>(cin + row * 96 + c2) = o;
+        }
+        return;
+    }
+    // rows nobody marched: 64 rows per wave at a time
+    const uint32_t waves = (gridDim.x - ray_blocks) * 4, w = (blockIdx.x - ray_blocks) * 4 + wv;
+    for (uint32_t r0 = w * 64; r0 < M; r0 += waves * 64) {
+        const uint32_t r = r0 + lane;
+        unsigned long long empty = __ballot(r < M && deltas[(size_t)r * 2] == 0.0f);
+        while (empty) {
+            const uint32_t b = (uint32_t)__ffsll(empty) - 1;
+            empty &= empty - 1;
+            if (lane < 48) *reinterpret_cast<Pair *>(cin + (size_t)(r0 + b) * 96 + lane * 2) = Pair{(E)0.0f, (E)0.0f};
+        }
+    }
 }
 
 template <typename E>
@@ -133,6 +192,19 @@ int color_input(const float *dirs, const void *h16, uint32_t M, uint32_t degree,
     return lnh_check_launch("lnh_ragged_color_input");
 }
 template <typename E>
+int color_input_rays(const float *dirs, const void *h16, const int32_t *rays, const float *deltas, uint32_t N, uint32_t M,
+                     uint32_t degree, void *cin, lnh_stream_t stream) {
+    LNH_REQUIRE(dirs && h16 && rays && deltas && cin, LNH_ERR_INVALID_ARG, "ragged_color_input_rays: null pointer");
+    const uint32_t kd = 3 + 6 * degree;
+    LNH_REQUIRE(kd + 15 <= 96, LNH_ERR_UNSUPPORTED, "ragged_color_input_rays: 3 + 6 * degree + 15 must fit 96 columns");
+    LNH_REQUIRE((uint64_t)M * 96 < (1ull << 40), LNH_ERR_UNSUPPORTED, "ragged_color_input_rays: M too large");
+    if (M == 0) return LNH_OK;
+    const uint32_t ray_blocks = div_up(N, 4), scan_blocks = std::min(div_up(M, 256), 512u);
+    LNH_LAUNCH(k_ragged_color_input_rays<E>, dim3(ray_blocks + scan_blocks), dim3(256), 0, (hipStream_t)stream, dirs,
+               (const E *)h16, rays, deltas, N, M, kd, ray_blocks, (E *)cin);
+    return lnh_check_launch("lnh_ragged_color_input_rays");
+}
+template <typename E>
 int color_output(const void *y, uint32_t M, float *rgb, lnh_stream_t stream) {
     LNH_REQUIRE(y && rgb, LNH_ERR_INVALID_ARG, "ragged_color_output: null pointer");
     if (M == 0) return LNH_OK;
@@ -184,6 +256,10 @@ int lnh_ragged_points(const float *xyz, float bound, uint32_t M, float *x01, lnh
     int lnh_ragged_color_input##SFX(const float *dirs, const void *h16, uint32_t M, uint32_t degree, void *cin,             \
                                     lnh_stream_t stream) {                                                                   \
         return color_input<E>(dirs, h16, M, degree, cin, stream);                                                            \
+    }                                                                                                                        \
+    int lnh_ragged_color_input_rays##SFX(const float *dirs, const void *h16, const int32_t *rays, const float *deltas,      \
+                                         uint32_t N, uint32_t M, uint32_t degree, void *cin, lnh_stream_t stream) {          \
+        return color_input_rays<E>(dirs, h16, rays, deltas, N, M, degree, cin, stream);                                      \
     }                                                                                                                        \
     int lnh_ragged_color_output##SFX(const void *y16, uint32_t M, float *rgb, lnh_stream_t stream) {                         \
         return color_output<E>(y16, M, rgb, stream);                                                                         \

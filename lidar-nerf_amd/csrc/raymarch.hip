@@ -52,7 +52,7 @@ __device__ __forceinline__ int cell_coord(float x, float mip_rbound, uint32_t H)
 }
 
 struct Probe {
-    float x, y, z, dt, t_next;
+    float x, y, z, dt, t_next, tt;
     uint32_t index;
     bool occ;
 };
@@ -61,15 +61,21 @@ struct MarchRay {
     float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
 };
 
-// One decision of the marcher at parameter t (raymarching.cu:379-439).
-__device__ __forceinline__ Probe probe(const MarchRay &r, float t, const uint8_t *__restrict__ grid, float bound,
-                                       float dt_gamma, float dt_min, float dt_max, uint32_t C, uint32_t H, float rH,
-                                       float H3) {
+// The step length at parameter t (raymarching.cu:389): the marcher only ever moves by this amount, occupied or not.
+__device__ __forceinline__ float march_dt(float t, float dt_gamma, float dt_min, float dt_max) {
+    return clampf(t * dt_gamma, dt_min, dt_max);
+}
+
+// What the marcher sees at parameter t (raymarching.cu:379-430): the clamped position, its cell's occupancy bit and — for
+// an empty cell — tt, the parameter at which the ray leaves that cell.
+__device__ __forceinline__ Probe probe_cell(const MarchRay &r, float t, const uint8_t *__restrict__ grid, float bound,
+                                            float dt_gamma, float dt_min, float dt_max, uint32_t C, uint32_t H, float rH,
+                                            float H3) {
     Probe p;
     p.x = clampf(fmaf(t, r.dx, r.ox), -bound, bound);
     p.y = clampf(fmaf(t, r.dy, r.oy), -bound, bound);
     p.z = clampf(fmaf(t, r.dz, r.oz), -bound, bound);
-    p.dt = clampf(t * dt_gamma, dt_min, dt_max);
+    p.dt = march_dt(t, dt_gamma, dt_min, dt_max);
     const int level = max(mip_from_pos(p.x, p.y, p.z, (float)C), mip_from_dt(p.dt, (float)H, (float)C));
     const float mip_bound = fminf(scalbnf(1.0f, level), bound);
     const float mip_rbound = 1 / mip_bound;
@@ -77,15 +83,25 @@ __device__ __forceinline__ Probe probe(const MarchRay &r, float t, const uint8_t
               nz = cell_coord(p.z, mip_rbound, H);
     p.index = (uint32_t)((float)level * H3 + (float)morton_encode((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
     p.occ = (grid[p.index >> 3] & (1u << (p.index & 7u))) != 0;
-    p.t_next = t;
+    p.t_next = p.tt = t;
     if (!p.occ) {
         const float tx = (((nx + 0.5f + 0.5f * signf(r.dx)) * rH * 2 - 1) * mip_bound - p.x) * r.rdx;
         const float ty = (((ny + 0.5f + 0.5f * signf(r.dy)) * rH * 2 - 1) * mip_bound - p.y) * r.rdy;
         const float tz = (((nz + 0.5f + 0.5f * signf(r.dz)) * rH * 2 - 1) * mip_bound - p.z) * r.rdz;
-        const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+        p.tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+    }
+    return p;
+}
+
+// One decision of the serial marcher at parameter t (raymarching.cu:379-439): probe_cell + the walk out of an empty cell.
+__device__ __forceinline__ Probe probe(const MarchRay &r, float t, const uint8_t *__restrict__ grid, float bound,
+                                       float dt_gamma, float dt_min, float dt_max, uint32_t C, uint32_t H, float rH,
+                                       float H3) {
+    Probe p = probe_cell(r, t, grid, bound, dt_gamma, dt_min, dt_max, C, H, rH, H3);
+    if (!p.occ) {
         do {
-            t += clampf(t * dt_gamma, dt_min, dt_max);
-        } while (t < tt);
+            t += march_dt(t, dt_gamma, dt_min, dt_max);
+        } while (t < p.tt);
         p.t_next = t;
     }
     return p;
@@ -187,67 +203,161 @@ k_occupancy_lookup(const float *__restrict__ xyz, const float *__restrict__ dt, 
     occ[n] = (grid[index >> 3] & (1u << (index & 7u))) != 0;
 }
 
-// raymarching.cu:331-534.  One lane per ray (the march is a data-dependent serial walk); 64-thread workgroups so a
-// 4096-ray batch still spreads over 64 CUs.  Both passes recompute the walk; only pass 2 writes.
-__global__ void __launch_bounds__(64)
+// raymarching.cu:331-534, ONE WAVE PER RAY.
+// The reference walks a ray serially: at t it looks up the cell; occupied -> emit a sample, t += dt(t); empty -> t += dt(t)
+// until t passes the cell's exit tt.  Either way t only ever moves by dt(t) = clamp(t * dt_gamma, dt_min, dt_max), so the
+// parameters the walk can visit are the LATTICE t_0, t_1 = t_0 + dt(t_0), ... — the same floating-point recurrence whatever
+// the grid holds.  The wave takes 64 lattice points at a time: every lane runs the recurrence up to its own point (64
+// masked adds: the one serial part, a few hundred cycles), probes its cell in parallel, and lane-uniform bit arithmetic on
+// the ballots replays the walk — runs of occupied lanes are emitted whole, an empty lane jumps to the first lane whose
+// t >= its tt.  Same lattice, same probes, same comparisons as the serial walk: the (id, offset, count) table, the
+// positions and the deltas are bit-identical to it (tests/test_raymarch_gpu.py against the C oracle).
+// (Round 4: the lane-per-ray form ran 4096 rays as 64 one-wave workgroups, ~120 dependent iterations each, twice:
+// 106 us per step of the NeRF-MVL-shaped bench.)
+struct WalkState {
+    float t_base;                  // lattice point of lane 0 of the next chunk
+    float pending_tt;              // an empty cell's exit the walk has not reached yet (valid when pending)
+    bool pending, done;
+    uint32_t emitted;              // samples so far
+    float last_t;                  // t after the last emitted sample (deltas[:, 1] = t_after - last_t)
+};
+
+constexpr uint32_t kMarchRaysPerGroup = 16;
+__global__ void __launch_bounds__(64 * kMarchRaysPerGroup)
 k_march_rays_train(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                    const uint8_t *__restrict__ grid, float bound, float dt_gamma, uint32_t max_steps, uint32_t N,
                    uint32_t C, uint32_t H, uint32_t M, const float *__restrict__ nears,
                    const float *__restrict__ fars, float *__restrict__ xyzs, float *__restrict__ dirs,
                    float *__restrict__ deltas, int32_t *__restrict__ rays, int32_t *__restrict__ counter,
                    const float *__restrict__ noises) {
-    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t n = blockIdx.x * kMarchRaysPerGroup + wv;
+    const bool active = n < N;  // (wave-uniform; an idle wave of the last workgroup still meets the barriers)
+    const uint32_t nc = active ? n : 0;
+    __shared__ uint32_t s_count[kMarchRaysPerGroup], s_offset[kMarchRaysPerGroup], s_ray0;
     MarchRay r;
-    r.ox = rays_o[n * 3]; r.oy = rays_o[n * 3 + 1]; r.oz = rays_o[n * 3 + 2];
-    r.dx = rays_d[n * 3]; r.dy = rays_d[n * 3 + 1]; r.dz = rays_d[n * 3 + 2];
+    r.ox = rays_o[nc * 3]; r.oy = rays_o[nc * 3 + 1]; r.oz = rays_o[nc * 3 + 2];
+    r.dx = rays_d[nc * 3]; r.dy = rays_d[nc * 3 + 1]; r.dz = rays_d[nc * 3 + 2];
     r.rdx = 1 / r.dx; r.rdy = 1 / r.dy; r.rdz = 1 / r.dz;
     const float rH = 1 / (float)H, H3 = (float)(H * H * H);
-    const float far = fars[n];
+    const float far = fars[nc];
     const float SQRT3 = 1.7320508075688772f;
     const float dt_min = 2 * SQRT3 / max_steps;
     const float dt_max = 2 * SQRT3 * (float)(1 << (C - 1)) / H;
-    float t0 = nears[n];
-    t0 += clampf(t0 * dt_gamma, dt_min, dt_max) * noises[n];
+    float t0 = nears[nc];
+    t0 += march_dt(t0, dt_gamma, dt_min, dt_max) * noises[nc];
+    const unsigned long long below = (1ull << lane) - 1;
 
-    float t = t0;
-    uint32_t num_steps = 0;
-    while (t < far && num_steps < max_steps) {
-        const Probe p = probe(r, t, grid, bound, dt_gamma, dt_min, dt_max, C, H, rH, H3);
-        if (p.occ) {
-            num_steps++;
-            t += p.dt;
-        } else {
-            t = p.t_next;
+    // One chunk of the walk.  Returns the mask of the lanes whose lattice point becomes a sample; p_out = their probes.
+    auto chunk = [&](WalkState &w, Probe &p_out, float &t_lane) -> unsigned long long {
+        float t = w.t_base;
+#pragma unroll 8
+        for (uint32_t i = 0; i < 63; i++)
+            if (i < lane) t += march_dt(t, dt_gamma, dt_min, dt_max);
+        t_lane = t;
+        const float t_last = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 63));
+        w.t_base = t_last + march_dt(t_last, dt_gamma, dt_min, dt_max);
+        const bool valid_l = t < far;
+        const unsigned long long valid = __ballot(valid_l);
+        Probe p;
+        p.occ = false;
+        p.tt = t;
+        if (valid_l) p = probe_cell(r, t, grid, bound, dt_gamma, dt_min, dt_max, C, H, rH, H3);
+        p_out = p;
+        const unsigned long long occm = __ballot(valid_l && p.occ);
+        unsigned long long emit = 0;
+        uint32_t pos = 0;
+        if (w.pending) {  // still inside the empty cell an earlier chunk met
+            const unsigned long long ge = __ballot(t >= w.pending_tt);
+            if (!ge) {  // (t grows along the lanes: nobody here has left it; past `far` the walk is over all the same)
+                if (valid != ~0ull) w.done = true;
+                return 0;
+            }
+            pos = (uint32_t)__builtin_ctzll(ge);
+            w.pending = false;
         }
+        while (pos < 64) {
+            if (!((valid >> pos) & 1)) { w.done = true; break; }                 // t >= far: the walk ends
+            if (w.emitted + (uint32_t)__builtin_popcountll(emit) >= max_steps) { w.done = true; break; }
+            if ((occm >> pos) & 1) {                                             // a run of occupied lattice points
+                const unsigned long long rest = ~occm >> pos;
+                const uint32_t run = rest ? (uint32_t)__builtin_ctzll(rest) : 64 - pos;
+                emit |= (run >= 64 ? ~0ull : ((1ull << run) - 1)) << pos;
+                pos += run;
+            } else {                                                             // empty: on to the first t >= tt
+                const float tt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p.tt), (int)pos));
+                const unsigned long long ge = __ballot(t >= tt) & ~((2ull << pos) - 1);
+                if (!ge) { w.pending = true; w.pending_tt = tt; break; }
+                pos = (uint32_t)__builtin_ctzll(ge);
+            }
+        }
+        // at most max_steps samples per ray: drop what a run emitted beyond
+        while (w.emitted + (uint32_t)__builtin_popcountll(emit) > max_steps) {
+            emit &= ~(1ull << (63 - __builtin_clzll(emit)));
+            w.done = true;
+        }
+        if (valid != ~0ull) w.done = true;  // t >= far inside this chunk (also when an empty cell's exit lies beyond it)
+        return emit;
+    };
+
+    // pass 1: count
+    WalkState w{t0, 0.0f, false, !active, 0u, t0};
+    while (!w.done) {
+        Probe p;
+        float t;
+        const unsigned long long emit = chunk(w, p, t);
+        w.emitted += (uint32_t)__builtin_popcountll(emit);
     }
-    const uint32_t point_index = (uint32_t)atomicAdd(counter, (int32_t)num_steps);
-    const uint32_t ray_index = (uint32_t)atomicAdd(counter + 1, 1);
-    rays[ray_index * 3] = (int32_t)n;
-    rays[ray_index * 3 + 1] = (int32_t)point_index;
-    rays[ray_index * 3 + 2] = (int32_t)num_steps;
+    const uint32_t num_steps = w.emitted;
+    // sample offsets and ray-table slots: ONE pair of atomics per workgroup for its 16 rays (the reference takes a pair per
+    // ray, raymarching.cu:441-447; 4096 same-address returning atomics cost ~100 us by themselves — any disjoint
+    // allocation is a valid arrival order)
+    if (lane == 0) s_count[wv] = num_steps;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t here = min(kMarchRaysPerGroup, N - blockIdx.x * kMarchRaysPerGroup);
+        uint32_t total = 0;
+        for (uint32_t i = 0; i < here; i++) {
+            s_offset[i] = total;
+            total += s_count[i];
+        }
+        const uint32_t base = (uint32_t)atomicAdd(counter, (int32_t)total);
+        s_ray0 = (uint32_t)atomicAdd(counter + 1, (int32_t)here);
+        for (uint32_t i = 0; i < here; i++) s_offset[i] += base;
+    }
+    __syncthreads();
+    if (!active) return;
+    const uint32_t point_index = s_offset[wv], ray_index = s_ray0 + wv;
+    if (lane == 0) {
+        rays[ray_index * 3] = (int32_t)n;
+        rays[ray_index * 3 + 1] = (int32_t)point_index;
+        rays[ray_index * 3 + 2] = (int32_t)num_steps;
+    }
     if (num_steps == 0) return;
     if (point_index + num_steps > M) return;
 
-    float *px = xyzs + (size_t)point_index * 3, *pd = dirs + (size_t)point_index * 3,
-          *pl = deltas + (size_t)point_index * 2;
-    t = t0;
-    uint32_t step = 0;
-    float last_t = t;
-    while (t < far && step < num_steps) {
-        const Probe p = probe(r, t, grid, bound, dt_gamma, dt_min, dt_max, C, H, rH, H3);
-        if (p.occ) {
-            px[0] = p.x; px[1] = p.y; px[2] = p.z;
-            pd[0] = r.dx; pd[1] = r.dy; pd[2] = r.dz;
-            t += p.dt;
-            pl[0] = p.dt;
-            pl[1] = t - last_t;
-            last_t = t;
-            px += 3; pd += 3; pl += 2;
-            step++;
-        } else {
-            t = p.t_next;
+    // pass 2: the same walk, writing
+    w = WalkState{t0, 0.0f, false, false, 0u, t0};
+    while (!w.done) {
+        Probe p;
+        float t;
+        const unsigned long long emit = chunk(w, p, t);
+        if (!emit) continue;
+        const float t_after = t + p.dt;  // (= the next lattice point: the serial walk's `t += dt`)
+        const unsigned long long before = emit & below;
+        // t after the previous sample: the emitted lane below this one, or the carry from the chunks before
+        const int prev = before ? 63 - (int)__builtin_clzll(before) : 0;
+        const float prev_after = __shfl(t_after, prev, 64);
+        if ((emit >> lane) & 1) {
+            const size_t row = (size_t)point_index + w.emitted + (uint32_t)__builtin_popcountll(before);
+            xyzs[row * 3] = p.x; xyzs[row * 3 + 1] = p.y; xyzs[row * 3 + 2] = p.z;
+            dirs[row * 3] = r.dx; dirs[row * 3 + 1] = r.dy; dirs[row * 3 + 2] = r.dz;
+            deltas[row * 2] = p.dt;
+            deltas[row * 2 + 1] = t_after - (before ? prev_after : w.last_t);
         }
+        const int top = 63 - (int)__builtin_clzll(emit);
+        w.last_t = __shfl(t_after, top, 64);
+        w.emitted += (uint32_t)__builtin_popcountll(emit);
     }
 }
 
@@ -322,44 +432,81 @@ k_composite_train_bwd(const float *__restrict__ grad_ws, const float *__restrict
 //   z_i = (xyz_i - o) . d  (distance of the sample along its unit ray),  alpha_i = 1 - exp(-sigma_i dt_i),
 //   w_i = alpha_i T_i,  T_{i+1} = T_i (1 - alpha_i),  stop after the sample that takes T below T_thresh.
 // Backward, for any composited quantity O = sum w_i c_i:  dO/dsigma_i = dt_i (T_{i+1} c_i - (O - O_{<=i})).
+// One WAVE per ray, one lane per sample (chunks of 64 along the ray): T_i comes out of a multiplicative scan of (1 - alpha),
+// the running sums the backward needs out of additive scans, the early stop out of a ballot.  (Round 4: the thread-per-ray
+// form of these two kernels — the reference's shape, raymarching.cu:577-772 — ran 4096 rays as 64 single-wave workgroups
+// with ~77 dependent iterations each: 41 + 33 us per step of the NeRF-MVL-shaped bench, latency from end to end.)
+__device__ __forceinline__ float wave_scan_mul(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float u = __shfl_up(v, o, 64);
+        if (lane >= o) v *= u;
+    }
+    return v;
+}
+
 template <int K>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 k_lidar_composite_ragged_fwd(const float *__restrict__ sigmas, const float *__restrict__ feats,
                              const float *__restrict__ deltas, const float *__restrict__ xyzs,
                              const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                              const int32_t *__restrict__ rays, uint32_t M, uint32_t N, float T_thresh,
                              float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image) {
-    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;  // (wave-uniform)
     const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1],
                    num_steps = (uint32_t)rays[n * 3 + 2];
-    float acc[K], ws = 0, d = 0, T = 1.0f;
+    float acc[K], ws = 0, d = 0;
 #pragma unroll
     for (int k = 0; k < K; k++) acc[k] = 0;
     if (num_steps != 0 && offset + num_steps <= M) {
         const float ox = rays_o[index * 3], oy = rays_o[index * 3 + 1], oz = rays_o[index * 3 + 2];
         const float dx = rays_d[index * 3], dy = rays_d[index * 3 + 1], dz = rays_d[index * 3 + 2];
-        for (uint32_t step = 0; step < num_steps; step++) {
-            const size_t i = (size_t)offset + step;
-            const float alpha = 1.0f - expf(-sigmas[i] * deltas[i * 2]);
-            const float w = alpha * T;
-            const float z = (xyzs[i * 3] - ox) * dx + (xyzs[i * 3 + 1] - oy) * dy + (xyzs[i * 3 + 2] - oz) * dz;
+        float Tc = 1.0f;  // transmittance in front of this chunk
+        for (uint32_t base = 0; base < num_steps; base += 64) {
+            const uint32_t step = base + lane;
+            const bool in = step < num_steps;
+            const size_t i = (size_t)offset + (in ? step : 0);
+            float alpha = 0.0f, z = 0.0f, f[K];
 #pragma unroll
-            for (int k = 0; k < K; k++) acc[k] += w * feats[i * K + k];
-            d += w * z;
+            for (int k = 0; k < K; k++) f[k] = 0.0f;
+            if (in) {
+                alpha = 1.0f - expf(-sigmas[i] * deltas[i * 2]);
+                z = (xyzs[i * 3] - ox) * dx + (xyzs[i * 3 + 1] - oy) * dy + (xyzs[i * 3 + 2] - oz) * dz;
+#pragma unroll
+                for (int k = 0; k < K; k++) f[k] = feats[i * K + k];
+            }
+            const float incl = wave_scan_mul(1.0f - alpha, lane);
+            float excl = __shfl_up(incl, 1, 64);
+            if (lane == 0) excl = 1.0f;
+            const float T = Tc * excl, Tn = Tc * incl;  // T_i, T_{i+1}
+            // stop after the first sample that takes T below the threshold
+            const unsigned long long stop = __ballot(in && Tn < T_thresh);
+            const int last = stop ? __ffsll(stop) - 1 : 63;
+            const float w = (in && lane <= last) ? alpha * T : 0.0f;
             ws += w;
-            T *= 1.0f - alpha;
-            if (T < T_thresh) break;
-        }
-    }
-    weights_sum[index] = ws;
-    depth[index] = d;
+            d += w * z;
 #pragma unroll
-    for (int k = 0; k < K; k++) image[index * K + k] = acc[k];
+            for (int k = 0; k < K; k++) acc[k] += w * f[k];
+            if (stop) break;
+            Tc = __shfl(Tn, 63, 64);
+        }
+        ws = wave_sum(ws);
+        d = wave_sum(d);
+#pragma unroll
+        for (int k = 0; k < K; k++) acc[k] = wave_sum(acc[k]);
+    }
+    if (lane == 0) {
+        weights_sum[index] = ws;
+        depth[index] = d;
+#pragma unroll
+        for (int k = 0; k < K; k++) image[index * K + k] = acc[k];
+    }
 }
 
 template <int K>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 k_lidar_composite_ragged_bwd(const float *__restrict__ grad_ws, const float *__restrict__ grad_depth,
                              const float *__restrict__ grad_image, const float *__restrict__ sigmas,
                              const float *__restrict__ feats, const float *__restrict__ deltas,
@@ -368,7 +515,8 @@ k_lidar_composite_ragged_bwd(const float *__restrict__ grad_ws, const float *__r
                              const float *__restrict__ weights_sum, const float *__restrict__ depth,
                              const float *__restrict__ image, uint32_t M, uint32_t N, float T_thresh,
                              float *__restrict__ grad_sigmas, float *__restrict__ grad_feats) {
-    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
     const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1],
                    num_steps = (uint32_t)rays[n * 3 + 2];
@@ -376,32 +524,49 @@ k_lidar_composite_ragged_bwd(const float *__restrict__ grad_ws, const float *__r
     const float ox = rays_o[index * 3], oy = rays_o[index * 3 + 1], oz = rays_o[index * 3 + 2];
     const float dx = rays_d[index * 3], dy = rays_d[index * 3 + 1], dz = rays_d[index * 3 + 2];
     const float gws = grad_ws[index], gd = grad_depth[index], ws_final = weights_sum[index], d_final = depth[index];
-    float gi[K], fin[K], acc[K];
+    float gi[K], fin[K], accc[K];  // accc / dc: the sums over the chunks in front of this one
 #pragma unroll
     for (int k = 0; k < K; k++) {
         gi[k] = grad_image[index * K + k];
         fin[k] = image[index * K + k];
-        acc[k] = 0;
+        accc[k] = 0;
     }
-    float T = 1.0f, d = 0;
-    for (uint32_t step = 0; step < num_steps; step++) {
-        const size_t i = (size_t)offset + step;
-        const float dt = deltas[i * 2];
-        const float alpha = 1.0f - expf(-sigmas[i] * dt);
-        const float w = alpha * T;
-        const float z = (xyzs[i * 3] - ox) * dx + (xyzs[i * 3 + 1] - oy) * dy + (xyzs[i * 3 + 2] - oz) * dz;
-        d += w * z;
-        T *= 1.0f - alpha;  // T_{i+1}
-        float g = gws * (1.0f - ws_final) + gd * (T * z - (d_final - d));
+    float Tc = 1.0f, dc = 0.0f;
+    for (uint32_t base = 0; base < num_steps; base += 64) {
+        const uint32_t step = base + lane;
+        const bool in = step < num_steps;
+        const size_t i = (size_t)offset + (in ? step : 0);
+        float alpha = 0.0f, z = 0.0f, dt = 0.0f, f[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) f[k] = 0.0f;
+        if (in) {
+            dt = deltas[i * 2];
+            alpha = 1.0f - expf(-sigmas[i] * dt);
+            z = (xyzs[i * 3] - ox) * dx + (xyzs[i * 3 + 1] - oy) * dy + (xyzs[i * 3 + 2] - oz) * dz;
+#pragma unroll
+            for (int k = 0; k < K; k++) f[k] = feats[i * K + k];
+        }
+        const float incl = wave_scan_mul(1.0f - alpha, lane);
+        float excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.0f;
+        const float T = Tc * excl, Tn = Tc * incl;
+        const unsigned long long stop = __ballot(in && Tn < T_thresh);
+        const int last = stop ? __ffsll(stop) - 1 : 63;
+        const bool use = in && lane <= last;
+        const float w = use ? alpha * T : 0.0f;
+        const float d = dc + wave_scan_add(w * z, lane);  // sum_{j <= i} w_j z_j
+        float g = gws * (1.0f - ws_final) + gd * (Tn * z - (d_final - d));
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            const float c = feats[i * K + k];
-            acc[k] += w * c;
-            g += gi[k] * (T * c - (fin[k] - acc[k]));
-            grad_feats[i * K + k] = gi[k] * w;
+            const float a = accc[k] + wave_scan_add(w * f[k], lane);
+            g += gi[k] * (Tn * f[k] - (fin[k] - a));
+            if (use) grad_feats[i * K + k] = gi[k] * w;
+            accc[k] = __shfl(a, 63, 64);
         }
-        grad_sigmas[i] = dt * g;
-        if (T < T_thresh) break;
+        if (use) grad_sigmas[i] = dt * g;
+        if (stop) break;
+        dc = __shfl(d, 63, 64);
+        Tc = __shfl(Tn, 63, 64);
     }
 }
 
@@ -547,7 +712,8 @@ int lnh_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t
     LNH_REQUIRE(C >= 1 && C <= 8 && H >= 1 && H <= 1024 && max_steps >= 1, LNH_ERR_INVALID_ARG,
                 "march_rays_train: bad cascade / grid size / max_steps");
     if (N == 0) return LNH_OK;
-    LNH_LAUNCH(k_march_rays_train, dim3(div_up(N, 64)), dim3(64), 0, (hipStream_t)stream, rays_o, rays_d, grid,
+    LNH_LAUNCH(k_march_rays_train, dim3(div_up(N, kMarchRaysPerGroup)), dim3(64 * kMarchRaysPerGroup), 0,
+               (hipStream_t)stream, rays_o, rays_d, grid,
                        bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays, counter, noises);
     return lnh_check_launch("lnh_march_rays_train");
 }
@@ -587,7 +753,7 @@ int lnh_lidar_composite_rays_train_forward(const float *sigmas, const float *fea
     if (N == 0) return LNH_OK;
     hipStream_t s = (hipStream_t)stream;
 #define LNH_RAGGED_FWD(KK)                                                                                          \
-    LNH_LAUNCH(k_lidar_composite_ragged_fwd<KK>, dim3(div_up(N, 64)), dim3(64), 0, s, sigmas, feats, deltas, xyzs, \
+    LNH_LAUNCH(k_lidar_composite_ragged_fwd<KK>, dim3(div_up(N, 4)), dim3(256), 0, s, sigmas, feats, deltas, xyzs, \
                rays_o, rays_d, rays, M, N, T_thresh, weights_sum, depth, image)
     if (K == 1) LNH_RAGGED_FWD(1); else if (K == 2) LNH_RAGGED_FWD(2); else LNH_RAGGED_FWD(3);
 #undef LNH_RAGGED_FWD
@@ -607,7 +773,7 @@ int lnh_lidar_composite_rays_train_backward(const float *grad_weights_sum, const
     if (N == 0) return LNH_OK;
     hipStream_t s = (hipStream_t)stream;
 #define LNH_RAGGED_BWD(KK)                                                                                          \
-    LNH_LAUNCH(k_lidar_composite_ragged_bwd<KK>, dim3(div_up(N, 64)), dim3(64), 0, s, grad_weights_sum, grad_depth, \
+    LNH_LAUNCH(k_lidar_composite_ragged_bwd<KK>, dim3(div_up(N, 4)), dim3(256), 0, s, grad_weights_sum, grad_depth, \
                grad_image, sigmas, feats, deltas, xyzs, rays_o, rays_d, rays, weights_sum, depth, image, M, N,     \
                T_thresh, grad_sigmas, grad_feats)
     if (K == 1) LNH_RAGGED_BWD(1); else if (K == 2) LNH_RAGGED_BWD(2); else LNH_RAGGED_BWD(3);

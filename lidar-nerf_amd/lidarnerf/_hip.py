@@ -77,6 +77,7 @@ _SIGS = {
     "lnh_ragged_points": [P, F32, U32, P],
     "lnh_ragged_pack_weights": [P, U32, P, U32, P, U32, U32, P, U32, P, U32, P, P],
     "lnh_ragged_color_input": [P, P, U32, U32, P],
+    "lnh_ragged_color_input_rays": [P, P, P, P, U32, U32, U32, P],
     "lnh_ragged_color_output": [P, U32, P],
     "lnh_ragged_color_output_backward": [P, P, U32, P],
     "lnh_ragged_grad_rows": [P, F32, P, P, U32, U32, P],
@@ -84,7 +85,7 @@ _SIGS = {
 for _n in ("lnh_mlp_forward", "lnh_mlp_backward", "lnh_density_mlp_forward", "lnh_density_mlp_backward",
            "lnh_lidar_dir_term", "lnh_lidar_pack_weights", "lnh_lidar_color_forward", "lnh_lidar_color_backward",
            "lnh_lidar_color_composite_forward", "lnh_lidar_color_backward_image", "lnh_lidar_dir_term_freq",
-           "lnh_ragged_pack_weights", "lnh_ragged_color_input", "lnh_ragged_color_output",
+           "lnh_ragged_pack_weights", "lnh_ragged_color_input", "lnh_ragged_color_input_rays", "lnh_ragged_color_output",
            "lnh_ragged_color_output_backward", "lnh_ragged_grad_rows"):
     _SIGS[_n + "_bf16"] = _SIGS[_n]  # bf16-operand build of the MLP kernels (include/lidarnerf_hip.h, last section)
 EXPORTS = sorted(list(_SIGS) + ["lnh_version", "lnh_last_error", "lnh_arch", "lnh_build_variant",

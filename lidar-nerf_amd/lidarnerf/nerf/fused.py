@@ -519,7 +519,9 @@ class FusedLidarRagged(Function):
                   sigma.data_ptr())
         # colour head: [freq(d) | geo_feat | 0] -> MFMA MLP 96 -> 64 -> 64 -> 16 -> sigmoid of the first two outputs
         cin = torch.empty((M, 96), dtype=mdt, device=dev)
-        _hip.call("lnh_ragged_color_input" + sfx, dirs.data_ptr(), h16.data_ptr(), M, deg, cin.data_ptr())
+        # (ray by ray: the direction terms once per ray; rows no ray owns are zeroed — they enter the weight-gradient GEMM)
+        _hip.call("lnh_ragged_color_input_rays" + sfx, dirs.data_ptr(), h16.data_ptr(), rays.data_ptr(), deltas.data_ptr(),
+                  N, M, deg, cin.data_ptr())
         y = torch.empty((M, 16), dtype=mdt, device=dev)
         _hip.call("lnh_mlp_forward" + sfx, cin.data_ptr(), wcol16.data_ptr(), M, 96, 16, 64, 1, 0, 6, None, y.data_ptr())
         rgb = torch.empty((M, 2), dtype=torch.float32, device=dev)
@@ -569,8 +571,8 @@ class FusedLidarRagged(Function):
         M, N, L = x01.shape[0], rays.shape[0], enc.num_levels
         zN = lambda g, shape: torch.zeros(shape, dtype=torch.float32, device=dev) if g is None else g.contiguous().float()
         g_ws, g_depth, g_image = zN(g_ws, (N,)), zN(g_depth, (N,)), zN(g_image, (N, 2))
-        gs = torch.zeros(M, dtype=torch.float32, device=dev)
-        gf = torch.zeros((M, 2), dtype=torch.float32, device=dev)
+        gsf = torch.zeros(M * 3, dtype=torch.float32, device=dev)  # (one fill for both)
+        gs, gf = gsf[:M], gsf[M:].view(M, 2)
         _hip.call("lnh_lidar_composite_rays_train_backward", g_ws.data_ptr(), g_depth.data_ptr(), g_image.data_ptr(),
                   sig_s.data_ptr(), rgb.data_ptr(), deltas.data_ptr(), xyzs.data_ptr(), rays_o.data_ptr(),
                   rays_d.data_ptr(), rays.data_ptr(), ws.data_ptr(), depth.data_ptr(), image.data_ptr(), M, N, 2,

@@ -151,7 +151,10 @@ class LidarTrainer:
         self._graphs, self._graph_warm, self._graph_pool = {}, set(), None
         if self.graph:
             dev0 = self.table.device
-            params = [dict(g, lr=torch.tensor(float(g["lr"]), dtype=torch.float32, device=dev0)) for g in params]
+            # (initial_lr as a number: LambdaLR then computes the schedule on the host and fills the device scalar — with a
+            #  tensor it would run the schedule as GPU arithmetic, three more tiny kernels per step)
+            params = [dict(g, lr=torch.tensor(float(g["lr"]), dtype=torch.float32, device=dev0), initial_lr=float(g["lr"]))
+                      for g in params]
             self.optimizer = torch.optim.Adam(params, betas=(0.9, 0.99), eps=1e-15, fused=True, capturable=True)
         else:
             self.optimizer = torch.optim.Adam(params, betas=(0.9, 0.99), eps=1e-15, fused=on_gpu)
@@ -301,9 +304,7 @@ class LidarTrainer:
                 model._static_march = None
             self._graphs[key] = ent
         else:
-            ent["rays_o"].copy_(rays_o)
-            ent["rays_d"].copy_(rays_d)
-            ent["gt"].copy_(images_lidar)
+            torch._foreach_copy_([ent["rays_o"], ent["rays_d"], ent["gt"]], [rays_o, rays_d, images_lidar])  # one launch
         ent["graph"].replay()
         model.step_counter[model.local_step % 16].copy_(ent["counter"])
         model.local_step += 1

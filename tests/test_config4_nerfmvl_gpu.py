@@ -131,7 +131,7 @@ def test_config4_nerfmvl_shape_occupancy_path():
     for k in out:
         torch.testing.assert_close(out[k], out2[k], rtol=1e-6, atol=1e-7)
     dg = (grads[0].double() - grads2[0].double())
-    assert (dg.norm() / grads[0].double().norm()).item() < 1e-5 and int((dg.abs().sum(1) > 0).sum()) < 1000
+    assert (dg.norm() / grads[0].double().norm()).item() < 5e-5 and int((dg.abs().sum(1) > 0).sum()) < 1000
 
     # ---- 32 rays of the batch against the CPU restatement on the marcher's own samples for those rays
     sel = torch.arange(0, N, N // 32)[:32]

@@ -64,6 +64,44 @@ def test_ragged_color_input(sfx):
 
 
 @pytest.mark.parametrize("sfx", ["", "_bf16"])
+def test_ragged_color_input_ray_by_ray(sfx):
+    """lnh_ragged_color_input_rays on a marcher-shaped layout (rays own disjoint runs of rows in shuffled order, one ray
+    overflows the buffer, one has no sample, the tail is unused): bit-identical to the per-sample kernel on the rows rays
+    own; exact zeros on every other row (whatever the buffer held before)."""
+    from gpu_util import call
+    dt = _dt(sfx)
+    g = torch.Generator().manual_seed(4)
+    N = 37
+    counts = torch.randint(1, 140, (N,), generator=g)
+    counts[5] = 0
+    order = torch.randperm(N, generator=g)                     # the marcher hands out offsets in arrival order
+    offs = torch.zeros(N, dtype=torch.long)
+    acc = 0
+    for n in order.tolist():
+        offs[n] = acc
+        acc += int(counts[n])
+    last = int(order[-1])                                      # the ray that arrived last does not fit
+    Mbuf = acc - int(counts[last]) + int(counts[last]) // 2 + 200 if counts[last] > 1 else acc + 200
+    fits = (offs + counts <= Mbuf) & (counts > 0)
+    rays = torch.stack([torch.arange(N), offs, counts], -1).int()
+    dray = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1)
+    dirs, deltas = torch.zeros(Mbuf, 3), torch.zeros(Mbuf, 2)
+    owned = torch.zeros(Mbuf, dtype=torch.bool)
+    for n in range(N):
+        if fits[n]:
+            a, b = int(offs[n]), int(offs[n] + counts[n])
+            dirs[a:b], deltas[a:b, 0], owned[a:b] = dray[n], 0.003, True
+    assert 0 < int(owned.sum()) < Mbuf and not bool(fits.all())
+    h16 = torch.randn(Mbuf, 16, generator=g).to(dt)
+    want = torch.empty((Mbuf, 96), dtype=dt, device="cuda")
+    call("lnh_ragged_color_input" + sfx, dirs.cuda(), h16.cuda(), Mbuf, 12, want)
+    got = torch.full((Mbuf, 96), float("nan"), dtype=dt, device="cuda")
+    call("lnh_ragged_color_input_rays" + sfx, dirs.cuda(), h16.cuda(), rays.cuda(), deltas.cuda(), N, Mbuf, 12, got)
+    assert torch.equal(got[owned.cuda()], want[owned.cuda()])
+    assert float(got[~owned.cuda()].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("sfx", ["", "_bf16"])
 def test_ragged_color_output_and_backward(sfx):
     from gpu_util import call
     dt = _dt(sfx)

@@ -131,6 +131,65 @@ def test_march_rays_train(cascade, bound, dt_gamma):
     assert P > 0
 
 
+@pytest.mark.parametrize("max_steps,dt_gamma", [(40, 0.0), (96, 1 / 64), (1024, 0.0)])
+def test_march_rays_train_caps(max_steps, dt_gamma):
+    """Coarse and fine lattices (max_steps sets dt_min: 1 .. 5 chunks of 64 lattice points per ray), a sample buffer that
+    holds about half of what the rays ask for (the rays that arrive late keep their table entry and write nothing), rays
+    that miss the box (near = far = FLT_MAX) and rays that start beyond `far` — bit-exact against the C oracle."""
+    from gpu_util import call, dev, host
+    cascade, bound = 1, 1.0
+    bits, Hh = _scene(cascade)
+    r = np.random.default_rng(17)
+    N = 777                                                    # not a multiple of the 4 rays a workgroup takes
+    o = (r.standard_normal((N, 3)) * 0.05 + np.array([-0.8 * bound, 0.1, 0.0])).astype(np.float32)
+    d = r.standard_normal((N, 3)).astype(np.float32)
+    d[:, 0] = np.abs(d[:, 0]) + 0.7
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    o[::13] += np.array([0.0, 5.0, 0.0], np.float32)           # these miss the box
+    aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)
+    wn, wf = c_oracle.near_far_from_aabb(o, d, aabb, 0.05)
+    wf[5::13] = wn[5::13] * 0.5                                # far in front of near: no lattice point is visited
+    noises = r.random(N, dtype=np.float32)
+    big = N * max_steps
+    _, _, _, _, want_all = c_oracle.march_rays_train(o, d, bits, bound, dt_gamma, max_steps, cascade, Hh, big, wn, wf, noises)
+    total = int(want_all[0])
+    assert total > 0
+    # a ray's samples are written iff offset + count <= M, and offsets depend on the arrival order: compare per ray, through
+    # the oracle run with room for everything
+    wx, wd, wdl, wr, wc = c_oracle.march_rays_train(o, d, bits, bound, dt_gamma, max_steps, cascade, Hh, big, wn, wf, noises)
+    assert int(wr[:, 2].max()) <= max_steps   # (dt >= 2 sqrt(3) / max_steps: a ray cannot hold more lattice points)
+    M = max(total // 2, 1)
+    xyzs = torch.zeros((M, 3), device="cuda")
+    dirs = torch.zeros((M, 3), device="cuda")
+    deltas = torch.zeros((M, 2), device="cuda")
+    rays = torch.zeros((N, 3), dtype=torch.int32, device="cuda")
+    counter = torch.zeros(2, dtype=torch.int32, device="cuda")
+    call("lnh_march_rays_train", dev(o), dev(d), dev(bits), bound, dt_gamma, max_steps, N, cascade, Hh, M, dev(wn), dev(wf),
+         xyzs, dirs, deltas, rays, counter, dev(noises))
+    g_rays, g_cnt = host(rays), host(counter)
+    np.testing.assert_array_equal(g_cnt, wc)                   # every ray counted, dropped or not
+    g_sorted = g_rays[np.argsort(g_rays[:, 0])]
+    np.testing.assert_array_equal(g_sorted[:, 0], np.arange(N))
+    np.testing.assert_array_equal(g_sorted[:, 2], wr[:, 2])
+    assert int((g_sorted[::13, 2] != 0).sum()) == 0 and int((g_sorted[5::13, 2] != 0).sum()) == 0
+    gx, gd, gdl = host(xyzs), host(dirs), host(deltas)
+    kept = dropped = 0
+    for n in range(N):
+        a, k = int(g_sorted[n, 1]), int(g_sorted[n, 2])
+        if k == 0:
+            continue
+        if a + k <= M:
+            b = int(wr[n, 1])
+            np.testing.assert_array_equal(gx[a:a + k], wx[b:b + k])
+            np.testing.assert_array_equal(gd[a:a + k], wd[b:b + k])
+            np.testing.assert_array_equal(gdl[a:a + k], wdl[b:b + k])
+            kept += 1
+        else:
+            assert float(np.abs(gdl[a:M]).max(initial=0.0)) == 0.0   # nothing written into a dropped ray's slots
+            dropped += 1
+    assert kept > 0 and dropped > 0
+
+
 @pytest.mark.parametrize("cascade,bound,dt_gamma", [(1, 1.0, 0.0), (2, 2.0, 1 / 128)])
 def test_march_and_composite_rays_inference(cascade, bound, dt_gamma):
     """Inference loop of torch-ngp's run_cuda (raymarching.cu:808-928, 966-1053; raymarching.py:362-512): rounds of
