@@ -73,10 +73,10 @@ k_ragged_color_input(const float *__restrict__ dirs, const E *__restrict__ h16, 
     cin[(size_t)m * 96 + c2 + 1] = out[1];
 }
 
-// The same rows, ONE WAVE PER RAY: every marched sample of a ray carries the ray's direction (raymarching.cu:331-534 writes
+// The same rows, RAY BY RAY (one workgroup each): every marched sample of a ray carries the ray's direction (raymarching.cu:331-534 writes
 // dirs = the ray's d for each of its samples), so the 2 * 6 * degree sines are evaluated once per ray instead of once per
 // sample (the per-sample kernel above spends its 49 us per step of the NeRF-MVL-shaped bench on 312 K x 72 sinf).  48 lanes
-// hold one column pair each; the wave walks the ray's rows writing 192 contiguous bytes per row.  Rows no ray owns — the
+// hold one column pair each; a wave walks every fourth row of the ray writing 192 contiguous bytes per row.  Rows no ray owns — the
 // unused tail of the sample buffer, and the slots of a ray the marcher dropped for lack of room — still enter the weight
 // gradient GEMM (with a zero output gradient), so they must hold finite numbers: the blocks behind the ray blocks find them
 // by their delta == 0 (the marcher never wrote them; a marched sample has dt > 0) and zero them.
@@ -88,8 +88,8 @@ k_ragged_color_input_rays(const float *__restrict__ dirs, const E *__restrict__ 
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     struct alignas(4) Pair { E a, b; };
     if (blockIdx.x < ray_blocks) {
-        const uint32_t n = blockIdx.x * 4 + wv;
-        if (n >= N || lane >= 48) return;
+        const uint32_t n = blockIdx.x;  // one workgroup per ray: its four waves take every fourth row (a lone wave walking
+        if (lane >= 48) return;         // ~80 rows is a chain of ~10 load round trips)
         const uint32_t offset = (uint32_t)rays[n * 3 + 1], count = (uint32_t)rays[n * 3 + 2];
         if (count == 0 || offset + count > M) return;  // (a dropped ray's slots: zeroed by the scanning blocks)
         const uint32_t c2 = lane * 2;
@@ -107,8 +107,8 @@ k_ragged_color_input_rays(const float *__restrict__ dirs, const E *__restrict__ 
         const bool g0 = c2 >= kd && c2 < kd + 15, g1 = c2 + 1 >= kd && c2 + 1 < kd + 15;
         const uint32_t h0 = 1 + (c2 - kd), h1 = 1 + (c2 + 1 - kd);
         Pair fixed{(E)fv[0], (E)fv[1]};
-#pragma unroll 8  // (independent rows: the loads of several in flight)
-        for (uint32_t j = 0; j < count; j++) {
+#pragma unroll 4  // (independent rows: the loads of several in flight)
+        for (uint32_t j = wv; j < count; j += 4) {
             const size_t row = (size_t)offset + j;
             Pair o = fixed;
             if (g0) o.a = h16[row * 16 + h0];
@@ -199,7 +199,7 @@ int color_input_rays(const float *dirs, const void *h16, const int32_t *rays, co
     LNH_REQUIRE(kd + 15 <= 96, LNH_ERR_UNSUPPORTED, "ragged_color_input_rays: 3 + 6 * degree + 15 must fit 96 columns");
     LNH_REQUIRE((uint64_t)M * 96 < (1ull << 40), LNH_ERR_UNSUPPORTED, "ragged_color_input_rays: M too large");
     if (M == 0) return LNH_OK;
-    const uint32_t ray_blocks = div_up(N, 4), scan_blocks = std::min(div_up(M, 256), 512u);
+    const uint32_t ray_blocks = N, scan_blocks = std::min(div_up(M, 256), 512u);
     LNH_LAUNCH(k_ragged_color_input_rays<E>, dim3(ray_blocks + scan_blocks), dim3(256), 0, (hipStream_t)stream, dirs,
                (const E *)h16, rays, deltas, N, M, kd, ray_blocks, (E *)cin);
     return lnh_check_launch("lnh_ragged_color_input_rays");

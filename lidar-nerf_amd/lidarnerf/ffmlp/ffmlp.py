@@ -96,7 +96,7 @@ def kernel_supported(in_dim, hidden, nhm):
 
 
 def gemm_mlp(x, w, in_dim, hidden, nhm, act, out_act):
-    """The reference's remaining hidden widths (16, 128, 256: ffmlp.py:202-209) as a chain of plain library GEMMs
+    """The reference's remaining hidden widths (128, 256: ffmlp.py:202-209) and deeper nets — FFMLP(gemm_chain=True) only — as a chain of plain library GEMMs
     (rocBLAS / hipBLASLt through torch.matmul, fp32 accumulation) with the same storage model as the fused kernels: every
     layer's activations are stored in the 16-bit element type.  At 128 / 256 the layers ARE library-sized GEMMs (weights
     no longer fit a wave's registers, the point of the fused kernel); autograd differentiates the chain."""
@@ -129,7 +129,14 @@ def fused_mlp(x, mats, activation=0, inference=False):
 
 
 class FFMLP(nn.Module):
-    def __init__(self, input_dim, output_dim, hidden_dim, num_layers, activation="relu"):
+    """Shapes with a fused MFMA kernel in this build: hidden 16 (zero-padded onto the hidden-32 kernels) / 32 / 64, at most
+    3 hidden layers (2 hidden->hidden matrices), input <= 128.  The reference's other widths (128, 256; ffmlp.cu:756-800)
+    and deeper nets have NONE: the constructor refuses them exactly as the C ABI does (lnh_mlp_forward ->
+    LNH_ERR_UNSUPPORTED) instead of quietly being a different kind of implementation behind the same class.  A caller who
+    wants them anyway says so — `gemm_chain=True` runs the layers as library GEMMs (rocBLAS / hipBLASLt through
+    torch.matmul, the same 16-bit storage model, autograd for the backward), which at 128 / 256 is what the layers are."""
+
+    def __init__(self, input_dim, output_dim, hidden_dim, num_layers, activation="relu", gemm_chain=False):
         super().__init__()
         self.input_dim, self.output_dim, self.hidden_dim, self.num_layers = input_dim, output_dim, hidden_dim, num_layers
         self.activation = convert_activation(activation)
@@ -140,6 +147,14 @@ class FFMLP(nn.Module):
         assert input_dim > 0 and input_dim % 16 == 0, f"FFMLP input_dim should be 16 * m (m  > 0), but got {input_dim}"
         assert output_dim <= 16, f"FFMLP current only supports output dim <= 16, but got {output_dim}"
         assert num_layers >= 2, f"FFMLP num_layers should be larger than 2 (3 matmuls), but got {num_layers}"
+        self.gemm_chain = bool(gemm_chain)
+        fused = kernel_supported(input_dim, 32 if hidden_dim == 16 else hidden_dim, num_layers - 1)
+        if not fused and not self.gemm_chain:
+            raise RuntimeError(
+                f"FFMLP(input_dim={input_dim}, hidden_dim={hidden_dim}, num_layers={num_layers}): no fused MFMA kernel for "
+                "this shape in this build (kernels: hidden_dim 16 / 32 / 64, num_layers <= 3, input_dim <= 128 — the C ABI "
+                "refuses it the same way: lnh_mlp_forward returns LNH_ERR_UNSUPPORTED).  Pass gemm_chain=True to run it as a "
+                "chain of library GEMMs instead.")
         self.padded_output_dim = int(math.ceil(output_dim / 16)) * 16
         self.num_parameters = hidden_dim * (input_dim + hidden_dim * (num_layers - 1) + self.padded_output_dim)
         self.weights = nn.Parameter(torch.zeros(self.num_parameters))
@@ -178,7 +193,7 @@ class FFMLP(nn.Module):
         elif kernel_supported(self.input_dim, self.hidden_dim, self.num_layers - 1):
             y = _FusedMLP.apply(inputs, self.weights, self.input_dim, self.hidden_dim, self.num_layers - 1,
                                 self.activation, self.output_activation, not self.training)
-        else:  # hidden 128 / 256, deeper or wider-input nets: library GEMM chain, same semantics
+        else:  # hidden 128 / 256, deeper or wider-input nets, asked for with gemm_chain=True: library GEMM chain, same semantics
             if not inputs.is_cuda:
                 raise RuntimeError("lidarnerf_hip: tensor must live on the GPU (no CPU path in this library)")
             y = gemm_mlp(inputs, self.weights, self.input_dim, self.hidden_dim, self.num_layers - 1, self.activation,

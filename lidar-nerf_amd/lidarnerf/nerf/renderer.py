@@ -235,7 +235,9 @@ class NeRFRenderer(nn.Module):
                     indices = torch.cat([indices, occ], 0)
                 splat(cas, coords.contiguous(), indices)
         valid = (self.density_grid >= 0) & (tmp >= 0)
-        self.density_grid[valid] = torch.maximum(self.density_grid[valid] * decay, tmp[valid])
+        # (renderer.py:517-519 writes this as a masked assignment; the same values as one element-wise pass — boolean-mask
+        #  indexing costs two compactions, two gathers and a scatter over the 2 M cells)
+        self.density_grid.copy_(torch.where(valid, torch.maximum(self.density_grid * decay, tmp), self.density_grid))
         self.mean_density = float(self.density_grid.clamp(min=0).mean())
         self.iter_density += 1
         raymarching.packbits(self.density_grid, min(self.mean_density, self.density_thresh), self.density_bitfield)

@@ -74,6 +74,12 @@ def test_module_api_and_state_dict_layout():
     torch.manual_seed(42)
     w = torch.empty(m.num_parameters).uniform_(-np.sqrt(3 / 64), np.sqrt(3 / 64))
     assert torch.equal(m.weights.data, w)  # seed-42 initialisation of the reference (ffmlp.py:242-245)
+    # widths / depths without a fused kernel are refused like the C ABI refuses them, unless the GEMM chain is asked for
+    for hidden, layers in ((128, 2), (256, 3), (64, 5)):
+        with pytest.raises(RuntimeError, match="no fused MFMA kernel"):
+            FFMLP(32, 3, hidden, layers)
+        assert FFMLP(32, 3, hidden, layers, gemm_chain=True).weights.numel() == hidden * (32 + hidden * (layers - 1) + 16)
+    assert FFMLP(32, 3, 16, 2).hidden_dim == 16               # zero-padded onto the hidden-32 kernels
     net = NeRFNetwork(encoding="hashgrid", desired_resolution=2048, bound=1, min_near_lidar=0.01)
     keys = set(net.state_dict().keys())
     assert {"encoder.embeddings", "encoder.offsets", "sigma_net.0.weight", "sigma_net.1.weight",

@@ -173,10 +173,16 @@ def test_bf16_ffmlp_module_under_bf16_autocast():
 
 @pytest.mark.parametrize("hidden,layers,in_dim", [(16, 2, 32), (128, 3, 48), (256, 2, 64), (64, 5, 32)])
 def test_ffmlp_module_all_reference_widths(hidden, layers, in_dim):
-    """FFMLP accepts every width the reference does (ffmlp.py:202-209: 16 .. 256); the ones outside the fused kernels'
-    register budget run as library GEMMs with the same fp16 storage model — forward and gradients vs the oracle."""
+    """Every width the reference accepts (ffmlp.py:202-209: 16 .. 256).  Hidden 16 runs on the fused kernels; 128 / 256 and
+    deeper nets have no fused kernel: the module refuses them like the C ABI does, and runs them as library GEMMs with the
+    same fp16 storage model only when asked to (gemm_chain=True) — forward and gradients vs the oracle either way."""
     from lidarnerf.ffmlp import FFMLP
-    m = FFMLP(in_dim, 5, hidden, layers).cuda()
+    if hidden == 16:
+        m = FFMLP(in_dim, 5, hidden, layers).cuda()
+    else:
+        with pytest.raises(RuntimeError, match="no fused MFMA kernel.*gemm_chain=True"):
+            FFMLP(in_dim, 5, hidden, layers)
+        m = FFMLP(in_dim, 5, hidden, layers, gemm_chain=True).cuda()
     with torch.no_grad():
         m.weights.copy_(m.weights.half().float())
     r = np.random.default_rng(hidden)
