@@ -236,6 +236,7 @@ class LidarTrainer:
         shadow = table16_of(tp)  # (re-cast first if somebody wrote the parameter since the last step)
         if shards:
             self._step_table_shards(shards, shadow, float(lr), inv_scale_table, found_inf, s_in, s_out)
+            self.t_flip = 1 - self.t_flip
         elif torch.is_tensor(lr):
             # graph mode: lr is a device scalar the scheduler fills; the step counter is copied back instead of flipped
             # (a captured step always reads and writes the same two buffers)
