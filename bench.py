@@ -295,12 +295,16 @@ def run_nerfmvl(args):
     t0 = time.perf_counter()
     counts = []
     covered = 0  # marches the ring reads below cover (the first block may reach a few steps back into the warm-up)
-    for s in range(args.steps):
-        if trainer.global_step % trainer.update_extra_interval == 0 and model.local_step:
+    host_step, host_update = [], []  # host time per step: plain steps / steps that begin with a grid update (which reads the
+    for s in range(args.steps):      # sample counts back, i.e. WAITS for the device to drain its queue)
+        upd = trainer.global_step % trainer.update_extra_interval == 0
+        if upd and model.local_step:
             # the ring of the last 16 marches, before the grid update resets it: ONE tiny kernel per 16 steps
             counts.append(model.step_counter[:model.local_step, 0].sum())
             covered += model.local_step
+        t1 = time.perf_counter()
         loss = trainer.step(*batches[n_pre + args.warmup + s])
+        (host_update if upd else host_step).append((time.perf_counter() - t1) * 1e3)
     counts.append(model.step_counter[:model.local_step, 0].sum())
     covered += model.local_step
     host_ms = (time.perf_counter() - t0) * 1e3 / args.steps
@@ -362,6 +366,13 @@ def run_nerfmvl(args):
                               "one per sample capacity; steps at a new capacity run launch by launch once, then capture)")
                    if use_graph else "launch by launch from Python"},
         "samples_per_s": round(samples_total / elapsed, 1), "host_enqueue_ms_per_step": round(host_ms, 3),
+        "host_ms": {"per_plain_step_median": round(float(np.median(host_step)), 4) if host_step else None,
+                    "per_update_step_mean": round(float(np.mean(host_update)), 3) if host_update else None,
+                    "update_steps": len(host_update),
+                    "note": "host_enqueue_ms_per_step is the wall time of the loop / steps: it CONTAINS the waits of the grid "
+                            "updates (every 16th step reads the marched-sample counts back and so waits for the queued steps to "
+                            "finish) — with a replayed graph the host runs ~15 steps ahead and spends that wait there.  "
+                            "per_plain_step_median is what the host needs to issue one step."},
         "roofline": roof(bwd_name, GRID_BWD_BYTES), "roofline_fwd": roof("lnh_grid_encode_forward", GRID_FWD_BYTES),
         "kernels": kernels, "entry_points_avg_us": per_call}))
 
