@@ -188,6 +188,24 @@ LNH_API int lnh_mlp_backward(const void *grad, const void *inputs, const void *w
                              uint32_t activation, uint32_t output_activation, void *grad_inputs, float *grad_weights,
                              lnh_stream_t stream);
 
+/*
+ * Shapes.  hidden_dim 32 / 64 with n_hidden_mats <= 2: register-resident kernels, and lnh_mlp_backward is ONE kernel.
+ * hidden_dim 128 / 256 (ffmlp.cu:756-800) and n_hidden_mats 3 .. 14 at any of the four widths: lnh_mlp_forward runs
+ * kernels that load a weight fragment where it is used (csrc/mlp_wide.hip); the backward is the reference's own split
+ * (ffmlp.cu:578-733 fused activation gradients + 1107-1263 split-K GEMMs for the weights):
+ *   lnh_mlp_backward_data: from grad [B,output_dim], the forward_buffer lnh_mlp_forward filled, and weights_t — the
+ *     matrices TRANSPOSED, flat [input*hidden (W0^T, rows = inputs) | hidden*hidden*n_hidden_mats (each Wh^T) |
+ *     hidden*output_dim (Wo^T, rows = hidden units)] — writes backward_buffer [n_hidden_mats+1, B, hidden] f16 =
+ *     dL/d(pre-activation) of every hidden layer and grad_inputs (NULL or [B,input_dim]);
+ *   the weight gradients are the GEMMs dW0 = backward_buffer[0]^T inputs, dWh_m = backward_buffer[m+1]^T
+ *     forward_buffer[m], dWo = grad^T forward_buffer[n_hidden_mats]: left to the caller's BLAS (ffmlp/ffmlp.py: torch.mm).
+ *   lnh_mlp_backward returns LNH_ERR_UNSUPPORTED for these shapes and says so.  Works for the narrow shapes too.
+ * hidden_dim 16 has no kernel of its own (the module zero-pads it onto 32); input_dim > 128: LNH_ERR_UNSUPPORTED.
+ */
+LNH_API int lnh_mlp_backward_data(const void *grad, const void *forward_buffer, const void *weights_t, uint32_t B,
+                                  uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t n_hidden_mats,
+                                  uint32_t activation, void *backward_buffer, void *grad_inputs, lnh_stream_t stream);
+
 /* ------------------------------------------------------------------ ray utilities / occupancy grid ----------- */
 /* Replaces near_far_from_aabb    lidarnerf/raymarching/src/raymarching.h:6-12 (raymarching.cu:104-177). */
 LNH_API int lnh_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb, uint32_t N,
@@ -521,6 +539,10 @@ LNH_API int lnh_mlp_backward_bf16(const void *grad, const void *inputs, const vo
                              uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t n_hidden_mats,
                              uint32_t activation, uint32_t output_activation, void *grad_inputs, float *grad_weights,
                              lnh_stream_t stream);
+LNH_API int lnh_mlp_backward_data_bf16(const void *grad, const void *forward_buffer, const void *weights_t, uint32_t B,
+                                       uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim,
+                                       uint32_t n_hidden_mats, uint32_t activation, void *backward_buffer,
+                                       void *grad_inputs, lnh_stream_t stream);
 LNH_API int lnh_density_mlp_forward_bf16(const void *features, const void *weights, uint32_t B, uint32_t T_cur,
                                     uint32_t T_tot, uint32_t slot_off, uint32_t feat_rows, void *h16, float *sigma,
                                     lnh_stream_t stream);

@@ -18,6 +18,10 @@ int lnh_mlp_backward_nhm0(uint32_t in_ks, const MlpBwdArgs &a, hipStream_t s);
 int lnh_mlp_backward_nhm1(uint32_t in_ks, const MlpBwdArgs &a, hipStream_t s);
 int lnh_mlp_backward_nhm2(uint32_t in_ks, const MlpBwdArgs &a, hipStream_t s);
 int lnh_density_mlp_backward_launch(const MlpBwdArgs &a, hipStream_t s);
+// mlp_wide.hip: hidden 128 / 256 and nets with more than two hidden->hidden matrices (weights loaded where they are used)
+int lnh_mlp_forward_wide(const void *inputs, const void *weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
+                         uint32_t hidden_dim, uint32_t n_hidden_mats, uint32_t activation, uint32_t output_activation,
+                         void *forward_buffer, void *outputs, hipStream_t s);
 
 namespace {
 
@@ -191,7 +195,7 @@ int check_shape(uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, ui
     LNH_REQUIRE(output_dim == 16, LNH_ERR_UNSUPPORTED,
                 "FFMLP current only supports (padded) output dim == 16, but got %u", output_dim);
     LNH_REQUIRE(hidden_dim == 64 || hidden_dim == 32, LNH_ERR_UNSUPPORTED,
-                "fused MLP: hidden_dim must be 32 or 64 in this build (reference: 16..256), got %u", hidden_dim);
+                "fused MLP: hidden_dim must be 32, 64, 128 or 256 (16 runs zero-padded on 32), got %u", hidden_dim);
     LNH_REQUIRE(n_hidden_mats <= 2, LNH_ERR_UNSUPPORTED,
                 "fused MLP: at most 2 hidden->hidden matrices in this build (got %u)", n_hidden_mats);
     return LNH_OK;
@@ -233,6 +237,11 @@ int LNH_MLP_FN(lnh_mlp_forward)(const void *inputs, const void *weights, uint32_
     LNH_REQUIRE(inputs && weights && outputs, LNH_ERR_INVALID_ARG, "mlp forward: null pointer");
     LNH_REQUIRE(activation <= LNH_ACT_NONE && output_activation <= LNH_ACT_NONE, LNH_ERR_INVALID_ARG,
                 "mlp forward: unknown activation");
+    if (hidden_dim == 128 || hidden_dim == 256 || (n_hidden_mats > 2 && (hidden_dim == 32 || hidden_dim == 64))) {
+        if (B == 0) return LNH_OK;
+        return lnh_mlp_forward_wide(inputs, weights, B, input_dim, output_dim, hidden_dim, n_hidden_mats, activation,
+                                    output_activation, forward_buffer, outputs, (hipStream_t)stream);
+    }
     int rc = check_shape(input_dim, output_dim, hidden_dim, n_hidden_mats);
     if (rc) return rc;
     if (B == 0) return LNH_OK;
@@ -251,6 +260,12 @@ int LNH_MLP_FN(lnh_mlp_backward)(const void *grad, const void *inputs, const voi
                 "mlp backward: Sine needs stored pre-activations (unsupported by the reference as well, utils.h:626-630)");
     LNH_REQUIRE(output_activation == LNH_ACT_NONE, LNH_ERR_UNSUPPORTED,
                 "mlp backward: output activation is not supported (ffmlp.py:196 'not supported currently')");
+    LNH_REQUIRE(!(hidden_dim == 128 || hidden_dim == 256 || (n_hidden_mats > 2 && (hidden_dim == 32 || hidden_dim == 64))),
+                LNH_ERR_UNSUPPORTED,
+                "mlp backward: hidden_dim %u with %u hidden matrices has no one-kernel backward (its weight-gradient tiles do "
+                "not fit a wave): call lnh_mlp_backward_data for the activation / input gradients and form dW_l = G_l^T "
+                "A_(l-1) from backward_buffer and forward_buffer with a GEMM, as the reference does (ffmlp.cu:1107-1263)",
+                hidden_dim, n_hidden_mats);
     int rc = check_shape(input_dim, output_dim, hidden_dim, n_hidden_mats);
     if (rc) return rc;
     if (B == 0) return LNH_OK;

@@ -47,6 +47,60 @@ def _backward_raw(gy16, x16, w16, in_dim, hidden, nhm, act, need_dx):
     return gx, gw
 
 
+def one_kernel_backward(hidden, nhm):
+    """Shapes whose backward is ONE kernel (weights and all weight-gradient tiles in a wave's registers)."""
+    return hidden in (32, 64) and nhm <= 2
+
+
+def _split(w, in_dim, hidden, nhm):
+    """The matrices of a flat weight vector: W0 [hidden, in], Wh_m [hidden, hidden], Wo [16, hidden]."""
+    o = hidden * in_dim
+    mats = [w[:o].view(hidden, in_dim)]
+    for _ in range(nhm):
+        mats.append(w[o:o + hidden * hidden].view(hidden, hidden))
+        o += hidden * hidden
+    mats.append(w[o:o + 16 * hidden].view(16, hidden))
+    return mats
+
+
+_SPLIT_K_ROWS = 4096
+
+
+def _mm_f32(a, b):
+    """a^T b ([B, M], [B, N] -> [M, N]) in fp32 from 16-bit operands: a library GEMM whose contraction runs over the BATCH
+    — a million rows for a 64 .. 256-wide result.  As one GEMM rocBLAS gives it 1.2 .. 1.9 ms at B = 1 M whatever M and N
+    (no split-K for the shape); as a batched GEMM over 4096-row slices summed afterwards — the reference's split-K
+    (cutlass_matmul.h:481-616), spelled with the library's own batching — 75 .. 240 us (tools/bench_wgrad.py on MI355X:
+    128 x 128: 1699 -> 128 us, 256 x 256: 1866 -> 237 us; same result to 1e-5)."""
+    B = a.shape[0]
+    S = B // _SPLIT_K_ROWS
+    if S < 2:
+        return torch.mm(a.t(), b, out_dtype=torch.float32)
+    main = S * _SPLIT_K_ROWS
+    out = torch.bmm(a[:main].view(S, _SPLIT_K_ROWS, -1).transpose(1, 2), b[:main].view(S, _SPLIT_K_ROWS, -1),
+                    out_dtype=torch.float32).sum(0)
+    if main < B:
+        out += torch.mm(a[main:].t(), b[main:], out_dtype=torch.float32)
+    return out
+
+
+def _backward_wide(gy16, x16, w16, fb, in_dim, hidden, nhm, act, need_dx):
+    """Backward of the shapes without a one-kernel backward (hidden 128 / 256, more than two hidden matrices), structured
+    as the reference's own (ffmlp.cu:578-733 + 1107-1263): lnh_mlp_backward_data — one fused kernel for the activation and
+    input gradients — then the weight gradients dW_l = G_l^T A_(l-1) as library GEMMs over the two buffers."""
+    B = x16.shape[0]
+    wt = torch.cat([m.t().contiguous().reshape(-1) for m in _split(w16, in_dim, hidden, nhm)])
+    gb = torch.empty((nhm + 1, B, hidden), dtype=x16.dtype, device=x16.device)
+    gx = torch.empty((B, in_dim), dtype=x16.dtype, device=x16.device) if need_dx else None
+    _hip.call("lnh_mlp_backward_data" + _hip.mlp_suffix(x16.dtype), gy16.data_ptr(), fb.data_ptr(), wt.data_ptr(), B, in_dim,
+              16, hidden, nhm, act, gb.data_ptr(), _hip.ptr(gx))
+    parts = [_mm_f32(gb[0], x16)]
+    for m in range(nhm):
+        parts.append(_mm_f32(gb[m + 1], fb[m]))
+    parts.append(_mm_f32(gy16, fb[nhm]))
+    return gx, torch.cat([p.reshape(-1) for p in parts])
+
+
 class _FusedMLP(Function):
     """x [B,in_pad] (any float dtype), flat weights (any float dtype) -> y [B,16] fp16 (bf16 under bf16 autocast)."""
 
@@ -56,19 +110,25 @@ class _FusedMLP(Function):
         x16 = x.contiguous().to(dt)
         w16 = w.contiguous().to(dt)
         _hip.require_cuda(x16, w16)
-        y, _ = _forward_raw(x16, w16, in_dim, hidden, nhm, act, out_act)
+        # (the one-kernel backward recomputes the hidden activations; the wide shapes' backward reads them back)
+        keep = not inference and not one_kernel_backward(hidden, nhm)
+        y, fb = _forward_raw(x16, w16, in_dim, hidden, nhm, act, out_act, save_hidden=keep)
         if not inference:
-            ctx.save_for_backward(x16, w16)
+            ctx.save_for_backward(x16, w16, *([fb] if keep else []))
             ctx.meta = (in_dim, hidden, nhm, act, out_act, x.dtype, w.dtype, x.requires_grad)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x16, w16 = ctx.saved_tensors
+        x16, w16 = ctx.saved_tensors[:2]
         in_dim, hidden, nhm, act, out_act, xdt, wdt, need_dx = ctx.meta
         if out_act != 6:
             raise RuntimeError("fused MLP: backward through an output activation is not supported (ffmlp.py:196)")
-        gx, gw = _backward_raw(gy.contiguous().to(x16.dtype), x16, w16, in_dim, hidden, nhm, act, need_dx)
+        gy16 = gy.contiguous().to(x16.dtype)
+        if one_kernel_backward(hidden, nhm):
+            gx, gw = _backward_raw(gy16, x16, w16, in_dim, hidden, nhm, act, need_dx)
+        else:
+            gx, gw = _backward_wide(gy16, x16, w16, ctx.saved_tensors[2], in_dim, hidden, nhm, act, need_dx)
         return (gx.to(xdt) if gx is not None else None), gw.to(wdt), None, None, None, None, None, None
 
 
@@ -91,15 +151,16 @@ def _act_torch(a, x):
 
 
 def kernel_supported(in_dim, hidden, nhm):
-    """Shapes the register-resident MFMA kernels (csrc/mlp.hip) are instantiated for."""
-    return hidden in (32, 64) and nhm <= 2 and in_dim <= 128 and in_dim % 16 == 0
+    """Shapes with fused MFMA kernels: hidden 32 / 64 with <= 2 hidden matrices in the register-resident kernels
+    (csrc/mlp.hip), hidden 128 / 256 and up to 14 hidden matrices at any width in the kernels that load a weight fragment
+    where it is used (csrc/mlp_wide.hip)."""
+    return hidden in (32, 64, 128, 256) and nhm <= 14 and in_dim <= 128 and in_dim % 16 == 0
 
 
 def gemm_mlp(x, w, in_dim, hidden, nhm, act, out_act):
-    """The reference's remaining hidden widths (128, 256: ffmlp.py:202-209) and deeper nets — FFMLP(gemm_chain=True) only — as a chain of plain library GEMMs
+    """Shapes without a fused kernel (input_dim > 128, more than 15 hidden layers) — FFMLP(gemm_chain=True) only — as a chain of plain library GEMMs
     (rocBLAS / hipBLASLt through torch.matmul, fp32 accumulation) with the same storage model as the fused kernels: every
-    layer's activations are stored in the 16-bit element type.  At 128 / 256 the layers ARE library-sized GEMMs (weights
-    no longer fit a wave's registers, the point of the fused kernel); autograd differentiates the chain."""
+    layer's activations are stored in the 16-bit element type; autograd differentiates the chain."""
     dt = mlp_dtype()
     with torch.autocast("cuda", enabled=False):
         h = x.to(dt)
@@ -129,12 +190,13 @@ def fused_mlp(x, mats, activation=0, inference=False):
 
 
 class FFMLP(nn.Module):
-    """Shapes with a fused MFMA kernel in this build: hidden 16 (zero-padded onto the hidden-32 kernels) / 32 / 64, at most
-    3 hidden layers (2 hidden->hidden matrices), input <= 128.  The reference's other widths (128, 256; ffmlp.cu:756-800)
-    and deeper nets have NONE: the constructor refuses them exactly as the C ABI does (lnh_mlp_forward ->
-    LNH_ERR_UNSUPPORTED) instead of quietly being a different kind of implementation behind the same class.  A caller who
-    wants them anyway says so — `gemm_chain=True` runs the layers as library GEMMs (rocBLAS / hipBLASLt through
-    torch.matmul, the same 16-bit storage model, autograd for the backward), which at 128 / 256 is what the layers are."""
+    """Every width of the reference (16 .. 256, ffmlp.py:202-209) runs on fused MFMA kernels: hidden 16 zero-padded onto the
+    hidden-32 kernels, 32 / 64 with at most 3 hidden layers with weights AND weight gradients in registers (forward and
+    backward one kernel each), 128 / 256 and deeper nets with weight fragments loaded where they are used and the backward
+    split as the reference splits its own — a fused kernel for the activation / input gradients, library GEMMs for the
+    weight gradients (ffmlp.cu:578-733, 1107-1263).  What has no kernel — input_dim > 128, more than 15 hidden layers — is
+    refused exactly as the C ABI refuses it (LNH_ERR_UNSUPPORTED) unless the caller asks for the alternative:
+    `gemm_chain=True` runs every layer as a library GEMM (torch.matmul, the same 16-bit storage model, autograd)."""
 
     def __init__(self, input_dim, output_dim, hidden_dim, num_layers, activation="relu", gemm_chain=False):
         super().__init__()
@@ -152,7 +214,7 @@ class FFMLP(nn.Module):
         if not fused and not self.gemm_chain:
             raise RuntimeError(
                 f"FFMLP(input_dim={input_dim}, hidden_dim={hidden_dim}, num_layers={num_layers}): no fused MFMA kernel for "
-                "this shape in this build (kernels: hidden_dim 16 / 32 / 64, num_layers <= 3, input_dim <= 128 — the C ABI "
+                "this shape in this build (kernels: hidden_dim 16 .. 256, num_layers <= 15, input_dim <= 128 — the C ABI "
                 "refuses it the same way: lnh_mlp_forward returns LNH_ERR_UNSUPPORTED).  Pass gemm_chain=True to run it as a "
                 "chain of library GEMMs instead.")
         self.padded_output_dim = int(math.ceil(output_dim / 16)) * 16
@@ -193,7 +255,7 @@ class FFMLP(nn.Module):
         elif kernel_supported(self.input_dim, self.hidden_dim, self.num_layers - 1):
             y = _FusedMLP.apply(inputs, self.weights, self.input_dim, self.hidden_dim, self.num_layers - 1,
                                 self.activation, self.output_activation, not self.training)
-        else:  # hidden 128 / 256, deeper or wider-input nets, asked for with gemm_chain=True: library GEMM chain, same semantics
+        else:  # wider-input or very deep nets, asked for with gemm_chain=True: library GEMM chain, same semantics
             if not inputs.is_cuda:
                 raise RuntimeError("lidarnerf_hip: tensor must live on the GPU (no CPU path in this library)")
             y = gemm_mlp(inputs, self.weights, self.input_dim, self.hidden_dim, self.num_layers - 1, self.activation,

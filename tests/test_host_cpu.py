@@ -74,12 +74,14 @@ def test_module_api_and_state_dict_layout():
     torch.manual_seed(42)
     w = torch.empty(m.num_parameters).uniform_(-np.sqrt(3 / 64), np.sqrt(3 / 64))
     assert torch.equal(m.weights.data, w)  # seed-42 initialisation of the reference (ffmlp.py:242-245)
-    # widths / depths without a fused kernel are refused like the C ABI refuses them, unless the GEMM chain is asked for
-    for hidden, layers in ((128, 2), (256, 3), (64, 5)):
+    # every width of the reference and deeper nets construct (fused kernels exist for all of them) ...
+    for hidden, layers in ((16, 2), (128, 2), (256, 3), (64, 5)):
+        assert FFMLP(32, 3, hidden, layers).weights.numel() == hidden * (32 + hidden * (layers - 1) + 16)
+    # ... what has no kernel is refused like the C ABI refuses it, unless the GEMM chain is asked for
+    for in_dim, layers in ((256, 2), (32, 17)):
         with pytest.raises(RuntimeError, match="no fused MFMA kernel"):
-            FFMLP(32, 3, hidden, layers)
-        assert FFMLP(32, 3, hidden, layers, gemm_chain=True).weights.numel() == hidden * (32 + hidden * (layers - 1) + 16)
-    assert FFMLP(32, 3, 16, 2).hidden_dim == 16               # zero-padded onto the hidden-32 kernels
+            FFMLP(in_dim, 3, 64, layers)
+        assert FFMLP(in_dim, 3, 64, layers, gemm_chain=True).gemm_chain
     net = NeRFNetwork(encoding="hashgrid", desired_resolution=2048, bound=1, min_near_lidar=0.01)
     keys = set(net.state_dict().keys())
     assert {"encoder.embeddings", "encoder.offsets", "sigma_net.0.weight", "sigma_net.1.weight",

@@ -171,18 +171,75 @@ def test_bf16_ffmlp_module_under_bf16_autocast():
     assert torch.isfinite(m.weights.grad).all() and float(m.weights.grad.abs().max()) > 0
 
 
-@pytest.mark.parametrize("hidden,layers,in_dim", [(16, 2, 32), (128, 3, 48), (256, 2, 64), (64, 5, 32)])
+@pytest.mark.parametrize("sfx", ["", "_bf16"])
+@pytest.mark.parametrize("hidden,nhm,in_dim,act", [(128, 1, 48, 0), (256, 2, 64, 0), (64, 4, 32, 0), (32, 3, 16, 0),
+                                                    (128, 0, 128, 0), (256, 1, 32, 3), (128, 2, 96, 5)])
+def test_wide_kernels_vs_oracle(hidden, nhm, in_dim, act, sfx):
+    """csrc/mlp_wide.hip through the C ABI: lnh_mlp_forward at hidden 128 / 256 and with more than two hidden matrices
+    (output + every saved hidden activation), lnh_mlp_backward_data (the activation gradients of every layer + the input
+    gradient) against the oracle's MLP (16-bit storage of every layer), a batch that is not a multiple of anything, ReLU /
+    sigmoid / softplus; lnh_mlp_backward refuses these shapes and names the entry point that serves them."""
+    from gpu_util import call
+    dt = torch.bfloat16 if sfx else torch.float16
+    npd = np.float32
+    r = np.random.default_rng(hidden + nhm)
+    B = 1000
+    acts = {0: "relu", 3: "sigmoid", 5: "softplus"}
+    x = torch.from_numpy((r.standard_normal((B, in_dim)) * 0.5).astype(npd)).to(dt)
+    std = np.sqrt(3 / hidden)
+    mats = [r.uniform(-std, std, (hidden, in_dim))] + [r.uniform(-std, std, (hidden, hidden)) for _ in range(nhm)] + \
+        [r.uniform(-std, std, (16, hidden))]
+    mats = [torch.from_numpy(m.astype(npd)).to(dt) for m in mats]
+    w = torch.cat([m.reshape(-1) for m in mats]).cuda()
+    y = torch.empty((B, 16), dtype=dt, device="cuda")
+    fb = torch.empty((nhm + 1, B, hidden), dtype=dt, device="cuda")
+    call("lnh_mlp_forward" + sfx, x.cuda(), w, B, in_dim, 16, hidden, nhm, act, 6, fb, y)
+    # reference chain in fp64 on the 16-bit values, every layer's activation rounded to the element type
+    f = {0: torch.relu, 3: torch.sigmoid, 5: lambda v: torch.log1p(torch.exp(v * 10.0)) / 10.0}[act]
+    hs, h = [], x.double()
+    for m in mats[:-1]:
+        h = f(h @ m.double().t()).to(dt).double()
+        hs.append(h)
+    want_y = (h @ mats[-1].double().t())
+    tol = 4e-3 if not sfx else 3e-2
+    for l in range(nhm + 1):
+        torch.testing.assert_close(fb[l].cpu().double(), hs[l], rtol=tol, atol=tol)
+    torch.testing.assert_close(y.cpu().double(), want_y, rtol=tol, atol=tol * max(1.0, float(want_y.abs().max())))
+    # backward (data): from the kernel's own saved activations
+    gy = torch.zeros((B, 16), dtype=dt)
+    gy[:, :5] = torch.from_numpy((r.standard_normal((B, 5)) * 0.1).astype(npd)).to(dt)
+    wt = torch.cat([m.t().contiguous().reshape(-1) for m in mats]).cuda()
+    gb = torch.empty((nhm + 1, B, hidden), dtype=dt, device="cuda")
+    gx = torch.empty((B, in_dim), dtype=dt, device="cuda")
+    call("lnh_mlp_backward_data" + sfx, gy.cuda(), fb, wt, B, in_dim, 16, hidden, nhm, act, gb, gx)
+    fbh = fb.cpu().double()
+    dact = {0: lambda p: (p > 0).double(), 3: lambda p: p * (1 - p), 5: lambda p: 1 - torch.exp(-p * 10.0)}[act]
+    g = (gy.double() @ mats[-1].double()) * dact(fbh[nhm])
+    want_gb = [None] * (nhm + 1)
+    want_gb[nhm] = g.to(dt).double()
+    for m in range(nhm - 1, -1, -1):
+        g = (want_gb[m + 1] @ mats[m + 1].double()) * dact(fbh[m])
+        want_gb[m] = g.to(dt).double()
+    want_gx = want_gb[0] @ mats[0].double()
+    for l in range(nhm + 1):
+        scale = float(want_gb[l].abs().max())
+        torch.testing.assert_close(gb[l].cpu().double(), want_gb[l], rtol=tol, atol=tol * scale)
+    torch.testing.assert_close(gx.cpu().double(), want_gx, rtol=tol, atol=tol * float(want_gx.abs().max()))
+    # the one-kernel backward does not exist for these shapes: refused, and the message names the split
+    gw = torch.zeros(w.numel(), device="cuda")
+    if hidden >= 128 or nhm > 2:
+        with pytest.raises(RuntimeError, match="lnh_mlp_backward_data"):
+            call("lnh_mlp_backward" + sfx, gy.cuda(), x.cuda(), w, B, in_dim, 16, hidden, nhm, act, 6, gx, gw)
+
+
+@pytest.mark.parametrize("hidden,layers,in_dim", [(16, 2, 32), (128, 3, 48), (256, 2, 64), (64, 5, 32), (256, 4, 32)])
 def test_ffmlp_module_all_reference_widths(hidden, layers, in_dim):
-    """Every width the reference accepts (ffmlp.py:202-209: 16 .. 256).  Hidden 16 runs on the fused kernels; 128 / 256 and
-    deeper nets have no fused kernel: the module refuses them like the C ABI does, and runs them as library GEMMs with the
-    same fp16 storage model only when asked to (gemm_chain=True) — forward and gradients vs the oracle either way."""
+    """Every width the reference accepts (ffmlp.py:202-209: 16 .. 256) and deeper nets, all on fused kernels (hidden 16 on
+    the hidden-32 kernels; 128 / 256 and more than 3 hidden layers on csrc/mlp_wide.hip with the weight gradients as
+    library GEMMs): forward and gradients vs the oracle, and the launches that ran."""
     from lidarnerf.ffmlp import FFMLP
-    if hidden == 16:
-        m = FFMLP(in_dim, 5, hidden, layers).cuda()
-    else:
-        with pytest.raises(RuntimeError, match="no fused MFMA kernel.*gemm_chain=True"):
-            FFMLP(in_dim, 5, hidden, layers)
-        m = FFMLP(in_dim, 5, hidden, layers, gemm_chain=True).cuda()
+    from lidarnerf import _hip
+    m = FFMLP(in_dim, 5, hidden, layers).cuda()
     with torch.no_grad():
         m.weights.copy_(m.weights.half().float())
     r = np.random.default_rng(hidden)
@@ -201,13 +258,21 @@ def test_ffmlp_module_all_reference_widths(hidden, layers, in_dim):
     dw_want = np.concatenate([d.ravel() for d in dws])
     np.testing.assert_allclose(xt.grad.cpu().numpy(), gx_want, rtol=1e-2, atol=4e-3)
     np.testing.assert_allclose(m.weights.grad.cpu().numpy(), dw_want, rtol=1e-2, atol=4e-3 * np.abs(dw_want).max())
-    if hidden == 16:  # runs on the hidden-32 MFMA kernels (zero-padded units), not on the library-GEMM chain
-        from lidarnerf import _hip
-        _hip.enable_timers(["lnh_mlp_forward", "lnh_mlp_backward"])
-        with torch.autocast("cuda", dtype=torch.float16):
-            m(xt.detach().requires_grad_(True)).float().sum().backward()
-        calls = _hip.disable_timers()
-        assert len(calls.get("lnh_mlp_forward", [])) == 1 and len(calls.get("lnh_mlp_backward", [])) == 1
+    # which kernels ran: one forward launch; one-kernel backward for the narrow shapes, the data kernel for the wide ones
+    names = ["lnh_mlp_forward", "lnh_mlp_backward", "lnh_mlp_backward_data"]
+    _hip.enable_timers(names)
+    with torch.autocast("cuda", dtype=torch.float16):
+        m(xt.detach().requires_grad_(True)).float().sum().backward()
+    calls = _hip.disable_timers()
+    n = {k: len(calls.get(k, [])) for k in names}
+    wide = hidden >= 128 or layers - 1 > 2
+    assert n == {"lnh_mlp_forward": 1, "lnh_mlp_backward": 0 if wide else 1, "lnh_mlp_backward_data": 1 if wide else 0}, n
+    # what still has no kernel is refused, unless the GEMM chain is asked for
+    with pytest.raises(RuntimeError, match="no fused MFMA kernel.*gemm_chain=True"):
+        FFMLP(256, 5, hidden, layers)
+    big = FFMLP(256, 5, hidden, layers, gemm_chain=True).cuda()
+    with torch.autocast("cuda", dtype=torch.float16):
+        assert big(torch.randn(64, 256, device="cuda")).shape == (64, 5)
 
 
 def test_ffmlp_module_hidden_32():
@@ -226,4 +291,4 @@ def test_unsupported_shapes_fail_loudly():
     with pytest.raises(RuntimeError, match="input_dim should be 16"):
         _hip.call("lnh_mlp_forward", t.data_ptr(), t.data_ptr(), 16, 20, 16, 64, 0, 0, 6, None, t.data_ptr())
     with pytest.raises(RuntimeError, match="hidden_dim"):
-        _hip.call("lnh_mlp_forward", t.data_ptr(), t.data_ptr(), 16, 32, 16, 256, 0, 0, 6, None, t.data_ptr())
+        _hip.call("lnh_mlp_forward", t.data_ptr(), t.data_ptr(), 16, 32, 16, 96, 0, 0, 6, None, t.data_ptr())
