@@ -1,3 +1,4 @@
+"""The weight-gradient GEMM (contraction over the batch) as one GEMM and as a batched split-K GEMM: python tools/bench_wgrad.py"""
 import torch, time
 def timed(fn, reps=10):
     fn(); torch.cuda.synchronize(); ts = []
