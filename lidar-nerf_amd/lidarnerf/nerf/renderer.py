@@ -261,10 +261,10 @@ class NeRFRenderer(nn.Module):
         N = rays_o.shape[0]
         # (a constant per ray count: kept — never freed, a captured step may hold its address)
         cache = self.__dict__.setdefault("_nears_cache", {})
-        nears = cache.get((N, rays_o.device))
+        key = (N, rays_o.device, float(self.min_near_lidar))
+        nears = cache.get(key)
         if nears is None:
-            nears = cache[(N, rays_o.device)] = torch.full((N,), float(self.min_near_lidar), dtype=torch.float32,
-                                                           device=rays_o.device)
+            nears = cache[key] = torch.full((N,), float(self.min_near_lidar), dtype=torch.float32, device=rays_o.device)
         # 1 m .. 81 m, cut at the ray's exit from the box: the marcher clamps sample POSITIONS to the box, and the compositing
         # kernel recovers a sample's depth from its position ((xyz - o) . d) — a sample marched past the box would enter
         # the depth sum with a shortened z (the dense path keeps the true z next to the clamped position, renderer.py:164-167)
