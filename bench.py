@@ -404,7 +404,7 @@ def main():
     ap.add_argument("--cpu-baseline-quick", action="store_true", help="bounded sample of that protocol (1 + up to 10 steps per leg, ~12 s each)")
     ap.add_argument("--no-mfma-states", action="store_true", help="skip the two fixed-state MFMA measurements (fresh table with a frozen optimizer; 600-step trained table)")
     ap.add_argument("--no-eval", action="store_true", help="skip the secondary full-frame evaluation measurement")
-    ap.add_argument("--kernel-timers", action="store_true", help="HIP-event timing of every C-ABI call (adds ~4 %)")
+    ap.add_argument("--kernel-timers", action="store_true", help="HIP-event timing of every C-ABI call (adds ~4 %%)")
     args = ap.parse_args()
 
     from lidarnerf import _hip, parallel
