@@ -158,3 +158,31 @@ def test_config4_nerfmvl_shape_occupancy_path():
     for i in range(1, len(grads)):
         rel = ((grads[i].double() - acc[i]).norm() / acc[i].norm()).item()
         assert rel < 1e-4, (i, rel)
+
+
+def test_config4_nerfmvl_shape_captured_training():
+    """The benchmarked form of config 4 at its shape: LidarTrainer(graph=True) — 4096 rays per step through the 32768-resolution
+    grid, the step captured in a hipGraph per sample capacity and replayed.  64 steps on the synthetic object: the loss falls,
+    every step after the first grid-update block is a replay (a handful of captures at most), the marched samples stay far
+    below the dense path's 832 per ray, and the replayed steps advance optimizer state exactly once each."""
+    from lidarnerf.nerf.network import NeRFNetwork
+    from lidarnerf.nerf.train_step import LidarTrainer
+    torch.manual_seed(5)
+    net = NeRFNetwork(encoding="hashgrid", desired_resolution=32768, log2_hashmap_size=19, bound=1, min_near=SCALE,
+                      min_near_lidar=SCALE, density_thresh=10, cuda_ray=True).cuda().train()
+    tr = LidarTrainer(net, lr=1e-2, iters=30000, fp16=True, scale=SCALE, graph=True)
+    assert tr.graph and tr.occupancy and tr.table is not None
+    o, d, gt = _batch(4096)
+    o, d, gt = o.cuda()[None], d.cuda()[None], gt.cuda()[None]
+    losses, replays = [], 0
+    for step in range(64):
+        n_before = len(tr._graphs)
+        warm = bool(tr._graph_warm) and tr._graph_capacity() > 0
+        losses.append(float(tr.step(o, d, gt)))
+        replays += int(warm and len(tr._graphs) == n_before)
+    assert np.isfinite(losses).all() and np.mean(losses[-8:]) < 0.5 * losses[0], (losses[:8], losses[-8:])
+    assert 1 <= len(tr._graphs) <= 4 and replays >= 64 - 17 - len(tr._graphs), (len(tr._graphs), replays)
+    skipped = 64 - int(tr.t_steps[tr.t_flip])
+    assert 0 <= skipped <= 4                                   # (loss-scale back-offs)
+    assert int(tr.optimizer.state[tr.params[0]]["step"]) == 64 - skipped
+    assert 0 < net.mean_count < 0.25 * 832 * 4096
