@@ -95,15 +95,17 @@ def _grid_bwd(g_feat, x01, g_table16, enc, B):
 
 # Data parallel: level windows of the table gradient.  The scatter pass of the backward runs once for all levels
 # (lnh_grid_encode_backward_ws_begin); the reduce pass runs per window (_finish), and a window's rows are final as soon as its
-# reduce has run, so its collective (fp16, RCCL's own stream) overlaps with the reduce of the next window.  Two windows:
-# a reduce launch is as slow as its slowest bucket (one workgroup per bucket, ~150 .. 250 us), so every extra window costs
-# compute — measured on one MI355X with the exchange a no-op (bench.py --dp-windows, 4096 rays, ms per step / backward us):
-#   1 window 2.309 / 1013    2 windows (0,10,16) 2.498 / 1196    3 (0,8,12,16) 2.529 / 1221    4 (0,7,10,13,16) 2.603 / 1291
-# (round 2 cut the SCATTER pass into 4 windows as well: 2.683 / 1362).  With two windows 54 % of the 27 MB hide behind the
-# second reduce for +0.19 ms of compute; which count wins depends on the all-reduce time, which no box of this build could
-# measure (LNH_DP_WINDOWS overrides the cut for such a measurement).
+# reduce has run, so its collective (fp16, RCCL's own stream) overlaps with the reduce of the next window.  What a window
+# costs in compute, measured on one MI355X with the exchange a no-op (bench.py --dp-windows, 4096 rays, ms per step / backward
+# us), round 4 — after the reduce pass stopped being as slow as its slowest bucket (rows of the dense levels dealt to 64
+# buckets):   no windows 2.149 / 854    1 window 2.154 / 855    2 (0,10,16) 2.192 / 889    3 (0,8,12,16) 2.198 / 890
+#             4 (0,7,10,13,16) 2.270 / 957    6 2.412 / 1093
+# (round 3: 1 window 2.309 / 1013, 2 -> 2.498 / 1196, 3 -> 2.529 / 1221, 4 -> 2.603 / 1291; round 2 cut the SCATTER pass
+# into windows as well: 2.683 / 1362.)  Three windows cost what two cost and cut the table into thirds by rows (39 % / 31 % / 31 %):
+# only the last third's exchange has nothing left to hide behind, instead of 46 % with two.  Which count wins in the end
+# depends on the all-reduce time, which no box of this build could measure (LNH_DP_WINDOWS overrides the cut for that).
 import os as _os
-_DP_LEVEL_WINDOWS = ((0, 10), (10, 16))
+_DP_LEVEL_WINDOWS = ((0, 8), (8, 12), (12, 16))
 if _os.environ.get("LNH_DP_WINDOWS"):  # developer override for A/B runs: "0,10,16" = two windows
     _c = [int(v) for v in _os.environ["LNH_DP_WINDOWS"].split(",")]
     # (must be the same on every rank: the shard layout follows the windows)

@@ -40,7 +40,7 @@ def test_bench_launches_its_own_ranks_and_reports_the_exchange():
     assert d["value"] > 0 and abs(d["value"] - 2 * 256 * 1e3 / d["ms_per_step"]) <= 1e-3 * d["value"]
     assert {"ms_per_step_inclusive", "ms_per_step_without_allreduce", "allreduce_exposed_ms", "payload_bytes",
             "window_plan"} <= set(d["comm"])
-    assert d["comm"]["payload_bytes"]["table_gradient_fp16"] == 6837544 * 4 and len(d["comm"]["window_plan"]) == 2
+    assert d["comm"]["payload_bytes"]["table_gradient_fp16"] == 6837544 * 4 and len(d["comm"]["window_plan"]) == 3
     assert sum(w["rows"] for w in d["comm"]["window_plan"]) == 6837544
     # world size that does not match --gpus: refused
     env_bad = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")

@@ -111,7 +111,7 @@ def _worker_layout8(rank, world, port, out):
     pls = np.exp2(np.log2(32768 / 16) / 15)
     off = level_offsets(3, 16, pls, 16, 19, False)
     rows = int(off[-1])
-    assert rows == 6837544 and _DP_LEVEL_WINDOWS == ((0, 10), (10, 16))
+    assert rows == 6837544 and _DP_LEVEL_WINDOWS == ((0, 8), (8, 12), (12, 16))
     idx = torch.arange(rows, dtype=torch.int64)
 
     def grad_of(r):  # small integers: every partial sum is exact in fp16
