@@ -215,6 +215,9 @@ _SAMPLE_DIST = {}
 
 def _sample_dist(N, value, dev):
     """[N] fp32 tensor filled with `value` — the same every step, so it is kept instead of re-filled (read-only)."""
+    if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+        # (a captured step keeps the POINTER: never hand it a tensor this cache may drop later)
+        return torch.full((N,), value, dtype=torch.float32, device=dev)
     key = (N, value, str(dev))
     t = _SAMPLE_DIST.get(key)
     if t is None:

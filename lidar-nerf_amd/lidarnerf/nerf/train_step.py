@@ -136,18 +136,20 @@ class LidarTrainer:
         if len(params) > 1 and all({k: v for k, v in g.items() if k != "params"} ==
                                    {k: v for k, v in params[0].items() if k != "params"} for g in params):
             params = [dict(params[0], params=[p for g in params for p in g["params"]])]
-        # graph=True (occupancy-grid sampling + fused table optimizer, one GPU): the whole step — march, ragged chain, loss,
-        # backward, both optimizers, loss-scale update — is captured in a hipGraph per (batch shape, sample capacity) and
-        # replayed (_step_graphed).  The step is ~45 launches over ~0.4 M samples: eager, the host cannot issue them as fast
+        # graph=True (fused chain + fused table optimizer, one GPU): the whole step — (march,) render chain, loss, backward,
+        # both optimizers, loss-scale update — is captured in a hipGraph per (batch shape, sample capacity) and replayed
+        # (_step_graphed).  Built for occupancy-grid sampling; the dense step (no data-dependent sizes at all) captures the
+        # same way and then costs the host 0.05 ms instead of ~0.8 — it is GPU-bound either way on the hosts of this build,
+        # a slower host would not be.  The step is ~45 launches over ~0.4 M samples: eager, the host cannot issue them as fast
         # as the GPU retires them (profiles/r04_bench_nerfmvl.json: 1.0 ms of host time per 0.7 ms of kernels).  What a
         # capture freezes — kernel arguments — must not change between replays, so the learning rate becomes a device
         # scalar (torch's capturable Adam, lnh_adam_table_step_dlr) and the marcher's sample capacity comes from a ladder
         # of sizes (_graph_capacity; the reference sizes it to the running mean rounded to 128, raymarching.py:223-229: a
         # larger buffer drops fewer rays on overflow, nothing else changes).
-        self.graph = bool(graph and self.table is not None and self.occupancy and world_size == 1 and on_gpu)
+        self.graph = bool(graph and self.table is not None and world_size == 1 and on_gpu)
         if graph and not self.graph:
-            raise RuntimeError("LidarTrainer(graph=True): the captured step exists for occupancy-grid sampling (cuda_ray) "
-                               "through the fused ragged chain with the fused table optimizer, on one GPU")
+            raise RuntimeError("LidarTrainer(graph=True): the captured step needs the fused chain with the fused table "
+                               "optimizer (fp16, a fusable field on the GPU) on one GPU — collectives are not captured")
         self._graphs, self._graph_warm, self._graph_pool = {}, set(), None
         if self.graph:
             dev0 = self.table.device
@@ -273,7 +275,8 @@ class LidarTrainer:
 
     def _step_graphed(self, rays_o, rays_d, images_lidar, patch):
         model = self.model
-        cap = self._graph_capacity()
+        # (the dense step has no sample buffers to size: one graph per batch shape)
+        cap = self._graph_capacity() if self.occupancy else -1
         if cap == 0 or not self._graph_warm:
             # eager: no sample mean yet / the very first step (it takes every lazy initialisation — workspaces, kernel
             # attributes, optimizer state — out of the captures that follow).
@@ -296,7 +299,8 @@ class LidarTrainer:
                    "graph": torch.cuda.CUDAGraph()}
             for k, src in (("rays_o", rays_o), ("rays_d", rays_d), ("gt", images_lidar)):
                 ent[k].copy_(src)
-            model._static_march = (ent["counter"], cap - 128)  # (march_rays_train adds its 128-alignment on top)
+            if self.occupancy:
+                model._static_march = (ent["counter"], cap - 128)  # (march_rays_train adds its 128-alignment on top)
             try:
                 torch.cuda.synchronize()
                 with torch.cuda.graph(ent["graph"], pool=self._graph_pool):
@@ -307,8 +311,9 @@ class LidarTrainer:
         else:
             torch._foreach_copy_([ent["rays_o"], ent["rays_d"], ent["gt"]], [rays_o, rays_d, images_lidar])  # one launch
         ent["graph"].replay()
-        model.step_counter[model.local_step % 16].copy_(ent["counter"])
-        model.local_step += 1
+        if self.occupancy:
+            model.step_counter[model.local_step % 16].copy_(ent["counter"])
+            model.local_step += 1
         self.scheduler.step()
         return ent["loss"].clone()  # (the graphs share a pool: the next replay of another one may reuse this memory)
 

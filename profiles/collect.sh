@@ -11,18 +11,19 @@ out=gpurun_out/profiles; mkdir -p $out
 STEPS=10; WARM=3
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -o r -- python bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-eval --no-mfma-states > /dev/null 2>&1
 find /tmp/prof_kt -name "*kernel_stats.csv" -exec cp {} $out/${tag}_kernel_stats.csv \;
-# (+5 steps: the MFMA pass bench.py runs after the timed region; + 2 x STEPS: the two repeats of the timed region it lists as spread)
-python - $out/${tag}_kernel_stats.csv $((3*STEPS+WARM+5)) > $out/${tag}_kernel_summary.txt <<'PY'
+# (+5 steps: the MFMA pass bench.py runs after the timed region; + STEPS: the launch-by-launch region behind the replayed one;
+#  + 2 x STEPS: the two repeats of the timed region it lists as spread)
+python - $out/${tag}_kernel_stats.csv $((4*STEPS+WARM+5)) > $out/${tag}_kernel_summary.txt <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1]))); n = float(sys.argv[2])
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
-print(f"rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-eval   ({int(n)} steps incl. warm-up and the 5-step MFMA pass)")
+print(f"rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-eval   ({int(n)} steps: warm-up, 10 replayed, 10 launch by launch, the 5-step MFMA pass, 2 x 10 repeats)")
 print(f"total kernel time per training step: {tot/n/1e6:.3f} ms")
 for r in rows[:40]:
     print(f"{float(r['TotalDurationNs'])/n/1e6:8.3f} ms/step {int(r['Calls'])/n:6.1f} calls/step  avg {float(r['AverageNs'])/1e3:9.1f} us  {r['Name'][:110]}")
 PY
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/prof_$c -o r -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-eval --no-mfma-states > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/prof_$c -o r -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-eval --no-mfma-states --no-graph > /dev/null 2>&1
 done
 python - $out/${tag}_pmc.json <<'PY'
 import csv, glob, json, sys, collections
@@ -48,7 +49,7 @@ for k, d in res.items():
         d["hbm_bytes_per_launch"] = int((d["fetch_scale"] * f + w) * 1024)
 import hashlib, os
 lib = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "lidar-nerf_amd", "lib", "liblidarnerf_hip.so")
-json.dump({"command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-eval --no-mfma-states",
+json.dump({"command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-eval --no-mfma-states --no-graph",
            "lib_sha16": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16],   # bench.py compares it with the library it runs
            "note": "KB per launch, averaged over all launches. hbm_bytes_per_launch = fetch_scale*FETCH_SIZE + WRITE_SIZE "
                    "(fetch_scale 2 for the 16 B/lane streaming loads of k_grid_bwd_reduce, 1 elsewhere; see profiles/README.md)",

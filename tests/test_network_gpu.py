@@ -356,3 +356,45 @@ def test_fused_render_full_size_properties():
         if name.startswith(("encoder.", "sigma_net.", "lidar_color_net.")):
             assert p.grad is not None and torch.isfinite(p.grad).all(), name
             assert float(p.grad.abs().max()) > 0.0, name
+
+
+def test_captured_dense_step_trains_like_the_eager_step():
+    """LidarTrainer(graph=True) on the DENSE path (768 + 64 samples per ray, no occupancy grid): one hipGraph per batch shape,
+    replayed.  Against an eager trainer from the same initial state on the same batches: the same parameters to run-to-run
+    noise after every step (the jitter comes from the generator's graph-safe stream, hence a loss tolerance rather than
+    equality) and the same amount of parameter movement, step counters and schedule advance once per replay, and a second
+    batch shape gets its own graph."""
+    import copy
+    from lidarnerf.nerf.train_step import LidarTrainer
+    net_a, _ = _pair(seed=17, table_scale=0.3)
+    net_a.train()
+    net_b = copy.deepcopy(net_a)
+    kw = dict(lr=1e-2, iters=100, fp16=True, scale=SCALE, render_kwargs=dict(num_steps=768, upsample_steps=64))
+    eager, graph = LidarTrainer(net_a, **kw), LidarTrainer(net_b, graph=True, **kw)
+    assert graph.graph and not graph.occupancy and not eager.graph
+
+    def batch(seed, n=64):
+        o, d = _rays(n, seed)
+        gt = torch.rand(1, n, 3, generator=torch.Generator().manual_seed(seed + 1)).cuda()
+        gt[..., 0] = (gt[..., 0] > 0.2).float()
+        return o.cuda()[None], d.cuda()[None], gt
+
+    le, lg = [], []
+    for s in range(12):
+        b = batch(40 + s)
+        le.append(float(eager.step(*b).detach()))
+        lg.append(float(graph.step(*b)))
+    assert len(graph._graphs) == 1                              # step 0 ran launch by launch, step 1 captured, the rest replayed
+    np.testing.assert_allclose(lg, le, rtol=0.1, atol=1e-3 * abs(le[0]))
+    assert np.mean(lg[-3:]) < np.mean(lg[:3])
+    assert float(graph.t_steps[graph.t_flip]) == float(eager.t_steps[eager.t_flip]) == 12.0
+    np.testing.assert_allclose(float(graph.optimizer.param_groups[0]["lr"]), 1e-2 * 0.1 ** (12 / 100), rtol=1e-5)
+    # (parameters are NOT comparable entry by entry: the two runs draw different jitter, and Adam with eps = 1e-15 moves every
+    #  touched weight by ~lr per step whatever the gradient — the same amount of movement is)
+    t0 = _pair(seed=17, table_scale=0.3)[0].encoder.embeddings.detach().cuda()
+    moved_e = (net_a.encoder.embeddings.detach() - t0).norm()
+    moved_g = (net_b.encoder.embeddings.detach() - t0).norm()
+    assert 0.8 < float(moved_g / moved_e) < 1.25, (float(moved_e), float(moved_g))
+    # another batch shape: its own graph (one eager step is NOT needed again: lazy initialisation is done)
+    graph.step(*batch(90, n=32))
+    assert len(graph._graphs) == 2
