@@ -289,6 +289,7 @@ def run_nerfmvl(args):
     for s in range(n_pre + args.warmup):
         trainer.step(*batches[s])
     torch.cuda.synchronize()
+    use_graph = use_graph and trainer.graph  # (False if a capture did not go through: launch by launch from there on)
     grid_calls = ["lnh_grid_encode_forward", "lnh_grid_encode_backward_ws", "lnh_grid_encode_backward"]
     if not use_graph:  # (a replayed graph makes no library calls to put events around: the eager pass below times them)
         _hip.enable_timers(grid_calls)
@@ -488,9 +489,10 @@ def main():
                                           "lnh_freq_encode_forward", "lnh_lidar_merge_weights",
                                           "lnh_lidar_sample_points", "lnh_adam_table_step"]
     if use_graph:  # (a graph exists after two steps at a batch shape: never capture inside the timed region)
-        while not trainer._graphs:
+        while trainer.graph and not trainer._graphs:
             trainer.step(*batches[0], **step_kw)
         sync()
+        use_graph = trainer.graph  # (False if the capture did not go through: launch by launch, reason in the line)
     _hip.enable_timers(all_calls if args.kernel_timers else grid_calls)
     t0 = time.perf_counter()
     for s in range(args.steps):
@@ -733,6 +735,8 @@ def main():
         "roofline_mfma": roofline_mfma,
         "kernels": kernels,
     }
+    if getattr(trainer, "graph_error", None):
+        result["graph"] = {"error": trainer.graph_error, "note": "capture failed: every step was issued launch by launch"}
     if graph_info is not None:
         result["graph"] = graph_info
         result["config"]["launch"] = "hipGraph replay of the whole step in the timed region (LidarTrainer graph mode)"

@@ -150,7 +150,7 @@ class LidarTrainer:
         if graph and not self.graph:
             raise RuntimeError("LidarTrainer(graph=True): the captured step needs the fused chain with the fused table "
                                "optimizer (fp16, a fusable field on the GPU) on one GPU — collectives are not captured")
-        self._graphs, self._graph_warm, self._graph_pool = {}, set(), None
+        self._graphs, self._graph_warm, self._graph_pool, self.graph_error = {}, set(), None, None
         if self.graph:
             dev0 = self.table.device
             # (initial_lr as a number: LambdaLR then computes the schedule on the host and fills the device scalar — with a
@@ -305,6 +305,12 @@ class LidarTrainer:
                 torch.cuda.synchronize()
                 with torch.cuda.graph(ent["graph"], pool=self._graph_pool):
                     ent["loss"] = self._step_fused_table(ent["rays_o"], ent["rays_d"], ent["gt"], patch).detach()
+            except Exception as e:  # noqa: BLE001 — a capture that does not go through must not cost the run
+                # (nothing of a captured step has executed: the state is what it was.)  Launch by launch from here on; the
+                # reason stays readable (bench.py reports it).
+                model._static_march = None
+                self.graph, self.graph_error = False, f"{type(e).__name__}: {e}"
+                return self._step_fused_table(rays_o, rays_d, images_lidar, patch).detach()
             finally:
                 model._static_march = None
             self._graphs[key] = ent
