@@ -398,3 +398,31 @@ def test_captured_dense_step_trains_like_the_eager_step():
     # another batch shape: its own graph (one eager step is NOT needed again: lazy initialisation is done)
     graph.step(*batch(90, n=32))
     assert len(graph._graphs) == 2
+
+
+def test_failed_capture_falls_back_to_launch_by_launch(monkeypatch):
+    """A capture that does not go through (here: torch.cuda.graph made to raise) must not cost the run: the trainer keeps the
+    reason, switches graph mode off and takes that very step — and every later one — launch by launch."""
+    from lidarnerf.nerf.train_step import LidarTrainer
+    net, _ = _pair(seed=19, table_scale=0.3)
+    tr = LidarTrainer(net.train(), lr=1e-2, iters=100, fp16=True, scale=SCALE, graph=True,
+                      render_kwargs=dict(num_steps=768, upsample_steps=64))
+    o, d = _rays(64, 3)
+    gt = torch.rand(1, 64, 3, generator=torch.Generator().manual_seed(4)).cuda()
+    b = (o.cuda()[None], d.cuda()[None], gt)
+    l0 = float(tr.step(*b))                                   # launch by launch (first step at this shape)
+
+    class _Boom:
+        def __init__(self, *a, **k):
+            pass
+
+        def __enter__(self):
+            raise RuntimeError("capture refused (test)")
+
+        def __exit__(self, *a):
+            return False
+    monkeypatch.setattr(torch.cuda, "graph", _Boom)
+    l1 = float(tr.step(*b))                                   # would have been the capture
+    assert tr.graph is False and "capture refused" in tr.graph_error and not tr._graphs
+    l2 = float(tr.step(*b))
+    assert np.isfinite([l0, l1, l2]).all() and float(tr.t_steps[tr.t_flip]) == 3.0
