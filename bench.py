@@ -44,6 +44,7 @@ COLOR_FLOPS_EXECUTED = 2 * (16 * 64 + 64 * 64 + 64 * 16)
 # algorithmic bytes per sample point, fp16 tables, L=16, F=2, D=3
 GRID_FWD_BYTES = 12 + 16 * 8 * 2 * 2 + 16 * 2 * 2  # 588
 GRID_BWD_BYTES = 12 + 16 * 2 * 2 + 2 * (16 * 8 * 2 * 2)  # 1100
+COMPOSITE_BYTES = 16 + 28  # compositing forward 16 B + backward 28 B per sample (K = 2 channels)
 
 
 def synthetic_frames(n_frames, device):
@@ -437,7 +438,10 @@ def main():
     # build the step is GPU-bound either way (2.124 against 2.136 ms), on a host 2.4 x slower (such boxes exist in the pool:
     # the config-4 step took 2.0 instead of 0.85 ms there) it would not be.  The per-entry-point timings (rooflines, MFMA)
     # come from a launch-by-launch region of the same length right after it (HIP events need calls to bracket).
-    use_graph = bool(not args.no_graph and world == 1 and not args.dp_windows)
+    # Data parallel (round 5): under RCCL the step is captured WITH its collectives (LidarTrainer graph mode), so that N ranks
+    # replay N identical graphs instead of issuing ~60 launches per 2 ms step from N Python processes sharing the box's CPU
+    # quota; gloo (functional runs with several ranks on one GPU) cannot be captured and runs launch by launch.
+    use_graph = bool(not args.no_graph and not args.dp_windows and (world == 1 or parallel.backend() == "nccl"))
     trainer = LidarTrainer(model, lr=1e-2, iters=30000, fp16=True, scale=SCALE, world_size=world,
                            render_kwargs=dict(num_steps=NUM_STEPS, upsample_steps=UPSAMPLE),
                            mlp_dtype=torch.bfloat16 if args.mlp_dtype == "bf16" else torch.float16, graph=use_graph)
@@ -479,6 +483,9 @@ def main():
                   "lnh_grid_encode_backward_ws", "lnh_grid_encode_backward_ws_levels", "lnh_grid_encode_backward_ws_begin",
                   "lnh_grid_encode_backward_ws_finish"]
     sfx = "_bf16" if args.mlp_dtype == "bf16" else ""
+    # roofline_path (encode forward + backward + compositing): the compositing backward and the fused forward tail (merged
+    # weights + colour head + compositing sums of a ray in ONE kernel) are timed beside the encoder entry points
+    path_calls = grid_calls + ["lnh_lidar_composite_backward", "lnh_lidar_color_composite_forward" + sfx]
     # (the colour head's forward runs inside the fused forward tail — merged weights + colour head + compositing sums of a
     #  ray in one kernel — whose whole time is charged to the MLPs here)
     mlp_calls = [n + sfx for n in ("lnh_density_mlp_forward", "lnh_density_mlp_backward", "lnh_lidar_color_forward",
@@ -493,7 +500,7 @@ def main():
             trainer.step(*batches[0], **step_kw)
         sync()
         use_graph = trainer.graph  # (False if the capture did not go through: launch by launch, reason in the line)
-    _hip.enable_timers(all_calls if args.kernel_timers else grid_calls)
+    _hip.enable_timers(all_calls if args.kernel_timers else path_calls)
     t0 = time.perf_counter()
     for s in range(args.steps):
         loss = trainer.step(*batches[(args.warmup + s) % len(batches)], **step_kw)
@@ -508,7 +515,7 @@ def main():
         # the same number of steps launch by launch: entry-point timings for the rooflines, and the eager step time beside it
         graph_info = {"graphs_captured": len(trainer._graphs), "host_enqueue_ms_per_step_graph": round(host_ms, 4)}
         trainer.graph = False
-        _hip.enable_timers(all_calls if args.kernel_timers else grid_calls)
+        _hip.enable_timers(all_calls if args.kernel_timers else path_calls)
         t1 = time.perf_counter()
         for s in range(args.steps):
             trainer.step(*batches[(args.warmup + args.steps + s) % len(batches)], **step_kw)
@@ -545,7 +552,7 @@ def main():
     #      first learns the analytic scene for --pretrain-steps untimed steps, mask ~ 0.15).  One GPU only.
     def mfma_pass(tr, bats, n):
         fused.MASK_STATS = []
-        _hip.enable_timers(mlp_calls)
+        _hip.enable_timers(mlp_calls + path_calls)
         for s in range(n):
             tr.step(*bats[s % len(bats)], **step_kw)
         sync()
@@ -598,8 +605,9 @@ def main():
     #      timing only, the replicas are not used afterwards) -> all-reduce cost = inclusive - exclusive
     comm = None
     if world > 1:
-        saved_ws, trainer.world = parallel.world_size, 1
+        saved_ws, saved_dp, trainer.world, trainer.dp = parallel.world_size, parallel.dp_active, 1, False
         parallel.world_size = lambda: 1
+        parallel.dp_active = lambda: False
         n_nc = min(args.steps, 10)
         for s in range(2):
             trainer.step(*batches[s % len(batches)], **step_kw)
@@ -609,7 +617,7 @@ def main():
             trainer.step(*batches[(2 + s) % len(batches)], **step_kw)
         sync()
         t_nc = parallel_max = time.perf_counter() - t0
-        parallel.world_size, trainer.world = saved_ws, world
+        parallel.world_size, parallel.dp_active, trainer.world, trainer.dp = saved_ws, saved_dp, world, True
         t_nc = parallel.max_over_ranks(parallel_max, device) / n_nc
         # the exchange in numbers: bytes per rank and step, and the level windows they travel in (fused._DP_LEVEL_WINDOWS)
         from lidarnerf.nerf.fused import _DP_LEVEL_WINDOWS
@@ -628,12 +636,18 @@ def main():
                                   "per_rank_on_the_wire_ring_allreduce": int(2 * (world - 1) / world *
                                                                            (sum(w["bytes_fp16"] for w in plan) + mlp_bytes))},
                 "window_plan": plan,
-                "backend": os.environ.get("LNH_DIST_BACKEND", "nccl (RCCL)"),
+                "backend": "nccl (RCCL)" if parallel.backend() == "nccl" else str(parallel.backend()),
                 "payload": "hash-table gradient fp16, SUM over ranks, one all-reduce per level window (the scatter pass runs once, "
                            "the reduce pass per window) + the MLP gradients fp32 in one flat buffer"}
 
     if rank != 0:
         return
+    # SURVEY 8(d) asks for >= 100 steps and the median: with fewer steps the timed region is tens of milliseconds and one
+    # region moves by ~2 % against the next, so the reported step time is the MEDIAN of the three regions of K steps each
+    # (ms_per_step_repeats lists all three, the first being the region bracketed right after the warm-up)
+    elapsed_first = elapsed
+    if args.steps < 100:
+        elapsed = sorted(spread)[1] * args.steps / 1e3
     rays_total = args.rays * world * args.steps
     kernels = event_table(timers)
     if "lnh_grid_encode_backward_ws_begin" in kernels:  # DP: one scatter (begin) + the window reduces (finish) = one logical launch
@@ -690,30 +704,64 @@ def main():
     pts = args.rays * (NUM_STEPS + UPSAMPLE)
 
     def mfma_entry(tm, mf, n):
+        tm = {k: v for k, v in tm.items() if k in mlp_calls}  # (the fixed-state passes time the encoder calls as well)
         ms = sum(v["total_ms"] for v in tm.values()) / max(n, 1)
         fl = 3 * pts * (SIGMA_FLOPS + COLOR_FLOPS * mf)
         fl_exec = 3 * pts * (SIGMA_FLOPS + COLOR_FLOPS_EXECUTED * mf)
         tf_ = fl / (ms * 1e-3) / 1e12 if ms else 0.0
+        tf_exec = fl_exec / (ms * 1e-3) / 1e12 if ms else 0.0
         return {"achieved": round(tf_, 1), "frac": round(tf_ / MFMA_PEAK_TFLOPS, 4), "flops_per_step": int(fl),
                 "mask_fraction": round(mf, 4), "mlp_kernel_ms_per_step": round(ms, 4),
-                "executed_tflops": round(fl_exec / (ms * 1e-3) / 1e12, 1) if ms else 0.0,
+                "executed_tflops": round(tf_exec, 1), "executed_frac": round(tf_exec / MFMA_PEAK_TFLOPS, 4),
                 "per_kernel_us": {k: v["avg_us"] for k, v in tm.items()}}
 
+    # the headline MFMA figure is the one of THIS run (round 4 headlined the favourable fixed state; the fixed states stay
+    # beside it so that the number can be compared across rounds whatever --steps / --warmup the caller chose)
     as_run = mfma_entry(mlp_timers, mask_frac, n_prof)
-    head_state = "fresh_frozen" if "fresh_frozen" in mfma_states else "as_run"
-    head = mfma_entry(*mfma_states["fresh_frozen"]) if head_state == "fresh_frozen" else as_run
     roofline_mfma = dict({"bound": "mfma", "kernel": "+".join(sorted(mlp_timers)), "peak": MFMA_PEAK_TFLOPS,
-                          "unit": "TFLOP/s", "state": head_state}, **head)
+                          "unit": "TFLOP/s", "state": "as_run"}, **as_run)
     roofline_mfma["states"] = dict({"as_run": dict(as_run, note=f"the {n_prof} steps after the timed region of THIS run "
                                                                    f"(--warmup {args.warmup} --steps {args.steps}): the mask "
                                                                    "fraction depends on how far training got")},
                                    **{k: mfma_entry(*v) for k, v in mfma_states.items()})
-    roofline_mfma["note"] = ("flops per SURVEY 8(d): 3 x points x (6144 + 22528 x mask fraction); the headline figures are those "
-                             "of state '" + head_state + "' (fresh table, optimizer frozen at lr = 0: every step sees the initial "
-                             "field, mask ~ 1.0; 'trained' = after --pretrain-steps untimed steps on the analytic scene, mask "
-                             "~ 0.15); 'executed' counts the colour head at K = 16 per sample (direction columns folded into a "
-                             "per-ray term); the MLP kernels also read the encoder output and write activations: at 61 flop/B "
-                             "the sigma net is HBM-bound by construction (DESIGN.md)")
+    roofline_mfma["note"] = ("flops per SURVEY 8(d): 3 x points x (6144 + 22528 x mask fraction), 'frac' = that nominal count over "
+                             "the dense fp16 peak; 'executed_frac' counts the colour head at the K = 16 per sample the kernels "
+                             "really multiply (the 75 direction columns are folded into a per-ray term) and is the hardware "
+                             "figure; the headline is the state 'as_run' (the steps right after the timed region of this run); "
+                             "'fresh_frozen' = fresh table with the optimizer frozen at lr = 0 (every step sees the initial "
+                             "field, mask ~ 1.0), 'trained' = after --pretrain-steps untimed steps on the analytic scene (mask "
+                             "~ 0.1); the MLP kernels also read the encoder output and write activations: at 61 flop/B the sigma "
+                             "net is HBM-bound by construction (DESIGN.md)")
+
+    # ---- path-level HBM roofline (north_star states its 60 % bar on encode + composite together): algorithmic bytes of the
+    #      encode forward (588 B), the encode backward (1100 B) and the compositing (44 B) per sample point of a step over
+    #      the summed HIP-event time of the kernels that do that work.  The forward compositing sums are formed inside the
+    #      fused forward tail (merged weights + colour head + sums, one kernel per ray): 'frac' charges that kernel's WHOLE
+    #      time to the path (conservative), 'frac_encode_only' is encode forward + backward alone.
+    def path_entry(tm, n, note):
+        def ms_of(names):
+            return sum(tm[k]["total_ms"] for k in names if k in tm) / max(n, 1)
+        t_fwd = ms_of(fwd_names)
+        t_bwd = ms_of(bwd_names + ("lnh_grid_encode_backward_ws_begin", "lnh_grid_encode_backward_ws_finish"))
+        t_cb, t_tail = ms_of(("lnh_lidar_composite_backward",)), ms_of(("lnh_lidar_color_composite_forward" + sfx,))
+        b_enc = (GRID_FWD_BYTES + GRID_BWD_BYTES) * pts
+        b_all = b_enc + COMPOSITE_BYTES * pts
+        t_all = t_fwd + t_bwd + t_cb + t_tail
+        if not (t_fwd and t_bwd):
+            return None
+        return {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "achieved": round(b_all / (t_all * 1e-3) / 1e9, 1), "frac": round(b_all / (t_all * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "frac_encode_only": round(b_enc / ((t_fwd + t_bwd) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "algorithmic_bytes_per_step": int(b_all), "bytes_per_point": GRID_FWD_BYTES + GRID_BWD_BYTES + COMPOSITE_BYTES,
+                "kernel_ms_per_step": {"encode_forward": round(t_fwd, 4), "encode_backward": round(t_bwd, 4),
+                                       "composite_backward": round(t_cb, 4), "fused_forward_tail": round(t_tail, 4)},
+                "note": note}
+
+    roofline_path = path_entry(kernels, args.steps, "as run: the launch-by-launch region of this run (the timed workload)")
+    if roofline_path is not None:
+        roofline_path["state"] = "as_run"
+        roofline_path["states"] = {k: path_entry(v[0], v[2], "fixed state, see roofline_mfma.note") for k, v in mfma_states.items()
+                                   if path_entry(v[0], v[2], "") is not None}
     result = {
         "metric": "train rays/sec (encode+MLP+composite+bwd), KITTI-360 66x1030",
         "value": round(rays_total / elapsed, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps,
@@ -729,17 +777,24 @@ def main():
                             f"trained-like: {args.pretrain_steps} untimed steps on the analytic scene (sphere + ground plane)",
                    "patch": args.patch, "dp_windows_forced": bool(args.dp_windows),
                    "optimizer": "Adam + dynamic loss scaling, in the timed region (hash table: fused lnh_adam_table_step; MLPs: torch fused Adam)", "final_loss": round(loss_val, 5)},
-        "ms_per_step_repeats": spread,  # [the reported timed region, two more of the same length]
+        "ms_per_step_repeats": spread,  # three timed regions of K steps each; `value` / `ms_per_step` = their median when K < 100
+        "ms_per_step_first_region": round(1e3 * elapsed_first / args.steps, 3),
         "roofline": hbm_roofline(dom),
         "roofline_fwd": hbm_roofline(max(fwd_names, key=lambda k: kernels.get(k, {}).get("total_ms", 0))),
         "roofline_mfma": roofline_mfma,
+        "roofline_path": roofline_path,
         "kernels": kernels,
     }
     if getattr(trainer, "graph_error", None):
         result["graph"] = {"error": trainer.graph_error, "note": "capture failed: every step was issued launch by launch"}
     if graph_info is not None:
         result["graph"] = graph_info
-        result["config"]["launch"] = "hipGraph replay of the whole step in the timed region (LidarTrainer graph mode)"
+        result["config"]["launch"] = "hipGraph replay of the whole step in the timed region (LidarTrainer graph mode)" + (
+            f"; data parallel: the step's collectives ({parallel.backend()}: table-gradient windows, MLP gradients) are "
+            "captured inside the graph, every rank replays its own copy" if trainer.dp else "")
+    elif world > 1:
+        result["config"]["launch"] = ("launch by launch on every rank (" + ("--no-graph" if args.no_graph else
+                                      f"backend {parallel.backend()}: only RCCL collectives can be captured") + ")")
     if comm is not None:
         result["comm"] = comm
     if pretrain is not None:

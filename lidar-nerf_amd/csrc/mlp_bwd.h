@@ -303,32 +303,54 @@ k_mlp_backward(MlpBwdArgs a) {
 
 
 // ---------------------------------------------------------------------------------------------------- wave-independent
-// Backward for ONE-hidden-layer nets (NHM = 0: the sigma net) without LDS transposes or workgroup barriers.
+// Backward for ONE-hidden-layer nets (NHM = 0: the sigma net) without workgroup barriers in the point loop.
 //
-// The MFMA operand layouts are symmetric (A: row = lane&15, B: column = lane&15, same k enumeration), so swapping
-// the two operands of a product yields the TRANSPOSED result in the accumulator layout:
-//      MFMA(A = W, B = X^T)  ->  D[channel 4g+r][point c]      ("channel-major", feeds the next layer as B operand)
-//      MFMA(A = X^T-as-A, B = W-as-B)  ->  D[point 4g+r][channel c]   ("point-major")
-// and a point-major accumulator tile IS a wgrad operand fragment: dW[o][i] = sum_p dH[p][o] * act[p][i] contracts over
-// points, i.e. needs lane (g, o) to hold dH[points 4g+r][o] — exactly D[point 4g+r][channel c = o].  So every wave
-// recomputes its 32 points once in each orientation (MFMA time is negligible here) and accumulates ALL weight-gradient
-// tiles of the net in its own registers; quantities that are not products (dY, x) are transposed by multiplying with an
-// identity fragment.  Waves never wait for each other; the four partial sums of a workgroup are combined through LDS
-// once at the end of the kernel and flushed with one atomic per weight.
+// Every wave back-propagates its 32 points through the layer chain in registers (channel-major: lane (g, c) holds channels
+// 4g + r of point c) and accumulates ALL weight-gradient tiles of the net in its own registers.  A weight gradient
+// contracts over points, so its MFMA operands are the transposes of the chain's fragments: each packed fragment (hidden
+// activation, its gradient, the input rows, the output gradient) is written to a wave-private LDS slab as it is formed and
+// read back transposed with ds_read_b64_tr_b16 (mlp_common.h, "transposes through LDS").  Rounds 1-4 obtained the
+// transposed operands by running the chain a second time with the MFMA operands swapped (the A and B layouts are mirror
+// images, so the product comes out point-major) and by multiplying the quantities that are not products with an identity
+// fragment: 22 MFMAs and a second copy of the activation arithmetic per 32 points, now 12 LDS writes and 22 LDS reads.
+// Waves never wait for each other; the partial sums of a workgroup are combined through LDS once at the end of the
+// kernel and flushed with one atomic per weight.
+template <int IN_KS, int HT>
+struct WiCfg {
+    static constexpr int IT = IN_KS * 2, NT = 2;
+    // slabs of a wave: hidden activation (n, t), its gradient (n, t), input rows (n, i), output gradient (n)
+    static constexpr int SL_H = 0, SL_D = NT * HT, SL_X = 2 * NT * HT, SL_Y = SL_X + NT * IT, NSLAB = SL_Y + NT;
+    static constexpr int NTILE = HT + HT * IT;
+    static constexpr size_t lds_bytes(int nwaves) {
+        const size_t slabs = (size_t)nwaves * NSLAB * kSlabBytes, red = (size_t)NTILE * 256 * sizeof(float);
+        return slabs > red ? slabs : red;
+    }
+};
+
+#ifndef LNH_WI_WAVES
+#define LNH_WI_WAVES 8  // waves per workgroup = 2 per SIMD
+#endif
 template <int IN_KS, int HT, typename IO, int ACT>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(64 * LNH_WI_WAVES)
 k_mlp_backward_wi(MlpBwdArgs a) {
-    constexpr int HS = HT / 2, IT = IN_KS * 2, NT = 2;
-    __shared__ float red[(HT + HT * IT) * 256];
+    using Cfg = WiCfg<IN_KS, HT>;
+    constexpr int HS = HT / 2, IT = Cfg::IT, NT = Cfg::NT;
+    extern __shared__ __attribute__((aligned(16))) char smem_wi[];
+    float *red = reinterpret_cast<float *>(smem_wi);  // (after the point loop, over the slabs)
     const uint32_t wid = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
     const uint32_t hidden = HT * 16, in_dim = a.in_dim, act = a.act, in_tiles = in_dim / 16;
     const bool want_dx = a.dX != nullptr;
     const uint32_t nw = blockDim.x >> 6;
     const uint32_t wave = blockIdx.x * nw + wid, nwaves = gridDim.x * nw;
+    char *slabs = smem_wi + (size_t)__builtin_amdgcn_readfirstlane((int)wid) * Cfg::NSLAB * kSlabBytes;
+    const uint32_t wr_off = (4 * c + g) * 8, rd_off = lane * 8;
+    // natural-k fragments (input rows, output gradients): lane (g, c) holds values 8g .. 8g+7 of a 32-wide k-step =
+    // chunk groups 2(g & 1), 2(g & 1) + 1 of the 16-wide tile g >> 1 of that step
+    const uint32_t wr_nat = (g >> 1) * kSlabBytes + c * 32 + (g & 1) * 16;
 
     const half_t *W0 = a.W;
     const half_t *Wo = W0 + (size_t)hidden * in_dim;
-    half8_t w0[HT][IN_KS], woT[HT], w0T[IT][HS], ident[IT];
+    half8_t w0[HT][IN_KS], woT[HT], w0T[IT][HS];
 #pragma unroll
     for (int t = 0; t < HT; t++) {
 #pragma unroll
@@ -336,15 +358,10 @@ k_mlp_backward_wi(MlpBwdArgs a) {
         woT[t] = load_at_natural(Wo, hidden, 16 * t + c, 0, g, 16);
     }
 #pragma unroll
-    for (int t = 0; t < IT; t++) {
+    for (int t = 0; t < IT; t++)
 #pragma unroll
         for (int s = 0; s < HS; s++)
             w0T[t][s] = (want_dx && (uint32_t)t < in_tiles) ? load_at_nu(W0, in_dim, 16 * t + c, s, g) : zero_h8();
-        // identity fragment selecting natural-k element (16 t' + c) with t' = t & 1 inside a 32-wide k-step:
-        // element j of lane (g, c) is k = 8g + j
-#pragma unroll
-        for (int j = 0; j < 8; j++) ident[t][j] = (8 * g + j == 16 * (t & 1) + c) ? (half_t)1.0f : (half_t)0.0f;
-    }
     f32x4 gWo[HT], gW0[HT][IT];
 #pragma unroll
     for (int t = 0; t < HT; t++) {
@@ -352,16 +369,11 @@ k_mlp_backward_wi(MlpBwdArgs a) {
 #pragma unroll
         for (int i = 0; i < IT; i++) gW0[t][i] = zero_f4();
     }
-    auto pack2 = [](const f32x4 &lo, const f32x4 &hi) {
-        half8_t r = {(half_t)lo[0], (half_t)lo[1], (half_t)lo[2], (half_t)lo[3],
-                     (half_t)hi[0], (half_t)hi[1], (half_t)hi[2], (half_t)hi[3]};
-        return r;
-    };
+    auto slab = [&](int q, int idx) { return slabs + (q + idx) * kSlabBytes; };
 
-    // The kernel runs at 2 waves per SIMD (176 VGPRs: every weight-gradient tile lives in registers), too few to hide the
-    // HBM latency of a tile's input rows behind another wave's arithmetic: the rows of the NEXT tile are requested
-    // before the current tile is processed (software pipelining, one tile deep: 153 -> 137 us; two deep measures the
-    // same and makes the wider instantiations spill).
+    // The kernel runs at 2 waves per SIMD, too few to hide the HBM latency of a tile's input rows behind another wave's
+    // arithmetic: the rows of the NEXT tile are requested before the current tile is processed (software pipelining, one
+    // tile deep: 153 -> 137 us; two deep measures the same and makes the wider instantiations spill).
     auto load_tile = [&](uint64_t base, half8_t (&bx)[NT][IN_KS], half8_t (&by)[NT]) {
 #pragma unroll
         for (int n = 0; n < NT; n++) {
@@ -396,8 +408,14 @@ k_mlp_backward_wi(MlpBwdArgs a) {
         } else {
             load_tile(base, bx, by);
         }
+#pragma unroll
+        for (int n = 0; n < NT; n++) {
+#pragma unroll
+            for (int s = 0; s < IN_KS; s++)
+                *reinterpret_cast<half8_t *>(slab(Cfg::SL_X, n * IT + 2 * s) + wr_nat) = bx[n][s];
+            if (g < 2) *reinterpret_cast<half8_t *>(slab(Cfg::SL_Y, n) + wr_nat) = by[n];
+        }
         // ---- channel-major chain: hidden, its gradient, dX
-        half8_t bd[NT][HS];
 #pragma unroll
         for (int n = 0; n < NT; n++) {
             f32x4 h[HT], d[HT];
@@ -408,19 +426,24 @@ k_mlp_backward_wi(MlpBwdArgs a) {
                 for (int s = 0; s < IN_KS; s++) h[t] = MFMA16(w0[t][s], bx[n][s], h[t]);
                 d[t] = MFMA16(woT[t], by[n], zero_f4());
             }
+            half8_t bd[HS];
 #pragma unroll
             for (int s = 0; s < HS; s++) {
+                half8_t bh;
                 if constexpr (ACT == (int)LNH_ACT_RELU) {
-                    bd[n][s] = pack_pair_relu_bwd(d[2 * s], d[2 * s + 1], pack_pair_relu(h[2 * s], h[2 * s + 1]));
+                    bh = pack_pair_relu(h[2 * s], h[2 * s + 1]);
+                    bd[s] = pack_pair_relu_bwd(d[2 * s], d[2 * s + 1], bh);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        const float p0 = (float)(half_t)act_fwd<ACT>(act, h[2 * s][j]);
-                        const float p1 = (float)(half_t)act_fwd<ACT>(act, h[2 * s + 1][j]);
-                        bd[n][s][j] = (half_t)act_bwd<ACT>(act, d[2 * s][j], p0);
-                        bd[n][s][4 + j] = (half_t)act_bwd<ACT>(act, d[2 * s + 1][j], p1);
+                        bh[j] = (half_t)act_fwd<ACT>(act, h[2 * s][j]);
+                        bh[4 + j] = (half_t)act_fwd<ACT>(act, h[2 * s + 1][j]);
+                        bd[s][j] = (half_t)act_bwd<ACT>(act, d[2 * s][j], (float)bh[j]);
+                        bd[s][4 + j] = (half_t)act_bwd<ACT>(act, d[2 * s + 1][j], (float)bh[4 + j]);
                     }
                 }
+                slab_put_pair(slab(Cfg::SL_H, n * HT + 2 * s), wr_off, bh);
+                slab_put_pair(slab(Cfg::SL_D, n * HT + 2 * s), wr_off, bd[s]);
             }
             if (want_dx) {
                 const uint64_t p = base + n * 16 + c;
@@ -428,59 +451,32 @@ k_mlp_backward_wi(MlpBwdArgs a) {
                 for (int t = 0; t < IT; t++) {
                     f32x4 acc = zero_f4();
 #pragma unroll
-                    for (int s = 0; s < HS; s++) acc = MFMA16(w0T[t][s], bd[n][s], acc);
+                    for (int s = 0; s < HS; s++) acc = MFMA16(w0T[t][s], bd[s], acc);
                     if (p < a.B && (uint32_t)t < in_tiles) IO::store_dx((typename IO::in_t *)a.dX, p, t, g, a.B, in_dim, acc);
                 }
             }
         }
-        // ---- point-major operands + weight gradients
-        f32x4 dy_pm[NT];
+        // ---- weight gradients from the transposed (point-major) operands
+        {
+            const half8_t fy = slab_get_span(slab(Cfg::SL_Y, 0), kSlabBytes, rd_off);
+            half8_t fx[IT];
 #pragma unroll
-        for (int n = 0; n < NT; n++) dy_pm[n] = MFMA16(by[n], ident[0], zero_f4());  // D[point][output c]
-        const half8_t fa_y = pack2(dy_pm[0], dy_pm[1]);
-        half8_t fx[IT];
+            for (int i = 0; i < IT; i++) fx[i] = slab_get_span(slab(Cfg::SL_X, i), IT * kSlabBytes, rd_off);
 #pragma unroll
-        for (int i = 0; i < IT; i++) {
-            f32x4 x_pm[NT];
+            for (int t = 0; t < HT; t++) {
+                const half8_t fh = slab_get_span(slab(Cfg::SL_H, t), HT * kSlabBytes, rd_off);
+                const half8_t fd = slab_get_span(slab(Cfg::SL_D, t), HT * kSlabBytes, rd_off);
+                gWo[t] = MFMA16(fy, fh, gWo[t]);  // dWo[o][16t + c]
 #pragma unroll
-            for (int n = 0; n < NT; n++) x_pm[n] = MFMA16(bx[n][i >> 1], ident[i], zero_f4());  // D[point][feature 16i+c]
-            fx[i] = pack2(x_pm[0], x_pm[1]);
-        }
-#pragma unroll
-        for (int t = 0; t < HT; t++) {
-            f32x4 h_pm[NT], d_pm[NT];
-#pragma unroll
-            for (int n = 0; n < NT; n++) {
-                h_pm[n] = zero_f4();
-#pragma unroll
-                for (int s = 0; s < IN_KS; s++) h_pm[n] = MFMA16(bx[n][s], w0[t][s], h_pm[n]);  // D[point][channel 16t+c]
-                d_pm[n] = MFMA16(by[n], woT[t], zero_f4());
-                if constexpr (ACT != (int)LNH_ACT_RELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const float post = (float)(half_t)act_fwd<ACT>(act, h_pm[n][r]);
-                        h_pm[n][r] = post;
-                        d_pm[n][r] = act_bwd<ACT>(act, d_pm[n][r], post);
-                    }
-                }
+                for (int i = 0; i < IT; i++) gW0[t][i] = MFMA16(fd, fx[i], gW0[t][i]);  // dW0[16t + .][16i + c]
             }
-            half8_t fh, fd;
-            if constexpr (ACT == (int)LNH_ACT_RELU) {
-                fh = pack_pair_relu(h_pm[0], h_pm[1]);
-                fd = pack_pair_relu_bwd(d_pm[0], d_pm[1], fh);
-            } else {
-                fh = pack2(h_pm[0], h_pm[1]);
-                fd = pack2(d_pm[0], d_pm[1]);
-            }
-            gWo[t] = MFMA16(fa_y, fh, gWo[t]);  // dWo[o][16t + c]
-#pragma unroll
-            for (int i = 0; i < IT; i++) gW0[t][i] = MFMA16(fd, fx[i], gW0[t][i]);  // dW0[16t + .][16i + c]
         }
     }
 
     // ---- combine the waves of the workgroup through LDS, then one atomic per weight.  The whole gradient is only
     //      ~100 cache lines, so device atomics on it serialise: keep the number of flushing workgroups ~ #CUs.
-    constexpr int NTILE = HT + HT * IT;
+    constexpr int NTILE = Cfg::NTILE;
+    __syncthreads();  // (the reduction buffer lies over the slabs)
     for (uint32_t w = 0; w < nw; w++) {
         if (wid == w) {
 #pragma unroll
@@ -517,13 +513,12 @@ k_mlp_backward_wi(MlpBwdArgs a) {
 
 template <int IN_KS, int HT, typename IO = RowMajorIO>
 int launch_mlp_backward_wi(const MlpBwdArgs &a, hipStream_t s) {
-    const uint32_t iters = div_up(a.B, 8 * 32);
+    const uint32_t iters = div_up(a.B, LNH_WI_WAVES * 32);
     const uint32_t grid = iters < 256 ? iters : 256;
-    if (a.act == LNH_ACT_RELU) {
-        LNH_LAUNCH((k_mlp_backward_wi<IN_KS, HT, IO, (int)LNH_ACT_RELU>), dim3(grid), dim3(512), 0, s, a);
-    } else {
-        LNH_LAUNCH((k_mlp_backward_wi<IN_KS, HT, IO, -1>), dim3(grid), dim3(512), 0, s, a);
-    }
+    const size_t lds = WiCfg<IN_KS, HT>::lds_bytes(LNH_WI_WAVES);
+    auto k = a.act == LNH_ACT_RELU ? k_mlp_backward_wi<IN_KS, HT, IO, (int)LNH_ACT_RELU> : k_mlp_backward_wi<IN_KS, HT, IO, -1>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    LNH_LAUNCH(k, dim3(grid), dim3(64 * LNH_WI_WAVES), lds, s, a);
     return lnh_check_launch("lnh_mlp_backward");
 }
 

@@ -190,22 +190,58 @@ __device__ __forceinline__ half8_t pack_pair_relu(const f32x4 &lo, const f32x4 &
 #endif
 }
 // ReLU backward on packed halves: narrow(d) where the stored (non-negative, never -0) activation h is non-zero, else 0.
-// Three packed integer ops per PAIR of values: nz = min(bits(h), 1) per half, m = 0 - nz (0 / 0xffff), d & m.
+// Two packed integer ops per PAIR of values: nz = min(bits(h), 1) per half (0 / 1), bits(d) * nz (16-bit low product:
+// the bits themselves or 0; rounds 1-4: m = 0 - nz, d & m — three).  The min is inline asm so that the compiler cannot
+// know nz is 0 / 1 (told so, it rewrites the product as 8 compares + 8 selects + 4 byte permutes per fragment); the
+// product — the instruction whose result feeds an MFMA operand — is a vector multiply the compiler sees
+// (v_pk_mul_lo_u16), because the hazard recogniser only pads instructions it knows (see pack_pair_relu).
 __device__ __forceinline__ half8_t pack_pair_relu_bwd(const f32x4 &lo, const f32x4 &hi, const half8_t &h) {
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    typedef unsigned short us8 __attribute__((ext_vector_type(8)));
     const half4_t a = __builtin_convertvector(lo, half4_t), b = __builtin_convertvector(hi, half4_t);
     const half8_t d = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-    u4 dw = __builtin_bit_cast(u4, d);
     const u4 hw = __builtin_bit_cast(u4, h);
+    u4 nz;
     const uint32_t ones = 0x00010001u;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        uint32_t nz, m;
-        asm("v_pk_min_u16 %0, %1, %2" : "=v"(nz) : "v"(hw[i]), "v"(ones));
-        asm("v_pk_sub_i16 %0, 0, %1" : "=v"(m) : "v"(nz));
-        dw[i] &= m;
-    }
-    return __builtin_bit_cast(half8_t, dw);
+    for (int i = 0; i < 4; i++) asm("v_pk_min_u16 %0, %1, %2" : "=v"(nz[i]) : "v"(hw[i]), "v"(ones));
+    return __builtin_bit_cast(half8_t, (us8)(__builtin_bit_cast(us8, d) * __builtin_bit_cast(us8, nz)));
+}
+
+// ---------------------------------------------------------------------------------- transposes through LDS (gfx950)
+// Weight gradients contract over POINTS, the layer chain over CHANNELS: the chain leaves, per 16x16 tile, lane (g, c)
+// holding channels 4g .. 4g+3 of point c (four 16-bit values = one 8-byte CHUNK), a weight-gradient MFMA operand wants
+// lane (g, c) to hold channel c of four points.  ds_read_b64_tr_b16 is that transpose: within a group of 16 lanes,
+// element j of lane l comes from the chunk whose address lane 4j + (l >> 2) supplies, element l & 3 of it.  A tile's 64
+// chunks are kept as a SLAB of 512 bytes, chunk (point c, channel group q) at byte (4c + q) * 8; the read with the
+// lane-linear address slab + 8 * lane then returns, in lane (g, c): channel c of points 4g .. 4g+3.  Two such reads
+// (the two 16-point tiles of a 32-point span) are one 8-value operand with the point enumeration k(g, j) = tile j >> 2,
+// point 4g + (j & 3) — the same for both operands of a product, which is all a dot product asks.  Slabs are private to
+// a wave and LDS instructions of a wave execute in order: no barrier, no fence.  (Rounds 2-4 transposed with an MFMA
+// against an identity fragment plus two packed conversions per tile; this is one LDS write per PAIR of tiles and one
+// read per tile, and no VALU instruction at all.)
+typedef short lds_tr_raw_t __attribute__((__vector_size__(4 * sizeof(short))));
+constexpr uint32_t kSlabBytes = 512;
+// chunks of a nu-enumerated packed pair (M-tiles 2s and 2s+1 of one point tile): slabs of the two tiles 512 bytes apart
+__device__ __forceinline__ void slab_put_pair(char *slab2, uint32_t wr_off, const half8_t &v) {
+    const half4_t lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
+    *reinterpret_cast<half4_t *>(slab2 + wr_off) = lo;
+    *reinterpret_cast<half4_t *>(slab2 + kSlabBytes + wr_off) = hi;
+}
+__device__ __forceinline__ half4_t slab_get(const char *slab, uint32_t rd_off) {
+    const lds_tr_raw_t r = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) lds_tr_raw_t *)(slab + rd_off));
+    return __builtin_bit_cast(half4_t, r);
+}
+// the 8-value operand of one channel tile over the 32 points of a span: slabs of point tiles 0 and 1, `stride` bytes apart
+__device__ __forceinline__ half8_t slab_get_span(const char *slab_n0, uint32_t stride, uint32_t rd_off) {
+    const half4_t a = slab_get(slab_n0, rd_off), b = slab_get(slab_n0 + stride, rd_off);
+    const half8_t r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return r;
+}
+// acc += a * b, accumulator pinned to AGPRs, operands that come straight out of LDS reads (no VALU producer: no wait states)
+__device__ __forceinline__ void mfma16_acc_agpr_ld(f32x4 &acc, const half8_t &a, const half8_t &b) {
+    asm(LNH_MFMA16_MNEMONIC " %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
 // activation resolved at compile time: ReLU takes the packed path, everything else the generic one
 template <int ACT>

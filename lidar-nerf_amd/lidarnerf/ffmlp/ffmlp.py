@@ -194,11 +194,16 @@ class FFMLP(nn.Module):
     hidden-32 kernels, 32 / 64 with at most 3 hidden layers with weights AND weight gradients in registers (forward and
     backward one kernel each), 128 / 256 and deeper nets with weight fragments loaded where they are used and the backward
     split as the reference splits its own — a fused kernel for the activation / input gradients, library GEMMs for the
-    weight gradients (ffmlp.cu:578-733, 1107-1263).  What has no kernel — input_dim > 128, more than 15 hidden layers — is
-    refused exactly as the C ABI refuses it (LNH_ERR_UNSUPPORTED) unless the caller asks for the alternative:
-    `gemm_chain=True` runs every layer as a library GEMM (torch.matmul, the same 16-bit storage model, autograd)."""
+    weight gradients (ffmlp.cu:578-733, 1107-1263).  What has no kernel — input_dim > 128, more than 15 hidden layers — the
+    reference's constructor accepts (any input_dim % 16 == 0, ffmlp.py:202-216), so it is accepted here too and runs every
+    layer as a library GEMM (torch.matmul, the same 16-bit storage model, autograd) with a one-time warning;
+    `gemm_chain=True` asks for that chain explicitly (no warning), `strict_fused=True` refuses such shapes the way the C
+    ABI does (LNH_ERR_UNSUPPORTED)."""
 
-    def __init__(self, input_dim, output_dim, hidden_dim, num_layers, activation="relu", gemm_chain=False):
+    _warned_gemm_chain = False
+
+    def __init__(self, input_dim, output_dim, hidden_dim, num_layers, activation="relu", gemm_chain=False,
+                 strict_fused=False):
         super().__init__()
         self.input_dim, self.output_dim, self.hidden_dim, self.num_layers = input_dim, output_dim, hidden_dim, num_layers
         self.activation = convert_activation(activation)
@@ -212,11 +217,16 @@ class FFMLP(nn.Module):
         self.gemm_chain = bool(gemm_chain)
         fused = kernel_supported(input_dim, 32 if hidden_dim == 16 else hidden_dim, num_layers - 1)
         if not fused and not self.gemm_chain:
-            raise RuntimeError(
-                f"FFMLP(input_dim={input_dim}, hidden_dim={hidden_dim}, num_layers={num_layers}): no fused MFMA kernel for "
-                "this shape in this build (kernels: hidden_dim 16 .. 256, num_layers <= 15, input_dim <= 128 — the C ABI "
-                "refuses it the same way: lnh_mlp_forward returns LNH_ERR_UNSUPPORTED).  Pass gemm_chain=True to run it as a "
-                "chain of library GEMMs instead.")
+            msg = (f"FFMLP(input_dim={input_dim}, hidden_dim={hidden_dim}, num_layers={num_layers}): no fused MFMA kernel for "
+                   "this shape in this build (kernels: hidden_dim 16 .. 256, num_layers <= 15, input_dim <= 128; the C ABI "
+                   "returns LNH_ERR_UNSUPPORTED for it)")
+            if strict_fused:
+                raise RuntimeError(msg + ".  Drop strict_fused to run it as a chain of library GEMMs instead.")
+            if not FFMLP._warned_gemm_chain:
+                import warnings
+                warnings.warn(msg + ": running it as a chain of library GEMMs (torch.matmul), same storage model.")
+                FFMLP._warned_gemm_chain = True
+            self.gemm_chain = True
         self.padded_output_dim = int(math.ceil(output_dim / 16)) * 16
         self.num_parameters = hidden_dim * (input_dim + hidden_dim * (num_layers - 1) + self.padded_output_dim)
         self.weights = nn.Parameter(torch.zeros(self.num_parameters))

@@ -386,7 +386,7 @@ class FusedLidarRender(Function):
         g_feat = torch.empty((enc.num_levels, B_all, 2), dtype=torch.half, device=dev)
         _hip.call("lnh_density_mlp_backward" + sfx, g_h16.data_ptr(), feat.data_ptr(), wsig16.data_ptr(), B_all, Ttot, Ttot, 0,
                   g_feat.data_ptr(), g_wsig.data_ptr())
-        if parallel.world_size() > 1 and getattr(ctx.table_param, "_lnh_shard_optimizer", False):
+        if parallel.dp_active() and getattr(ctx.table_param, "_lnh_shard_optimizer", False):
             # data parallel, sharded table optimizer: reduce-scatter per window; the trainer steps this rank's rows
             ctx.table_param._lnh_grad16_shards = _grid_bwd_sharded(g_feat, x01, enc, B_all, ctx.table_param)
             ctx.table_param._lnh_grad16_div = parallel.world_size()
@@ -396,7 +396,7 @@ class FusedLidarRender(Function):
                     g_wsig[64 * 32:].view(16, 64).to(dts[2]), g_wc0.to(dts[3]), g_wc1.to(dts[4]), g_wc2.to(dts[5]),
                     None, None, None, None, None, None, None)
         g_table16 = torch.zeros((int(enc._offsets_host[-1]), 2), dtype=torch.half, device=dev)
-        if parallel.world_size() > 1 or FORCE_DP_WINDOWS:
+        if parallel.dp_active() or FORCE_DP_WINDOWS:
             # data parallel: the table gradient goes on the wire as fp16, window by window, behind the kernels of the
             # following windows
             handles = _grid_bwd_overlapped(g_feat, x01, g_table16, enc, B_all, ctx.table_param)
@@ -553,7 +553,7 @@ class FusedLidarRagged(Function):
             dev = table_param.device
             g_table16 = torch.zeros((int(enc._offsets_host[-1]), 2), dtype=torch.half, device=dev)
             world = parallel.world_size()
-            if world > 1:
+            if parallel.dp_active():
                 off = enc._offsets_host
                 handles = []
                 for l0, l1 in (_DP_LEVEL_WINDOWS if enc.num_levels == 16 else ((0, enc.num_levels),)):
@@ -598,7 +598,7 @@ class FusedLidarRagged(Function):
                   g_feat.data_ptr(), g_wsig.data_ptr())
         g_table16 = torch.zeros((int(enc._offsets_host[-1]), 2), dtype=torch.half, device=dev)
         world = parallel.world_size()
-        if world > 1:
+        if parallel.dp_active():
             for handle in _grid_bwd_overlapped(g_feat, x01, g_table16, enc, M, table_param):
                 handle.wait()
         else:

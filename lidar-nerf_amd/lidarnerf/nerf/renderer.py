@@ -259,12 +259,21 @@ class NeRFRenderer(nn.Module):
         rays_o = rays_o.contiguous().view(-1, 3).float()
         rays_d = rays_d.contiguous().view(-1, 3).float()
         N = rays_o.shape[0]
-        # (a constant per ray count: kept — never freed, a captured step may hold its address)
-        cache = self.__dict__.setdefault("_nears_cache", {})
-        key = (N, rays_o.device, float(self.min_near_lidar))
-        nears = cache.get(key)
-        if nears is None:
-            nears = cache[key] = torch.full((N,), float(self.min_near_lidar), dtype=torch.float32, device=rays_o.device)
+        # (a constant per ray count: kept.  While a step is being captured the tensor is made for the occasion and NOT
+        #  kept — it would come from the graph's private pool with its fill recorded as a graph node only, and a capture
+        #  that fails would leave later eager steps reading uninitialised memory; the cache is bounded: evaluation with
+        #  varying batch sizes must not grow it for ever.  A captured step holds its own reference to the tensor it used.)
+        if rays_o.is_cuda and torch.cuda.is_current_stream_capturing():
+            nears = torch.full((N,), float(self.min_near_lidar), dtype=torch.float32, device=rays_o.device)
+        else:
+            cache = self.__dict__.setdefault("_nears_cache", {})
+            key = (N, rays_o.device, float(self.min_near_lidar))
+            nears = cache.get(key)
+            if nears is None:
+                if len(cache) >= 8:
+                    cache.pop(next(iter(cache)))
+                nears = cache[key] = torch.full((N,), float(self.min_near_lidar), dtype=torch.float32,
+                                                device=rays_o.device)
         # 1 m .. 81 m, cut at the ray's exit from the box: the marcher clamps sample POSITIONS to the box, and the compositing
         # kernel recovers a sample's depth from its position ((xyz - o) . d) — a sample marched past the box would enter
         # the depth sum with a shortened z (the dense path keeps the true z next to the clamped position, renderer.py:164-167)

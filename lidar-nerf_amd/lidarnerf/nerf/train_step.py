@@ -92,6 +92,9 @@ class LidarTrainer:
             raise RuntimeError(f"LidarTrainer(world_size={world_size}) but the initialised process group has "
                                f"{parallel.world_size()} rank(s): call torch.distributed.init_process_group first")
         self.model, self.fp16, self.world, self.amp_dtype = model, fp16, world_size, mlp_dtype
+        # the gradient exchange runs with more than one rank — or on a one-rank process group that was asked to exchange
+        # all the same (parallel.FORCE_SINGLE_RANK: the way to run the collectives through RCCL on a one-GPU box)
+        self.dp = world_size > 1 or parallel.dp_active()
         self.alpha = (alpha_d, alpha_r, alpha_i, alpha_grad)
         self.scale = scale
         self.render_kwargs = render_kwargs or {}
@@ -126,7 +129,7 @@ class LidarTrainer:
                 # data parallel, second cut (parallel.py): reduce-scatter of the table gradient, every rank steps 1/N of
                 # the rows, all-gather of the fp16 compute copy.  The fp32 master table and the Adam moments of a rank are
                 # then current on ITS rows only: gather_table_state() completes them (checkpoints call it).
-                self.sharded = bool(shard_table_optimizer and world_size > 1)
+                self.sharded = bool(shard_table_optimizer and self.dp)
                 tp._lnh_shard_optimizer = self.sharded
                 tp._lnh_master_stale = False
         params = [g for g in params if len(g["params"])]
@@ -136,20 +139,26 @@ class LidarTrainer:
         if len(params) > 1 and all({k: v for k, v in g.items() if k != "params"} ==
                                    {k: v for k, v in params[0].items() if k != "params"} for g in params):
             params = [dict(params[0], params=[p for g in params for p in g["params"]])]
-        # graph=True (fused chain + fused table optimizer, one GPU): the whole step — (march,) render chain, loss, backward,
-        # both optimizers, loss-scale update — is captured in a hipGraph per (batch shape, sample capacity) and replayed
-        # (_step_graphed).  Built for occupancy-grid sampling; the dense step (no data-dependent sizes at all) captures the
-        # same way and then costs the host 0.05 ms instead of ~0.8 — it is GPU-bound either way on the hosts of this build,
-        # a slower host would not be.  The step is ~45 launches over ~0.4 M samples: eager, the host cannot issue them as fast
-        # as the GPU retires them (profiles/r04_bench_nerfmvl.json: 1.0 ms of host time per 0.7 ms of kernels).  What a
-        # capture freezes — kernel arguments — must not change between replays, so the learning rate becomes a device
-        # scalar (torch's capturable Adam, lnh_adam_table_step_dlr) and the marcher's sample capacity comes from a ladder
-        # of sizes (_graph_capacity; the reference sizes it to the running mean rounded to 128, raymarching.py:223-229: a
-        # larger buffer drops fewer rays on overflow, nothing else changes).
-        self.graph = bool(graph and self.table is not None and world_size == 1 and on_gpu)
+        # graph=True (fused chain + fused table optimizer): the whole step — (march,) render chain, loss, backward, (the
+        # gradient exchange,) both optimizers, loss-scale update — is captured in a hipGraph per (batch shape, sample
+        # capacity) and replayed (_step_graphed).  Built for occupancy-grid sampling; the dense step (no data-dependent sizes
+        # at all) captures the same way and then costs the host 0.05 ms instead of ~0.8 — it is GPU-bound either way on the
+        # fast hosts of this build, a slower host is not (3.42 against 2.21 ms).  The step is ~45 launches over
+        # ~0.4 M samples: eager, the host cannot issue them as fast as the GPU retires them (profiles/r04_bench_nerfmvl.json:
+        # 1.0 ms of host time per 0.7 ms of kernels).  What a capture freezes — kernel arguments — must not change between
+        # replays, so the learning rate becomes a device scalar (torch's capturable Adam, lnh_adam_table_step_dlr) and the
+        # marcher's sample capacity comes from a ladder of sizes (_graph_capacity; the reference sizes it to the running
+        # mean rounded to 128, raymarching.py:223-229: a larger buffer drops fewer rays on overflow, nothing else changes).
+        # Data parallel (round 5): under RCCL (backend "nccl") the collectives of the step — the windowed fp16 all-reduce
+        # or reduce-scatter / all-gather of the table, the MLP gradients, the found-inf MAX — are captured with it, each on
+        # RCCL's own stream inside the graph, so N ranks replay N identical graphs and none of them is host-bound (eight
+        # processes share the 16-CPU quota of a box).  gloo cannot be captured (its collectives synchronise with the host).
+        self.graph = bool(graph and self.table is not None and on_gpu and (not self.dp or parallel.backend() == "nccl"))
         if graph and not self.graph:
             raise RuntimeError("LidarTrainer(graph=True): the captured step needs the fused chain with the fused table "
-                               "optimizer (fp16, a fusable field on the GPU) on one GPU — collectives are not captured")
+                               "optimizer (fp16, a fusable field on the GPU)" +
+                               (f" and, data parallel, the 'nccl' (RCCL) backend — this process group runs "
+                                f"'{parallel.backend()}', whose collectives cannot be captured" if self.dp else ""))
         self._graphs, self._graph_warm, self._graph_pool, self.graph_error = {}, set(), None, None
         if self.graph:
             dev0 = self.table.device
@@ -197,7 +206,7 @@ class LidarTrainer:
         with torch.autocast("cuda", dtype=self.amp_dtype):
             loss = self.loss(rays_o, rays_d, images_lidar, patch)
         loss.backward(gradient=self.loss_scale.to(loss.dtype))  # = (loss * scale).backward() without the product and its ones_like
-        if self.world > 1:
+        if self.dp:
             parallel.allreduce_gradients(self.params, self.world)
         # --- GradScaler.step / update, with the table handled by the fused kernels
         found_inf = torch.zeros((), dtype=torch.float32, device=tp.device)
@@ -285,7 +294,17 @@ class LidarTrainer:
             self._graph_warm.add("eager")
             model._static_march = None
             return self._step_fused_table(rays_o, rays_d, images_lidar, patch).detach()
-        key = (tuple(rays_o.shape), tuple(images_lidar.shape), tuple(patch), cap)
+        # what a capture bakes in as kernel arguments is part of the key: the loss weights, the scene scale, the render
+        # arguments (a change of any of them captures a new step instead of silently replaying the old values)
+        key = (tuple(rays_o.shape), tuple(images_lidar.shape), tuple(patch), cap, tuple(self.alpha), float(self.scale),
+               tuple(sorted((k, repr(v)) for k, v in self.render_kwargs.items())))
+        tp = self.table
+        if getattr(tp, "_lnh_table16_version", None) != tp._version:
+            # somebody wrote the fp32 table through torch since the last step (model.load_state_dict, a manual
+            # re-initialisation): a replay never runs table16_of, so the fp16 compute copy is re-cast here — the captured
+            # kernels read it in place
+            from .fused import table16_of
+            table16_of(tp)
         ent = self._graphs.get(key)
         if ent is None:
             dev = self.table.device
@@ -303,8 +322,14 @@ class LidarTrainer:
                 model._static_march = (ent["counter"], cap - 128)  # (march_rays_train adds its 128-alignment on top)
             try:
                 torch.cuda.synchronize()
-                with torch.cuda.graph(ent["graph"], pool=self._graph_pool):
+                # (data parallel: RCCL's watchdog thread polls its events while this thread captures — a capture that
+                #  polices every thread of the process would trip over it)
+                with torch.cuda.graph(ent["graph"], pool=self._graph_pool,
+                                      capture_error_mode="thread_local" if self.dp else "global"):
                     ent["loss"] = self._step_fused_table(ent["rays_o"], ent["rays_d"], ent["gt"], patch).detach()
+                # the gradient and the scale it carries live in THIS graph's buffers: table_grad() must see the ones of
+                # the graph that was replayed last, not of the one that was captured last
+                ent["g16"], ent["last_scale"] = tp._lnh_grad16, self._last_scale
             except Exception as e:  # noqa: BLE001 — a capture that does not go through must not cost the run
                 # (nothing of a captured step has executed: the state is what it was.)  Launch by launch from here on; the
                 # reason stays readable (bench.py reports it).
@@ -317,6 +342,7 @@ class LidarTrainer:
         else:
             torch._foreach_copy_([ent["rays_o"], ent["rays_d"], ent["gt"]], [rays_o, rays_d, images_lidar])  # one launch
         ent["graph"].replay()
+        tp._lnh_grad16, self._last_scale = ent["g16"], ent["last_scale"]
         if self.occupancy:
             model.step_counter[model.local_step % 16].copy_(ent["counter"])
             model.local_step += 1
@@ -476,6 +502,12 @@ class LidarTrainer:
         self.optimizer.load_state_dict(own)
         self._after_optimizer_load()
 
+    def _drop_graphs(self):
+        """Forget every captured step: the next step runs launch by launch (taking every lazy initialisation and version
+        check with it), the one after is captured afresh."""
+        self._graphs.clear()
+        self._graph_warm.clear()
+
     def _after_optimizer_load(self):
         """Graph mode: the learning rate stays a device scalar whatever the loaded state held, and every captured step is
         dropped (Optimizer.load_state_dict replaces the tensors a capture holds pointers to)."""
@@ -484,8 +516,7 @@ class LidarTrainer:
         for g in self.optimizer.param_groups:
             if not torch.is_tensor(g["lr"]) or not g["lr"].is_cuda:
                 g["lr"] = torch.tensor(float(g["lr"]), dtype=torch.float32, device=self.table.device)
-        self._graphs.clear()
-        self._graph_warm.clear()
+        self._drop_graphs()
 
     def _own_group_of_ref_group(self):
         """For every parameter group of the reference's optimizer: index of the group of self.optimizer that steps its
@@ -567,6 +598,9 @@ class LidarTrainer:
     def load_checkpoint(self, path, model_only=False):
         """Trainer.load_checkpoint (utils.py:1511-1568): a bare state dict or the dictionary above; strict=False."""
         ck = torch.load(path, map_location=next(self.model.parameters()).device, weights_only=False)
+        # whatever the file holds, the model is about to change under the captured steps (a bare state dict and
+        # model_only=True never reach _after_optimizer_load): drop them on every path
+        self._drop_graphs()
         if "model" not in ck:
             self.model.load_state_dict(ck)
             return [], []
@@ -605,7 +639,7 @@ class LidarTrainer:
         with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.fp16):
             loss = self.loss(rays_o, rays_d, images_lidar, patch)
         self.scaler.scale(loss).backward()
-        if self.world > 1:
+        if self.dp:
             parallel.allreduce_gradients(self.params, self.world)
         self.scaler.step(self.optimizer)
         self.scaler.update()

@@ -22,7 +22,7 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or FORCE_SINGLE_RANK) and not dist.is_initialized():
         backend = backend or os.environ.get("LNH_DIST_BACKEND")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -44,7 +44,7 @@ def allreduce_gradients(params, world=None, small_numel=1 << 20):
     """Average .grad over ranks.  Large tensors individually, small ones through one flat buffer."""
     if world is None:
         world = dist.get_world_size() if dist.is_initialized() else 1
-    if world <= 1:
+    if world <= 1 and not dp_active():
         return
     big, small = [], []
     for p in params:
@@ -73,6 +73,26 @@ def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+# A process group of ONE rank normally exchanges nothing (every `world > 1` test below is false).  LNH_DP_SINGLE_RANK=1 (or
+# parallel.FORCE_SINGLE_RANK = True) makes an initialised one-rank group take the data-parallel code paths all the same —
+# windowed fp16 all-reduce, reduce-scatter -> sharded optimizer -> all-gather, sharded evaluation — with collectives that
+# are identities: the way to run the exchange through RCCL (backend "nccl") on a box with a single GPU, bit-identical to
+# the step without a process group (tests/test_rccl_gpu.py).
+FORCE_SINGLE_RANK = os.environ.get("LNH_DP_SINGLE_RANK", "") not in ("", "0")
+
+
+def dp_active():
+    """True when the gradient exchange runs: more than one rank, or a one-rank group with FORCE_SINGLE_RANK."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or FORCE_SINGLE_RANK
+
+
+def backend():
+    """Backend of the default process group ('nccl' = RCCL on ROCm, 'gloo'), or None without one."""
+    return dist.get_backend() if dist.is_available() and dist.is_initialized() else None
+
+
 def allreduce_half_table(g_table16, param):
     """SUM the hash-table gradient over ranks WHILE IT IS STILL fp16 (27 MB instead of 55 MB on the wire; the kernels
     produce it in fp16 anyway).  Returns a handle to wait on; marks `param` so allreduce_gradients skips it.
@@ -81,8 +101,7 @@ def allreduce_half_table(g_table16, param):
     log2(world) bits at the bottom of the fp16 range and flush small scaled gradients to zero.  An fp16 overflow of the
     sum surfaces as inf, which GradScaler turns into a skipped step + smaller scale, exactly as it does for a
     single-rank overflow."""
-    w = world_size()
-    if w <= 1:
+    if not dp_active():
         return None
     param._lnh_grad_reduced = True
     return dist.all_reduce(g_table16, op=dist.ReduceOp.SUM, async_op=True)
@@ -117,7 +136,7 @@ def render_sharded(model, rays_o, rays_d, **render_kwargs):
     depth / image pieces are all-gathered, every rank returns the complete result (the reference's dormant hooks:
     lidarnerf/nerf/utils.py:1327-1350 gather `preds` the same way).  rays_o / rays_d [1, N, 3]."""
     world = world_size()
-    if world <= 1:
+    if not dp_active():
         return model.render(rays_o, rays_d, **render_kwargs)
     rank = dist.get_rank()
     N = rays_o.shape[1]
@@ -143,7 +162,7 @@ def render_sharded(model, rays_o, rays_d, **render_kwargs):
 
 def broadcast_parameters(module, src=0):
     """Make every replica start from rank `src`'s weights."""
-    if not dist.is_initialized() or dist.get_world_size() <= 1:
+    if not dp_active():
         return
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):

@@ -77,10 +77,18 @@ def test_module_api_and_state_dict_layout():
     # every width of the reference and deeper nets construct (fused kernels exist for all of them) ...
     for hidden, layers in ((16, 2), (128, 2), (256, 3), (64, 5)):
         assert FFMLP(32, 3, hidden, layers).weights.numel() == hidden * (32 + hidden * (layers - 1) + 16)
-    # ... what has no kernel is refused like the C ABI refuses it, unless the GEMM chain is asked for
+    # ... what has no kernel constructs like the reference's does (any input_dim % 16 == 0, ffmlp.py:202-216) and takes the
+    # library-GEMM chain with ONE warning; strict_fused=True refuses it like the C ABI refuses it
+    import warnings
+    FFMLP._warned_gemm_chain = False
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        for in_dim, layers in ((256, 2), (32, 17)):
+            assert FFMLP(in_dim, 3, 64, layers).gemm_chain
+    assert len([w for w in rec if "no fused MFMA kernel" in str(w.message)]) == 1
     for in_dim, layers in ((256, 2), (32, 17)):
         with pytest.raises(RuntimeError, match="no fused MFMA kernel"):
-            FFMLP(in_dim, 3, 64, layers)
+            FFMLP(in_dim, 3, 64, layers, strict_fused=True)
         assert FFMLP(in_dim, 3, 64, layers, gemm_chain=True).gemm_chain
     net = NeRFNetwork(encoding="hashgrid", desired_resolution=2048, bound=1, min_near_lidar=0.01)
     keys = set(net.state_dict().keys())

@@ -267,10 +267,11 @@ def test_ffmlp_module_all_reference_widths(hidden, layers, in_dim):
     n = {k: len(calls.get(k, [])) for k in names}
     wide = hidden >= 128 or layers - 1 > 2
     assert n == {"lnh_mlp_forward": 1, "lnh_mlp_backward": 0 if wide else 1, "lnh_mlp_backward_data": 1 if wide else 0}, n
-    # what still has no kernel is refused, unless the GEMM chain is asked for
-    with pytest.raises(RuntimeError, match="no fused MFMA kernel.*gemm_chain=True"):
-        FFMLP(256, 5, hidden, layers)
-    big = FFMLP(256, 5, hidden, layers, gemm_chain=True).cuda()
+    # what still has no kernel runs as the library-GEMM chain (the reference's constructor accepts it); strict_fused refuses
+    with pytest.raises(RuntimeError, match="no fused MFMA kernel"):
+        FFMLP(256, 5, hidden, layers, strict_fused=True)
+    big = FFMLP(256, 5, hidden, layers).cuda()
+    assert big.gemm_chain
     with torch.autocast("cuda", dtype=torch.float16):
         assert big(torch.randn(64, 256, device="cuda")).shape == (64, 5)
 

