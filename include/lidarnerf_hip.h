@@ -387,7 +387,8 @@ LNH_API int lnh_lidar_merge_weights(const float *z, const float *sigma_pt, const
  *   [64,32 | 16,64]) and lnh_lidar_color_* (wcol16: W0g [64,16] = (0 | wc0[:, n_dir:n_dir+15]) | wc1 [64,64] | wc2 -> [16,64]).
  * lnh_lidar_loss: nerf/utils.py:712-746 default criteria, loss = mean_n(alpha_d*|d-gd| + alpha_r*(r-gr)^2 +
  *   alpha_i*(i-gi)^2) with predictions/targets masked by gt ray-drop; gt [N,3] = (raydrop, intensity, depth); also
- *   writes d loss/d depth [N] and d loss/d image [N,2].
+ *   writes d loss/d depth [N] and d loss/d image [N,2], multiplied by *grad_scale when grad_scale != NULL (the loss
+ *   scale of the training step: backward() then has nothing left to multiply).  `loss` need not be cleared.
  */
 LNH_API int lnh_lidar_coarse_samples(const float *u, uint32_t N, uint32_t T, float near, float far, float *z,
                                      lnh_stream_t stream);
@@ -397,22 +398,25 @@ LNH_API int lnh_lidar_dir_term(const float *dir_features, const float *w0, uint3
  * (lnh_freq_encode_forward's layout and arithmetic: x | sin(2^f x), sin(2^f x + pi/2) per band) -> features16, cdir. */
 LNH_API int lnh_lidar_dir_term_freq(const float *dirs, uint32_t degree, const float *w0, uint32_t ldw, uint32_t N,
                                     float *features16, float *cdir, lnh_stream_t stream);
-/* grad_w0[o*ldw + k] += sum_n ray_sum[n,o] * features16[n,k]  (ray_sum [N,64] from lnh_lidar_color_backward);
- * scratch: ceil(N/32) * 64 * 128 floats. */
+/* grad_w0[o*ldw + k] += sum_n ray_sum[n,o] * features16[n,k], k < K  (ray_sum [N,64] from lnh_lidar_color_backward; the
+ * sums are ADDED with device atomics: clear grad_w0 first).  grad_w0g != NULL: the packed [64,16] gradient of the colour
+ * head's geo-feature columns (what lnh_lidar_color_backward accumulates at the front of its grad_w) is copied to
+ * grad_w0[o*ldw + K + c] = grad_w0g[o*16 + 1 + c], c < 15 — the whole gradient of network.py:199's first Linear in one launch. */
 LNH_API int lnh_lidar_dir_term_backward(const float *ray_sum, const float *features16, uint32_t N, uint32_t K,
-                                        float *scratch, float *grad_w0, uint32_t ldw, lnh_stream_t stream);
+                                        const float *grad_w0g, float *grad_w0, uint32_t ldw, lnh_stream_t stream);
 LNH_API int lnh_lidar_pack_weights(const float *ws0, uint32_t ld_s0, const float *ws1, uint32_t ld_s1,
                                    const float *wc0, uint32_t ld_c0, uint32_t n_dir, const float *wc1, uint32_t ld_c1,
                                    const float *wc2, uint32_t ld_c2, void *wsig16, void *wcol16, lnh_stream_t stream);
 LNH_API int lnh_lidar_loss(const float *depth, const float *image, const float *gt, uint32_t N, float alpha_d,
-                           float alpha_r, float alpha_i, float *loss, float *grad_depth, float *grad_image,
-                           lnh_stream_t stream);
+                           float alpha_r, float alpha_i, const float *grad_scale, float *loss, float *grad_depth,
+                           float *grad_image, lnh_stream_t stream);
 /* The same with the structural-gradient term of the reference's patch epochs (nerf/utils.py:760-876, non-sobel grad_loss):
  * rays come as N / (px * py) patches of px x py pixels, row-major; + alpha_grad * mean_{patch, row, j < py-1} |
  * |pd_j - pd_j+1| m_j - (gd_j - gd_j+1) m_j |, depths in metres (value / scale), m_j = raydrop_j * (|gd_j - gd_j+1| < 0.01). */
 LNH_API int lnh_lidar_loss_patch(const float *depth, const float *image, const float *gt, uint32_t N, uint32_t px,
                                  uint32_t py, float scale, float alpha_d, float alpha_r, float alpha_i, float alpha_grad,
-                                 float *loss, float *grad_depth, float *grad_image, lnh_stream_t stream);
+                                 const float *grad_scale, float *loss, float *grad_depth, float *grad_image,
+                                 lnh_stream_t stream);
 /*
  * Element-wise stages of the occupancy-grid render chain over the marcher's flat sample list [M] (BASELINE config 4; the
  * reference kept torch-ngp's kernels, raymarching.cu:331-772, and dropped this caller — what runs between them are the
@@ -520,6 +524,50 @@ LNH_API int lnh_adam_table_step_dlr(float *param, float *exp_avg, float *exp_avg
                                     uint64_t n, const float *lr, double beta1, double beta2, double eps,
                                     const float *inv_scale, const float *found_inf, const float *step_in,
                                     float *step_out, lnh_stream_t stream);
+
+/* ---- the whole optimizer step of a training iteration as two launches (nerf/utils.py:1216-1226: scaler.step(optimizer),
+ * scaler.update(), lr_scheduler.step(); main_lidarnerf.py:389-391, 408-410: Adam(betas .9/.99, eps 1e-15), lr0 * 0.1^(it/iters))
+ * The scalars of the step live in ONE device buffer `state` of LNH_TRAIN_STATE_FLOATS floats (indices LNH_TS_*), so a
+ * training step captured in a hipGraph needs no host value:
+ *   SCALE / GROWTH   GradScaler's loss scale and growth counter          T / T_NEXT     Adam's step count, before / after
+ *   FOUND            stamp IT + 1 of the last step that saw an inf/nan   IT / IT_NEXT   scheduler steps taken, before / after
+ *   INV / INV_TABLE  1 / (scale * div_small), 1 / (scale * div_table)    LR             lr0 * 0.1^min(IT / iters, 1)
+ *   LAST_SCALE       the scale the gradients of the last step carry      SKIPPED        1 if the last step was skipped
+ * lnh_train_check: commits T_NEXT / IT_NEXT of the previous step, forms INV / INV_TABLE / LAST_SCALE / LR, and stamps
+ *   FOUND = IT + 1 if the n16 fp16 values at grad16 or any of the small fp32 gradients holds an inf / nan (idempotent:
+ *   may be called once per piece of a gradient that arrives in pieces; a MAX all-reduce of FOUND over ranks keeps the
+ *   stamp).  div_table / div_small = what the SUMMED gradients still have to be divided by (data parallel: the world size).
+ * lnh_train_step: Adam with torch's fused arithmetic on the fp32 table (n values, fp16 gradient, also writes the fp16
+ *   copy; n = 0: the table is stepped elsewhere, e.g. lnh_adam_table_step_dlr per shard with lr = &state[LNH_TS_LR],
+ *   inv_scale = &state[LNH_TS_INV_TABLE], found_inf = &state[LNH_TS_SKIPPED], step_in / step_out = &state[LNH_TS_T] /
+ *   &state[LNH_TS_T_NEXT]) and on n_small <= LNH_TRAIN_MAX_SMALL fp32 tensors (host arrays of device pointers; a null
+ *   gradient skips that tensor; their moments lie back to back in small_exp_avg / small_exp_avg_sq in the order given),
+ *   skipped as a whole when FOUND == IT + 1; then T_NEXT, IT_NEXT, SKIPPED and torch's amp_update_scale_.
+ * lnh_zero_regions: clears up to 8 device regions (host arrays of pointers and byte counts, 4-byte granular) with ONE launch.
+ */
+#define LNH_TRAIN_STATE_FLOATS 16
+#define LNH_TRAIN_MAX_SMALL 16
+#define LNH_TS_SCALE 0
+#define LNH_TS_GROWTH 1
+#define LNH_TS_FOUND 2
+#define LNH_TS_INV 3
+#define LNH_TS_INV_TABLE 4
+#define LNH_TS_LAST_SCALE 5
+#define LNH_TS_T 6
+#define LNH_TS_IT 7
+#define LNH_TS_LR 8
+#define LNH_TS_T_NEXT 9
+#define LNH_TS_IT_NEXT 10
+#define LNH_TS_SKIPPED 11
+LNH_API int lnh_train_check(float *state, const void *grad16, uint64_t n16, const float *const *small_grads,
+                            const uint32_t *small_numel, uint32_t n_small, float div_table, float div_small, double lr0,
+                            double iters, lnh_stream_t stream);
+LNH_API int lnh_train_step(float *state, float *param, float *exp_avg, float *exp_avg_sq, const void *grad16,
+                           void *param16, uint64_t n, float *const *small_params, const float *const *small_grads,
+                           const uint32_t *small_numel, uint32_t n_small, float *small_exp_avg, float *small_exp_avg_sq,
+                           double beta1, double beta2, double eps, double growth_factor, double backoff_factor,
+                           uint32_t growth_interval, lnh_stream_t stream);
+LNH_API int lnh_zero_regions(void *const *ptrs, const uint64_t *bytes, uint32_t count, lnh_stream_t stream);
 
 
 /* ------------------------------------------------------------------ bf16 MLP operands (BASELINE config 5) ---- */

@@ -289,23 +289,16 @@ k_color_forward_ray(ColorArgs a) {
     }
 }
 
-// Wave-independent colour-head backward: one WAVE per ray at a time, 32 merged samples per iteration, no barriers in the
-// sample loop.  Weight gradients contract over samples, so their MFMA operands are the TRANSPOSES of what the layer chain
-// leaves in registers.  Round 5: every packed fragment of the chain (two hidden activations, their two gradients, the
-// input rows, the output gradient) is dropped into a wave-private LDS slab when it is formed — 20 LDS writes per span —
-// and the weight-gradient section reads its operands back transposed with ds_read_b64_tr_b16 (mlp_common.h: 36 reads, no
-// VALU work), where rounds 2-4 transposed each tile with an MFMA against an identity fragment and two packed conversions
-// (36 MFMAs + 72 conversions + 32 adds per span, a fifth of the kernel).  The per-ray sum of dH0 (the direction term's
-// gradient) comes out of four more products against a fragment of ones.
+// Wave-independent colour-head backward: one WAVE per ray at a time, 32 merged samples per iteration, no LDS tiles and
+// no barriers in the sample loop.  Weight gradients contract over samples, so their MFMA operands are the TRANSPOSES of
+// what the layer chain leaves in registers; a transpose of a packed fp16 fragment is one MFMA against an identity
+// fragment (the A and B operand layouts are mirror images: row/col = lane & 15, same k enumeration), which is exact.
 // Every wave owns all 24 gradient tiles (dW2 4, dW1 16, dW0g 4) in accumulators; the four waves of a workgroup are
 // combined through LDS once at the end and flushed with one atomic per weight.
-// WG selects how the weight-gradient operands are transposed (all three compute the same sums; the product runs
-// kColorBwdWgrad, the others are kept for the A/B record in profiles/r05_color_backward_wgrad.txt):
-//   0  identity-fragment MFMAs + packed conversions, everything in registers (rounds 2-4)
-//   1  LDS slabs written as the chain forms its fragments, read back transposed right after the chain
-//   2  as 1 with two sets of slabs: the weight gradients of span i are formed during span i + 1, so that their LDS reads
-//      never wait for a write of the same iteration and their MFMAs run under the packing arithmetic of the next chain
-template <bool FROM_IMAGE, int WG>  // FROM_IMAGE: d loss / d rgb formed as weights (x) a.g_image instead of read from a.g_rgb
+// Round 5 built the transposes on gfx950's transposing LDS read as well (ds_read_b64_tr_b16: the sigma-net backward in
+// mlp_bwd.h runs on it) — for THIS kernel, one wave per SIMD, both LDS forms lost to the identity MFMAs (283.9 / 291.4
+// against 268.4 us: profiles/r05_color_backward_wgrad.txt) and were removed again.
+template <bool FROM_IMAGE>  // d loss / d rgb read from a.g_rgb, or formed as weights (x) a.g_image
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 k_color_backward_wi(ColorArgs a) {
     constexpr int HT = 4, HS = 2, NT = 2, NTILE = HT + HT * HT + HT;
@@ -315,16 +308,10 @@ k_color_backward_wi(ColorArgs a) {
     // from LDS every iteration (48 ds_read_b128 issued just ahead of their MFMAs) cost 11 % of the kernel; sharing them
     // between two waves per SIMD that way was built in round 4 and lost (434 against 217 us: profiles/r04_color_backward_2wave.txt).
     enum { F_W0 = 0, F_W1 = 4, F_W2 = 12, F_W2T = 14, F_W1T = 18, F_W0T = 26, NFRAG = 28 };
-    // slabs of a wave (mlp_common.h): quantity q, point tile n, channel tile t at slab q + 4 n + t
-    enum { SL_H0 = 0, SL_H1 = 8, SL_D1 = 16, SL_D0 = 24, SL_X = 32, SL_Y = 34, NSLAB = 36 };
-    constexpr uint32_t kSetBytes = NSLAB * kSlabBytes, kSets = WG == 2 ? 2 : 1;
-    extern __shared__ __attribute__((aligned(16))) char smem_cb[];
-    float *red = reinterpret_cast<float *>(smem_cb);  // (after the sample loop: the slabs have served their purpose)
+    __shared__ float red[NTILE * 256];
     const uint32_t wid = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
     const uint32_t nw = blockDim.x >> 6, nwaves = gridDim.x * nw;
     const uint32_t wave = blockIdx.x * nw + (uint32_t)__builtin_amdgcn_readfirstlane((int)wid);  // known wave-uniform
-    char *const slabs0 = smem_cb + (size_t)__builtin_amdgcn_readfirstlane((int)wid) * kSets * kSetBytes;
-    const uint32_t wr_off = (4 * c + g) * 8, rd_off = lane * 8;
     half8_t wreg[NFRAG];
     auto frag = [&](int i) -> half8_t {  // fragment i of this lane (see the F_* enumeration)
         if (i < F_W1) return load_a_natural(a.W + kW0g, 16, 16 * (i - F_W0) + c, 0, g, 16);
@@ -337,26 +324,15 @@ k_color_backward_wi(ColorArgs a) {
 #pragma unroll
     for (int i = 0; i < NFRAG; i++) wreg[i] = frag(i);
 #define WF(i) wreg[(i)]
-    // WG 0: identity fragments.  idn selects natural-k element c (k = 8g + j); idv[tt] selects nu-enumerated channel
+    // identity fragments: idn selects natural-k element c (k = 8g + j); idv[tt] selects nu-enumerated channel
     // 16 * (2s + tt) + c out of k-step s (element j of lane group g is channel 16 * (2s + (j >> 2)) + 4g + (j & 3))
-    half8_t idn, idv[2], ones;
+    half8_t idn, idv[2];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         idn[j] = (8 * g + j == c) ? (half_t)1.0f : (half_t)0.0f;
 #pragma unroll
         for (int tt = 0; tt < 2; tt++)
             idv[tt][j] = ((uint32_t)(j >> 2) == (uint32_t)tt && 4 * g + (j & 3) == c) ? (half_t)1.0f : (half_t)0.0f;
-        ones[j] = (half_t)1.0f;
-    }
-    if constexpr (WG != 0) {
-        // the output-gradient slabs hold two real channels (lanes g == 0 write chunk group 0 of their point); the other
-        // three chunk groups stay zero for the whole kernel.  WG 2: the first iteration forms the weight gradients of a
-        // span that never was — every slab starts as zeros
-        if constexpr (WG == 2) {
-            for (uint32_t o = lane * 16; o < kSets * kSetBytes; o += 64 * 16) *reinterpret_cast<half8_t *>(slabs0 + o) = zero_h8();
-        } else {
-            *reinterpret_cast<half8_t *>(slabs0 + SL_Y * kSlabBytes + lane * 16) = zero_h8();
-        }
     }
     f32x4 gW2[HT], gW1[HT][HT], gW0[HT];
 #pragma unroll
@@ -515,23 +491,14 @@ k_color_backward_wi(ColorArgs a) {
 #pragma unroll
         for (int t = 0; t < HT; t++) cb[t] = *reinterpret_cast<const f32x4 *>(a.cdir + (size_t)r * 64 + 16 * t + 4 * g);
     };
-    // S[ray][channel] = sum over the ray's samples of dH0.  WG 0: lane (g, c) holds the partial sum of channel 16t + c over
-    // the samples 4g + r of every span; WG 1, 2: a product against a fragment of ones leaves the whole sum of channel
-    // 16t + 4g + r in every column of an accumulator tile
-    auto store_ray_sum = [&](uint32_t ray, const float (&ssum)[HT], const f32x4 (&msum)[HT]) {
-        if constexpr (WG == 0) {
+    // S[ray][channel 16t + c] = sum over the ray's samples of dH0 (lane (g,c) holds samples 4g + r)
+    auto store_ray_sum = [&](uint32_t ray, const float (&ssum)[HT]) {
 #pragma unroll
-            for (int t = 0; t < HT; t++) {
-                float v = ssum[t];
-                v += __shfl_xor(v, 16, 64);
-                v += __shfl_xor(v, 32, 64);
-                if (g == 0) a.S[(size_t)ray * 64 + 16 * t + c] = v;
-            }
-        } else {
-            if (c == 0) {
-#pragma unroll
-                for (int t = 0; t < HT; t++) *reinterpret_cast<f32x4 *>(a.S + (size_t)ray * 64 + 16 * t + 4 * g) = msum[t];
-            }
+        for (int t = 0; t < HT; t++) {
+            float v = ssum[t];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (g == 0) a.S[(size_t)ray * 64 + 16 * t + c] = v;
         }
     };
     StageA A0 = load_a(next_item()), A1 = load_a(next_item());
@@ -539,72 +506,17 @@ k_color_backward_wi(ColorArgs a) {
     f32x4 cb[HT], cb_next[HT];
     load_cb(A0.ray, cb_next);
     float ssum[HT] = {0.0f, 0.0f, 0.0f, 0.0f};
-    f32x4 msum[HT];
-#pragma unroll
-    for (int t = 0; t < HT; t++) msum[t] = zero_f4();
     bool first_of_ray = true;
-    // WG 2: what the deferred weight-gradient section needs to know about the span it works on (the previous one)
-    bool pend = false, pend_first = false, pend_last = false;
-    uint32_t pend_ray = 0, cur_set = 0;
 
-    while (A0.live || (WG == 2 && pend)) {
+    while (A0.live) {
         const uint32_t ray = A0.ray;
-        char *const slabs = slabs0 + (WG == 2 ? cur_set * kSetBytes : 0u);        // this span's chain writes here
-        const char *const slabs_w = slabs0 + (WG == 2 ? (cur_set ^ 1u) * kSetBytes : 0u);  // the weight gradients read here
-        auto slab = [&](int q, int n, int t) { return slabs + (q + 4 * n + t) * kSlabBytes; };
-        auto slab_w = [&](int q, int n, int t) { return slabs_w + (q + 4 * n + t) * kSlabBytes; };
-        // weight gradients from slabs, in four pieces so that WG 2 can lay them between the phases of the chain
-        half8_t fd1[HT], fh0[HT];
-        auto wg_read_1 = [&]() {
-#pragma unroll
-            for (int t = 0; t < HT; t++) {
-                fd1[t] = slab_get_span(slab_w(SL_D1, 0, t), 4 * kSlabBytes, rd_off);
-                fh0[t] = slab_get_span(slab_w(SL_H0, 0, t), 4 * kSlabBytes, rd_off);
-            }
-        };
-        auto wg_w1 = [&](int t0, int t1) {
-#pragma unroll
-            for (int t = t0; t < t1; t++)
-#pragma unroll
-                for (int i = 0; i < HT; i++) mfma16_acc_agpr_ld(gW1[t][i], fd1[t], fh0[i]);  // dW1[16t + 4g + r][16i + c]
-        };
-        half8_t fy, fh1[HT], fx, fd0[HT];
-        auto wg_read_2 = [&]() {
-            fy = slab_get_span(slab_w(SL_Y, 0, 0), kSlabBytes, rd_off);
-#pragma unroll
-            for (int t = 0; t < HT; t++) fh1[t] = slab_get_span(slab_w(SL_H1, 0, t), 4 * kSlabBytes, rd_off);
-        };
-        auto wg_w2 = [&]() {
-#pragma unroll
-            for (int t = 0; t < HT; t++) mfma16_acc_agpr_ld(gW2[t], fy, fh1[t]);  // dW2[o = 4g + r][16t + c]
-        };
-        auto wg_read_0 = [&]() {
-            fx = slab_get_span(slab_w(SL_X, 0, 0), kSlabBytes, rd_off);
-#pragma unroll
-            for (int t = 0; t < HT; t++) fd0[t] = slab_get_span(slab_w(SL_D0, 0, t), 4 * kSlabBytes, rd_off);
-        };
-        auto wg_w0 = [&]() {
-#pragma unroll
-            for (int t = 0; t < HT; t++) {
-                mfma16_acc_agpr_ld(gW0[t], fd0[t], fx);  // dW0g[16t + 4g + r][c]
-                msum[t] = MFMA16(fd0[t], ones, msum[t]);  // sum over the span's samples, the same in every column
-            }
-        };
         const StageA A2 = load_a(next_item());
         const StageB B1 = load_b(A1);
-        if constexpr (WG == 2) {
-            if (pend_first) {
-#pragma unroll
-                for (int t = 0; t < HT; t++) msum[t] = zero_f4();
-            }
-            wg_read_1();
-        }
         if (first_of_ray) {
 #pragma unroll
             for (int t = 0; t < HT; t++) {
                 cb[t] = cb_next[t];
                 ssum[t] = 0.0f;
-                if constexpr (WG == 1) msum[t] = zero_f4();
             }
         }
         const bool last_of_ray = !A1.live || A1.ray != ray;
@@ -615,9 +527,6 @@ k_color_backward_wi(ColorArgs a) {
         for (int n = 0; n < NT; n++) {
             msk[n] = A0.valid[n] && A0.wgt[n] > kMaskThresh;
             bx[n] = (A0.valid[n] && g < 2) ? B0.x[n] : zero_h8();
-            // input rows: lane (g < 2, c) holds features 8g .. 8g+7 = chunk groups 2g, 2g+1 of its point
-            if constexpr (WG != 0)
-                if (g < 2) *reinterpret_cast<half8_t *>(slab(SL_X, 0, n) + c * 32 + g * 16) = bx[n];
         }
         {
             half8_t by[NT], bh0[NT][HS], bh1[NT][HS], bd1[NT][HS], bd0[NT][HS];
@@ -628,18 +537,10 @@ k_color_backward_wi(ColorArgs a) {
             for (int n = 0; n < NT; n++)
 #pragma unroll
                 for (int t = 0; t < HT; t++) acc[n][t] = MFMA16(WF(F_W0 + t), bx[n], cb[t]);
-            if constexpr (WG == 2) {
-                wg_w1(0, 2);
-                wg_read_2();  // (the next piece's operands are requested while this piece's products run)
-            }
 #pragma unroll
             for (int n = 0; n < NT; n++)
 #pragma unroll
-                for (int s = 0; s < HS; s++) {
-                    bh0[n][s] = pack_pair_relu(acc[n][2 * s], acc[n][2 * s + 1]);
-                    if constexpr (WG != 0) slab_put_pair(slab(SL_H0, n, 2 * s), wr_off, bh0[n][s]);
-                }
-            if constexpr (WG == 2) wg_w1(2, 4);
+                for (int s = 0; s < HS; s++) bh0[n][s] = pack_pair_relu(acc[n][2 * s], acc[n][2 * s + 1]);
 #pragma unroll
             for (int n = 0; n < NT; n++)
 #pragma unroll
@@ -651,14 +552,7 @@ k_color_backward_wi(ColorArgs a) {
 #pragma unroll
             for (int n = 0; n < NT; n++)
 #pragma unroll
-                for (int s = 0; s < HS; s++) {
-                    bh1[n][s] = pack_pair_relu(acc[n][2 * s], acc[n][2 * s + 1]);
-                    if constexpr (WG != 0) slab_put_pair(slab(SL_H1, n, 2 * s), wr_off, bh1[n][s]);
-                }
-            if constexpr (WG == 2) {
-                wg_w2();
-                wg_read_0();
-            }
+                for (int s = 0; s < HS; s++) bh1[n][s] = pack_pair_relu(acc[n][2 * s], acc[n][2 * s + 1]);
             f32x4 o[NT];
 #pragma unroll
             for (int n = 0; n < NT; n++) {
@@ -670,30 +564,21 @@ k_color_backward_wi(ColorArgs a) {
 #pragma unroll
             for (int n = 0; n < NT; n++) {
                 by[n] = zero_h8();
-                if (g == 0) {
-                    if (msk[n]) {
-                        const float r0 = sigmoidf((float)(half_t)o[n][0]), r1 = sigmoidf((float)(half_t)o[n][1]);
-                        by[n][0] = (half_t)(A0.gr[n].x * r0 * (1.0f - r0));
-                        by[n][1] = (half_t)(A0.gr[n].y * r1 * (1.0f - r1));
-                    }
-                    if constexpr (WG != 0) {
-                        const half4_t y4 = {by[n][0], by[n][1], (half_t)0.0f, (half_t)0.0f};
-                        *reinterpret_cast<half4_t *>(slab(SL_Y, 0, n) + c * 32) = y4;
-                    }
+                if (g == 0 && msk[n]) {
+                    const float r0 = sigmoidf((float)(half_t)o[n][0]), r1 = sigmoidf((float)(half_t)o[n][1]);
+                    by[n][0] = (half_t)(A0.gr[n].x * r0 * (1.0f - r0));
+                    by[n][1] = (half_t)(A0.gr[n].y * r1 * (1.0f - r1));
                 }
             }
 #pragma unroll
             for (int n = 0; n < NT; n++)
 #pragma unroll
                 for (int t = 0; t < HT; t++) acc[n][t] = MFMA16(WF(F_W2T + t), by[n], zero_f4());
-            if constexpr (WG == 2) wg_w0();
 #pragma unroll
             for (int n = 0; n < NT; n++)
 #pragma unroll
-                for (int s = 0; s < HS; s++) {
+                for (int s = 0; s < HS; s++)
                     bd1[n][s] = pack_pair_relu_bwd(acc[n][2 * s], acc[n][2 * s + 1], bh1[n][s]);
-                    if constexpr (WG != 0) slab_put_pair(slab(SL_D1, n, 2 * s), wr_off, bd1[n][s]);
-                }
 #pragma unroll
             for (int n = 0; n < NT; n++)
 #pragma unroll
@@ -705,19 +590,8 @@ k_color_backward_wi(ColorArgs a) {
 #pragma unroll
             for (int n = 0; n < NT; n++)
 #pragma unroll
-                for (int s = 0; s < HS; s++) {
+                for (int s = 0; s < HS; s++)
                     bd0[n][s] = pack_pair_relu_bwd(acc[n][2 * s], acc[n][2 * s + 1], bh0[n][s]);
-                    if constexpr (WG != 0) slab_put_pair(slab(SL_D0, n, 2 * s), wr_off, bd0[n][s]);
-                }
-            // WG 1: weight gradients of THIS span, operands read back transposed (sample-major).  Oldest slabs first: the
-            // hidden matrix needs dH1 and H0, written layers ago; dH0 — written last — is read last.
-            if constexpr (WG == 1) {
-                wg_read_1();
-                wg_read_2();
-                wg_w1(0, 4);
-                wg_w2();
-                wg_read_0();
-            }
             // d(sigma-net row) = W0g^T dH0, col 0 <- trunc_exp backward of the compositing gradient
 #pragma unroll
             for (int n = 0; n < NT; n++) {
@@ -730,41 +604,29 @@ k_color_backward_wi(ColorArgs a) {
                     *reinterpret_cast<half4_t *>(a.g_h16 + src_of(A0, n) * 16 + 4 * g) = v;
                 }
             }
-            if constexpr (WG == 1) wg_w0();
-            if constexpr (WG == 0) {
-                // ---- sample-major operands (exact transposes through identity-fragment MFMAs) and the weight gradients
-                const half8_t fy = pack2(MFMA16(by[0], idn, zero_f4()), MFMA16(by[1], idn, zero_f4()));
-                const half8_t fx = pack2(MFMA16(bx[0], idn, zero_f4()), MFMA16(bx[1], idn, zero_f4()));
-                half8_t th0[HT], td1[HT];
+            // ---- sample-major operands (exact transposes) and the weight gradients
+            const half8_t fy = pack2(MFMA16(by[0], idn, zero_f4()), MFMA16(by[1], idn, zero_f4()));
+            const half8_t fx = pack2(MFMA16(bx[0], idn, zero_f4()), MFMA16(bx[1], idn, zero_f4()));
+            half8_t fh0[HT], fd1[HT];
 #pragma unroll
-                for (int t = 0; t < HT; t++) {
-                    th0[t] = pack2(MFMA16(bh0[0][t >> 1], idv[t & 1], zero_f4()), MFMA16(bh0[1][t >> 1], idv[t & 1], zero_f4()));
-                    td1[t] = pack2(MFMA16(bd1[0][t >> 1], idv[t & 1], zero_f4()), MFMA16(bd1[1][t >> 1], idv[t & 1], zero_f4()));
-                }
+            for (int t = 0; t < HT; t++) {
+                fh0[t] = pack2(MFMA16(bh0[0][t >> 1], idv[t & 1], zero_f4()), MFMA16(bh0[1][t >> 1], idv[t & 1], zero_f4()));
+                fd1[t] = pack2(MFMA16(bd1[0][t >> 1], idv[t & 1], zero_f4()), MFMA16(bd1[1][t >> 1], idv[t & 1], zero_f4()));
+            }
 #pragma unroll
-                for (int t = 0; t < HT; t++) {
-                    const half8_t fh1 = pack2(MFMA16(bh1[0][t >> 1], idv[t & 1], zero_f4()),
-                                              MFMA16(bh1[1][t >> 1], idv[t & 1], zero_f4()));
-                    mfma16_acc_agpr(gW2[t], fy, fh1);  // dW2[o = 4g + r][16t + c]
-                    const f32x4 e0 = MFMA16(bd0[0][t >> 1], idv[t & 1], zero_f4());
-                    const f32x4 e1 = MFMA16(bd0[1][t >> 1], idv[t & 1], zero_f4());
-                    ssum[t] += (e0[0] + e0[1]) + (e0[2] + e0[3]) + (e1[0] + e1[1]) + (e1[2] + e1[3]);
-                    mfma16_acc_agpr(gW0[t], pack2(e0, e1), fx);  // dW0g[16t + 4g + r][c]
+            for (int t = 0; t < HT; t++) {
+                const half8_t fh1 = pack2(MFMA16(bh1[0][t >> 1], idv[t & 1], zero_f4()),
+                                          MFMA16(bh1[1][t >> 1], idv[t & 1], zero_f4()));
+                mfma16_acc_agpr(gW2[t], fy, fh1);  // dW2[o = 4g + r][16t + c]
+                const f32x4 e0 = MFMA16(bd0[0][t >> 1], idv[t & 1], zero_f4());
+                const f32x4 e1 = MFMA16(bd0[1][t >> 1], idv[t & 1], zero_f4());
+                ssum[t] += (e0[0] + e0[1]) + (e0[2] + e0[3]) + (e1[0] + e1[1]) + (e1[2] + e1[3]);
+                mfma16_acc_agpr(gW0[t], pack2(e0, e1), fx);  // dW0g[16t + 4g + r][c]
 #pragma unroll
-                    for (int i = 0; i < HT; i++) mfma16_acc_agpr(gW1[t][i], td1[t], th0[i]);  // dW1[16t + 4g + r][16i + c]
-                }
+                for (int i = 0; i < HT; i++) mfma16_acc_agpr(gW1[t][i], fd1[t], fh0[i]);  // dW1[16t + 4g + r][16i + c]
             }
         }
-        if constexpr (WG == 2) {
-            if (pend && pend_last) store_ray_sum(pend_ray, ssum, msum);
-            pend = A0.live;
-            pend_first = first_of_ray;
-            pend_last = last_of_ray;
-            pend_ray = ray;
-            cur_set ^= 1u;
-        } else {
-            if (last_of_ray) store_ray_sum(ray, ssum, msum);
-        }
+        if (last_of_ray) store_ray_sum(ray, ssum);
         first_of_ray = last_of_ray;
         A0 = A1;
         A1 = A2;
@@ -778,9 +640,7 @@ k_color_backward_wi(ColorArgs a) {
         for (int i = 0; i < HT; i++) agpr_settle(gW1[t][i]);
     }
 
-    // ---- combine the waves of the workgroup through LDS (over the slabs: every wave is past its last read), then one
-    //      atomic per weight
-    __syncthreads();
+    // ---- combine the waves of the workgroup through LDS, then one atomic per weight
     for (uint32_t w = 0; w < nw; w++) {
         if (wid == w) {
 #pragma unroll
@@ -815,14 +675,6 @@ k_color_backward_wi(ColorArgs a) {
     }
 #undef WF
 }
-#ifndef LNH_COLOR_BWD_WGRAD
-#define LNH_COLOR_BWD_WGRAD 0
-#endif
-constexpr int kColorBwdWgrad = LNH_COLOR_BWD_WGRAD;
-// dynamic LDS: four waves x (one or two sets of) 36 slabs, and never less than the 24.5 KB of the final reduction
-constexpr size_t kColorBwdLds = kColorBwdWgrad == 0 ? (size_t)(4 + 16 + 4) * 256 * sizeof(float)
-                                                     : (size_t)4 * (kColorBwdWgrad == 2 ? 2 : 1) * 36 * kSlabBytes;
-
 }  // namespace
 
 extern "C" {
@@ -875,13 +727,10 @@ static int color_backward_launch(const float *grad_rgb, const float *grad_image,
     // persistent workgroups: each flushes 6144 weight-gradient partials with device atomics (~20 G/s chip-wide), so
     // keep the workgroup count near the CU count rather than one per ray
     const uint32_t nwg = (N + 3) / 4;
-    if (kColorBwdLds > 64 * 1024)  // (above the 64 KiB a kernel gets without asking)
-        (void)hipFuncSetAttribute((const void *)(grad_rgb ? k_color_backward_wi<false, kColorBwdWgrad> : k_color_backward_wi<true, kColorBwdWgrad>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kColorBwdLds);
     if (grad_rgb) {
-        LNH_LAUNCH((k_color_backward_wi<false, kColorBwdWgrad>), dim3(nwg < 256 ? nwg : 256), dim3(256), kColorBwdLds, (hipStream_t)stream, a);
+        LNH_LAUNCH((k_color_backward_wi<false>), dim3(nwg < 256 ? nwg : 256), dim3(256), 0, (hipStream_t)stream, a);
     } else {
-        LNH_LAUNCH((k_color_backward_wi<true, kColorBwdWgrad>), dim3(nwg < 256 ? nwg : 256), dim3(256), kColorBwdLds, (hipStream_t)stream, a);
+        LNH_LAUNCH((k_color_backward_wi<true>), dim3(nwg < 256 ? nwg : 256), dim3(256), 0, (hipStream_t)stream, a);
     }
     return lnh_check_launch("lnh_lidar_color_backward");
 }

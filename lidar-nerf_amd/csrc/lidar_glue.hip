@@ -57,59 +57,47 @@ k_dir_term(const float *__restrict__ enc, const float *__restrict__ W0, uint32_t
 }
 
 // d cdir / d W0_dir:  gW[o, k] += sum_n S[n, o] * enc16[n, k]  (S = per-ray sum of dH0 from the colour backward).
-// A library GEMM with M = 64, N = K <= 128 and a 4096-long reduction runs as one tile for ~43 us.  Two tiny passes
-// instead: every workgroup reduces a 32-ray chunk (staged in LDS) to a [64, 128] partial in scratch, then one thread
-// per output sums the partials.  (Atomics instead of the second pass were measured slower: 64*K addresses are so
-// few cache lines that device atomics on them serialise.)
-constexpr int kDirChunk = 32;
+// A library GEMM with M = 64, N = K <= 128 and a 4096-long reduction runs as one tile for ~43 us; rounds 1-4 ran two
+// passes (32-ray chunks staged in LDS to [64, 128] partials in scratch, then a sum over the 128 partials: 16 + 8 us).
+// Round 5, one launch: a workgroup owns the 64 outputs of ONE feature over a 1/16th of the rays (grid K x 16), its four
+// waves taking every fourth ray (S rows are 256-byte lines, one lane per output; the feature is a wave-uniform value), eight
+// rays in flight per wave; the four partial sums meet in LDS and 64 device atomics per workgroup add them into the
+// gradient — 16 adds per address instead of the 128 that made the atomic form lose in round 1.  Block (0, 0) also copies
+// the geo-feature columns of the colour head's first matrix, which the colour backward produced in its packed [64, 16]
+// layout (col 0 unused), to columns K .. K+14 of the same gradient.
+constexpr uint32_t kDirSegments = 16;
 __global__ void __launch_bounds__(256)
-k_dir_term_backward_partial(const float *__restrict__ S, const float *__restrict__ enc16, uint32_t N, uint32_t K,
-                            float *__restrict__ partial) {
-    constexpr int KPT = 32, CH = kDirChunk;  // k values per thread (k = kg + 4*j), rays per workgroup
-    __shared__ float sS[CH][64];
-    __shared__ __attribute__((aligned(16))) float sE[CH][128];
-    const uint32_t o = threadIdx.x & 63, kg = threadIdx.x >> 6;
-    const uint32_t n0 = blockIdx.x * CH, cnt = min((uint32_t)CH, N - n0);
-    for (uint32_t i = threadIdx.x; i < CH * 64; i += 256) {  // coalesced staging, zero-filled beyond the valid part
-        const uint32_t r = i >> 6;
-        sS[r][i & 63] = r < cnt ? S[(size_t)(n0 + r) * 64 + (i & 63)] : 0.0f;
+k_dir_term_backward(const float *__restrict__ S, const float *__restrict__ enc16, uint32_t N, uint32_t K,
+                    const float *__restrict__ g_w0g, float *__restrict__ gW, uint32_t ldw) {
+    __shared__ float part[4][64];
+    const uint32_t o = threadIdx.x & 63, w = threadIdx.x >> 6, k = blockIdx.x;
+    const uint32_t per = (N + kDirSegments - 1) / kDirSegments;
+    const uint32_t r0 = blockIdx.y * per, r1 = min(N, r0 + per);
+    constexpr int U = 8;
+    float acc[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) acc[u] = 0.0f;
+    uint32_t r = r0 + w;
+    for (; r + 4 * (U - 1) < r1; r += 4 * U) {  // U independent chains: the loop waits for L2 once per U rays
+        float sv[U], ev[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            sv[u] = S[(size_t)(r + 4 * u) * 64 + o];
+            ev[u] = enc16[(size_t)(r + 4 * u) * K + k];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) acc[u] = fmaf(sv[u], ev[u], acc[u]);
     }
-    // enc is staged as [ray][kg][j] (k = kg + 4 j): the 32 values a thread multiplies by one S element are contiguous, so
-    // the inner loop reads them with 8 wave-uniform 16-byte LDS loads instead of 32 4-byte ones (the kernel was bound by
-    // its LDS instruction count)
-    for (uint32_t i = threadIdx.x; i < CH * 128; i += 256) {
-        const uint32_t r = i >> 7, k = i & 127;
-        sE[r][(k & 3) * KPT + (k >> 2)] = (r < cnt && k < K) ? enc16[(size_t)(n0 + r) * K + k] : 0.0f;
-    }
+    for (; r < r1; r += 4) acc[0] = fmaf(S[(size_t)r * 64 + o], enc16[(size_t)r * K + k], acc[0]);
+    part[w][o] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     __syncthreads();
-    float acc[KPT];
-#pragma unroll
-    for (int j = 0; j < KPT; j++) acc[j] = 0.0f;
-    for (uint32_t r = 0; r < CH; r++) {
-        const float s = sS[r][o];
-        const float4 *e4 = reinterpret_cast<const float4 *>(&sE[r][kg * KPT]);
-#pragma unroll
-        for (int q = 0; q < KPT / 4; q++) {
-            const float4 e = e4[q];
-            acc[4 * q + 0] = fmaf(s, e.x, acc[4 * q + 0]);
-            acc[4 * q + 1] = fmaf(s, e.y, acc[4 * q + 1]);
-            acc[4 * q + 2] = fmaf(s, e.z, acc[4 * q + 2]);
-            acc[4 * q + 3] = fmaf(s, e.w, acc[4 * q + 3]);
+    if (w == 0) unsafeAtomicAdd(gW + (size_t)o * ldw + k, (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]));
+    if (g_w0g && blockIdx.x == 0 && blockIdx.y == 0) {
+        for (uint32_t i = threadIdx.x; i < 64 * 15; i += 256) {
+            const uint32_t oo = i / 15, c = i % 15;
+            gW[(size_t)oo * ldw + K + c] = g_w0g[oo * 16 + 1 + c];
         }
     }
-    float *out = partial + (size_t)blockIdx.x * 64 * 128;
-#pragma unroll
-    for (int j = 0; j < KPT; j++) out[(kg + 4 * j) * 64 + o] = acc[j];  // [k][o]: consecutive lanes, consecutive floats
-}
-__global__ void __launch_bounds__(256)
-k_dir_term_backward_sum(const float *__restrict__ partial, uint32_t chunks, uint32_t K, float *__restrict__ gW,
-                        uint32_t ldw) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // i = k*64 + o
-    if (i >= K * 64) return;
-    float a = 0.0f;  // blockIdx.y strides over the chunks: 8-way split keeps the dependent-load chain short
-    for (uint32_t c = blockIdx.y; c < chunks; c += gridDim.y) a += partial[(size_t)c * 64 * 128 + i];
-    const uint32_t k = i >> 6, o = i & 63;
-    unsafeAtomicAdd(gW + (size_t)o * ldw + k, a);
 }
 
 // ------------------------------------------------------------------------------------------------ weight packing
@@ -148,12 +136,50 @@ k_pack_weights(PackArgs<E> a) {
 // nerf/utils.py:712-746 with the default criteria: per ray
 //   l = a_d |pd - gd| + a_r (pr - gr)^2 + a_i (pi - gi)^2,  pd = depth * gr, gd = gt_depth * gr, pi = intensity * gr,
 // loss = mean(l).  Emits the loss and d loss / d depth, d loss / d image in the same pass.
+// The loss is the sum of the workgroups' partial sums: every workgroup leaves its partial in a scratch slot and the one
+// that arrives LAST (device-scope counter) adds them up in slot order and writes the loss — no accumulator to clear before
+// the launch (rounds 1-4: a zero-fill launch + atomics), and the same bits whatever the arrival order.  The counter is
+// left at zero for the next launch.  (Static device scratch: launches of these two kernels must not overlap in time —
+// they are issued on one stream, or replayed inside one graph.)
+constexpr uint32_t kLossMaxBlocks = 4096;
+__device__ float g_loss_part[kLossMaxBlocks];
+__device__ unsigned int g_loss_arrived;
+__device__ __forceinline__ void loss_finish(float l, float scale_out, float *__restrict__ loss) {
+    __shared__ float part[4];
+    __shared__ bool last;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = l;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&g_loss_part[blockIdx.x], (part[0] + part[1]) + (part[2] + part[3]), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        last = __hip_atomic_fetch_add(&g_loss_arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    float t = 0.0f;
+    for (uint32_t i = threadIdx.x; i < gridDim.x; i += blockDim.x)
+        t += __hip_atomic_load(&g_loss_part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *loss = ((part[0] + part[1]) + (part[2] + part[3])) * scale_out;
+        __hip_atomic_store(&g_loss_arrived, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// `grad_scale` (device scalar, or null): the gradients come out multiplied by it — the loss scale of the training step, so
+// that backward() has nothing left to multiply (one element-wise launch less per step).
 __global__ void __launch_bounds__(256)
 k_lidar_loss(const float *__restrict__ depth, const float *__restrict__ image, const float *__restrict__ gt, uint32_t N,
-             float a_d, float a_r, float a_i, float *__restrict__ loss, float *__restrict__ g_depth,
-             float *__restrict__ g_image) {
-    __shared__ float part[4];
+             float a_d, float a_r, float a_i, const float *__restrict__ grad_scale, float *__restrict__ loss,
+             float *__restrict__ g_depth, float *__restrict__ g_image) {
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    const float gsc = grad_scale ? *grad_scale : 1.0f;
     float l = 0.0f;
     if (n < N) {
         const float gr = gt[n * 3], gi = gt[n * 3 + 1] * gr, gd = gt[n * 3 + 2] * gr;
@@ -162,15 +188,11 @@ k_lidar_loss(const float *__restrict__ depth, const float *__restrict__ image, c
         l = a_d * fabsf(dd) + a_r * dr * dr + a_i * di * di;
         const float inv = 1.0f / (float)N;
         const float sgn = dd > 0.0f ? 1.0f : (dd < 0.0f ? -1.0f : 0.0f);  // torch: sign(0) = 0
-        g_depth[n] = a_d * sgn * gr * inv;
-        g_image[n * 2] = 2.0f * a_r * dr * inv;
-        g_image[n * 2 + 1] = 2.0f * a_i * di * gr * inv;
+        g_depth[n] = a_d * sgn * gr * inv * gsc;
+        g_image[n * 2] = 2.0f * a_r * dr * inv * gsc;
+        g_image[n * 2 + 1] = 2.0f * a_i * di * gr * inv * gsc;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o, 64);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = l;
-    __syncthreads();
-    if (threadIdx.x == 0) unsafeAtomicAdd(loss, (part[0] + part[1] + part[2] + part[3]) / (float)N);
+    loss_finish(l, 1.0f / (float)N, loss);
 }
 
 // The same loss on the reference's PATCH epochs (nerf/utils.py:760-876, grad_loss, non-sobel): rays arrive as patches of
@@ -181,9 +203,10 @@ k_lidar_loss(const float *__restrict__ depth, const float *__restrict__ image, c
 __global__ void __launch_bounds__(256)
 k_lidar_loss_patch(const float *__restrict__ depth, const float *__restrict__ image, const float *__restrict__ gt,
                    uint32_t N, uint32_t py, float inv_scale, float a_d, float a_r, float a_i, float a_g,
-                   float *__restrict__ loss, float *__restrict__ g_depth, float *__restrict__ g_image) {
-    __shared__ float part[4];
+                   const float *__restrict__ grad_scale, float *__restrict__ loss, float *__restrict__ g_depth,
+                   float *__restrict__ g_image) {
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    const float gsc = grad_scale ? *grad_scale : 1.0f;
     float l = 0.0f;
     if (n < N) {
         const float gr = gt[n * 3], gi = gt[n * 3 + 1] * gr, gd = gt[n * 3 + 2] * gr;
@@ -193,8 +216,8 @@ k_lidar_loss_patch(const float *__restrict__ depth, const float *__restrict__ im
         l = (a_d * fabsf(dd) + a_r * dr * dr + a_i * di * di) * inv;
         const float sgn = dd > 0.0f ? 1.0f : (dd < 0.0f ? -1.0f : 0.0f);
         float gdep = a_d * sgn * gr * inv;
-        g_image[n * 2] = 2.0f * a_r * dr * inv;
-        g_image[n * 2 + 1] = 2.0f * a_i * di * gr * inv;
+        g_image[n * 2] = 2.0f * a_r * dr * inv * gsc;
+        g_image[n * 2 + 1] = 2.0f * a_i * di * gr * inv * gsc;
         // pairs (n, n + 1) and (n - 1, n) of this ray's patch row; N / py rows of py - 1 pairs each
         const uint32_t c = n % py;
         const float inv_pairs = a_g / ((float)(N / py) * (float)(py - 1));
@@ -221,13 +244,9 @@ k_lidar_loss_patch(const float *__restrict__ depth, const float *__restrict__ im
             (void)pair_term(n - 1, dj, dj1);
             acc += dj1;
         }
-        g_depth[n] = gdep + acc * inv_pairs * gr * inv_scale;
+        g_depth[n] = (gdep + acc * inv_pairs * gr * inv_scale) * gsc;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o, 64);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = l;
-    __syncthreads();
-    if (threadIdx.x == 0) unsafeAtomicAdd(loss, part[0] + part[1] + part[2] + part[3]);
+    loss_finish(l, 1.0f, loss);
 }
 
 }  // namespace
@@ -295,20 +314,15 @@ int lnh_lidar_dir_term_freq_bf16(const float *dirs, uint32_t degree, const float
     return dir_term_freq<__bf16>(dirs, degree, w0, ldw, N, features16, cdir, stream);
 }
 
-int lnh_lidar_dir_term_backward(const float *ray_sum, const float *features16, uint32_t N, uint32_t K, float *scratch,
-                                float *grad_w0, uint32_t ldw, lnh_stream_t stream) {
-    LNH_REQUIRE(ray_sum && features16 && grad_w0 && scratch, LNH_ERR_INVALID_ARG, "lidar_dir_term_backward: null pointer");
-    LNH_REQUIRE(K >= 1 && K <= 128 && ldw >= K, LNH_ERR_INVALID_ARG,
-                "lidar_dir_term_backward: need 1 <= K <= 128 and ldw >= K");
-    if (N == 0) return LNH_OK;
-    const uint32_t chunks = div_up(N, kDirChunk);
-    LNH_LAUNCH(k_dir_term_backward_partial, dim3(chunks), dim3(256), 0, (hipStream_t)stream, ray_sum, features16, N, K,
-               scratch);
-    int rc = lnh_check_launch("lnh_lidar_dir_term_backward(partial)");
-    if (rc) return rc;
-    LNH_LAUNCH(k_dir_term_backward_sum, dim3(div_up(K * 64, 256), chunks < 8 ? chunks : 8), dim3(256), 0, (hipStream_t)stream, scratch, chunks, K,
-               grad_w0, ldw);
-    return lnh_check_launch("lnh_lidar_dir_term_backward(sum)");
+int lnh_lidar_dir_term_backward(const float *ray_sum, const float *features16, uint32_t N, uint32_t K,
+                                const float *grad_w0g, float *grad_w0, uint32_t ldw, lnh_stream_t stream) {
+    LNH_REQUIRE(ray_sum && features16 && grad_w0, LNH_ERR_INVALID_ARG, "lidar_dir_term_backward: null pointer");
+    LNH_REQUIRE(K >= 1 && K <= 128 && ldw >= K + (grad_w0g ? 15u : 0u), LNH_ERR_INVALID_ARG,
+                "lidar_dir_term_backward: need 1 <= K <= 128 and ldw >= K (+ 15 with grad_w0g)");
+    if (N == 0 && !grad_w0g) return LNH_OK;
+    LNH_LAUNCH(k_dir_term_backward, dim3(K, kDirSegments), dim3(256), 0, (hipStream_t)stream, ray_sum, features16,
+               N, K, grad_w0g, grad_w0, ldw);
+    return lnh_check_launch("lnh_lidar_dir_term_backward");
 }
 
 int lnh_lidar_pack_weights(const float *ws0, uint32_t ld_s0, const float *ws1, uint32_t ld_s1, const float *wc0,
@@ -323,27 +337,28 @@ int lnh_lidar_pack_weights_bf16(const float *ws0, uint32_t ld_s0, const float *w
 }
 
 int lnh_lidar_loss(const float *depth, const float *image, const float *gt, uint32_t N, float alpha_d, float alpha_r,
-                   float alpha_i, float *loss, float *grad_depth, float *grad_image, lnh_stream_t stream) {
+                   float alpha_i, const float *grad_scale, float *loss, float *grad_depth, float *grad_image,
+                   lnh_stream_t stream) {
     LNH_REQUIRE(depth && image && gt && loss && grad_depth && grad_image, LNH_ERR_INVALID_ARG,
                 "lidar_loss: null pointer");
-    if (int zrc = lnh_zero_async(loss, sizeof(float), (hipStream_t)stream, "lidar_loss (accumulator clear)")) return zrc;
-    if (N == 0) return LNH_OK;
+    LNH_REQUIRE(div_up(N, 256) <= kLossMaxBlocks, LNH_ERR_UNSUPPORTED, "lidar_loss: at most %u rays per call", kLossMaxBlocks * 256);
+    if (N == 0) return lnh_zero_async(loss, sizeof(float), (hipStream_t)stream, "lidar_loss (no rays)");
     LNH_LAUNCH(k_lidar_loss, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, depth, image, gt, N, alpha_d,
-               alpha_r, alpha_i, loss, grad_depth, grad_image);
+               alpha_r, alpha_i, grad_scale, loss, grad_depth, grad_image);
     return lnh_check_launch("lnh_lidar_loss");
 }
 
 int lnh_lidar_loss_patch(const float *depth, const float *image, const float *gt, uint32_t N, uint32_t px, uint32_t py,
-                         float scale, float alpha_d, float alpha_r, float alpha_i, float alpha_grad, float *loss,
-                         float *grad_depth, float *grad_image, lnh_stream_t stream) {
+                         float scale, float alpha_d, float alpha_r, float alpha_i, float alpha_grad,
+                         const float *grad_scale, float *loss, float *grad_depth, float *grad_image, lnh_stream_t stream) {
     LNH_REQUIRE(depth && image && gt && loss && grad_depth && grad_image, LNH_ERR_INVALID_ARG,
                 "lidar_loss_patch: null pointer");
     LNH_REQUIRE(px >= 1 && py >= 2 && scale > 0.0f && N % (px * py) == 0, LNH_ERR_INVALID_ARG,
                 "lidar_loss_patch: need py >= 2, scale > 0 and N a multiple of px * py");
-    if (int zrc = lnh_zero_async(loss, sizeof(float), (hipStream_t)stream, "lidar_loss_patch (accumulator clear)")) return zrc;
-    if (N == 0) return LNH_OK;
+    LNH_REQUIRE(div_up(N, 256) <= kLossMaxBlocks, LNH_ERR_UNSUPPORTED, "lidar_loss_patch: at most %u rays per call", kLossMaxBlocks * 256);
+    if (N == 0) return lnh_zero_async(loss, sizeof(float), (hipStream_t)stream, "lidar_loss_patch (no rays)");
     LNH_LAUNCH(k_lidar_loss_patch, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, depth, image, gt, N, py,
-               1.0f / scale, alpha_d, alpha_r, alpha_i, alpha_grad, loss, grad_depth, grad_image);
+               1.0f / scale, alpha_d, alpha_r, alpha_i, alpha_grad, grad_scale, loss, grad_depth, grad_image);
     return lnh_check_launch("lnh_lidar_loss_patch");
 }
 

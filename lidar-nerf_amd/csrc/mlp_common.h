@@ -217,9 +217,10 @@ __device__ __forceinline__ half8_t pack_pair_relu_bwd(const f32x4 &lo, const f32
 // lane-linear address slab + 8 * lane then returns, in lane (g, c): channel c of points 4g .. 4g+3.  Two such reads
 // (the two 16-point tiles of a 32-point span) are one 8-value operand with the point enumeration k(g, j) = tile j >> 2,
 // point 4g + (j & 3) — the same for both operands of a product, which is all a dot product asks.  Slabs are private to
-// a wave and LDS instructions of a wave execute in order: no barrier, no fence.  (Rounds 2-4 transposed with an MFMA
-// against an identity fragment plus two packed conversions per tile; this is one LDS write per PAIR of tiles and one
-// read per tile, and no VALU instruction at all.)
+// a wave and LDS instructions of a wave execute in order: no barrier, no fence.  One LDS write per PAIR of tiles and one
+// read per tile, no VALU instruction at all.  Used by the sigma-net backward (mlp_bwd.h, two waves per SIMD: 5 % faster
+// than its second pass with swapped MFMA operands); the colour backward (one wave per SIMD) keeps its identity-fragment
+// MFMAs — nothing runs under an LDS round trip there (profiles/r05_color_backward_wgrad.txt).
 typedef short lds_tr_raw_t __attribute__((__vector_size__(4 * sizeof(short))));
 constexpr uint32_t kSlabBytes = 512;
 // chunks of a nu-enumerated packed pair (M-tiles 2s and 2s+1 of one point tile): slabs of the two tiles 512 bytes apart
@@ -238,10 +239,6 @@ __device__ __forceinline__ half8_t slab_get_span(const char *slab_n0, uint32_t s
     const half4_t a = slab_get(slab_n0, rd_off), b = slab_get(slab_n0 + stride, rd_off);
     const half8_t r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
     return r;
-}
-// acc += a * b, accumulator pinned to AGPRs, operands that come straight out of LDS reads (no VALU producer: no wait states)
-__device__ __forceinline__ void mfma16_acc_agpr_ld(f32x4 &acc, const half8_t &a, const half8_t &b) {
-    asm(LNH_MFMA16_MNEMONIC " %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
 // activation resolved at compile time: ReLU takes the packed path, everything else the generic one
 template <int ACT>

@@ -71,8 +71,12 @@ _SIGS = {
     "lnh_grad_check_f16": [P, C.c_uint64, P],
     "lnh_adam_table_step": [P, P, P, P, P, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_double, P, P, P, P],
     "lnh_adam_table_step_dlr": [P, P, P, P, P, C.c_uint64, P, C.c_double, C.c_double, C.c_double, P, P, P, P],
-    "lnh_lidar_loss": [P, P, P, U32, F32, F32, F32, P, P, P],
-    "lnh_lidar_loss_patch": [P, P, P, U32, U32, U32, F32, F32, F32, F32, F32, P, P, P],
+    "lnh_lidar_loss": [P, P, P, U32, F32, F32, F32, P, P, P, P],
+    "lnh_lidar_loss_patch": [P, P, P, U32, U32, U32, F32, F32, F32, F32, F32, P, P, P, P],
+    "lnh_train_check": [P, P, C.c_uint64, P, P, U32, F32, F32, C.c_double, C.c_double],
+    "lnh_train_step": [P, P, P, P, P, P, C.c_uint64, P, P, P, U32, P, P, C.c_double, C.c_double, C.c_double, C.c_double,
+                       C.c_double, U32],
+    "lnh_zero_regions": [P, P, U32],
     "lnh_lidar_color_backward": [P, P, P, P, P, P, P, U32, U32, P, P, P],
     "lnh_lidar_color_backward_image": [P, P, P, P, P, P, P, U32, U32, P, P, P],
     "lnh_ragged_points": [P, F32, U32, P],
@@ -190,6 +194,34 @@ def call(name, *args, tag=None):
         TIMERS.setdefault(name, []).append((e0, e1, tag))
     if rc != 0:
         raise RuntimeError(f"{name} failed ({rc}): {L.lnh_last_error().decode()}")
+
+
+def zero_regions(tensors):
+    """Clear up to 8 device tensors with ONE launch (lnh_zero_regions; zero fills are kernels, never memset nodes)."""
+    ts = [t for t in tensors if t is not None and t.numel()]
+    if not ts:
+        return
+    for t in ts:
+        if not (t.is_cuda and t.is_contiguous()):
+            raise RuntimeError("lidarnerf_hip: zero_regions needs contiguous GPU tensors")
+    ptrs = (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    sizes = (C.c_uint64 * len(ts))(*[t.numel() * t.element_size() for t in ts])
+    call("lnh_zero_regions", C.cast(ptrs, C.c_void_p), C.cast(sizes, C.c_void_p), len(ts))
+
+
+def ptr_array(values):
+    """Host array of device pointers (None -> NULL) for the entry points that take `T *const *`; keep the returned object
+    alive until the call has returned."""
+    return (C.c_void_p * max(len(values), 1))(*[(v if v else None) for v in values])
+
+
+def u32_array(values):
+    return (C.c_uint32 * max(len(values), 1))(*[int(v) for v in values])
+
+
+# indices into the optimizer's device-side scalar buffer (include/lidarnerf_hip.h LNH_TS_*)
+TS_SCALE, TS_GROWTH, TS_FOUND, TS_INV, TS_INV_TABLE, TS_LAST_SCALE, TS_T, TS_IT, TS_LR, TS_T_NEXT, TS_IT_NEXT, TS_SKIPPED = range(12)
+TRAIN_STATE_FLOATS, TRAIN_MAX_SMALL = 16, 16
 
 
 def mlp_suffix(dt):

@@ -337,6 +337,11 @@ class FusedLidarRender(Function):
         ctx.model, ctx.dims, ctx.density_scale, ctx.enc = model, (N, T, t_new), density_scale, enc
         ctx.table_param, ctx.mdt = spec.table_param, mdt
         ctx.param_dtypes = (embeddings.dtype, ws0.dtype, ws1.dtype, wc0.dtype, wc1.dtype, wc2.dtype)
+        # the five small matrices as the Parameters they are (network.NeRFNetwork) — or None when the field hands out views of
+        # flat parameter vectors (network_tcnn): LidarTrainer takes their gradients straight from this node's arena then
+        small = (ws0, ws1, wc0, wc1, wc2)
+        ctx.small_params = small if all(isinstance(w, torch.nn.Parameter) and w.dtype == torch.float32 and
+                                        w.is_contiguous() for w in small) else None
         ctx.mark_non_differentiable(weights, z_all)
         # outputs the loss does not use (weights_sum in the LiDAR loss) arrive as None instead of a zero tensor filled
         # for the occasion; the compositing backward takes a null pointer for them
@@ -367,7 +372,12 @@ class FusedLidarRender(Function):
         g_h16 = torch.empty((N * Ttot, 16), dtype=mdt, device=dev)
         kd = enc_d16.shape[1]
         n_col, n_sig, n_c0 = wcol16.numel(), wsig16.numel(), 64 * (kd + 15)
-        zeros = torch.zeros(n_col + n_sig + n_c0, dtype=torch.float32, device=dev)  # one fill for all small gradients
+        # every gradient that is ACCUMULATED into (the small matrices' by atomics, the table's by the reduce pass) is cleared
+        # by one launch: the arena of all small gradients and — unless the sharded backward brings its own — the fp16 table
+        zeros = torch.empty(n_col + n_sig + n_c0, dtype=torch.float32, device=dev)
+        sharded = parallel.dp_active() and getattr(ctx.table_param, "_lnh_shard_optimizer", False)
+        g_table16 = None if sharded else torch.empty((int(enc._offsets_host[-1]), 2), dtype=torch.half, device=dev)
+        _hip.zero_regions((zeros, g_table16))
         g_wcol, g_wsig = zeros[:n_col], zeros[n_col:n_col + n_sig]
         ray_sum = torch.empty((N, 64), dtype=torch.float32, device=dev)
         _hip.call("lnh_lidar_color_backward_image" + sfx, g_image.data_ptr(), g_sigma.data_ptr(), h16.data_ptr(), perm.data_ptr(),
@@ -375,27 +385,34 @@ class FusedLidarRender(Function):
                   ray_sum.data_ptr())
         g_w0g = g_wcol[:64 * 16].view(64, 16)
         g_wc0 = zeros[n_col + n_sig:].view(64, kd + 15)
-        scratch = torch.empty(((N + 31) // 32) * 64 * 128, dtype=torch.float32, device=dev)
-        _hip.call("lnh_lidar_dir_term_backward", ray_sum.data_ptr(), enc_d16.data_ptr(), N, kd, scratch.data_ptr(),
+        # the whole gradient of the colour head's first matrix in one launch: direction columns = S^T enc(d), geo-feature
+        # columns copied out of the packed [64, 16] block the colour backward accumulated
+        _hip.call("lnh_lidar_dir_term_backward", ray_sum.data_ptr(), enc_d16.data_ptr(), N, kd, g_w0g.data_ptr(),
                   g_wc0.data_ptr(), kd + 15)
-        g_wc0[:, kd:] = g_w0g[:, 1:16]
         g_wc1 = g_wcol[64 * 16:64 * 16 + 64 * 64].view(64, 64)
         g_wc2 = g_wcol[64 * 16 + 64 * 64:].view(16, 64)[:2]
+        dts = ctx.param_dtypes
+        g_small = (g_wsig[:64 * 32].view(64, 32), g_wsig[64 * 32:].view(16, 64), g_wc0, g_wc1, g_wc2)
+        if ctx.small_params is not None and getattr(ctx.table_param, "_lnh_direct_small_grads", False):
+            # LidarTrainer's fused optimizer: the gradients are handed over as views of the arena (autograd's AccumulateGrad
+            # would copy each view into a tensor of its own: five launches), and the arena goes on the wire as ONE tensor
+            for p_, g_ in zip(ctx.small_params, g_small):
+                p_.grad = g_
+            ctx.table_param._lnh_small_arena = zeros
+            g_small = (None,) * 5
+        else:
+            g_small = tuple(g_.to(dt_) for g_, dt_ in zip(g_small, dts[1:]))
 
         B_all = N * Ttot
         g_feat = torch.empty((enc.num_levels, B_all, 2), dtype=torch.half, device=dev)
         _hip.call("lnh_density_mlp_backward" + sfx, g_h16.data_ptr(), feat.data_ptr(), wsig16.data_ptr(), B_all, Ttot, Ttot, 0,
                   g_feat.data_ptr(), g_wsig.data_ptr())
-        if parallel.dp_active() and getattr(ctx.table_param, "_lnh_shard_optimizer", False):
+        if sharded:
             # data parallel, sharded table optimizer: reduce-scatter per window; the trainer steps this rank's rows
             ctx.table_param._lnh_grad16_shards = _grid_bwd_sharded(g_feat, x01, enc, B_all, ctx.table_param)
             ctx.table_param._lnh_grad16_div = parallel.world_size()
             ctx.table_param._lnh_grad16 = None
-            dts = ctx.param_dtypes
-            return (None, None, None, None, None, g_wsig[:64 * 32].view(64, 32).to(dts[1]),
-                    g_wsig[64 * 32:].view(16, 64).to(dts[2]), g_wc0.to(dts[3]), g_wc1.to(dts[4]), g_wc2.to(dts[5]),
-                    None, None, None, None, None, None, None)
-        g_table16 = torch.zeros((int(enc._offsets_host[-1]), 2), dtype=torch.half, device=dev)
+            return (None, None, None, None, None) + g_small + (None,) * 7
         if parallel.dp_active() or FORCE_DP_WINDOWS:
             # data parallel: the table gradient goes on the wire as fp16, window by window, behind the kernels of the
             # following windows
@@ -410,7 +427,6 @@ class FusedLidarRender(Function):
                     handle.wait()
         else:
             _grid_bwd(g_feat, x01, g_table16, enc, B_all)
-        dts = ctx.param_dtypes
         world = parallel.world_size()
         if getattr(ctx.table_param, "_lnh_keep_grad16", False):
             # the fused table optimizer consumes the fp16 gradient directly: no fp32 copy, no .grad on the table
@@ -422,9 +438,7 @@ class FusedLidarRender(Function):
             g_table = g_table16.to(dts[0])
             if world > 1:
                 g_table.div_(world)  # sum over ranks -> mean, after the widening
-        return (None, None, None, None, g_table, g_wsig[:64 * 32].view(64, 32).to(dts[1]),
-                g_wsig[64 * 32:].view(16, 64).to(dts[2]), g_wc0.to(dts[3]), g_wc1.to(dts[4]), g_wc2.to(dts[5]),
-                None, None, None, None, None, None, None)
+        return (None, None, None, None, g_table) + g_small + (None,) * 7
 
 
 MASK_STATS = None  # bench.py: set to a list to collect, per render call, the fraction of samples with weight > 1e-4
@@ -576,7 +590,13 @@ class FusedLidarRagged(Function):
         M, N, L = x01.shape[0], rays.shape[0], enc.num_levels
         zN = lambda g, shape: torch.zeros(shape, dtype=torch.float32, device=dev) if g is None else g.contiguous().float()
         g_ws, g_depth, g_image = zN(g_ws, (N,)), zN(g_depth, (N,)), zN(g_image, (N, 2))
-        gsf = torch.zeros(M * 3, dtype=torch.float32, device=dev)  # (one fill for both)
+        # every buffer that is accumulated into — both compositing gradients, the small matrices' gradients, the fp16 table
+        # gradient — cleared by ONE launch
+        gsf = torch.empty(M * 3, dtype=torch.float32, device=dev)
+        n_col, n_sig = wcol16.numel(), wsig16.numel()
+        zeros = torch.empty(n_col + n_sig, dtype=torch.float32, device=dev)
+        g_table16 = torch.empty((int(enc._offsets_host[-1]), 2), dtype=torch.half, device=dev)
+        _hip.zero_regions((gsf, zeros, g_table16))
         gs, gf = gsf[:M], gsf[M:].view(M, 2)
         _hip.call("lnh_lidar_composite_rays_train_backward", g_ws.data_ptr(), g_depth.data_ptr(), g_image.data_ptr(),
                   sig_s.data_ptr(), rgb.data_ptr(), deltas.data_ptr(), xyzs.data_ptr(), rays_o.data_ptr(),
@@ -585,8 +605,6 @@ class FusedLidarRagged(Function):
         gy = torch.empty((M, 16), dtype=mdt, device=dev)
         _hip.call("lnh_ragged_color_output_backward" + sfx, gf.data_ptr(), rgb.data_ptr(), M, gy.data_ptr())
         gx = torch.empty((M, 96), dtype=mdt, device=dev)
-        n_col, n_sig = wcol16.numel(), wsig16.numel()
-        zeros = torch.zeros(n_col + n_sig, dtype=torch.float32, device=dev)
         g_wcol, g_wsig = zeros[:n_col], zeros[n_col:]
         _hip.call("lnh_mlp_backward" + sfx, gy.data_ptr(), cin.data_ptr(), wcol16.data_ptr(), M, 96, 16, 64, 1, 0, 6,
                   gx.data_ptr(), g_wcol.data_ptr())
@@ -596,7 +614,6 @@ class FusedLidarRagged(Function):
         g_feat = torch.empty((L, M, 2), dtype=torch.half, device=dev)
         _hip.call("lnh_density_mlp_backward" + sfx, g_h16.data_ptr(), feat.data_ptr(), wsig16.data_ptr(), M, M, M, 0,
                   g_feat.data_ptr(), g_wsig.data_ptr())
-        g_table16 = torch.zeros((int(enc._offsets_host[-1]), 2), dtype=torch.half, device=dev)
         world = parallel.world_size()
         if parallel.dp_active():
             for handle in _grid_bwd_overlapped(g_feat, x01, g_table16, enc, M, table_param):

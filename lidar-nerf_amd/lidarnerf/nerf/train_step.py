@@ -25,38 +25,57 @@ class _FusedLidarLoss(torch.autograd.Function):
     """lidar_loss as ONE kernel that also emits d loss / d (depth, image); backward only scales by the upstream scalar."""
 
     @staticmethod
-    def forward(ctx, depth, image, gt, ad, ar, ai, patch=None):
+    def forward(ctx, depth, image, gt, ad, ar, ai, patch=None, grad_scale=None):
         # patch = (px, py, scale, alpha_grad): the reference's patch epochs, structural-gradient term included
+        # grad_scale (device scalar): the kernel multiplies the gradients it emits by it — the caller then starts
+        # backward() from a gradient of ONE (LidarTrainer: the loss scale, without an element-wise launch in backward)
         from .. import _hip
         n = depth.numel()
         depth, image, gt = depth.reshape(n).float().contiguous(), image.reshape(n, 2).float().contiguous(), \
             gt.reshape(n, 3).float().contiguous()
         loss = torch.empty((), dtype=torch.float32, device=depth.device)
         grads = torch.empty(3 * n, dtype=torch.float32, device=depth.device)  # [d/d depth (n) | d/d image (n, 2)]
+        gs = None if grad_scale is None else grad_scale.data_ptr()
         if patch is None:
             _hip.call("lnh_lidar_loss", depth.data_ptr(), image.data_ptr(), gt.data_ptr(), n, float(ad), float(ar), float(ai),
-                      loss.data_ptr(), grads.data_ptr(), grads.data_ptr() + 4 * n)
+                      gs, loss.data_ptr(), grads.data_ptr(), grads.data_ptr() + 4 * n)
         else:
             px, py, scale, ag = patch
             _hip.call("lnh_lidar_loss_patch", depth.data_ptr(), image.data_ptr(), gt.data_ptr(), n, int(px), int(py),
-                      float(scale), float(ad), float(ar), float(ai), float(ag), loss.data_ptr(), grads.data_ptr(),
+                      float(scale), float(ad), float(ar), float(ai), float(ag), gs, loss.data_ptr(), grads.data_ptr(),
                       grads.data_ptr() + 4 * n)
         ctx.save_for_backward(grads)
-        ctx.n = n
+        ctx.n, ctx.prescaled = n, grad_scale is not None
         return loss
 
     @staticmethod
     def backward(ctx, g):
         (grads,) = ctx.saved_tensors
-        scaled = grads * g  # one launch for both
-        return scaled[:ctx.n], scaled[ctx.n:].view(ctx.n, 2), None, None, None, None, None
+        # (pre-scaled gradients: the contract of grad_scale is that backward() starts from ONE)
+        scaled = grads if ctx.prescaled else grads * g  # one launch for both
+        return scaled[:ctx.n], scaled[ctx.n:].view(ctx.n, 2), None, None, None, None, None, None
 
 
-def fused_lidar_loss(outputs, images_lidar, alpha_d=1000.0, alpha_r=1.0, alpha_i=10.0, patch=None):
+class _ScaleGrad(torch.autograd.Function):
+    """Identity whose gradient is multiplied by a device scalar (the loss scale, for the loss paths without a kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.save_for_backward(scale)
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.saved_tensors[0], None
+
+
+def fused_lidar_loss(outputs, images_lidar, alpha_d=1000.0, alpha_r=1.0, alpha_i=10.0, patch=None, grad_scale=None):
     """lidar_loss (+ patch_gradient_loss when patch = (px, py, scale, alpha_grad)) through the single-launch kernel (GPU
-    tensors only); same value and gradients."""
+    tensors only); same value and gradients.  grad_scale (device scalar): the gradients come out multiplied by it and
+    backward() must then be started from a gradient of one."""
     depth, image = outputs["depth_lidar"], outputs["image_lidar"]
-    loss = _FusedLidarLoss.apply(depth.reshape(-1), image.reshape(-1, 2), images_lidar, alpha_d, alpha_r, alpha_i, patch)
+    loss = _FusedLidarLoss.apply(depth.reshape(-1), image.reshape(-1, 2), images_lidar, alpha_d, alpha_r, alpha_i, patch,
+                                 grad_scale)
     return loss
 
 
@@ -70,6 +89,11 @@ def patch_gradient_loss(pred_depth, gt_depth, gt_raydrop, px, py, scale, alpha_g
     gt_gx = gt[..., :-1] - gt[..., 1:]
     mask = rd[..., :-1] * (gt_gx.abs() < 0.01)
     return alpha_grad * (pred_gx * mask - gt_gx * mask).abs().mean()
+
+
+def _hip_consts():
+    from .. import _hip
+    return _hip
 
 
 class LidarTrainer:
@@ -115,17 +139,36 @@ class LidarTrainer:
                 tp = model.fused_spec().table_param
             except AttributeError:
                 tp = None
-            if tp is not None and tp.dtype == torch.float32 and tp.is_contiguous() and tp.numel() % 4 == 0:
+            others = [p for g in params for p in g["params"] if p is not tp]
+            # the fused optimizer steps EVERY parameter: the table from its fp16 gradient and the other tensors (the MLP
+            # weights: a handful of small fp32 matrices) in the same launch
+            if tp is not None and tp.dtype == torch.float32 and tp.is_contiguous() and tp.numel() % 4 == 0 and \
+                    len(others) <= _hip_consts().TRAIN_MAX_SMALL and \
+                    all(p.dtype == torch.float32 and p.is_contiguous() and p.is_cuda for p in others):
+                H = _hip_consts()
                 self.table = tp
                 params = [dict(g, params=[p for p in g["params"] if p is not tp]) for g in params]
                 self.t_m, self.t_v = torch.zeros_like(tp), torch.zeros_like(tp)
-                self.t_steps = [torch.zeros((), device=tp.device), torch.zeros((), device=tp.device)]
-                self.t_flip = 0
+                # every scalar of the optimizer in ONE device buffer (include/lidarnerf_hip.h LNH_TS_*): a captured step
+                # needs no host value.  loss_scale / growth_tracker / t_steps are views of it (the names rounds 2-4 used).
+                self.opt_state = torch.zeros(H.TRAIN_STATE_FLOATS, dtype=torch.float32, device=tp.device)
+                self.opt_state[H.TS_SCALE] = 65536.0
+                self.loss_scale = self.opt_state[H.TS_SCALE:H.TS_SCALE + 1].view(())
+                self.growth_tracker = self.opt_state[H.TS_GROWTH:H.TS_GROWTH + 1].view(())
+                self.t_steps, self.t_flip = [self.opt_state[H.TS_T_NEXT:H.TS_T_NEXT + 1].view(())] * 2, 0
+                self._one = torch.ones((), dtype=torch.float32, device=tp.device)
+                self._lr0, self._iters = float(lr), float(iters)
+                self.small = others
+                self.small_off = [0]
+                for p in others:
+                    self.small_off.append(self.small_off[-1] + p.numel())
+                self.small_m = torch.zeros(max(self.small_off[-1], 1), dtype=torch.float32, device=tp.device)
+                self.small_v = torch.zeros_like(self.small_m)
+                self._small_stepped = set()  # ids of the small parameters that have taken a step (torch creates state lazily)
                 tp._lnh_keep_grad16 = True
+                tp._lnh_direct_small_grads = True
                 tp._lnh_table16 = tp.detach().to(torch.half).reshape(-1, 2).contiguous()
                 tp._lnh_table16_version = tp._version  # fused.table16_of re-casts when the parameter is written elsewhere
-                self.loss_scale = torch.full((), 65536.0, dtype=torch.float32, device=tp.device)
-                self.growth_tracker = torch.zeros((), dtype=torch.int32, device=tp.device)
                 # data parallel, second cut (parallel.py): reduce-scatter of the table gradient, every rank steps 1/N of
                 # the rows, all-gather of the fp16 compute copy.  The fp32 master table and the Adam moments of a rank are
                 # then current on ITS rows only: gather_table_state() completes them (checkpoints call it).
@@ -160,15 +203,12 @@ class LidarTrainer:
                                (f" and, data parallel, the 'nccl' (RCCL) backend — this process group runs "
                                 f"'{parallel.backend()}', whose collectives cannot be captured" if self.dp else ""))
         self._graphs, self._graph_warm, self._graph_pool, self.graph_error = {}, set(), None, None
-        if self.graph:
-            dev0 = self.table.device
-            # (initial_lr as a number: LambdaLR then computes the schedule on the host and fills the device scalar — with a
-            #  tensor it would run the schedule as GPU arithmetic, three more tiny kernels per step)
-            params = [dict(g, lr=torch.tensor(float(g["lr"]), dtype=torch.float32, device=dev0), initial_lr=float(g["lr"]))
-                      for g in params]
-            self.optimizer = torch.optim.Adam(params, betas=(0.9, 0.99), eps=1e-15, fused=True, capturable=True)
-        else:
-            self.optimizer = torch.optim.Adam(params, betas=(0.9, 0.99), eps=1e-15, fused=on_gpu)
+        # With the fused optimizer (self.table is not None) this torch optimizer never steps: it holds the parameter groups
+        # the scheduler and the checkpoint layout are written against (lr stays a host number; the kernels form the same
+        # schedule on the device from their own step counter).
+        self.optimizer = torch.optim.Adam(params, betas=(0.9, 0.99), eps=1e-15, fused=on_gpu)
+        if self.table is not None:
+            self.optimizer._opt_called = True  # (the scheduler's "step() before optimizer.step()" check: the kernels are the optimizer)
         self.scheduler = torch.optim.lr_scheduler.LambdaLR(self.optimizer, lambda it: 0.1 ** min(it / iters, 1))
         self.scaler = torch.amp.GradScaler("cuda", enabled=fp16)
         self.params = [p for g in self.optimizer.param_groups for p in g["params"]]
@@ -181,90 +221,109 @@ class LidarTrainer:
         from . import fused
         return bool(getattr(model, "fused_lidar", False)) and fused.ragged_supported(model)
 
-    def loss(self, rays_o, rays_d, images_lidar, patch=(1, 1)):
+    def loss(self, rays_o, rays_d, images_lidar, patch=(1, 1), grad_scale=None):
+        """grad_scale (device scalar): the loss comes back unscaled, its gradient multiplied by it."""
         out = self.model.render(rays_o, rays_d, cal_lidar_color=True, staged=False, perturb=True,
                                 **self.render_kwargs)
         ad, ar, ai, ag = self.alpha
         if out["depth_lidar"].is_cuda and (patch[0] <= 1 or (patch[1] >= 2 and out["depth_lidar"].numel() %
                                                                (patch[0] * patch[1]) == 0)):
             return fused_lidar_loss(out, images_lidar, ad, ar, ai,
-                                    None if patch[0] <= 1 else (patch[0], patch[1], self.scale, ag))
+                                    None if patch[0] <= 1 else (patch[0], patch[1], self.scale, ag), grad_scale)
         loss, pred_depth, gt_depth = lidar_loss(out, images_lidar, ad, ar, ai)
         if patch[0] > 1:
             loss = loss + patch_gradient_loss(pred_depth, gt_depth, images_lidar[..., 0], patch[0], patch[1],
                                               self.scale, ag)
-        return loss
+        return loss if grad_scale is None else _ScaleGrad.apply(loss, grad_scale)
 
     def _step_fused_table(self, rays_o, rays_d, images_lidar, patch):
+        """One iteration with the fused optimizer: render + loss + backward, (the gradient exchange,) and the optimizer as two
+        launches — lnh_train_check (finite check of every gradient, 1 / scale, the learning rate of this step) and
+        lnh_train_step (Adam on the table and on the small tensors, GradScaler's skip / scale update, the step counters)."""
         from .. import _hip
         from .fused import table16_of
-        tp = self.table
-        self.optimizer.zero_grad(set_to_none=True)
+        H = _hip
+        tp, st = self.table, self.opt_state
+        for p in self.small:
+            p.grad = None
         tp._lnh_grad16 = None
         tp._lnh_grad_reduced = False
         tp._lnh_grad16_handles = None
+        tp._lnh_small_arena = None
         with torch.autocast("cuda", dtype=self.amp_dtype):
-            loss = self.loss(rays_o, rays_d, images_lidar, patch)
-        loss.backward(gradient=self.loss_scale.to(loss.dtype))  # = (loss * scale).backward() without the product and its ones_like
+            loss = self.loss(rays_o, rays_d, images_lidar, patch, grad_scale=self.loss_scale)
+        loss.backward(gradient=self._one)  # (the loss kernel has multiplied its gradients by the loss scale)
+        # --- data parallel: the small gradients.  The fused chain leaves all of them in ONE arena (views): that tensor goes
+        # on the wire as it is, summed — the division by the world size is folded into 1 / scale like the table's
+        div_small, small_handle = 1.0, None
         if self.dp:
-            parallel.allreduce_gradients(self.params, self.world)
-        # --- GradScaler.step / update, with the table handled by the fused kernels
-        found_inf = torch.zeros((), dtype=torch.float32, device=tp.device)
-        inv_scale = self.loss_scale.reciprocal()
-        # data parallel: the fp16 table gradient arrives as the sum over ranks; its mean is taken here, in fp32
+            arena = getattr(tp, "_lnh_small_arena", None)
+            if arena is not None:
+                import torch.distributed as dist
+                small_handle = dist.all_reduce(arena, op=dist.ReduceOp.SUM, async_op=True)
+                div_small = float(self.world)
+            else:
+                parallel.allreduce_gradients(self.small, self.world)
+        # data parallel: the fp16 table gradient arrives as the sum over ranks; its mean is taken in fp32 by the kernels
         div = float(getattr(tp, "_lnh_grad16_div", 1))
-        inv_scale_table = inv_scale / div if div != 1.0 else inv_scale
-        grads = [p.grad for p in self.params if p.grad is not None]
-        if grads:
-            torch._amp_foreach_non_finite_check_and_unscale_(grads, found_inf, inv_scale)
         shards = getattr(tp, "_lnh_grad16_shards", None) if self.sharded else None
         g16 = tp._lnh_grad16
         if g16 is None and not shards:
             raise RuntimeError("fused table optimizer: the backward pass produced no fp16 table gradient "
                                "(render did not go through the fused LiDAR chain)")
+        grads = [p.grad for p in self.small]
+        for p, g in zip(self.small, grads):
+            if g is not None:
+                if not (g.dtype == torch.float32 and g.is_contiguous()):
+                    raise RuntimeError("fused optimizer: gradients of the small parameters must be contiguous fp32")
+                self._small_stepped.add(id(p))
+        n_small = len(self.small)
+        gp = H.ptr_array([None if g is None else g.data_ptr() for g in grads])
+        pp = H.ptr_array([p.data_ptr() for p in self.small])
+        nn_ = H.u32_array([p.numel() for p in self.small])
+        cast = lambda arr: H.C.cast(arr, H.C.c_void_p)
+        if small_handle is not None:
+            small_handle.wait()
+        check = lambda ptr, n, first: _hip.call("lnh_train_check", st.data_ptr(), ptr, n, cast(gp), cast(nn_),
+                                                n_small if first else 0, div, div_small, self._lr0, self._iters)
+        step_args = (cast(pp), cast(gp), cast(nn_), n_small, self.small_m.data_ptr(), self.small_v.data_ptr(), 0.9, 0.99,
+                     1e-15, 2.0, 0.5, 2000)
         if shards:
             import torch.distributed as dist
             rank = dist.get_rank()
-            for r0, r1, mine, handle, _padded in shards:
+            for i, (r0, r1, mine, handle, _padded) in enumerate(shards):
                 handle.wait()
                 rows = max(0, min(mine.shape[0], r1 - (r0 + rank * mine.shape[0])))
-                if rows:
-                    _hip.call("lnh_grad_check_f16", mine.data_ptr(), rows * 2, found_inf.data_ptr())
-            # every rank has looked at its own rows only: the skip / back-off decision must be the same everywhere
-            dist.all_reduce(found_inf, op=dist.ReduceOp.MAX)
+                check(mine.data_ptr() if rows else None, rows * 2, i == 0)
+            # every rank has looked at its own rows only: the skip / back-off decision must be the same everywhere (the stamp
+            # of a step is the same number on every rank, so MAX keeps it)
+            dist.all_reduce(st[H.TS_FOUND:H.TS_FOUND + 1], op=dist.ReduceOp.MAX)
+            shadow = table16_of(tp)  # (re-cast first if somebody wrote the parameter since the last step)
+            _hip.call("lnh_train_step", st.data_ptr(), None, None, None, None, None, 0, *step_args)
+            self._step_table_shards(shards, shadow)
         else:
             for handle in getattr(tp, "_lnh_grad16_handles", None) or ():
                 handle.wait()  # the table windows' all-reduce (left in flight by the backward pass)
             tp._lnh_grad16_handles = None
-            _hip.call("lnh_grad_check_f16", g16.data_ptr(), g16.numel(), found_inf.data_ptr())
-        self.optimizer.grad_scale, self.optimizer.found_inf = None, found_inf
-        try:
-            self.optimizer.step()
-        finally:
-            del self.optimizer.grad_scale, self.optimizer.found_inf
-        lr = self.optimizer.param_groups[0]["lr"]
-        s_in, s_out = self.t_steps[self.t_flip], self.t_steps[1 - self.t_flip]
-        shadow = table16_of(tp)  # (re-cast first if somebody wrote the parameter since the last step)
-        if shards:
-            self._step_table_shards(shards, shadow, float(lr), inv_scale_table, found_inf, s_in, s_out)
-            self.t_flip = 1 - self.t_flip
-        elif torch.is_tensor(lr):
-            # graph mode: lr is a device scalar the scheduler fills; the step counter is copied back instead of flipped
-            # (a captured step always reads and writes the same two buffers)
-            _hip.call("lnh_adam_table_step_dlr", tp.data_ptr(), self.t_m.data_ptr(), self.t_v.data_ptr(), g16.data_ptr(),
-                      shadow.data_ptr(), tp.numel(), lr.data_ptr(), 0.9, 0.99, 1e-15, inv_scale_table.data_ptr(),
-                      found_inf.data_ptr(), s_in.data_ptr(), s_out.data_ptr())
-            s_in.copy_(s_out)
-        else:
-            _hip.call("lnh_adam_table_step", tp.data_ptr(), self.t_m.data_ptr(), self.t_v.data_ptr(), g16.data_ptr(),
-                      shadow.data_ptr(), tp.numel(), float(lr), 0.9, 0.99, 1e-15, inv_scale_table.data_ptr(),
-                      found_inf.data_ptr(), s_in.data_ptr(), s_out.data_ptr())
-            self.t_flip = 1 - self.t_flip
-        self._last_scale = self.loss_scale.clone()  # the scale this step's gradient carries (table_grad divides by it)
-        torch._amp_update_scale_(self.loss_scale, self.growth_tracker, found_inf, 2.0, 0.5, 2000)
+            check(g16.data_ptr(), g16.numel(), True)
+            shadow = table16_of(tp)  # (re-cast first if somebody wrote the parameter since the last step)
+            _hip.call("lnh_train_step", st.data_ptr(), tp.data_ptr(), self.t_m.data_ptr(), self.t_v.data_ptr(), g16.data_ptr(),
+                      shadow.data_ptr(), tp.numel(), *step_args)
         if not torch.cuda.is_current_stream_capturing():
-            self.scheduler.step()  # (host arithmetic + a fill of the lr scalar: _step_graphed does it after each replay)
+            self.scheduler.step()  # (host bookkeeping only: the kernels form the schedule from their own counter)
         return loss
+
+    def steps_taken(self):
+        """Number of optimizer steps applied so far (skipped steps — inf / nan gradients — do not count).  Synchronises."""
+        return int(self.opt_state[_hip_consts().TS_T_NEXT]) if self.table is not None else None
+
+    def _sync_counters(self, steps=None):
+        """After a load: the device-side counters follow the host's (scheduler position; optionally the Adam step count)."""
+        H = _hip_consts()
+        it = float(self.scheduler.last_epoch)
+        self.opt_state[H.TS_IT], self.opt_state[H.TS_IT_NEXT] = it, it
+        if steps is not None:
+            self.opt_state[H.TS_T], self.opt_state[H.TS_T_NEXT] = float(steps), float(steps)
 
     # ---- the captured step (graph=True)
     def _graph_capacity(self):
@@ -296,8 +355,8 @@ class LidarTrainer:
             return self._step_fused_table(rays_o, rays_d, images_lidar, patch).detach()
         # what a capture bakes in as kernel arguments is part of the key: the loss weights, the scene scale, the render
         # arguments (a change of any of them captures a new step instead of silently replaying the old values)
-        key = (tuple(rays_o.shape), tuple(images_lidar.shape), tuple(patch), cap, tuple(self.alpha), float(self.scale),
-               tuple(sorted((k, repr(v)) for k, v in self.render_kwargs.items())))
+        key = (tuple(rays_o.shape), tuple(images_lidar.shape), tuple(patch), tuple(self.alpha), float(self.scale),
+               tuple(sorted((k, repr(v)) for k, v in self.render_kwargs.items())), cap)
         tp = self.table
         if getattr(tp, "_lnh_table16_version", None) != tp._version:
             # somebody wrote the fp32 table through torch since the last step (model.load_state_dict, a manual
@@ -329,7 +388,7 @@ class LidarTrainer:
                     ent["loss"] = self._step_fused_table(ent["rays_o"], ent["rays_d"], ent["gt"], patch).detach()
                 # the gradient and the scale it carries live in THIS graph's buffers: table_grad() must see the ones of
                 # the graph that was replayed last, not of the one that was captured last
-                ent["g16"], ent["last_scale"] = tp._lnh_grad16, self._last_scale
+                ent["g16"] = tp._lnh_grad16
             except Exception as e:  # noqa: BLE001 — a capture that does not go through must not cost the run
                 # (nothing of a captured step has executed: the state is what it was.)  Launch by launch from here on; the
                 # reason stays readable (bench.py reports it).
@@ -342,40 +401,39 @@ class LidarTrainer:
         else:
             torch._foreach_copy_([ent["rays_o"], ent["rays_d"], ent["gt"]], [rays_o, rays_d, images_lidar])  # one launch
         ent["graph"].replay()
-        tp._lnh_grad16, self._last_scale = ent["g16"], ent["last_scale"]
+        tp._lnh_grad16 = ent["g16"]
         if self.occupancy:
             model.step_counter[model.local_step % 16].copy_(ent["counter"])
             model.local_step += 1
         self.scheduler.step()
         return ent["loss"].clone()  # (the graphs share a pool: the next replay of another one may reuse this memory)
 
-    def _step_table_shards(self, shards, shadow, lr, inv_scale_table, found_inf, s_in, s_out):
-        """Sharded table optimizer: Adam on this rank's rows of every level window, then the all-gather of the fp16 compute
-        copy (the only part of the table the next forward pass reads)."""
+    def _step_table_shards(self, shards, shadow):
+        """Sharded table optimizer: Adam on this rank's rows of every level window (learning rate, 1 / scale, the skip flag
+        and the step counter read from the optimizer's device scalars, which lnh_train_check / lnh_train_step have set), then
+        the all-gather of the fp16 compute copy (the only part of the table the next forward pass reads)."""
         from .. import _hip
         import torch.distributed as dist
-        tp = self.table
+        H = _hip
+        tp, st = self.table, self.opt_state
+        sp = lambda i: st.data_ptr() + 4 * i
         rank = dist.get_rank()
         flat16, table16 = shadow.view(-1), shadow.view(-1, 2)
-        gathers, stepped = [], False
+        gathers = []
         for r0, r1, mine, _h, padded in shards:
             s = mine.shape[0]
             row0 = r0 + rank * s
             rows = max(0, min(s, r1 - row0))
             if rows:
                 o = row0 * 2  # element offset of the shard in the [rows, 2] table
-                # (the device-side step counter: every window reads s_in and writes s_in + 1 to s_out)
-                _hip.call("lnh_adam_table_step", tp.data_ptr() + 4 * o, self.t_m.data_ptr() + 4 * o,
-                          self.t_v.data_ptr() + 4 * o, mine.data_ptr(), flat16.data_ptr() + 2 * o, rows * 2, lr, 0.9, 0.99,
-                          1e-15, inv_scale_table.data_ptr(), found_inf.data_ptr(), s_in.data_ptr(), s_out.data_ptr())
-                stepped = True
+                _hip.call("lnh_adam_table_step_dlr", tp.data_ptr() + 4 * o, self.t_m.data_ptr() + 4 * o,
+                          self.t_v.data_ptr() + 4 * o, mine.data_ptr(), flat16.data_ptr() + 2 * o, rows * 2, sp(H.TS_LR), 0.9,
+                          0.99, 1e-15, sp(H.TS_INV_TABLE), sp(H.TS_SKIPPED), sp(H.TS_T), sp(H.TS_T_NEXT))
             mine16 = torch.zeros_like(mine)
             if rows:
                 mine16[:rows] = table16[row0:row0 + rows]
             # (the window's padded gradient buffer has served its purpose: it receives the gathered copy)
             gathers.append((dist.all_gather_into_tensor(padded, mine16, async_op=True), padded, r0, r1))
-        if not stepped:  # a rank without rows (more ranks than shards): keep the double-buffered step counter moving
-            s_out.copy_(torch.where(found_inf != 0, s_in, s_in + 1))
         for handle, out, r0, r1 in gathers:
             handle.wait()
             table16[r0:r1] = out[:r1 - r0]  # the shards back to back; what lies beyond r1 is padding
@@ -420,8 +478,9 @@ class LidarTrainer:
         for handle in getattr(self.table, "_lnh_grad16_handles", None) or ():
             handle.wait()
         div = float(getattr(self.table, "_lnh_grad16_div", 1))
-        # (the scale the backward ran with — _amp_update_scale_ has already moved self.loss_scale on growth / backoff steps)
-        return g16.float().reshape(self.table.shape) / (getattr(self, "_last_scale", self.loss_scale) * div)
+        # (the scale the backward ran with — the optimizer kernel has already moved loss_scale on growth / backoff steps)
+        H = _hip_consts()
+        return g16.float().reshape(self.table.shape) / (self.opt_state[H.TS_LAST_SCALE] * div)
 
     def state_dict(self):
         """Everything a resume needs: torch optimizer / scheduler / scaler state plus — fused table optimizer — the
@@ -432,7 +491,10 @@ class LidarTrainer:
               "scaler": self.scaler.state_dict(), "fused_table": None}
         if self.table is not None:
             sd["fused_table"] = {"exp_avg": self.t_m, "exp_avg_sq": self.t_v, "step": self.t_steps[self.t_flip].clone(),
-                                 "loss_scale": self.loss_scale.clone(), "growth_tracker": self.growth_tracker.clone()}
+                                 "loss_scale": self.loss_scale.clone(), "growth_tracker": self.growth_tracker.clone(),
+                                 # the small tensors' moments, back to back in the order of self.small
+                                 "small_exp_avg": self.small_m, "small_exp_avg_sq": self.small_v,
+                                 "small_stepped": [id(p) in self._small_stepped for p in self.small]}
         return sd
 
     def load_state_dict(self, sd):
@@ -440,15 +502,20 @@ class LidarTrainer:
         self._after_optimizer_load()
         self.scheduler.load_state_dict(sd["scheduler"])
         self.scaler.load_state_dict(sd["scaler"])
+        self._pending_steps = None
         ft = sd.get("fused_table")
         if (ft is None) != (self.table is None):
             raise RuntimeError("LidarTrainer.load_state_dict: checkpoint and trainer disagree on the fused table optimizer")
         if ft is not None:
             self.t_m.copy_(ft["exp_avg"])
             self.t_v.copy_(ft["exp_avg_sq"])
-            self.t_steps[self.t_flip].copy_(ft["step"])
             self.loss_scale.copy_(ft["loss_scale"])
             self.growth_tracker.copy_(ft["growth_tracker"])
+            if "small_exp_avg" in ft:
+                self.small_m.copy_(ft["small_exp_avg"])
+                self.small_v.copy_(ft["small_exp_avg_sq"])
+                self._small_stepped = {id(p) for p, f in zip(self.small, ft["small_stepped"]) if f}
+            self._sync_counters(steps=float(ft["step"]))
 
     # ---- checkpoints in the reference Trainer's format (lidarnerf/nerf/utils.py:1449-1568)
     def _optimizer_state_ref_layout(self):
@@ -466,6 +533,14 @@ class LidarTrainer:
                 if self.table is not None and p is self.table:
                     state[idx] = {"step": self.t_steps[self.t_flip].detach().clone().float().cpu(),
                                   "exp_avg": self.t_m.detach().clone(), "exp_avg_sq": self.t_v.detach().clone()}
+                elif self.table is not None and id(p) in self._small_stepped:
+                    # stepped by the fused optimizer: its moments are a slice of the flat buffers, the step count is the
+                    # table's (one counter for all parameters: a skipped step skips every one of them)
+                    k = next(i for i, q in enumerate(self.small) if q is p)
+                    sl = slice(self.small_off[k], self.small_off[k + 1])
+                    state[idx] = {"step": self.t_steps[self.t_flip].detach().clone().float().cpu(),
+                                  "exp_avg": self.small_m[sl].detach().clone().view_as(p),
+                                  "exp_avg_sq": self.small_v[sl].detach().clone().view_as(p)}
                 elif id(p) in own_ids and own_ids[id(p)] in own["state"]:
                     state[idx] = own["state"][own_ids[id(p)]]
                 ids.append(idx)
@@ -478,7 +553,7 @@ class LidarTrainer:
     def _load_optimizer_state_ref_layout(self, sd):
         own_ids = {id(p): i for i, p in enumerate(p for g in self.optimizer.param_groups for p in g["params"])}
         own = self.optimizer.state_dict()
-        idx = 0
+        idx, loaded_steps = 0, None
         for group in self._ref_layout:
             for p in group:
                 st = sd["state"].get(idx)
@@ -486,7 +561,15 @@ class LidarTrainer:
                     if self.table is not None and p is self.table:
                         self.t_m.copy_(st["exp_avg"].to(self.t_m.device))
                         self.t_v.copy_(st["exp_avg_sq"].to(self.t_v.device))
-                        self.t_steps[self.t_flip].fill_(float(st["step"]))
+                        loaded_steps = float(st["step"])
+                    elif self.table is not None and any(q is p for q in self.small):
+                        k = next(i for i, q in enumerate(self.small) if q is p)
+                        sl = slice(self.small_off[k], self.small_off[k + 1])
+                        self.small_m[sl].copy_(st["exp_avg"].to(self.small_m.device).reshape(-1))
+                        self.small_v[sl].copy_(st["exp_avg_sq"].to(self.small_v.device).reshape(-1))
+                        self._small_stepped.add(id(p))
+                        if loaded_steps is None:
+                            loaded_steps = float(st["step"])
                     elif id(p) in own_ids:
                         own["state"][own_ids[id(p)]] = st
                 idx += 1
@@ -501,6 +584,8 @@ class LidarTrainer:
                 g["lr"] = lr
         self.optimizer.load_state_dict(own)
         self._after_optimizer_load()
+        if self.table is not None and loaded_steps is not None:
+            self._pending_steps = loaded_steps  # (committed by load_checkpoint once the scheduler's position is loaded too)
 
     def _drop_graphs(self):
         """Forget every captured step: the next step runs launch by launch (taking every lazy initialisation and version
@@ -509,14 +594,10 @@ class LidarTrainer:
         self._graph_warm.clear()
 
     def _after_optimizer_load(self):
-        """Graph mode: the learning rate stays a device scalar whatever the loaded state held, and every captured step is
-        dropped (Optimizer.load_state_dict replaces the tensors a capture holds pointers to)."""
-        if not self.graph:
-            return
-        for g in self.optimizer.param_groups:
-            if not torch.is_tensor(g["lr"]) or not g["lr"].is_cuda:
-                g["lr"] = torch.tensor(float(g["lr"]), dtype=torch.float32, device=self.table.device)
-        self._drop_graphs()
+        """Graph mode: every captured step is dropped after a load (the next step runs launch by launch and takes the
+        version checks and lazy initialisations with it)."""
+        if self.graph:
+            self._drop_graphs()
 
     def _own_group_of_ref_group(self):
         """For every parameter group of the reference's optimizer: index of the group of self.optimizer that steps its
@@ -618,6 +699,9 @@ class LidarTrainer:
             self._load_optimizer_state_ref_layout(ck["optimizer"])
         if "lr_scheduler" in ck:
             self._load_scheduler_state_ref_layout(ck["lr_scheduler"])
+        if self.table is not None:  # the device-side counters follow what was loaded
+            self._sync_counters(steps=getattr(self, "_pending_steps", None))
+            self._pending_steps = None
         if "scaler" in ck and ck["scaler"]:
             if self.table is not None:
                 self.loss_scale.fill_(float(ck["scaler"]["scale"]))

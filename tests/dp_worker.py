@@ -141,13 +141,19 @@ if parallel.backend() == "nccl":
         return t, m, losses
     tg, mg, lg = run_graph(True, 6)
     te, me, le = run_graph(False, 6)
+    te2, me2, le2 = run_graph(False, 6)
     assert tg.graph and tg.graph_error is None and len(tg._graphs) == 1, (tg.graph, tg.graph_error, len(tg._graphs))
     print(f"rank {rank}: captured DP step, losses graph {lg} eager {le}")
     for a_, b_ in zip(lg, le):
         assert abs(a_ - b_) <= 2e-3 * abs(b_) + 1e-6, (lg, le)
-    dt = (mg.encoder.embeddings.detach() - me.encoder.embeddings.detach()).abs()
-    # (two eager runs already differ in a few thousand rows after several steps: the MLP weight gradients meet in fp32 atomics)
-    assert float(dt.max()) <= 0.13 and int((dt.reshape(dt.shape[0], -1).sum(1) > 0).sum()) <= 60000, (float(dt.max()),)
+    def tdiff(ma, mb):
+        dt = (ma.encoder.embeddings.detach() - mb.encoder.embeddings.detach()).abs()
+        return float(dt.max()), int((dt.reshape(dt.shape[0], -1).sum(1) > 0).sum())
+    # two EAGER runs already differ after several steps (the MLP weight gradients meet in fp32 atomics, and Adam with
+    # eps = 1e-15 turns a last-bit difference of a tiny gradient into a step of lr): the replayed run must sit in that spread
+    d_same, d_graph = tdiff(me, me2), tdiff(mg, me)
+    print(f"rank {rank}: tables after 6 steps: eager vs eager max {d_same[0]:.2e} in {d_same[1]} rows; graph vs eager max {d_graph[0]:.2e} in {d_graph[1]} rows")
+    assert d_graph[0] <= 0.13 and d_graph[1] <= max(4 * d_same[1], 20000), (d_same, d_graph)
     chk = mg.encoder.embeddings.detach().double().sum()
     all_chk = [torch.zeros_like(chk) for _ in range(world)]
     torch.distributed.all_gather(all_chk, chk)

@@ -28,6 +28,17 @@ def test_loss_kernels_reproduce_the_reference_train_step(golden_dir, tag, patch)
     gd, gi = g[f"{tag}_grad_depth"], g[f"{tag}_grad_image"]
     np.testing.assert_allclose(depth.grad[0].cpu().numpy() / 4.0, gd, rtol=2e-5, atol=2e-6 * np.abs(gd).max())
     np.testing.assert_allclose(image.grad[0].cpu().numpy() / 4.0, gi, rtol=2e-5, atol=1e-9)
+    # the trainer's form: the kernel multiplies the gradients by a device scalar (the loss scale) and backward() starts
+    # from ONE — the same numbers, the loss itself unscaled, twice in a row (the kernel leaves no accumulator behind)
+    for rep in range(2):
+        depth.grad = image.grad = None
+        sc = torch.full((), 4.0, device="cuda")
+        loss2 = fused_lidar_loss({"depth_lidar": depth, "image_lidar": image}, gt, ad, ar, ai,
+                                 patch=None if patch is None else (patch[0], patch[1], scale, ag), grad_scale=sc)
+        loss2.backward(gradient=torch.ones((), device="cuda"))
+        assert float(loss2) == float(loss)
+        np.testing.assert_allclose(depth.grad[0].cpu().numpy() / 4.0, gd, rtol=2e-5, atol=2e-6 * np.abs(gd).max())
+        np.testing.assert_allclose(image.grad[0].cpu().numpy() / 4.0, gi, rtol=2e-5, atol=1e-9)
 
 
 def test_trainer_train_step_loss_is_the_reference_loss(golden_dir):

@@ -378,8 +378,13 @@ def test_dir_term_backward():
         S = torch.randn(N, 64, device="cuda")
         E = torch.randn(N, K, device="cuda")
         g = torch.zeros(64, K + 15, device="cuda")
-        scratch = torch.empty(((N + 31) // 32) * 64 * 128, device="cuda")
-        _hip.call("lnh_lidar_dir_term_backward", S.data_ptr(), E.data_ptr(), N, K, scratch.data_ptr(), g.data_ptr(), K + 15)
+        _hip.call("lnh_lidar_dir_term_backward", S.data_ptr(), E.data_ptr(), N, K, None, g.data_ptr(), K + 15)
         want = S.double().t() @ E.double()
         torch.testing.assert_close(g[:, :K].double(), want, rtol=1e-4, atol=1e-3)
         assert float(g[:, K:].abs().max()) == 0.0
+        # with the packed geo-feature block: its columns 1..15 land behind the K direction columns, in the same launch
+        g2 = torch.zeros(64, K + 15, device="cuda")
+        w0g = torch.randn(64, 16, device="cuda")
+        _hip.call("lnh_lidar_dir_term_backward", S.data_ptr(), E.data_ptr(), N, K, w0g.data_ptr(), g2.data_ptr(), K + 15)
+        torch.testing.assert_close(g2[:, :K].double(), want, rtol=1e-4, atol=1e-3)
+        assert torch.equal(g2[:, K:], w0g[:, 1:])

@@ -324,6 +324,182 @@ def test_fused_table_optimizer_matches_torch_adam_and_gradscaler():
     assert float(tr_b.t_steps[tr_b.t_flip]) == 4.0
 
 
+def test_rgb_branch_sh_encoder_and_color_net_vs_restatement():
+    """The RGB branch BASELINE configs[3] names (SH direction encoder + color_net; network.py:131-160 forward, 199-237 color,
+    181-196 background of the reference): NeRFNetwork.forward and color(cal_lidar_color=False) through lnh_sh_encode_forward
+    / backward + the colour stack, against oracle/encoders_ref.py (SH) and a torch restatement of the Linear stacks — fp32
+    (library GEMMs) and fp16 autocast (the stack as ONE fused MFMA kernel), values and gradients w.r.t. color_net, geo_feat
+    and the directions; the background branch as far as the reference lets it run (see below)."""
+    from oracle import encoders_ref, grid_ref
+    from lidarnerf.nerf.network import NeRFNetwork
+    torch.manual_seed(11)
+    net = NeRFNetwork(encoding="hashgrid", desired_resolution=2048, bound=1, min_near=SCALE, min_near_lidar=SCALE,
+                      bg_radius=32.0).cuda()
+    with torch.no_grad():
+        net.encoder.embeddings.uniform_(-0.4, 0.4)
+        net.encoder_bg.embeddings.uniform_(-0.4, 0.4)
+    g = torch.Generator().manual_seed(3)
+    B = 700
+    x = (torch.rand(B, 3, generator=g) * 2 - 1) * 0.9
+    d = torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=-1)
+    xs = torch.rand(B, 2, generator=g) * 2 - 1   # sphere coordinates of the background hit (sph_from_ray's range)
+    W = [m.weight.detach().cpu().double() for m in net.color_net]
+    sh = torch.from_numpy(encoders_ref.sh_forward(d.numpy(), 4)).double()
+
+    def stack(h, mats):
+        for i, w in enumerate(mats):
+            h = h @ w.t()
+            if i + 1 < len(mats):
+                h = torch.relu(h)
+        return torch.sigmoid(h)
+
+    # ---- forward(x, d): density + RGB colour, fp32
+    with torch.no_grad():
+        dens = net.density(x.cuda())
+        sigma, rgb = net(x.cuda(), d.cuda())
+    geo = dens["geo_feat"].float().cpu().double()
+    want_rgb = stack(torch.cat([sh, geo], dim=-1), W)
+    assert rgb.shape == (B, 3) and torch.equal(sigma, dens["sigma"])
+    torch.testing.assert_close(rgb.cpu().double(), want_rgb, rtol=1e-4, atol=2e-5)
+    # ---- color(cal_lidar_color=False) with gradients: color_net weights, geo_feat, directions (SH Jacobian)
+    for mode in ("fp32", "fp16"):
+        geo_g = geo.float().cuda().requires_grad_(True)
+        d_g = d.cuda().requires_grad_(True)
+        net.zero_grad(set_to_none=True)
+        net.out_dim = net.out_color_dim
+        mask = torch.rand(B, generator=g) > 0.3
+        with torch.autocast("cuda", dtype=torch.float16, enabled=mode == "fp16"):
+            out = net.color(x.cuda(), d_g, cal_lidar_color=False, mask=mask.cuda(), geo_feat=geo_g)
+        coef = torch.randn(B, 3, generator=g)
+        (out.float() * coef.cuda()).sum().backward()
+        # restatement on the CPU (fp64), SH as a differentiable function of d through its finite-difference Jacobian
+        geo_c = geo.clone().requires_grad_(True)
+        Wc = [w.clone().requires_grad_(True) for w in W]
+        sh_c = sh.clone().requires_grad_(True)
+        want = torch.zeros(B, 3, dtype=torch.float64)
+        want[mask] = stack(torch.cat([sh_c, geo_c], dim=-1)[mask], Wc)
+        (want * coef.double()).sum().backward()
+        jac = torch.from_numpy(encoders_ref.sh_jacobian_fd(d.numpy(), 4)).double()          # [B, 3, 16]
+        want_gd = torch.einsum("bc,bdc->bd", sh_c.grad, jac)
+        tol = dict(rtol=2e-4, atol=2e-5) if mode == "fp32" else dict(rtol=2e-2, atol=4e-3)
+        torch.testing.assert_close(out.float().cpu().double(), want.detach(), **tol)
+        assert float(out[~mask.cuda()].abs().max()) == 0.0
+        gscale = lambda t: float(t.abs().max())
+        for m, wc in zip(net.color_net, Wc):
+            assert float((m.weight.grad.cpu().double() - wc.grad).abs().max()) <= (1e-4 if mode == "fp32" else 2e-2) * gscale(wc.grad)
+        assert float((geo_g.grad.cpu().double() - geo_c.grad).abs().max()) <= (1e-4 if mode == "fp32" else 2e-2) * gscale(geo_c.grad)
+        assert float((d_g.grad.cpu().double() - want_gd).abs().max()) <= (2e-3 if mode == "fp32" else 3e-2) * gscale(want_gd)
+    # ---- background(x_sph, d): the reference sizes bg_net's first Linear to in_dim_bg + in_dim_dir AFTER in_dim_dir has been
+    #      overwritten by the LiDAR frequency encoder (network.py:82, 105-112: 8 + 75 = 83 inputs) while background() feeds it
+    #      SH (16) + grid (8) = 24 features (network.py:181-196): with bg_radius > 0 the reference's background() cannot run.
+    #      The drop-in keeps the reference's layer sizes (its checkpoints must load), hence the same failure; what CAN be
+    #      checked is its 2-D, 4-level hash grid and the SH features it concatenates.
+    enc = net.encoder_bg
+    assert tuple(net.bg_net[0].weight.shape) == (64, 83)
+    with pytest.raises(RuntimeError):
+        net.background(xs.cuda(), d.cuda())
+    off = enc.offsets.cpu().numpy().astype(np.int32)
+    feat = grid_ref.forward(((xs.numpy() + 1) / 2).astype(np.float32), enc.embeddings.detach().cpu().numpy(), off,
+                            float(np.log2(enc.per_level_scale)), enc.base_resolution)
+    with torch.no_grad():
+        got_bg = enc(xs.cuda())
+        got_sh = net.encoder_dir(d.cuda())
+    want_feat = torch.from_numpy(np.ascontiguousarray(np.asarray(feat).transpose(1, 0, 2))).reshape(B, -1)
+    torch.testing.assert_close(got_bg.cpu(), want_feat, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(got_sh.cpu().double(), sh, rtol=2e-6, atol=2e-6)
+
+
+def test_train_step_kernels_match_torch_adam_and_gradscaler():
+    """lnh_train_check + lnh_train_step — the whole optimizer step as two launches — against torch.optim.Adam(fused=True) on
+    the same unscaled gradients with GradScaler's bookkeeping done by hand: table (fp16 gradient) and three small fp32
+    tensors (one without a gradient), a step with an inf in a SMALL gradient (skipped as a whole, scale halved, counters
+    held), the lr schedule formed on the device, growth of the scale at the interval, zero_regions."""
+    from lidarnerf import _hip
+    H = _hip
+    torch.manual_seed(5)
+    n = 50001 * 4 + 2
+    shapes = [(64, 32), (16, 64), (7,)]
+    p0 = (torch.rand(n, device="cuda") - 0.5) * 2e-4
+    q0 = [torch.randn(sh, device="cuda") * 0.1 for sh in shapes]
+    ref = [torch.nn.Parameter(p0.clone())] + [torch.nn.Parameter(q.clone()) for q in q0]
+    lr0, iters = 1e-2, 10.0
+    opt = torch.optim.Adam(ref, lr=lr0, betas=(0.9, 0.99), eps=1e-15, fused=True)
+    p, m, v = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    p16 = torch.zeros(n, dtype=torch.half, device="cuda")
+    q = [t.clone() for t in q0]
+    tot = sum(t.numel() for t in q)
+    sm, sv = torch.zeros(tot, device="cuda"), torch.zeros(tot, device="cuda")
+    st = torch.zeros(H.TRAIN_STATE_FLOATS, device="cuda")
+    st[H.TS_SCALE] = 1024.0
+    interval = 3
+    cast = lambda a: H.C.cast(a, H.C.c_void_p)
+    scale, growth, t_ref, div_t, div_s = 1024.0, 0, 0, 2.0, 4.0
+    for it in range(7):
+        g16 = (torch.randn(n, device="cuda") * (10.0 ** torch.randint(-3, 3, (n,), device="cuda"))).half()
+        g16[::7] = 0
+        gq = [torch.randn_like(t) * scale for t in q]
+        gq[2] = None                                  # a parameter without a gradient this step: skipped, like torch's Adam
+        bad = it == 2
+        if bad:
+            gq[1][3, 5] = float("inf")                # an inf in a SMALL gradient skips the table too
+        if it == 4:
+            g16[-1] = float("nan")                    # ... and one in the table's tail skips the small tensors
+            bad = True
+        lr = lr0 * 0.1 ** min(it / iters, 1)
+        if not bad:
+            ref[0].grad = g16.float() / (scale * div_t)
+            for r, g in zip(ref[1:], gq):
+                r.grad = None if g is None else g / (scale * div_s)
+            for grp in opt.param_groups:
+                grp["lr"] = lr
+            opt.step()
+            t_ref += 1
+        gp = H.ptr_array([None if g is None else g.data_ptr() for g in gq])
+        pp = H.ptr_array([t.data_ptr() for t in q])
+        nn_ = H.u32_array([t.numel() for t in q])
+        _hip.call("lnh_train_check", st.data_ptr(), g16.data_ptr(), n, cast(gp), cast(nn_), 3, div_t, div_s, lr0, iters)
+        _hip.call("lnh_train_step", st.data_ptr(), p.data_ptr(), m.data_ptr(), v.data_ptr(), g16.data_ptr(), p16.data_ptr(), n,
+                  cast(pp), cast(gp), cast(nn_), 3, sm.data_ptr(), sv.data_ptr(), 0.9, 0.99, 1e-15, 2.0, 0.5, interval)
+        # GradScaler.update by hand
+        if bad:
+            scale, growth = scale * 0.5, 0
+        elif growth + 1 == interval:
+            scale, growth = scale * 2.0, 0
+        else:
+            growth += 1
+        host = st.cpu()
+        assert float(host[H.TS_SKIPPED]) == float(bad) and float(host[H.TS_T_NEXT]) == t_ref and float(host[H.TS_IT_NEXT]) == it + 1
+        assert float(host[H.TS_SCALE]) == scale and float(host[H.TS_GROWTH]) == growth, (it, host[:3], scale, growth)
+        np.testing.assert_allclose(float(host[H.TS_LR]), lr, rtol=1e-6)
+        if t_ref:
+            so = opt.state[ref[0]]
+            torch.testing.assert_close(m, so["exp_avg"], rtol=2e-6, atol=1e-8 * float(m.abs().max()))
+            torch.testing.assert_close(v, so["exp_avg_sq"], rtol=2e-6, atol=0)
+            torch.testing.assert_close(p, ref[0].detach(), rtol=0, atol=5e-8)
+            off = 0
+            for k, t in enumerate(q):
+                sl = slice(off, off + t.numel())
+                off += t.numel()
+                if k == 2:
+                    assert torch.equal(t, q0[2]) and float(sm[sl].abs().sum()) == 0.0 and ref[3] not in opt.state
+                    continue
+                so = opt.state[ref[1 + k]]
+                torch.testing.assert_close(sm[sl].view_as(t), so["exp_avg"], rtol=2e-6, atol=1e-8 * float(sm[sl].abs().max()))
+                torch.testing.assert_close(sv[sl].view_as(t), so["exp_avg_sq"], rtol=2e-6, atol=0)
+                torch.testing.assert_close(t, ref[1 + k].detach(), rtol=0, atol=2e-7)
+            if not bad:
+                assert torch.equal(p16, p.half())
+    assert t_ref == 5
+    # lnh_zero_regions: one launch, odd sizes and alignments, neighbours untouched
+    buf = torch.full((5000,), 7.0, device="cuda")
+    h = torch.full((33,), 3.0, dtype=torch.half, device="cuda")[:32]
+    _hip.zero_regions((buf[1:4], buf[100:3001], None, h, buf[4000:4001]))
+    torch.cuda.synchronize()
+    want = torch.full((5000,), 7.0)
+    want[1:4] = 0; want[100:3001] = 0; want[4000] = 0
+    assert torch.equal(buf.cpu(), want) and float(h.float().abs().sum()) == 0.0
+
+
 def test_fused_render_full_size_properties():
     """BASELINE size (4096 rays x (768 + 64) samples) through the fused chain: compositing invariants that do not
     depend on the size — weights of a ray sum to at most 1, depth is a convex combination of sample depths

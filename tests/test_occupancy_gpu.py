@@ -298,15 +298,16 @@ def test_captured_step_trains_like_the_eager_step():
     assert sg[-1] < 0.35 * sg[0]
     assert np.abs(sg - se).max() < 0.25 * se[0], (se[::8], sg[::8])
     assert abs(sg[-1] - se[-1]) < 0.5 * se[-1] + 0.02 * se[0], (se[-1], sg[-1])
-    # learning rate: the schedule's value, in the device scalar both optimizers read
-    lr = graph.optimizer.param_groups[0]["lr"]
-    assert torch.is_tensor(lr) and lr.is_cuda
-    np.testing.assert_allclose(float(lr), 1e-2 * 0.1 ** (n_steps / 200), rtol=1e-5)
-    # step counters: the table's device-side counter and torch Adam's per-parameter counters moved once per step
+    # learning rate: the schedule's value — on the host (scheduler bookkeeping) and in the device scalar the optimizer
+    # kernel formed from its own step counter for the LAST step (n_steps - 1 scheduler steps before it)
+    from lidarnerf import _hip
+    np.testing.assert_allclose(float(graph.optimizer.param_groups[0]["lr"]), 1e-2 * 0.1 ** (n_steps / 200), rtol=1e-5)
+    np.testing.assert_allclose(float(graph.opt_state[_hip.TS_LR]), 1e-2 * 0.1 ** ((n_steps - 1) / 200), rtol=1e-5)
+    assert float(graph.opt_state[_hip.TS_IT_NEXT]) == n_steps == graph.scheduler.last_epoch
+    # step counter: one device-side counter for every parameter, moved once per step that was not skipped
     skipped = n_steps - int(graph.t_steps[graph.t_flip])
     assert 0 <= skipped <= 3                              # (the dynamic loss scale may back off a couple of times early on)
-    st = graph.optimizer.state[graph.params[0]]["step"]
-    assert int(st) == n_steps - skipped
+    assert graph.steps_taken() == n_steps - skipped
     # the marcher's counters reach the ring: update_extra_state derived a plausible mean from them
     assert 0 < nets[1].mean_count < 2048 * 832 * 0.25
     assert abs(nets[1].mean_count - nets[0].mean_count) < 0.3 * nets[0].mean_count
@@ -318,9 +319,9 @@ def test_captured_step_trains_like_the_eager_step():
         third = LidarTrainer(_net(seed=7).train(), lr=1e-2, iters=200, fp16=True, scale=SCALE, render_kwargs={})
         third.load_checkpoint(path)
         l3 = float(third.step(*_sphere_batch(2048, 500)).detach())
-        # ... and back into a graph-mode trainer: the captured steps are dropped, lr stays a device scalar
+        # ... and back into a graph-mode trainer: the captured steps are dropped, the device counters follow the file
         graph.load_checkpoint(path)
-        assert not graph._graphs and torch.is_tensor(graph.optimizer.param_groups[0]["lr"])
+        assert not graph._graphs and float(graph.opt_state[_hip.TS_IT_NEXT]) == graph.scheduler.last_epoch == n_steps
         l4 = float(graph.step(*_sphere_batch(2048, 500)).detach())
         l5 = float(graph.step(*_sphere_batch(2048, 501)).detach())   # (recaptured)
     assert np.isfinite([l3, l4, l5]).all() and abs(l3 - l4) < 0.3 * max(l3, l4) + 1e-3

@@ -245,7 +245,7 @@ def test_empty_batches_are_no_ops_on_the_fused_step_entry_points():
         ("lnh_lidar_composite_backward", d, d, d, d, d, d, d, 0, T + t, 2, 1.0, d, None),
         ("lnh_lidar_color_backward", d, d, d, d, d, d, d, 0, T + t, d, d, d),
         ("lnh_lidar_color_backward_image", d, d, d, d, d, d, d, 0, T + t, d, d, d),
-        ("lnh_lidar_dir_term_backward", d, d, 0, 75, d, d, 90),
+        ("lnh_lidar_dir_term_backward", d, d, 0, 75, None, d, 90),
         ("lnh_density_mlp_backward", d, d, d, 0, T + t, T + t, 0, d, d),
     ]
     for c in calls:
