@@ -130,6 +130,27 @@ LNH_API int lnh_grid_encode_backward_ws_finish(const void *grad, const float *in
                                                float S, uint32_t H, uint32_t gridtype, int align_corners,
                                                uint32_t interp, int dtype, void *workspace, uint64_t workspace_bytes,
                                                uint32_t level_begin, uint32_t level_end, lnh_stream_t stream);
+/* The same entry points behind ONE signature, for a caller that has just cleared its buffers itself (a training step that
+ * clears every accumulated-into buffer of its backward pass with one lnh_zero_regions launch):
+ *   split  0 = lnh_grid_encode_backward_ws_levels, 1 = ..._begin (level_begin / level_end ignored), 2 = ..._finish
+ *   flags  LNH_BWD_WS_CLEARED: the first lnh_grid_backward_workspace_clear_bytes(...) bytes of `workspace` are zero on
+ *          entry (the cursors of the batch's FIRST chunk: that chunk's clear launch is skipped);
+ *          LNH_BWD_TABLE_ZERO: grad_embeddings holds zeros on entry — the reduce pass of the first chunk stores its sums
+ *          instead of adding them to rows it would have to read first (the same values: 0 + x).
+ * A caller that sets a flag without having cleared gets garbage; without flags this is exactly the entry point `split` names.
+ * lnh_grid_backward_workspace_clear_bytes: size of that head for the chunk plan the call will choose for `workspace_bytes`
+ * (0: unsupported configuration / workspace too small). */
+#define LNH_BWD_WS_CLEARED 1u
+#define LNH_BWD_TABLE_ZERO 2u
+LNH_API int lnh_grid_encode_backward_ws_ex(const void *grad, const float *inputs, const int32_t *offsets_host,
+                                           void *grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                           uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, int dtype,
+                                           void *workspace, uint64_t workspace_bytes, uint32_t level_begin,
+                                           uint32_t level_end, int split, uint32_t flags, lnh_stream_t stream);
+LNH_API uint64_t lnh_grid_backward_workspace_clear_bytes(const int32_t *offsets_host, uint32_t B, uint32_t D, uint32_t C,
+                                                         uint32_t L, float S, uint32_t H, uint32_t gridtype,
+                                                         int align_corners, uint32_t interp, int dtype,
+                                                         uint64_t workspace_bytes);
 /*
  * Replaces grad_total_variation  gridencoder.h:43-55 (gridencoder.cu:695-910): adds the TV-regulariser gradient
  * of the cells visited by `inputs` into `grad` (same layout as embeddings).
@@ -407,6 +428,15 @@ LNH_API int lnh_lidar_dir_term_backward(const float *ray_sum, const float *featu
 LNH_API int lnh_lidar_pack_weights(const float *ws0, uint32_t ld_s0, const float *ws1, uint32_t ld_s1,
                                    const float *wc0, uint32_t ld_c0, uint32_t n_dir, const float *wc1, uint32_t ld_c1,
                                    const float *wc2, uint32_t ld_c2, void *wsig16, void *wcol16, lnh_stream_t stream);
+/* Everything a fused render step needs before its first encode, in ONE launch: lnh_lidar_pack_weights (n_dir = 3 + 6 *
+ * degree) + lnh_lidar_dir_term_freq (on rays_d, against wc0) + lnh_lidar_coarse_sample_points — the same arithmetic, bit
+ * for bit (renderer.py:129-167 sampling set-up, network.py:215-221 direction term). */
+LNH_API int lnh_lidar_step_prologue(const float *ws0, uint32_t ld_s0, const float *ws1, uint32_t ld_s1, const float *wc0,
+                                    uint32_t ld_c0, uint32_t degree, const float *wc1, uint32_t ld_c1, const float *wc2,
+                                    uint32_t ld_c2, void *wsig16, void *wcol16, const float *u, const float *rays_o,
+                                    const float *rays_d, const float *aabb, float bound, uint32_t N, uint32_t T,
+                                    uint32_t T_tot, float near, float far, float *z, float *x01, float *features16,
+                                    float *cdir, lnh_stream_t stream);
 LNH_API int lnh_lidar_loss(const float *depth, const float *image, const float *gt, uint32_t N, float alpha_d,
                            float alpha_r, float alpha_i, const float *grad_scale, float *loss, float *grad_depth,
                            float *grad_image, lnh_stream_t stream);
@@ -616,6 +646,12 @@ LNH_API int lnh_lidar_dir_term_freq_bf16(const float *dirs, uint32_t degree, con
 LNH_API int lnh_lidar_pack_weights_bf16(const float *ws0, uint32_t ld_s0, const float *ws1, uint32_t ld_s1,
                                    const float *wc0, uint32_t ld_c0, uint32_t n_dir, const float *wc1, uint32_t ld_c1,
                                    const float *wc2, uint32_t ld_c2, void *wsig16, void *wcol16, lnh_stream_t stream);
+LNH_API int lnh_lidar_step_prologue_bf16(const float *ws0, uint32_t ld_s0, const float *ws1, uint32_t ld_s1, const float *wc0,
+                                         uint32_t ld_c0, uint32_t degree, const float *wc1, uint32_t ld_c1, const float *wc2,
+                                         uint32_t ld_c2, void *wsig16, void *wcol16, const float *u, const float *rays_o,
+                                         const float *rays_d, const float *aabb, float bound, uint32_t N, uint32_t T,
+                                         uint32_t T_tot, float near, float far, float *z, float *x01, float *features16,
+                                         float *cdir, lnh_stream_t stream);
 LNH_API int lnh_lidar_color_forward_bf16(const void *h16, const int32_t *perm, const float *weights, const float *cdir,
                                     const void *w16, uint32_t N, uint32_t T, float *rgb, lnh_stream_t stream);
 LNH_API int lnh_lidar_color_composite_forward_bf16(const float *z, const float *sigma_pt, const int32_t *perm,

@@ -1338,7 +1338,7 @@ template <typename T>
 __global__ void __launch_bounds__(1024)
 k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, const char *__restrict__ pool_bytes,
                   const uint32_t *__restrict__ cursor, const uint32_t *__restrict__ spill_cursor,
-                  uint32_t *__restrict__ done, uint32_t L, ReduceOrder ord) {
+                  uint32_t *__restrict__ done, uint32_t L, ReduceOrder ord, uint32_t table_zero) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     unsigned long long *acc = reinterpret_cast<unsigned long long *>(smem_raw);  // [kBucketRows][2] fixed point
     __shared__ uint32_t sh_sum, sh_item[4], sh_wave[2][16];
@@ -1411,8 +1411,12 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
     // LDS atomic.  profiles/r04_reduce_levels.txt)
     typedef unsigned long long acc_t;
     acc_t *img = reinterpret_cast<acc_t *>(smem_raw);
-    for (uint32_t i = threadIdx.x; i < kBucketRows * 2; i += blockDim.x) acc[i] = 0ull;
-    __syncthreads();
+    // (the image is cleared inside `stream`, AFTER the first pool loads have been issued: a workgroup's HBM round trip
+    //  runs under its 128 KiB of LDS stores instead of behind them)
+    auto clear_image = [&]() {
+        for (uint32_t i = threadIdx.x; i < kBucketRows * 2; i += blockDim.x) acc[i] = 0ull;
+        __syncthreads();
+    };
     auto acc_add = [&](uint32_t idx, T v) {
         if constexpr (sizeof(T) == 2) atomicAdd(&img[idx], (unsigned long long)half_to_fixed24(v));
         else atomicAdd(&img[idx], (unsigned long long)(long long)ldexp((double)v, 40));
@@ -1448,16 +1452,6 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
         const uint32_t a_begin = bk * cap + i_begin, a_end = a_begin + n;  // level-relative slots (< 2^32, checked)
         const uint32_t qf_begin = (a_begin + 3) >> 2, qf_end = a_end >> 2;
         const uint32_t nfull = qf_end > qf_begin ? qf_end - qf_begin : 0u;
-        {
-            const uint32_t lo_end = nfull ? qf_begin * 4 : a_end, hi_begin = nfull ? qf_end * 4 : a_end;
-            const uint32_t n_lo = lo_end - a_begin, n_hi = a_end - hi_begin;
-            if (threadIdx.x < n_lo + n_hi) {
-                const uint32_t slot = threadIdx.x < n_lo ? a_begin + threadIdx.x : hi_begin + (threadIdx.x - n_lo);
-                const V2 *pv = reinterpret_cast<const V2 *>(vbytes + (size_t)slot * (2 * sizeof(V2)));
-                const uint32_t key = *reinterpret_cast<const unsigned short *>(rbytes + (size_t)slot * 2);
-                add_entry(hashed_c, key & (kBucketRows - 1), key >> kBucketRowsLog2, pv[0], pv[1]);
-            }
-        }
         // every lane keeps UNROLL independent quads outstanding (non-temporal loads: the pool is written once and read
         // once), double-buffered: the loads of batch i+1 are in flight while the LDS adds of batch i execute
         const uint32_t stride = blockDim.x * UNROLL;
@@ -1472,6 +1466,18 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
                 r[u] = __builtin_nontemporal_load(rows4 + q);
             }
         };
+        if (nfull) fetch(threadIdx.x, rv[0], rr[0]);
+        clear_image();
+        {
+            const uint32_t lo_end = nfull ? qf_begin * 4 : a_end, hi_begin = nfull ? qf_end * 4 : a_end;
+            const uint32_t n_lo = lo_end - a_begin, n_hi = a_end - hi_begin;
+            if (threadIdx.x < n_lo + n_hi) {
+                const uint32_t slot = threadIdx.x < n_lo ? a_begin + threadIdx.x : hi_begin + (threadIdx.x - n_lo);
+                const V2 *pv = reinterpret_cast<const V2 *>(vbytes + (size_t)slot * (2 * sizeof(V2)));
+                const uint32_t key = *reinterpret_cast<const unsigned short *>(rbytes + (size_t)slot * 2);
+                add_entry(hashed_c, key & (kBucketRows - 1), key >> kBucketRowsLog2, pv[0], pv[1]);
+            }
+        }
         auto consume = [&](uint32_t j0, const uint4_t (&v)[UNROLL][VQ], const uint2_t (&r)[UNROLL]) {
 #pragma unroll
             for (uint32_t u = 0; u < UNROLL; u++) {
@@ -1494,7 +1500,6 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
                 }
             }
         };
-        if (nfull) fetch(threadIdx.x, rv[0], rr[0]);
         uint32_t j0 = threadIdx.x;
         while (j0 < nfull) {  // unrolled by two so that the buffer index is a compile-time constant
             const uint32_t j1 = j0 + stride;
@@ -1542,10 +1547,17 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
         T *gt = grad_table + (size_t)lv.offset * 2;
         constexpr uint32_t RPT = kBucketRows / 1024;
         Vec<T, 2> cur[RPT];
+        // table_zero (workgroup-uniform): the caller has just cleared the gradient and this is its first chunk — the rows
+        // hold zeros, nothing to read (27 MB per step and the round trip at the end of every workgroup)
 #pragma unroll
         for (uint32_t i = 0; i < RPT; i++) {
             const uint32_t row = table_row(threadIdx.x + i * 1024u);
-            cur[i] = load_vec<T, 2>(gt + 2 * (size_t)(row < lv.hashmap_size ? row : 0u));
+            if (table_zero) {
+                cur[i].v[0] = (T)0.0f;
+                cur[i].v[1] = (T)0.0f;
+            } else {
+                cur[i] = load_vec<T, 2>(gt + 2 * (size_t)(row < lv.hashmap_size ? row : 0u));
+            }
         }
 #pragma unroll
         for (uint32_t i = 0; i < RPT; i++) {
@@ -1716,7 +1728,10 @@ uint32_t fit_chunk(uint32_t B, const GridMeta &m, uint32_t L, bool plain, uint64
 template <typename T>
 int launch_backward_bucketed(const T *grad, const float *inputs, T *ge, uint32_t B, uint32_t L, const GridMeta &m,
                              uint32_t align, uint32_t interp, void *workspace, uint64_t workspace_bytes,
-                             hipStream_t s, uint32_t level_begin = 0, uint32_t level_end = 0xffffffffu, int split = 0) {
+                             hipStream_t s, uint32_t level_begin = 0, uint32_t level_end = 0xffffffffu, int split = 0,
+                             uint32_t flags = 0) {
+    // flags (lnh_grid_encode_backward_ws_ex): LNH_BWD_WS_CLEARED — the head of the workspace is zero on entry (serves the
+    // FIRST chunk's scatter pass); LNH_BWD_TABLE_ZERO — grad_embeddings is zero on entry (serves the first chunk's reduce pass)
     if (level_end > L) level_end = L;
     if (level_begin >= level_end) return LNH_OK;
     // The workspace serves one chunk at a time, so a SMALLER workspace than lnh_grid_backward_workspace_size() asks for is
@@ -1746,8 +1761,11 @@ int launch_backward_bucketed(const T *grad, const float *inputs, T *ge, uint32_t
             if (!last) continue;
             phase = 2;
         }
+        const bool first = b0 == 0;
         const int rc = launch_backward_bucketed_chunk<T>(grad, inputs, ge, std::min(step, B - b0), L, m, align, interp,
-                                                         workspace, workspace_bytes, s, l0, l1, b0, B, step, phase);
+                                                         workspace, workspace_bytes, s, l0, l1, b0, B, step, phase,
+                                                         first && (flags & LNH_BWD_WS_CLEARED),
+                                                         first && (flags & LNH_BWD_TABLE_ZERO));
         if (rc) return rc;
     }
     return LNH_OK;
@@ -1757,8 +1775,10 @@ template <typename T>
 int launch_backward_bucketed_chunk(const T *grad, const float *inputs, T *ge, uint32_t B, uint32_t L, const GridMeta &m,
                                    uint32_t align, uint32_t interp, void *workspace, uint64_t workspace_bytes,
                                    hipStream_t s, uint32_t level_begin, uint32_t level_end, uint32_t b_begin,
-                                   uint32_t B_all, uint32_t B_plan, int phase) {
+                                   uint32_t B_all, uint32_t B_plan, int phase, bool cursors_cleared, bool table_zero) {
     // phase 0: scatter + reduce; 1: (zeroed cursors +) scatter only; 2: reduce only, of a scatter an earlier call has run
+    // cursors_cleared: the caller has zeroed the head of the workspace (lnh_grid_backward_workspace_clear_bytes) for this
+    // chunk; table_zero: grad_table holds zeros — the reduce pass stores its sums instead of adding them to what it reads
     BucketPlan plan;
     uint32_t nbt = 0;
     const bool plain = align == 0 && interp == 0;
@@ -1786,7 +1806,7 @@ int launch_backward_bucketed_chunk(const T *grad, const float *inputs, T *ge, ui
     uint32_t *cursor = reinterpret_cast<uint32_t *>(workspace);
     uint32_t *spill_cursor = cursor + nbt, *done = spill_cursor + L;
     char *pool = reinterpret_cast<char *>(workspace) + cursor_bytes;
-    if (phase != 2) {
+    if (phase != 2 && !cursors_cleared) {
         const int zrc = lnh_zero_async(cursor, cursor_bytes, s, "grid backward (cursor clear)");
         if (zrc != LNH_OK) return zrc;
     }
@@ -1837,7 +1857,7 @@ int launch_backward_bucketed_chunk(const T *grad, const float *inputs, T *ge, ui
     ord.n_extra = (uint32_t)extra;
     ord.slice_entries = g_slice_entries;
     LNH_LAUNCH(k, dim3(ord.n_extra + ord.n_buckets), dim3(1024), lds, s, ge, m, plan, pool, cursor, spill_cursor, done, L,
-               ord);
+               ord, table_zero ? 1u : 0u);
     return lnh_check_launch("lnh_grid_encode_backward_ws(reduce)");
 }
 
@@ -2259,6 +2279,59 @@ static int backward_ws_split(const void *grad, const float *inputs, const int32_
     return launch_backward_bucketed<half_t>((const half_t *)grad, inputs, (half_t *)grad_embeddings, B, L, m,
                                             align_corners != 0, interp, workspace, workspace_bytes, s, level_begin,
                                             level_end, split);
+}
+
+int lnh_grid_encode_backward_ws_ex(const void *grad, const float *inputs, const int32_t *offsets_host, void *grad_embeddings,
+                                   uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype,
+                                   int align_corners, uint32_t interp, int dtype, void *workspace, uint64_t workspace_bytes,
+                                   uint32_t level_begin, uint32_t level_end, int split, uint32_t flags, lnh_stream_t stream) {
+    LNH_REQUIRE(split >= 0 && split <= 2 && (flags & ~(uint32_t)(LNH_BWD_WS_CLEARED | LNH_BWD_TABLE_ZERO)) == 0,
+                LNH_ERR_INVALID_ARG, "grid backward: split must be 0 (whole) / 1 (begin) / 2 (finish), flags LNH_BWD_*");
+    int rc = check_common(inputs, offsets_host, B, D, C, L, dtype);
+    if (rc) return rc;
+    LNH_REQUIRE(grad && grad_embeddings, LNH_ERR_INVALID_ARG, "grid backward: null grad/grad_embeddings");
+    LNH_REQUIRE(D == 3 && C == 2, LNH_ERR_UNSUPPORTED,
+                "grid backward (bucketed): only D == 3, C == 2 (use lnh_grid_encode_backward otherwise)");
+    if (level_end > L) level_end = L;
+    LNH_REQUIRE(level_begin <= level_end, LNH_ERR_INVALID_ARG, "grid backward: need level_begin <= level_end <= L");
+    if (B == 0) return LNH_OK;
+    GridMeta m;
+    LNH_REQUIRE(build_meta(m, offsets_host, D, L, S, H, gridtype, align_corners != 0) == 0, LNH_ERR_INVALID_ARG,
+                "grid: offsets must be increasing and non-negative");
+    hipStream_t s = (hipStream_t)stream;
+    if (split == 1) {  // begin: everything but the last reduce pass, over all levels
+        level_begin = 0;
+        level_end = L;
+    }
+    if (dtype == LNH_F32)
+        return launch_backward_bucketed<float>((const float *)grad, inputs, (float *)grad_embeddings, B, L, m,
+                                               align_corners != 0, interp, workspace, workspace_bytes, s, level_begin,
+                                               level_end, split, flags);
+    return launch_backward_bucketed<half_t>((const half_t *)grad, inputs, (half_t *)grad_embeddings, B, L, m,
+                                            align_corners != 0, interp, workspace, workspace_bytes, s, level_begin,
+                                            level_end, split, flags);
+}
+
+uint64_t lnh_grid_backward_workspace_clear_bytes(const int32_t *offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                                                 float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
+                                                 int dtype, uint64_t workspace_bytes) {
+    if (!offsets_host || D != 3 || C != 2 || L == 0 || L > LNH_MAX_LEVELS || B == 0) return 0;
+    GridMeta m;
+    if (build_meta(m, offsets_host, D, L, S, H, gridtype, align_corners != 0) != 0) return 0;
+    const bool plain = align_corners == 0 && interp == 0;
+    BucketPlan plan;
+    uint32_t nbt = 0;
+    uint32_t step;
+    if (dtype == LNH_F32) {
+        step = fit_chunk<float>(B, m, L, plain, workspace_bytes);
+        if (step == 0) return 0;
+        (void)plan_buckets<float>(plan, m, L, step, 3, plain, nbt);
+    } else {
+        step = fit_chunk<half_t>(B, m, L, plain, workspace_bytes);
+        if (step == 0) return 0;
+        (void)plan_buckets<half_t>(plan, m, L, step, 3, plain, nbt);
+    }
+    return ((uint64_t)(2 * nbt + L) * 4 + kCursorAlign - 1) / kCursorAlign * kCursorAlign;
 }
 
 int lnh_grid_encode_backward_ws_begin(const void *grad, const float *inputs, const int32_t *offsets_host,

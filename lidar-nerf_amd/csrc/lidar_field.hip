@@ -21,6 +21,7 @@
 // (col 0 = trunc_exp backward of the compositing gradient, lidarnerf/activation.py:17-19), so the merge is undone for
 // free.  The per-ray sum of d(hidden0) gives the gradient of the direction part of W0 after one small GEMM.
 #include "common.h"
+#include "lidar_steps.h"
 
 namespace {
 
@@ -52,19 +53,7 @@ k_coarse_sample_points(const float *__restrict__ u, const float *__restrict__ ra
                        float far, float *__restrict__ z, float *__restrict__ x01) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= N * T) return;
-    const uint32_t n = idx / T, i = idx - n * T;
-    const float step = T > 1 ? 1.0f / (float)(T - 1) : 0.0f;
-    const float lin = i < T / 2 ? step * (float)i : 1.0f - step * (float)(T - 1 - i);
-    float t = near + (far - near) * lin;
-    if (u) t = t + (u[idx] - 0.5f) * ((far - near) / (float)T);
-    z[idx] = t;
-    float *o = x01 + ((size_t)n * T_tot + i) * 3;
-#pragma unroll
-    for (int d = 0; d < 3; d++) {
-        float p = rays_o[n * 3 + d] + rays_d[n * 3 + d] * t;
-        p = fminf(fmaxf(p, aabb[d]), aabb[3 + d]);
-        o[d] = (p + bound) / (2 * bound);
-    }
+    coarse_sample_point(idx, u, rays_o, rays_d, aabb, bound, T, T_tot, near, far, z, x01);
 }
 
 // ------------------------------------------------------------------------------------------------ merge + weights

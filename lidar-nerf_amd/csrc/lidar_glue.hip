@@ -2,6 +2,7 @@
 // launches per step (renderer.py:129-161 sampling set-up, network.py:215-221 direction term, nerf/utils.py:712-746
 // loss).  Each is one launch here; none of them is bandwidth- or compute-relevant, the point is the launch count.
 #include "common.h"
+#include "lidar_steps.h"
 
 namespace {
 
@@ -28,12 +29,12 @@ k_coarse_samples(const float *__restrict__ u, uint32_t N, uint32_t T, float near
 // x | sin(2^f x), sin(2^f x + pi/2) per band, the same operations in the same order) are formed here instead of being
 // read — the direction encoder and the direction term in one launch.
 template <typename E, bool FREQ>
-__global__ void __launch_bounds__(256)
-k_dir_term(const float *__restrict__ enc, const float *__restrict__ W0, uint32_t ldw, uint32_t N, uint32_t K,
-           float *__restrict__ enc16, float *__restrict__ cdir) {
+__device__ __forceinline__ void dir_term_block(uint32_t block, const float *__restrict__ enc, const float *__restrict__ W0,
+                                               uint32_t ldw, uint32_t N, uint32_t K, float *__restrict__ enc16,
+                                               float *__restrict__ cdir) {
     __shared__ float row[4][128];
     const uint32_t r = threadIdx.x >> 6, o = threadIdx.x & 63;
-    const uint32_t n = blockIdx.x * 4 + r;
+    const uint32_t n = block * 4 + r;
     const bool valid = n < N;
     for (uint32_t k = o; k < K; k += 64) {
         float feat;
@@ -54,6 +55,12 @@ k_dir_term(const float *__restrict__ enc, const float *__restrict__ W0, uint32_t
     const float *w = W0 + (size_t)o * ldw;
     for (uint32_t k = 0; k < K; k++) acc = fmaf(row[r][k], (float)(E)w[k], acc);
     if (valid) cdir[(size_t)n * 64 + o] = acc;
+}
+template <typename E, bool FREQ>
+__global__ void __launch_bounds__(256)
+k_dir_term(const float *__restrict__ enc, const float *__restrict__ W0, uint32_t ldw, uint32_t N, uint32_t K,
+           float *__restrict__ enc16, float *__restrict__ cdir) {
+    dir_term_block<E, FREQ>(blockIdx.x, enc, W0, ldw, N, K, enc16, cdir);
 }
 
 // d cdir / d W0_dir:  gW[o, k] += sum_n S[n, o] * enc16[n, k]  (S = per-ray sum of dH0 from the colour backward).
@@ -110,9 +117,8 @@ struct PackArgs {
     E *wsig, *wcol;
 };
 template <typename E>
-__global__ void __launch_bounds__(256)
-k_pack_weights(PackArgs<E> a) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pack_weights_block(uint32_t block, const PackArgs<E> &a) {
+    const uint32_t i = block * blockDim.x + threadIdx.x;
     constexpr uint32_t nS0 = 64 * 32, nS1 = 16 * 64, nC0 = 64 * 16, nC1 = 64 * 64, nC2 = 16 * 64;
     if (i < nS0) {
         a.wsig[i] = (E)a.ws0[(i / 32) * a.ld_s0 + i % 32];
@@ -129,6 +135,40 @@ k_pack_weights(PackArgs<E> a) {
     } else if (i < nC0 + nC1 + nC2) {
         const uint32_t j = i - nC0 - nC1, o = j / 64;
         a.wcol[i] = o < 2 ? (E)a.wc2[o * a.ld_c2 + j % 64] : (E)0.0f;
+    }
+}
+constexpr uint32_t kPackBlocks = (64 * 16 + 64 * 64 + 16 * 64 + 255) / 256;
+template <typename E>
+__global__ void __launch_bounds__(256)
+k_pack_weights(PackArgs<E> a) {
+    pack_weights_block<E>(blockIdx.x, a);
+}
+
+// ------------------------------------------------------------------------------------------------ step prologue
+// Everything a render step needs before its first encode, in ONE launch (round 5; three launches of 5 / 9 / 16 us before):
+// the weight packing (first blocks), the per-ray direction term with the frequency encoder folded in (next N / 4 blocks),
+// and the coarse pass — stratified depths and their grid coordinates (the rest).  The bodies are the stand-alone kernels'.
+struct PrologueArgs {
+    const float *dirs, *w0;  // direction term: raw directions [N, 3], the colour head's first matrix (row stride ldw)
+    uint32_t ldw, degree;
+    float *enc16, *cdir;
+    const float *u, *rays_o, *aabb;  // coarse pass (rays_d = dirs)
+    float bound, near, far;
+    uint32_t N, T, T_tot;
+    float *z, *x01;
+};
+template <typename E>
+__global__ void __launch_bounds__(256)
+k_step_prologue(PackArgs<E> pk, PrologueArgs a) {
+    const uint32_t dir_blocks = (a.N + 3) / 4;
+    if (blockIdx.x < kPackBlocks) {
+        pack_weights_block<E>(blockIdx.x, pk);
+    } else if (blockIdx.x < kPackBlocks + dir_blocks) {
+        dir_term_block<E, true>(blockIdx.x - kPackBlocks, a.dirs, a.w0, a.ldw, a.N, 3 + 6 * a.degree, a.enc16, a.cdir);
+    } else {
+        const uint32_t idx = (blockIdx.x - kPackBlocks - dir_blocks) * blockDim.x + threadIdx.x;
+        if (idx < a.N * a.T)
+            coarse_sample_point(idx, a.u, a.rays_o, a.dirs, a.aabb, a.bound, a.T, a.T_tot, a.near, a.far, a.z, a.x01);
     }
 }
 
@@ -284,7 +324,45 @@ static int pack_weights(const float *ws0, uint32_t ld_s0, const float *ws1, uint
     LNH_LAUNCH(k_pack_weights<E>, dim3(div_up(64 * 16 + 64 * 64 + 16 * 64, 256)), dim3(256), 0, (hipStream_t)stream, a);
     return lnh_check_launch("lnh_lidar_pack_weights");
 }
+template <typename E>
+static int step_prologue(const float *ws0, uint32_t ld_s0, const float *ws1, uint32_t ld_s1, const float *wc0, uint32_t ld_c0,
+                         uint32_t degree, const float *wc1, uint32_t ld_c1, const float *wc2, uint32_t ld_c2, void *wsig16,
+                         void *wcol16, const float *u, const float *rays_o, const float *rays_d, const float *aabb, float bound,
+                         uint32_t N, uint32_t T, uint32_t T_tot, float near, float far, float *z, float *x01, float *features16,
+                         float *cdir, lnh_stream_t stream) {
+    const uint32_t n_dir = 3 + 6 * degree;
+    LNH_REQUIRE(ws0 && ws1 && wc0 && wc1 && wc2 && wsig16 && wcol16 && rays_o && rays_d && aabb && z && x01 && features16 && cdir,
+                LNH_ERR_INVALID_ARG, "lidar_step_prologue: null pointer");
+    LNH_REQUIRE(n_dir <= 128 && ld_s0 >= 32 && ld_s1 >= 64 && ld_c0 >= n_dir + 15 && ld_c1 >= 64 && ld_c2 >= 64,
+                LNH_ERR_INVALID_ARG, "lidar_step_prologue: leading dimension smaller than the row (or 3 + 6 * degree > 128)");
+    LNH_REQUIRE(bound > 0.0f && T <= T_tot, LNH_ERR_INVALID_ARG, "lidar_step_prologue: bound must be positive, T <= T_tot");
+    LNH_REQUIRE((uint64_t)N * T_tot < 0xffffffffull, LNH_ERR_UNSUPPORTED, "lidar_step_prologue: N*T must fit 32 bits");
+    PackArgs<E> pk{ws0, ws1, wc0, wc1, wc2, ld_s0, ld_s1, ld_c0, ld_c1, ld_c2, n_dir, (E *)wsig16, (E *)wcol16};
+    PrologueArgs a{rays_d, wc0, ld_c0, degree, features16, cdir, u, rays_o, aabb, bound, near, far, N, T, T_tot, z, x01};
+    const uint32_t blocks = kPackBlocks + (N + 3) / 4 + div_up((uint64_t)N * T, 256);
+    LNH_LAUNCH(k_step_prologue<E>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pk, a);
+    return lnh_check_launch("lnh_lidar_step_prologue");
+}
+
 extern "C" {
+
+int lnh_lidar_step_prologue(const float *ws0, uint32_t ld_s0, const float *ws1, uint32_t ld_s1, const float *wc0, uint32_t ld_c0,
+                            uint32_t degree, const float *wc1, uint32_t ld_c1, const float *wc2, uint32_t ld_c2, void *wsig16,
+                            void *wcol16, const float *u, const float *rays_o, const float *rays_d, const float *aabb,
+                            float bound, uint32_t N, uint32_t T, uint32_t T_tot, float near, float far, float *z, float *x01,
+                            float *features16, float *cdir, lnh_stream_t stream) {
+    return step_prologue<half_t>(ws0, ld_s0, ws1, ld_s1, wc0, ld_c0, degree, wc1, ld_c1, wc2, ld_c2, wsig16, wcol16, u, rays_o,
+                                 rays_d, aabb, bound, N, T, T_tot, near, far, z, x01, features16, cdir, stream);
+}
+int lnh_lidar_step_prologue_bf16(const float *ws0, uint32_t ld_s0, const float *ws1, uint32_t ld_s1, const float *wc0,
+                                 uint32_t ld_c0, uint32_t degree, const float *wc1, uint32_t ld_c1, const float *wc2,
+                                 uint32_t ld_c2, void *wsig16, void *wcol16, const float *u, const float *rays_o,
+                                 const float *rays_d, const float *aabb, float bound, uint32_t N, uint32_t T, uint32_t T_tot,
+                                 float near, float far, float *z, float *x01, float *features16, float *cdir,
+                                 lnh_stream_t stream) {
+    return step_prologue<__bf16>(ws0, ld_s0, ws1, ld_s1, wc0, ld_c0, degree, wc1, ld_c1, wc2, ld_c2, wsig16, wcol16, u, rays_o,
+                                 rays_d, aabb, bound, N, T, T_tot, near, far, z, x01, features16, cdir, stream);
+}
 
 int lnh_lidar_coarse_samples(const float *u, uint32_t N, uint32_t T, float near, float far, float *z,
                              lnh_stream_t stream) {

@@ -24,6 +24,8 @@ _SIGS = {
     "lnh_grid_encode_backward_ws_begin": [P, P, P, P, U32, U32, U32, U32, F32, U32, U32, I32, U32, I32, P, C.c_uint64],
     "lnh_grid_encode_backward_ws_finish": [P, P, P, P, U32, U32, U32, U32, F32, U32, U32, I32, U32, I32, P, C.c_uint64,
                                            U32, U32],
+    "lnh_grid_encode_backward_ws_ex": [P, P, P, P, U32, U32, U32, U32, F32, U32, U32, I32, U32, I32, P, C.c_uint64, U32, U32,
+                                       I32, U32],
     "lnh_grad_total_variation": [P, P, P, P, F32, U32, U32, U32, U32, F32, U32, U32, I32, I32],
     "lnh_grid_corner_indices": [P, P, P, U32, U32, U32, U32, F32, U32, U32, I32],
     "lnh_freq_encode_forward": [P, U32, U32, U32, U32, P],
@@ -71,6 +73,8 @@ _SIGS = {
     "lnh_grad_check_f16": [P, C.c_uint64, P],
     "lnh_adam_table_step": [P, P, P, P, P, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_double, P, P, P, P],
     "lnh_adam_table_step_dlr": [P, P, P, P, P, C.c_uint64, P, C.c_double, C.c_double, C.c_double, P, P, P, P],
+    "lnh_lidar_step_prologue": [P, U32, P, U32, P, U32, U32, P, U32, P, U32, P, P, P, P, P, P, F32, U32, U32, U32, F32, F32, P, P, P,
+                                P],
     "lnh_lidar_loss": [P, P, P, U32, F32, F32, F32, P, P, P, P],
     "lnh_lidar_loss_patch": [P, P, P, U32, U32, U32, F32, F32, F32, F32, F32, P, P, P, P],
     "lnh_train_check": [P, P, C.c_uint64, P, P, U32, F32, F32, C.c_double, C.c_double],
@@ -88,17 +92,18 @@ _SIGS = {
     "lnh_ragged_grad_rows": [P, F32, P, P, U32, U32, P],
 }
 for _n in ("lnh_mlp_forward", "lnh_mlp_backward", "lnh_mlp_backward_data", "lnh_density_mlp_forward", "lnh_density_mlp_backward",
-           "lnh_lidar_dir_term", "lnh_lidar_pack_weights", "lnh_lidar_color_forward", "lnh_lidar_color_backward",
+           "lnh_lidar_dir_term", "lnh_lidar_pack_weights", "lnh_lidar_step_prologue", "lnh_lidar_color_forward", "lnh_lidar_color_backward",
            "lnh_lidar_color_composite_forward", "lnh_lidar_color_backward_image", "lnh_lidar_dir_term_freq",
            "lnh_ragged_pack_weights", "lnh_ragged_color_input", "lnh_ragged_color_input_rays", "lnh_ragged_color_output",
            "lnh_ragged_color_output_backward", "lnh_ragged_grad_rows"):
     _SIGS[_n + "_bf16"] = _SIGS[_n]  # bf16-operand build of the MLP kernels (include/lidarnerf_hip.h, last section)
 EXPORTS = sorted(list(_SIGS) + ["lnh_version", "lnh_last_error", "lnh_arch", "lnh_build_variant",
                                  "lnh_grid_backward_workspace_size", "lnh_grid_backward_workspace_size_min",
-                                 "lnh_grid_backward_plan_info",
+                                 "lnh_grid_backward_plan_info", "lnh_grid_backward_workspace_clear_bytes",
                                  "lnh_grid_backward_set_slice_entries"])
 
 LNH_F32, LNH_F16 = 0, 1
+LNH_BWD_WS_CLEARED, LNH_BWD_TABLE_ZERO = 1, 2
 
 _lib = None
 
@@ -124,6 +129,8 @@ def lib():
         L.lnh_grid_backward_workspace_size.restype = C.c_uint64
         L.lnh_grid_backward_workspace_size_min.argtypes = [P, U32, U32, U32, U32, F32, U32, U32, I32, I32]
         L.lnh_grid_backward_workspace_size_min.restype = C.c_uint64
+        L.lnh_grid_backward_workspace_clear_bytes.argtypes = [P, U32, U32, U32, U32, F32, U32, U32, I32, U32, I32, C.c_uint64]
+        L.lnh_grid_backward_workspace_clear_bytes.restype = C.c_uint64
         L.lnh_grid_backward_plan_info.argtypes = [P, U32, U32, U32, U32, F32, U32, U32, I32, I32, U32, P]
         L.lnh_grid_backward_plan_info.restype = C.c_int
         L.lnh_grid_backward_set_slice_entries.argtypes = [U32]
@@ -181,17 +188,19 @@ def disable_timers():
 _TIMED = None
 
 
-def call(name, *args, tag=None):
-    """Invoke an entry point on the current stream; raise on any non-zero status."""
+def call(name, *args, tag=None, timer=None):
+    """Invoke an entry point on the current stream; raise on any non-zero status.  `timer`: the name the optional HIP-event
+    timing files this call under (an entry point that serves several roles, e.g. lnh_grid_encode_backward_ws_ex)."""
     L = _lib if _lib is not None else lib()
-    timed = TIMERS is not None and (_TIMED is None or name in _TIMED)
+    tname = timer or name
+    timed = TIMERS is not None and (_TIMED is None or tname in _TIMED)
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     rc = getattr(L, name)(*args, stream())
     if timed:
         e1.record()
-        TIMERS.setdefault(name, []).append((e0, e1, tag))
+        TIMERS.setdefault(tname, []).append((e0, e1, tag))
     if rc != 0:
         raise RuntimeError(f"{name} failed ({rc}): {L.lnh_last_error().decode()}")
 

@@ -83,14 +83,37 @@ def _grid_fwd(x01, table16, enc, B):
     return out
 
 
-def _grid_bwd(g_feat, x01, g_table16, enc, B):
+def _grid_bwd_workspace(dev, enc, B):
+    """(workspace tensor, bytes at its head the backward wants cleared) for a batch of B points — cached per encoder and B:
+    the plan is host arithmetic, but the training step asks for it every step."""
+    cache = enc.__dict__.setdefault("_lnh_bwd_ws_plan", {})
+    ent = cache.get(B)
+    off = enc._offsets_host
+    if ent is None:
+        L = enc.num_levels
+        need = _hip.lib().lnh_grid_backward_workspace_size(off.data_ptr(), B, 3, 2, L, enc.log2_scale, enc.base_resolution, 0, 0,
+                                                           _hip.LNH_F16)
+        if len(cache) > 16:
+            cache.clear()
+        ent = cache[B] = [need, None]
+    ws = _workspace(dev, ent[0])
+    if ent[1] is None or ent[1][0] != ws.numel():
+        clear = _hip.lib().lnh_grid_backward_workspace_clear_bytes(off.data_ptr(), B, 3, 2, enc.num_levels, enc.log2_scale,
+                                                                   enc.base_resolution, 0, 0, 0, _hip.LNH_F16, ws.numel())
+        ent[1] = (ws.numel(), int(clear))
+    return ws, ent[1][1]
+
+
+def _grid_bwd(g_feat, x01, g_table16, enc, B, ws=None, flags=0):
+    """Table gradient of B points.  ws / flags: the caller has cleared the head of the workspace and / or the gradient table
+    itself (lnh_grid_encode_backward_ws_ex: LNH_BWD_WS_CLEARED, LNH_BWD_TABLE_ZERO)."""
     L = enc.num_levels
     off = enc._offsets_host
-    need = _hip.lib().lnh_grid_backward_workspace_size(off.data_ptr(), B, 3, 2, L, enc.log2_scale,
-                                                       enc.base_resolution, 0, 0, _hip.LNH_F16)
-    ws = _workspace(g_feat.device, need)
-    _hip.call("lnh_grid_encode_backward_ws", g_feat.data_ptr(), x01.data_ptr(), off.data_ptr(), g_table16.data_ptr(),
-              B, 3, 2, L, enc.log2_scale, enc.base_resolution, 0, 0, 0, _hip.LNH_F16, ws.data_ptr(), ws.numel(), tag=B)
+    if ws is None:
+        ws, _ = _grid_bwd_workspace(g_feat.device, enc, B)
+    _hip.call("lnh_grid_encode_backward_ws_ex", g_feat.data_ptr(), x01.data_ptr(), off.data_ptr(), g_table16.data_ptr(),
+              B, 3, 2, L, enc.log2_scale, enc.base_resolution, 0, 0, 0, _hip.LNH_F16, ws.data_ptr(), ws.numel(), 0, L, 0,
+              int(flags), tag=B, timer="lnh_grid_encode_backward_ws")
 
 
 # Data parallel: level windows of the table gradient.  The scatter pass of the backward runs once for all levels
@@ -116,29 +139,28 @@ if _os.environ.get("LNH_DP_WINDOWS"):  # developer override for A/B runs: "0,10,
 FORCE_DP_WINDOWS = False  # bench.py --dp-windows: take the windowed backward on one GPU too (the exchange is a no-op)
 
 
-def _grid_bwd_windows(g_feat, x01, g_table16, enc, B):
+def _grid_bwd_windows(g_feat, x01, g_table16, enc, B, ws=None, flags=0):
     """The table-gradient backward as a generator over level windows: `lnh_grid_encode_backward_ws_begin` once (everything
     but the last reduce pass: the scatter pass stays in ONE piece — cut into level windows it costs 0.33 ms more per 3.4 M
     points, profiles/r03_bench_dpwindows*.json of the first cut), then `..._finish` per window; yields (l0, l1) when the rows
     of that window are final, so that the caller can hand them to a collective while the next window is being reduced."""
     L = enc.num_levels
     off = enc._offsets_host
-    need = _hip.lib().lnh_grid_backward_workspace_size(off.data_ptr(), B, 3, 2, L, enc.log2_scale,
-                                                       enc.base_resolution, 0, 0, _hip.LNH_F16)
-    ws = _workspace(g_feat.device, need)
+    if ws is None:
+        ws, _ = _grid_bwd_workspace(g_feat.device, enc, B)
     args = (g_feat.data_ptr(), x01.data_ptr(), off.data_ptr(), g_table16.data_ptr(), B, 3, 2, L, enc.log2_scale,
             enc.base_resolution, 0, 0, 0, _hip.LNH_F16, ws.data_ptr(), ws.numel())
-    _hip.call("lnh_grid_encode_backward_ws_begin", *args, tag=B)
+    _hip.call("lnh_grid_encode_backward_ws_ex", *args, 0, L, 1, int(flags), tag=B, timer="lnh_grid_encode_backward_ws_begin")
     for l0, l1 in (_DP_LEVEL_WINDOWS if L == 16 else ((0, L),)):
-        _hip.call("lnh_grid_encode_backward_ws_finish", *args, l0, l1)
+        _hip.call("lnh_grid_encode_backward_ws_ex", *args, l0, l1, 2, int(flags), timer="lnh_grid_encode_backward_ws_finish")
         yield l0, l1
 
 
-def _grid_bwd_overlapped(g_feat, x01, g_table16, enc, B, table_param):
+def _grid_bwd_overlapped(g_feat, x01, g_table16, enc, B, table_param, ws=None, flags=0):
     """_grid_bwd + parallel.allreduce_half_table, pipelined over level windows.  Returns the handles to wait on."""
     off = enc._offsets_host
     handles = []
-    for l0, l1 in _grid_bwd_windows(g_feat, x01, g_table16, enc, B):
+    for l0, l1 in _grid_bwd_windows(g_feat, x01, g_table16, enc, B, ws, flags):
         h = parallel.allreduce_half_table(g_table16[int(off[l0]):int(off[l1])], table_param)
         if h is not None:
             handles.append(h)
@@ -257,9 +279,29 @@ class FusedLidarRender(Function):
         wcol16 = torch.empty(64 * 16 + 64 * 64 + 16 * 64, dtype=mdt, device=dev)
         mats = [m.detach() if m.dtype == torch.float32 and m.stride(-1) == 1 else m.detach().float().contiguous()
                 for m in (ws0, ws1, wc0, wc1, wc2)]
-        _hip.call("lnh_lidar_pack_weights" + sfx, mats[0].data_ptr(), mats[0].stride(0), mats[1].data_ptr(),
-                  mats[1].stride(0), mats[2].data_ptr(), mats[2].stride(0), kd, mats[3].data_ptr(), mats[3].stride(0),
-                  mats[4].data_ptr(), mats[4].stride(0), wsig16.data_ptr(), wcol16.data_ptr())
+        # direction features [N, kd] (constant along a ray), rounded to the MLP element type (what the MLP would see), and
+        # the per-ray direction term of the colour head's first layer
+        enc_d16 = torch.empty((N, kd), dtype=torch.float32, device=dev)
+        cdir = torch.empty((N, 64), dtype=torch.float32, device=dev)
+        z = torch.empty((N, T), dtype=torch.float32, device=dev)
+        x01 = torch.empty((N * Ttot, 3), dtype=torch.float32, device=dev)
+        deg = getattr(spec, "dir_freq_degree", None)
+        prologue = deg is not None and 3 + 6 * deg == kd
+        if prologue:
+            # weight packing + direction term (frequency encoder folded in) + the coarse pass (stratified depths and their
+            # grid coordinates) in ONE launch
+            _hip.call("lnh_lidar_step_prologue" + sfx, mats[0].data_ptr(), mats[0].stride(0), mats[1].data_ptr(),
+                      mats[1].stride(0), mats[2].data_ptr(), mats[2].stride(0), int(deg), mats[3].data_ptr(), mats[3].stride(0),
+                      mats[4].data_ptr(), mats[4].stride(0), wsig16.data_ptr(), wcol16.data_ptr(),
+                      None if noise is None else noise.data_ptr(), rays_o.data_ptr(), rays_d.data_ptr(), aabb.data_ptr(), bound,
+                      N, T, Ttot, float(near), float(far), z.data_ptr(), x01.data_ptr(), enc_d16.data_ptr(), cdir.data_ptr())
+        else:
+            _hip.call("lnh_lidar_pack_weights" + sfx, mats[0].data_ptr(), mats[0].stride(0), mats[1].data_ptr(),
+                      mats[1].stride(0), mats[2].data_ptr(), mats[2].stride(0), kd, mats[3].data_ptr(), mats[3].stride(0),
+                      mats[4].data_ptr(), mats[4].stride(0), wsig16.data_ptr(), wcol16.data_ptr())
+            enc_d = spec.dir_features(rays_d).contiguous()
+            _hip.call("lnh_lidar_dir_term" + sfx, enc_d.data_ptr(), mats[2].data_ptr(), mats[2].stride(0), N, kd,
+                      enc_d16.data_ptr(), cdir.data_ptr())
 
         h16 = torch.empty((N * Ttot, 16), dtype=mdt, device=dev)
         sigma_pt = torch.empty((N, Ttot), dtype=torch.float32, device=dev)
@@ -267,12 +309,11 @@ class FusedLidarRender(Function):
         # the backward pass is a single launch chain over all N*(T+t) points
         B_all = N * Ttot
         L = enc.num_levels
-        x01 = torch.empty((B_all, 3), dtype=torch.float32, device=dev)
         feat = torch.empty((L, B_all, 2), dtype=torch.half, device=dev)
 
         def density(zz, Tc, off, have_points=False):
             B = N * Tc
-            if have_points:  # (the resample kernel has written the coordinates of these samples)
+            if have_points:  # (the prologue / the resample kernel has written the coordinates of these samples)
                 pass
             elif zz is None:  # coarse pass: the stratified depths and their grid coordinates in one launch
                 _hip.call("lnh_lidar_coarse_sample_points", None if noise is None else noise.data_ptr(), rays_o.data_ptr(),
@@ -287,8 +328,7 @@ class FusedLidarRender(Function):
             _hip.call("lnh_density_mlp_forward" + sfx, feat.data_ptr(), wsig16.data_ptr(), B, Tc, Ttot, off, B_all,
                       h16.data_ptr(), sigma_pt.data_ptr())
 
-        z = torch.empty((N, T), dtype=torch.float32, device=dev)
-        density(None, T, 0)
+        density(None, T, 0, have_points=prologue)
         new_z = torch.empty((N, t_new), dtype=torch.float32, device=dev)
         z_all = torch.empty((N, Ttot), dtype=torch.float32, device=dev)
         perm = torch.empty((N, Ttot), dtype=torch.int32, device=dev)
@@ -303,18 +343,6 @@ class FusedLidarRender(Function):
 
         sigma_m = torch.empty((N, Ttot), dtype=torch.float32, device=dev)
         weights = torch.empty((N, Ttot), dtype=torch.float32, device=dev)
-        # direction features [N, kd] (constant along a ray), rounded to the MLP element type (what the MLP would see), and
-        # the per-ray direction term of the colour head's first layer
-        enc_d16 = torch.empty((N, kd), dtype=torch.float32, device=dev)
-        cdir = torch.empty((N, 64), dtype=torch.float32, device=dev)
-        deg = getattr(spec, "dir_freq_degree", None)
-        if deg is not None and 3 + 6 * deg == kd:
-            _hip.call("lnh_lidar_dir_term_freq" + sfx, rays_d.data_ptr(), int(deg), mats[2].data_ptr(), mats[2].stride(0), N,
-                      enc_d16.data_ptr(), cdir.data_ptr())
-        else:
-            enc_d = spec.dir_features(rays_d).contiguous()
-            _hip.call("lnh_lidar_dir_term" + sfx, enc_d.data_ptr(), mats[2].data_ptr(), mats[2].stride(0), N, kd,
-                      enc_d16.data_ptr(), cdir.data_ptr())
         rgb = torch.empty((N, Ttot, 2), dtype=torch.float32, device=dev)
         ws = torch.empty(N, dtype=torch.float32, device=dev)
         depth = torch.empty(N, dtype=torch.float32, device=dev)
@@ -377,7 +405,10 @@ class FusedLidarRender(Function):
         zeros = torch.empty(n_col + n_sig + n_c0, dtype=torch.float32, device=dev)
         sharded = parallel.dp_active() and getattr(ctx.table_param, "_lnh_shard_optimizer", False)
         g_table16 = None if sharded else torch.empty((int(enc._offsets_host[-1]), 2), dtype=torch.half, device=dev)
-        _hip.zero_regions((zeros, g_table16))
+        # ... and the cursors at the head of the table backward's workspace (its own clear launch is then skipped)
+        bwd_ws, bwd_clear = _grid_bwd_workspace(dev, enc, N * Ttot)
+        bwd_flags = 0 if sharded else (_hip.LNH_BWD_TABLE_ZERO | (_hip.LNH_BWD_WS_CLEARED if bwd_clear else 0))
+        _hip.zero_regions((zeros, g_table16, None if sharded or not bwd_clear else bwd_ws[:bwd_clear]))
         g_wcol, g_wsig = zeros[:n_col], zeros[n_col:n_col + n_sig]
         ray_sum = torch.empty((N, 64), dtype=torch.float32, device=dev)
         _hip.call("lnh_lidar_color_backward_image" + sfx, g_image.data_ptr(), g_sigma.data_ptr(), h16.data_ptr(), perm.data_ptr(),
@@ -416,7 +447,7 @@ class FusedLidarRender(Function):
         if parallel.dp_active() or FORCE_DP_WINDOWS:
             # data parallel: the table gradient goes on the wire as fp16, window by window, behind the kernels of the
             # following windows
-            handles = _grid_bwd_overlapped(g_feat, x01, g_table16, enc, B_all, ctx.table_param)
+            handles = _grid_bwd_overlapped(g_feat, x01, g_table16, enc, B_all, ctx.table_param, bwd_ws, bwd_flags)
             if getattr(ctx.table_param, "_lnh_keep_grad16", False):
                 # the fused table optimizer is the only consumer: it waits right before its kernels (train_step.py), so the
                 # last window's bytes travel under the MLP gradients' all-reduce and the loss-scale bookkeeping instead of
@@ -426,7 +457,7 @@ class FusedLidarRender(Function):
                 for handle in handles:
                     handle.wait()
         else:
-            _grid_bwd(g_feat, x01, g_table16, enc, B_all)
+            _grid_bwd(g_feat, x01, g_table16, enc, B_all, bwd_ws, bwd_flags)
         world = parallel.world_size()
         if getattr(ctx.table_param, "_lnh_keep_grad16", False):
             # the fused table optimizer consumes the fp16 gradient directly: no fp32 copy, no .grad on the table
@@ -596,7 +627,9 @@ class FusedLidarRagged(Function):
         n_col, n_sig = wcol16.numel(), wsig16.numel()
         zeros = torch.empty(n_col + n_sig, dtype=torch.float32, device=dev)
         g_table16 = torch.empty((int(enc._offsets_host[-1]), 2), dtype=torch.half, device=dev)
-        _hip.zero_regions((gsf, zeros, g_table16))
+        bwd_ws, bwd_clear = _grid_bwd_workspace(dev, enc, M)
+        bwd_flags = _hip.LNH_BWD_TABLE_ZERO | (_hip.LNH_BWD_WS_CLEARED if bwd_clear else 0)
+        _hip.zero_regions((gsf, zeros, g_table16, bwd_ws[:bwd_clear] if bwd_clear else None))
         gs, gf = gsf[:M], gsf[M:].view(M, 2)
         _hip.call("lnh_lidar_composite_rays_train_backward", g_ws.data_ptr(), g_depth.data_ptr(), g_image.data_ptr(),
                   sig_s.data_ptr(), rgb.data_ptr(), deltas.data_ptr(), xyzs.data_ptr(), rays_o.data_ptr(),
@@ -616,10 +649,10 @@ class FusedLidarRagged(Function):
                   g_feat.data_ptr(), g_wsig.data_ptr())
         world = parallel.world_size()
         if parallel.dp_active():
-            for handle in _grid_bwd_overlapped(g_feat, x01, g_table16, enc, M, table_param):
+            for handle in _grid_bwd_overlapped(g_feat, x01, g_table16, enc, M, table_param, bwd_ws, bwd_flags):
                 handle.wait()
         else:
-            _grid_bwd(g_feat, x01, g_table16, enc, M)
+            _grid_bwd(g_feat, x01, g_table16, enc, M, bwd_ws, bwd_flags)
         if getattr(table_param, "_lnh_keep_grad16", False):
             table_param._lnh_grad16, table_param._lnh_grad16_div = g_table16, world
             g_table = None

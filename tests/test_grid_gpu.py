@@ -351,6 +351,49 @@ def test_backward_bucketed_smaller_workspace_means_shorter_chunks(dt):
         call("lnh_grid_encode_backward_ws", gd, xd, offh, ge, B, 3, CH, L, S, H, 0, 0, 0, code, ws, least // 4)
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16])
+def test_backward_ws_ex_with_buffers_the_caller_cleared(dt):
+    """lnh_grid_encode_backward_ws_ex: split 0 / 1 + 2 behind one signature, and the two promises a caller can make — the head
+    of the workspace cleared (LNH_BWD_WS_CLEARED: the first chunk's clear launch is skipped) and the gradient table zero
+    (LNH_BWD_TABLE_ZERO: the first chunk's reduce pass stores instead of read-add-store) — must give the SAME BITS as
+    lnh_grid_encode_backward_ws on a garbage workspace: one chunk, several chunks (small workspace), level windows."""
+    from gpu_util import call, dev
+    from lidarnerf import _hip
+    B = 600 * 1024
+    x = np.concatenate([_ray_points(B // 512, 256, 31), _points(B - (B // 512) * 256, 32)])
+    nd = np.float32 if dt == torch.float32 else np.float16
+    g = (np.random.default_rng(33).standard_normal((L, B, CH)) * 0.05).astype(nd)
+    rows, code = int(OFF[-1]), (0 if dt == torch.float32 else 1)
+    offh = torch.from_numpy(OFF)
+    full = _hip.lib().lnh_grid_backward_workspace_size(offh.data_ptr(), B, 3, CH, L, S, H, 0, 0, code)
+    least = _hip.lib().lnh_grid_backward_workspace_size_min(offh.data_ptr(), B, 3, CH, L, S, H, 0, 0, code)
+    gd, xd = dev(g), dev(x)
+    args = lambda ge, ws, n: (gd, xd, offh, ge, B, 3, CH, L, S, H, 0, 0, 0, code, ws, n)
+    for nbytes in (full, least):                           # one chunk / four chunks
+        ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        ws.random_(0, 255)
+        ref = torch.zeros((rows, CH), dtype=dt, device="cuda")
+        call("lnh_grid_encode_backward_ws", *args(ref, ws, nbytes))
+        clear = _hip.lib().lnh_grid_backward_workspace_clear_bytes(offh.data_ptr(), B, 3, CH, L, S, H, 0, 0, 0, code, nbytes)
+        assert 0 < clear <= 64 * 1024 and clear % 256 == 0
+        for flags in (0, _hip.LNH_BWD_WS_CLEARED, _hip.LNH_BWD_TABLE_ZERO, _hip.LNH_BWD_WS_CLEARED | _hip.LNH_BWD_TABLE_ZERO):
+            for windows in (None, ((0, 8), (8, 12), (12, 16))):
+                ws.random_(0, 255)
+                ge = torch.full((rows, CH), 9.0, dtype=dt, device="cuda")   # (cleared below by one launch, like the step does)
+                _hip.zero_regions((ge, ws[:clear] if flags & _hip.LNH_BWD_WS_CLEARED else None))
+                if windows is None:
+                    call("lnh_grid_encode_backward_ws_ex", *args(ge, ws, nbytes), 0, L, 0, flags)
+                else:
+                    call("lnh_grid_encode_backward_ws_ex", *args(ge, ws, nbytes), 0, 0, 1, flags)
+                    for l0, l1 in windows:
+                        call("lnh_grid_encode_backward_ws_ex", *args(ge, ws, nbytes), l0, l1, 2, flags)
+                assert torch.equal(ge, ref), (nbytes, flags, windows)
+        del ws
+    with pytest.raises(RuntimeError, match="split must be"):
+        ws = torch.empty(full, dtype=torch.uint8, device="cuda")
+        call("lnh_grid_encode_backward_ws_ex", *args(ref, ws, full), 0, L, 3, 0)
+
+
 def test_dense_levels_are_dealt_to_64_buckets():
     """Plan of the dense plain levels (grid.hip bucket_of_row): rows go to min(64, ceil(rows / 128)) buckets in groups of
     128, so the few cells around the sensor that every LiDAR ray leaves are reduced by many workgroups, not one."""

@@ -319,6 +319,39 @@ def test_dir_term_with_the_frequency_encoder_folded_in(sfx):
     assert torch.equal(e_a, e_b) and torch.equal(c_a, c_b)
 
 
+@pytest.mark.parametrize("sfx,dt", [("", torch.half), ("_bf16", torch.bfloat16)])
+def test_step_prologue_equals_its_three_entry_points(sfx, dt):
+    """lnh_lidar_step_prologue == lnh_lidar_pack_weights + lnh_lidar_dir_term_freq + lnh_lidar_coarse_sample_points, bit for
+    bit (one launch instead of three), with and without the stratified noise, N not a multiple of 4."""
+    from gpu_util import call
+    N, T, Ttot, deg = 1001, 96, 128, 12
+    K = 3 + 6 * deg
+    g = torch.Generator().manual_seed(8)
+    o = ((torch.rand(N, 3, generator=g) - 0.5) * 0.05).cuda()
+    d = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1).cuda()
+    aabb = torch.tensor([-1, -1, -1, 1, 1, 1], dtype=torch.float32).cuda()
+    near = float(np.float32(0.0107848535))
+    far = float(np.float32(near) * np.float32(81.0))
+    u = torch.rand(N * T, generator=g).cuda()
+    ws0, ws1 = torch.randn(64, 32, generator=g).cuda(), torch.randn(16, 64, generator=g).cuda()
+    wc0 = (torch.randn(64, 96, generator=g) * 0.3).cuda()[:, :K + 15]      # strided rows, like the tcnn-shaped flat parameter
+    wc1, wc2 = torch.randn(64, 64, generator=g).cuda(), torch.randn(2, 64, generator=g).cuda()
+    new = lambda *shape, dtype=torch.float32: torch.full(shape, float("nan"), dtype=dtype, device="cuda")
+    for noise in (None, u):
+        a = dict(wsig=new(64 * 32 + 16 * 64, dtype=dt), wcol=new(64 * 16 + 64 * 64 + 16 * 64, dtype=dt), e=new(N, K), c=new(N, 64),
+                 z=new(N, T), x=new(N * Ttot, 3))
+        b = {k: v.clone() for k, v in a.items()}
+        call("lnh_lidar_pack_weights" + sfx, ws0, 32, ws1, 64, wc0, wc0.stride(0), K, wc1, 64, wc2, 64, a["wsig"], a["wcol"])
+        call("lnh_lidar_dir_term_freq" + sfx, d, deg, wc0, wc0.stride(0), N, a["e"], a["c"])
+        call("lnh_lidar_coarse_sample_points", noise, o, d, aabb, 1.0, N, T, Ttot, near, far, a["z"], a["x"])
+        call("lnh_lidar_step_prologue" + sfx, ws0, 32, ws1, 64, wc0, wc0.stride(0), deg, wc1, 64, wc2, 64, b["wsig"], b["wcol"],
+             noise, o, d, aabb, 1.0, N, T, Ttot, near, far, b["z"], b["x"], b["e"], b["c"])
+        for k in a:
+            fa, fb = torch.nan_to_num(a[k].float(), nan=-7.0), torch.nan_to_num(b[k].float(), nan=-7.0)
+            assert torch.equal(fa, fb), k
+        assert bool(torch.isnan(b["x"].view(N, Ttot, 3)[:, T:]).all()) and not bool(torch.isnan(b["x"].view(N, Ttot, 3)[:, :T]).any())
+
+
 def test_fused_lidar_loss_matches_train_step_loss():
     from lidarnerf.nerf.train_step import fused_lidar_loss, lidar_loss
     torch.manual_seed(1)

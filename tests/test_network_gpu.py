@@ -386,7 +386,11 @@ def test_rgb_branch_sh_encoder_and_color_net_vs_restatement():
         assert float(out[~mask.cuda()].abs().max()) == 0.0
         gscale = lambda t: float(t.abs().max())
         for m, wc in zip(net.color_net, Wc):
-            assert float((m.weight.grad.cpu().double() - wc.grad).abs().max()) <= (1e-4 if mode == "fp32" else 2e-2) * gscale(wc.grad)
+            # (fp16: 16-bit storage of the activations moves single entries of a weight gradient by percents — a hidden unit
+            #  within rounding error of the ReLU kink contributes or not, DESIGN 8 — so entry-wise loosely, in norm tightly)
+            dw = m.weight.grad.cpu().double() - wc.grad
+            assert float(dw.abs().max()) <= (1e-4 if mode == "fp32" else 8e-2) * gscale(wc.grad)
+            assert float(dw.norm()) <= (1e-4 if mode == "fp32" else 1.5e-2) * float(wc.grad.norm())
         assert float((geo_g.grad.cpu().double() - geo_c.grad).abs().max()) <= (1e-4 if mode == "fp32" else 2e-2) * gscale(geo_c.grad)
         assert float((d_g.grad.cpu().double() - want_gd).abs().max()) <= (2e-3 if mode == "fp32" else 3e-2) * gscale(want_gd)
     # ---- background(x_sph, d): the reference sizes bg_net's first Linear to in_dim_bg + in_dim_dir AFTER in_dim_dir has been
