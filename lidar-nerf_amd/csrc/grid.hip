@@ -912,6 +912,15 @@ __host__ __device__ inline bool level_is_generic(const LevelParams &lv, uint32_t
 #define LNH_SCATTER_THREADS 1024
 #endif
 constexpr int kScatterThreads = LNH_SCATTER_THREADS;  // points (= threads) of a scatter workgroup; 5 staging slots each
+// Paired write-out (round 5): a workgroup reserves an EVEN number of slots per bucket (an odd count is padded with one
+// zero-valued single on the bucket's local row 0, which adds nothing), so every bucket's segment starts at an even staging
+// slot AND at an even pool slot; a thread then writes TWO consecutive entries with one 16-byte value store and one 4-byte row
+// store (fp16 tables; 2 x 16 + 4 for fp32) instead of two 8-byte and two 2-byte stores, and reads its staging with 8-byte
+// LDS loads.  Round 3 tried pairs without the padding (the wide stores landed on 8- / 2-byte boundaries: 709 against 677 us).
+#ifndef LNH_SCATTER_PAIRED
+#define LNH_SCATTER_PAIRED 1
+#endif
+constexpr bool kScatterPaired = LNH_SCATTER_PAIRED != 0;
 // ---- scatter pass for the two PLAIN level classes (hashed power-of-two tables / dense levels, linear interpolation,
 // align_corners off — every level of the usual configuration).  Same contract as k_grid_bwd_scatter (which keeps the
 // generic classes): same pool format, same cursors, same spill rules; what differs is the instruction budget.  The scatter
@@ -949,6 +958,9 @@ k_grid_bwd_scatter_plain(const T *__restrict__ grad, const float *__restrict__ i
     __shared__ uint32_t lflag;                             // 1: everything fits staging and pool (the fast path)
     // staged key: bits 0-12 bucket-local row | 13-15 code | 16-23 bucket * 4
     __shared__ __attribute__((aligned(16))) uint32_t skey[CAP];
+    // (the two value pairs of an entry in ONE 8-byte LDS record — one write per entry, one 16-byte read per written-out slot
+    //  pair — was measured in round 5: 766 against 531 us, the random 8-byte LDS writes of the staging conflict; round 3 saw
+    //  the same with a 16-byte record)
     __shared__ __attribute__((aligned(16))) V2 sa[CAP], sb[CAP];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t level = level0 + blockIdx.x, chunk = blockIdx.y;
@@ -1141,14 +1153,26 @@ k_grid_bwd_scatter_plain(const T *__restrict__ grad, const float *__restrict__ i
     //      atomics' round trip (~66 us of the pass when it was waited for here) runs under the staging of all 16 waves, and
     //      the first wave turns the returned bases into pool / spill offsets only afterwards.
     uint32_t rs_n0 = 0, rs_base = 0, rs_st = 0, rs_incl = 0;
+    bool pad_unstaged = false;  // (paired write-out) this lane's padding entry lies beyond the staging area
     if (tid < 64) {
         static_assert(kMaxBucketsPerLevel == 64, "one bucket counter per lane of the first wave");
-        rs_n0 = lcnt[lane];
+        const uint32_t cnt = lcnt[lane];
+        rs_n0 = kScatterPaired ? (cnt + 1u) & ~1u : cnt;  // slots reserved: even
         if (lane < nb && rs_n0) rs_base = atomicAdd(&cursor[fb + lane], rs_n0);
         rs_incl = wave_scan_add_u32(rs_n0);  // DPP network: no LDS round trips while the atomics are in flight
         rs_st = rs_incl - rs_n0;
         lstart[lane] = rs_st;
         if (lane == 63) lstart[kMaxBucketsPerLevel] = rs_incl;
+        if (kScatterPaired && (cnt & 1u)) {  // the padding entry: a single with zero values on the bucket's local row 0
+            const uint32_t q = rs_st + cnt;
+            if (q < (uint32_t)CAP) {
+                skey[q] = (kCodeSingle << kBucketRowsLog2) | (lane << 18);
+                sa[q] = make_v2<T>(0.0f, 0.0f);
+                sb[q] = make_v2<T>(0.0f, 0.0f);
+            } else {
+                pad_unstaged = true;
+            }
+        }
     }
     __syncthreads();
     LNH_MARK("H stage");
@@ -1220,6 +1244,42 @@ k_grid_bwd_scatter_plain(const T *__restrict__ grad, const float *__restrict__ i
     LNH_MARK("I writeout");
     const bool fits = __builtin_amdgcn_readfirstlane((int)lflag) != 0;
     if (fits) {
+        if constexpr (kScatterPaired) {
+            // ---- write out in PAIRS of slots (see kScatterPaired): slot pair (2j, 2j + 1) of the staging area belongs to one
+            //      bucket and goes to an even pool slot; all LDS reads of a thread before the first use
+            constexpr int NW2 = (CAP + 2 * NTHREADS - 1) / (2 * NTHREADS);
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            struct V2x2 { V2 v[2]; };
+            u32x2 ks2[NW2];
+            V2x2 as2[NW2], bs2[NW2];
+            uint32_t dl2[NW2];
+#pragma unroll
+            for (int i = 0; i < NW2; i++) {
+                if ((uint32_t)i * 2 * NTHREADS >= total) break;  // scalar branch
+                const uint32_t q = 2 * (tid + (uint32_t)i * NTHREADS);
+                const uint32_t qc = q < (uint32_t)CAP ? q : 0u;  // (CAP is a multiple of 2: a pair never straddles the end)
+                ks2[i] = *reinterpret_cast<const u32x2 *>(&skey[qc]);
+                as2[i] = *reinterpret_cast<const V2x2 *>(&sa[qc]);
+                bs2[i] = *reinterpret_cast<const V2x2 *>(&sb[qc]);
+            }
+#pragma unroll
+            for (int i = 0; i < NW2; i++) {
+                if ((uint32_t)i * 2 * NTHREADS >= total) break;
+                dl2[i] = lds_at(lox, (ks2[i][0] >> 16) & 0xffu);
+            }
+#pragma unroll
+            for (int i = 0; i < NW2; i++) {
+                if ((uint32_t)i * 2 * NTHREADS >= total) break;
+                const uint32_t q = 2 * (tid + (uint32_t)i * NTHREADS);
+                if (q < total) {  // (total is even: the pair is whole)
+                    const uint32_t slot = dl2[i] + q;
+                    struct Pair2 { V2 a0, b0, a1, b1; };
+                    Pair2 pr = {as2[i].v[0], bs2[i].v[0], as2[i].v[1], bs2[i].v[1]};
+                    *reinterpret_cast<Pair2 *>(pvals + slot * (uint32_t)sizeof(Pair)) = pr;
+                    *reinterpret_cast<uint32_t *>(prows + slot * 2u) = (ks2[i][0] & 0xffffu) | (ks2[i][1] << 16);
+                }
+            }
+        } else {
         // ---- write out: consecutive lanes write consecutive pool slots; all LDS reads of a thread before the first use
         uint32_t ks[NW], dl[NW];
         V2 as[NW], bs[NW];
@@ -1247,6 +1307,7 @@ k_grid_bwd_scatter_plain(const T *__restrict__ grad, const float *__restrict__ i
                 *reinterpret_cast<Pair *>(pvals + slot * (uint32_t)sizeof(Pair)) = pr;
                 *reinterpret_cast<unsigned short *>(prows + slot * 2u) = (unsigned short)ks[i];
             }
+        }
         }
         if (all_staged) return;
     }
@@ -1278,6 +1339,9 @@ k_grid_bwd_scatter_plain(const T *__restrict__ grad, const float *__restrict__ i
     };
     if (!fits)
         for (uint32_t q = tid; q < total; q += NTHREADS) to_global(q, skey[q], sa[q], sb[q]);
+    if (pad_unstaged)  // (first wave: the padding entry of a bucket whose segment ends beyond the staging area)
+        to_global(rs_st + rs_n0 - 1u, (kCodeSingle << kBucketRowsLog2) | (lane << 18), make_v2<T>(0.0f, 0.0f),
+                  make_v2<T>(0.0f, 0.0f));
     if (!all_staged) {
         if (emit) {
 #pragma unroll
@@ -1633,6 +1697,7 @@ uint64_t plan_buckets(BucketPlan &plan, const GridMeta &m, uint32_t L, uint32_t 
         uint64_t cap = mean + mean / 8 + (uint64_t)(12.0 * sqrt((double)mean)) + 64;
         if (cap > worst) cap = worst;
         if (cap > 0xffffffffull) cap = 0xffffffffull;
+        cap &= ~1ull;  // even: with even reservations (k_grid_bwd_scatter_plain) every slot PAIR of a workgroup stays inside a pool
         plan.cap[l] = (uint32_t)cap;
         const uint64_t slots = cap * nb;
         // value stream (2 V2 per slot) | row stream (2 B per slot), each padded so that aligned quad reads stay inside

