@@ -371,6 +371,8 @@ def run_nerfmvl(args):
         "host_ms": {"per_plain_step_median": round(float(np.median(host_step)), 4) if host_step else None,
                     "per_update_step_mean": round(float(np.mean(host_update)), 3) if host_update else None,
                     "update_steps": len(host_update),
+                    "update_steps_ms": [round(v, 2) for v in host_update],
+                    "plain_step_max": round(float(np.max(host_step)), 3) if host_step else None,
                     "note": "host_enqueue_ms_per_step is the wall time of the loop / steps: it CONTAINS the waits of the grid "
                             "updates (every 16th step reads the marched-sample counts back and so waits for the queued steps to "
                             "finish) — with a replayed graph the host runs ~15 steps ahead and spends that wait there.  "

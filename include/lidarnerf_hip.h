@@ -448,6 +448,23 @@ LNH_API int lnh_lidar_loss_patch(const float *depth, const float *image, const f
                                  const float *grad_scale, float *loss, float *grad_depth, float *grad_image,
                                  lnh_stream_t stream);
 /*
+ * The LiDAR colour head on the marcher's RAGGED samples (BASELINE config 4; network.py:199-237 evaluated on the samples of
+ * renderer.run_cuda, which the reference dropped while keeping raymarching.cu:331-772), with the dense chain's two moves:
+ * the direction part of the first Linear once per RAY (cdir [N,64] from lnh_lidar_dir_term_freq on rays_d) and the
+ * sample's sigma-net row as the 16-wide input.  rays [N,3] i32 = the marcher's table (ray index, first sample, count);
+ * a ray whose samples do not fit M has none.  w16 = lnh_lidar_pack_weights' wcol16.
+ * lnh_ragged_color_forward: rgb[m] = sigmoid(head(h16[m], cdir[ray])) [M,2] for every owned sample (others untouched).
+ * lnh_ragged_color_backward: grad_h16 rows of the owned samples (col 0 = grad_sigma * density_scale * exp(clamp(h0)), cols
+ *   1..15 through the head; rows nobody owns are NOT written: clear grad_h16 first), grad_w += (layout of wcol16, fp32),
+ *   ray_sum [N,64] = sum over the ray's samples of d(first hidden pre-activation), indexed by ray INDEX (feeds
+ *   lnh_lidar_dir_term_backward; rows of rays without an entry are not written).
+ */
+LNH_API int lnh_ragged_color_forward(const void *h16, const int32_t *rays, const float *cdir, const void *w16, uint32_t N,
+                                     uint32_t M, float *rgb, lnh_stream_t stream);
+LNH_API int lnh_ragged_color_backward(const float *grad_rgb, const float *grad_sigma, float density_scale, const void *h16,
+                                      const int32_t *rays, const float *cdir, const void *w16, uint32_t N, uint32_t M,
+                                      void *grad_h16, float *grad_w, float *ray_sum, lnh_stream_t stream);
+/*
  * Element-wise stages of the occupancy-grid render chain over the marcher's flat sample list [M] (BASELINE config 4; the
  * reference kept torch-ngp's kernels, raymarching.cu:331-772, and dropped this caller — what runs between them are the
  * tensor expressions of network.py:162-237 on [M, *] tensors: one launch each here).
@@ -652,6 +669,12 @@ LNH_API int lnh_lidar_step_prologue_bf16(const float *ws0, uint32_t ld_s0, const
                                          const float *rays_d, const float *aabb, float bound, uint32_t N, uint32_t T,
                                          uint32_t T_tot, float near, float far, float *z, float *x01, float *features16,
                                          float *cdir, lnh_stream_t stream);
+LNH_API int lnh_ragged_color_forward_bf16(const void *h16, const int32_t *rays, const float *cdir, const void *w16, uint32_t N,
+                                          uint32_t M, float *rgb, lnh_stream_t stream);
+LNH_API int lnh_ragged_color_backward_bf16(const float *grad_rgb, const float *grad_sigma, float density_scale,
+                                           const void *h16, const int32_t *rays, const float *cdir, const void *w16,
+                                           uint32_t N, uint32_t M, void *grad_h16, float *grad_w, float *ray_sum,
+                                           lnh_stream_t stream);
 LNH_API int lnh_lidar_color_forward_bf16(const void *h16, const int32_t *perm, const float *weights, const float *cdir,
                                     const void *w16, uint32_t N, uint32_t T, float *rgb, lnh_stream_t stream);
 LNH_API int lnh_lidar_color_composite_forward_bf16(const float *z, const float *sigma_pt, const int32_t *perm,

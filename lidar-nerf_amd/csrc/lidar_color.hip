@@ -36,6 +36,12 @@ struct ColorArgs {
     float *sigma_m;         // out [N,T] densities in merged order
     float *weights_out;     // out [N,T]
     float *wsum, *depth, *image;  // out [N], [N], [N,2]
+    // ragged rays (occupancy-grid sampling, BASELINE config 4): the samples of ray-table entry r are the rows
+    // rays[3r+1] .. + rays[3r+2] of the flat [M, *] buffers, in order (no permutation, no weight mask: every marched
+    // sample lies in an occupied cell), rays[3r] is the ray's index into the per-ray buffers (cdir, S)
+    const int32_t *rays;
+    uint32_t M;
+    float gs_scale;         // bwd: d loss / d sigma is multiplied by it (the density scale of the ragged path; 1 dense)
 };
 
 // v_exp_f32 / v_rcp_f32 (1 ulp each) instead of the IEEE division and the range-reduced expf: the two outputs of a
@@ -289,6 +295,74 @@ k_color_forward_ray(ColorArgs a) {
     }
 }
 
+// The colour head on RAGGED rays (occupancy-grid sampling: renderer.run_cuda's samples, BASELINE config 4), one wave per
+// ray-table entry: the same two algebraic moves as the dense chain — the direction part of the first layer once per RAY
+// (cdir), the sample's sigma-net row as the 16-wide input — where rounds 2-4 assembled a [M, 96] input ([freq(d) | geo |
+// 0]) and ran the generic 96 -> 64 -> 64 -> 16 MFMA MLP on it (three launches and a K = 96 first layer per sample).  No
+// permutation and no weight mask here: every marched sample is evaluated.
+__global__ void __launch_bounds__(256)
+k_color_forward_ragged(ColorArgs a) {
+    constexpr int HT = 4, HS = 2, NT = 4;
+    const uint32_t wid = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+    const uint32_t nw = blockDim.x >> 6, nwaves = gridDim.x * nw;
+    half8_t w0[HT], w1[HT][HS], w2[HS];
+#pragma unroll
+    for (int t = 0; t < HT; t++) {
+        w0[t] = load_a_natural(a.W + kW0g, 16, 16 * t + c, 0, g, 16);
+#pragma unroll
+        for (int s = 0; s < HS; s++) w1[t][s] = load_a_nu(a.W + kW1, 64, 16 * t + c, s, g);
+    }
+#pragma unroll
+    for (int s = 0; s < HS; s++) w2[s] = load_a_nu(a.W + kW2, 64, c, s, g);
+    for (uint32_t r = blockIdx.x * nw + wid; r < a.N; r += nwaves) {
+        const uint32_t rid = (uint32_t)a.rays[3 * r], off = (uint32_t)a.rays[3 * r + 1];
+        uint32_t cnt = (uint32_t)a.rays[3 * r + 2];
+        if (off + cnt > a.M) cnt = 0;  // (a ray the marcher dropped: its samples do not exist)
+        if (cnt == 0) continue;
+        f32x4 cb[HT];
+#pragma unroll
+        for (int t = 0; t < HT; t++) cb[t] = *reinterpret_cast<const f32x4 *>(a.cdir + (size_t)(rid < a.N ? rid : 0) * 64 + 16 * t + 4 * g);
+        for (uint32_t s0 = 0; s0 < cnt; s0 += NT * 16) {
+            half8_t bx[NT];
+            bool valid[NT];
+#pragma unroll
+            for (int n = 0; n < NT; n++) {  // (all rows of the span requested before the first is used)
+                const uint32_t i = s0 + 16 * n + c;
+                valid[n] = i < cnt;
+                const size_t row = (size_t)off + (valid[n] ? i : 0u);
+                const half8_t v = *reinterpret_cast<const half8_t *>(a.h16 + row * 16 + (g < 2 ? 8 * g : 0));
+                bx[n] = (valid[n] && g < 2) ? v : zero_h8();
+            }
+#pragma unroll
+            for (int n = 0; n < NT; n++) {
+                if (s0 + 16 * n >= cnt) break;  // wave-uniform
+                f32x4 acc[HT];
+#pragma unroll
+                for (int t = 0; t < HT; t++) acc[t] = MFMA16(w0[t], bx[n], cb[t]);
+                half8_t bh[HS];
+#pragma unroll
+                for (int s = 0; s < HS; s++) bh[s] = pack_pair_relu(acc[2 * s], acc[2 * s + 1]);
+#pragma unroll
+                for (int t = 0; t < HT; t++) {
+                    acc[t] = zero_f4();
+#pragma unroll
+                    for (int s = 0; s < HS; s++) acc[t] = MFMA16(w1[t][s], bh[s], acc[t]);
+                }
+#pragma unroll
+                for (int s = 0; s < HS; s++) bh[s] = pack_pair_relu(acc[2 * s], acc[2 * s + 1]);
+                f32x4 o = zero_f4();
+#pragma unroll
+                for (int s = 0; s < HS; s++) o = MFMA16(w2[s], bh[s], o);
+                if (valid[n] && g == 0) {
+                    // the unfused path rounds the MLP output to fp16 before the sigmoid (autocast Linear output)
+                    const float r0 = sigmoidf((float)(half_t)o[0]), r1 = sigmoidf((float)(half_t)o[1]);
+                    *reinterpret_cast<float2 *>(a.rgb + ((size_t)off + s0 + 16 * n + c) * 2) = make_float2(r0, r1);
+                }
+            }
+        }
+    }
+}
+
 // Wave-independent colour-head backward: one WAVE per ray at a time, 32 merged samples per iteration, no LDS tiles and
 // no barriers in the sample loop.  Weight gradients contract over samples, so their MFMA operands are the TRANSPOSES of
 // what the layer chain leaves in registers; a transpose of a packed fp16 fragment is one MFMA against an identity
@@ -298,9 +372,11 @@ k_color_forward_ray(ColorArgs a) {
 // Round 5 built the transposes on gfx950's transposing LDS read as well (ds_read_b64_tr_b16: the sigma-net backward in
 // mlp_bwd.h runs on it) — for THIS kernel, one wave per SIMD, both LDS forms lost to the identity MFMAs (283.9 / 291.4
 // against 268.4 us: profiles/r05_color_backward_wgrad.txt) and were removed again.
-template <bool FROM_IMAGE>  // d loss / d rgb read from a.g_rgb, or formed as weights (x) a.g_image
+// RAGGED: the rays are entries of a ray table over flat sample buffers (see ColorArgs::rays) instead of rows of [N, T] arrays.
+template <bool FROM_IMAGE, bool RAGGED = false>  // FROM_IMAGE: d loss / d rgb formed as weights (x) a.g_image, else read from a.g_rgb
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 k_color_backward_wi(ColorArgs a) {
+    static_assert(!(FROM_IMAGE && RAGGED), "the ragged compositing backward hands over d loss / d rgb itself");
     constexpr int HT = 4, HS = 2, NT = 2, NTILE = HT + HT * HT + HT;
     // The 28 weight fragments (112 registers) stay in registers for the whole kernel: the 24 gradient tiles live in
     // AGPRs (mfma16_acc_agpr), which leaves the VGPRs to the fragments and the pipeline state, and hipcc places the
@@ -356,18 +432,39 @@ k_color_backward_wi(ColorArgs a) {
     // branch around the MFMA chain: with a transparent / active diamond inside the loop hipcc copied all 96
     // weight-gradient accumulators to other registers and back at every latch (192 moves per iteration).
     constexpr uint32_t kGroupSpans = 32, kGroupSamples = 32 * kGroupSpans, kGroupLoads = kGroupSamples / 64;
-    const uint32_t nsteps = (a.T + 31) / 32, ngroups = (nsteps + kGroupSpans - 1) / kGroupSpans;
+    const uint32_t nsteps = (a.T + 31) / 32, ngroups_dense = (nsteps + kGroupSpans - 1) / kGroupSpans;
     const uint32_t nrays = wave < a.N ? (a.N - wave + nwaves - 1) / nwaves : 0;
     struct Iter {
         uint32_t rr, grp, act;
         bool fresh, ray_any;
+        uint32_t base, cnt, rid, ng;  // RAGGED: first row, sample count, ray index, span groups of the open ray
     };
-    Iter it = {0u, 0u, 0u, true, false};
+    Iter it = {0u, 0u, 0u, true, false, 0u, 0u, 0u, ngroups_dense};
     struct Item {
         bool live;
         uint32_t ray, s0;
+        uint32_t base, cnt, rid;  // (RAGGED)
+    };
+    // geometry of table entry r (RAGGED; wave-uniform scalar loads).  A ray whose samples do not fit the buffers was
+    // dropped by the marcher: it has no samples here either.
+    auto open_ray = [&](uint32_t r) {
+        if constexpr (RAGGED) {
+            const uint32_t off = (uint32_t)a.rays[3 * r + 1], cnt = (uint32_t)a.rays[3 * r + 2];
+            it.rid = (uint32_t)a.rays[3 * r];
+            it.base = off;
+            it.cnt = off + cnt <= a.M ? cnt : 0u;
+            it.ng = ((it.cnt + 31) / 32 + kGroupSpans - 1) / kGroupSpans;
+            if (it.ng == 0) it.ng = 1;
+        }
     };
     auto enter_group = [&](uint32_t ray, uint32_t grp) -> uint32_t {
+        if constexpr (RAGGED) {  // every span that holds a sample is active; nothing transparent to write
+            uint32_t act = 0;
+#pragma unroll
+            for (uint32_t sp = 0; sp < kGroupSpans; sp++)
+                if ((grp * kGroupSpans + sp) * 32 < it.cnt) act |= 1u << sp;
+            return act;
+        }
         const uint32_t i0 = grp * kGroupSamples;
         bool v[kGroupLoads];
         uint32_t m[kGroupLoads];
@@ -421,17 +518,20 @@ k_color_backward_wi(ColorArgs a) {
         }
         return act;
     };
-    auto zero_ray_sum = [&](uint32_t ray) { a.S[(size_t)ray * 64 + lane] = 0.0f; };
+    auto zero_ray_sum = [&](uint32_t ray) { a.S[(size_t)(RAGGED ? it.rid : ray) * 64 + lane] = 0.0f; };
     auto next_item = [&]() {
-        Item I = {false, 0u, 0u};
+        Item I = {false, 0u, 0u, 0u, 0u, 0u};
         while (it.act == 0u) {
             if (!it.fresh) {
-                if (++it.grp >= ngroups) {
+                if (++it.grp >= (RAGGED ? it.ng : ngroups_dense)) {
                     if (!it.ray_any && it.rr < nrays) zero_ray_sum(wave + it.rr * nwaves);  // a ray without any active span
                     it.ray_any = false;
                     it.grp = 0;
                     if (it.rr < nrays) it.rr++;
+                    if (RAGGED && it.rr < nrays) open_ray(wave + it.rr * nwaves);
                 }
+            } else if (RAGGED && it.rr < nrays) {
+                open_ray(wave + it.rr * nwaves);
             }
             if (it.rr >= nrays) return I;  // exhausted (stays exhausted: rr no longer moves)
             it.fresh = false;
@@ -443,6 +543,11 @@ k_color_backward_wi(ColorArgs a) {
         I.live = true;
         I.ray = wave + it.rr * nwaves;
         I.s0 = (it.grp * kGroupSpans + sp) * 32;
+        if constexpr (RAGGED) {
+            I.base = it.base;
+            I.cnt = it.cnt;
+            I.rid = it.rid;
+        }
         return I;
     };
 
@@ -455,14 +560,26 @@ k_color_backward_wi(ColorArgs a) {
         uint32_t ray, m[NT], slot[NT];
         float wgt[NT], gs[NT];
         float2 gr[NT];
+        uint32_t base, rid;  // (RAGGED)
     };
     auto load_a = [&](const Item &I) {
         StageA A;
         A.live = I.live;
         A.ray = I.ray;
+        A.base = I.base;
+        A.rid = I.rid;
 #pragma unroll
         for (int n = 0; n < NT; n++) {
             const uint32_t i = I.s0 + 16 * n + c;
+            if constexpr (RAGGED) {
+                A.valid[n] = I.live && i < I.cnt;
+                A.m[n] = A.valid[n] ? I.base + i : 0;
+                A.wgt[n] = 1.0f;  // every marched sample is evaluated (msk = valid)
+                A.slot[n] = i;
+                A.gs[n] = a.g_sigma[A.m[n]];
+                A.gr[n] = *reinterpret_cast<const float2 *>(a.g_rgb + (size_t)A.m[n] * 2);
+                continue;
+            }
             A.valid[n] = I.live && i < a.T;
             A.m[n] = A.valid[n] ? I.ray * a.T + i : 0;
             A.wgt[n] = a.weights[A.m[n]];
@@ -477,7 +594,10 @@ k_color_backward_wi(ColorArgs a) {
         }
         return A;
     };
-    auto src_of = [&](const StageA &A, int n) { return A.valid[n] ? (size_t)A.ray * a.T + A.slot[n] : (size_t)0; };
+    auto src_of = [&](const StageA &A, int n) {
+        if constexpr (RAGGED) return A.valid[n] ? (size_t)A.base + A.slot[n] : (size_t)0;
+        else return A.valid[n] ? (size_t)A.ray * a.T + A.slot[n] : (size_t)0;
+    };
     struct StageB { half8_t x[NT]; };
     auto load_b = [&](const StageA &A) {
         StageB B;
@@ -486,7 +606,7 @@ k_color_backward_wi(ColorArgs a) {
             B.x[n] = *reinterpret_cast<const half8_t *>(a.h16 + src_of(A, n) * 16 + (g < 2 ? 8 * g : 0));
         return B;
     };
-    auto load_cb = [&](uint32_t ray, f32x4 (&cb)[HT]) {
+    auto load_cb = [&](uint32_t ray, f32x4 (&cb)[HT]) {  // (RAGGED: `ray` is the ray INDEX rays[3r] of the table entry)
         const uint32_t r = ray < a.N ? ray : 0;
 #pragma unroll
         for (int t = 0; t < HT; t++) cb[t] = *reinterpret_cast<const f32x4 *>(a.cdir + (size_t)r * 64 + 16 * t + 4 * g);
@@ -504,7 +624,7 @@ k_color_backward_wi(ColorArgs a) {
     StageA A0 = load_a(next_item()), A1 = load_a(next_item());
     StageB B0 = load_b(A0);
     f32x4 cb[HT], cb_next[HT];
-    load_cb(A0.ray, cb_next);
+    load_cb(RAGGED ? A0.rid : A0.ray, cb_next);
     float ssum[HT] = {0.0f, 0.0f, 0.0f, 0.0f};
     bool first_of_ray = true;
 
@@ -520,7 +640,7 @@ k_color_backward_wi(ColorArgs a) {
             }
         }
         const bool last_of_ray = !A1.live || A1.ray != ray;
-        if (last_of_ray) load_cb(A1.ray, cb_next);   // the next item opens another ray: its direction term, one item ahead
+        if (last_of_ray) load_cb(RAGGED ? A1.rid : A1.ray, cb_next);   // the next item opens another ray: its direction term, one item ahead
         bool msk[NT];
         half8_t bx[NT];
 #pragma unroll
@@ -599,7 +719,7 @@ k_color_backward_wi(ColorArgs a) {
 #pragma unroll
                 for (int s = 0; s < HS; s++) dx = MFMA16(WF(F_W0T + s), bd0[n][s], dx);
                 if (A0.valid[n]) {
-                    if (g == 0) dx[0] = A0.gs[n] * exp_clamped((float)bx[n][0]);
+                    if (g == 0) dx[0] = (RAGGED ? A0.gs[n] * a.gs_scale : A0.gs[n]) * exp_clamped((float)bx[n][0]);
                     half4_t v = {(half_t)dx[0], (half_t)dx[1], (half_t)dx[2], (half_t)dx[3]};
                     *reinterpret_cast<half4_t *>(a.g_h16 + src_of(A0, n) * 16 + 4 * g) = v;
                 }
@@ -626,7 +746,7 @@ k_color_backward_wi(ColorArgs a) {
                 for (int i = 0; i < HT; i++) mfma16_acc_agpr(gW1[t][i], fd1[t], fh0[i]);  // dW1[16t + 4g + r][16i + c]
             }
         }
-        if (last_of_ray) store_ray_sum(ray, ssum);
+        if (last_of_ray) store_ray_sum(RAGGED ? A0.rid : ray, ssum);
         first_of_ray = last_of_ray;
         A0 = A1;
         A1 = A2;
@@ -750,6 +870,33 @@ int LNH_MLP_FN(lnh_lidar_color_backward_image)(const float *grad_image, const fl
     LNH_REQUIRE(grad_image, LNH_ERR_INVALID_ARG, "lidar_color_backward_image: null pointer");
     return color_backward_launch(nullptr, grad_image, grad_sigma, h16, perm, weights, cdir, w16, N, T, grad_h16, grad_w,
                                  ray_sum, stream);
+}
+
+
+int LNH_MLP_FN(lnh_ragged_color_forward)(const void *h16, const int32_t *rays, const float *cdir, const void *w16, uint32_t N,
+                                        uint32_t M, float *rgb, lnh_stream_t stream) {
+    LNH_REQUIRE(h16 && rays && cdir && w16 && rgb, LNH_ERR_INVALID_ARG, "ragged_color_forward: null pointer");
+    if (N == 0 || M == 0) return LNH_OK;
+    ColorArgs a{};
+    a.h16 = (const half_t *)h16; a.rays = rays; a.cdir = cdir; a.W = (const half_t *)w16; a.rgb = rgb; a.N = N; a.M = M;
+    const uint32_t wgs = (N + 3) / 4;
+    LNH_LAUNCH(k_color_forward_ragged, dim3(wgs < 4096 ? wgs : 4096), dim3(256), 0, (hipStream_t)stream, a);
+    return lnh_check_launch("lnh_ragged_color_forward");
+}
+
+int LNH_MLP_FN(lnh_ragged_color_backward)(const float *grad_rgb, const float *grad_sigma, float density_scale, const void *h16,
+                                         const int32_t *rays, const float *cdir, const void *w16, uint32_t N, uint32_t M,
+                                         void *grad_h16, float *grad_w, float *ray_sum, lnh_stream_t stream) {
+    LNH_REQUIRE(grad_rgb && grad_sigma && h16 && rays && cdir && w16 && grad_h16 && grad_w && ray_sum, LNH_ERR_INVALID_ARG,
+                "ragged_color_backward: null pointer");
+    if (N == 0 || M == 0) return LNH_OK;
+    ColorArgs a{};
+    a.h16 = (const half_t *)h16; a.rays = rays; a.cdir = cdir; a.W = (const half_t *)w16; a.g_rgb = grad_rgb;
+    a.g_sigma = grad_sigma; a.g_h16 = (half_t *)grad_h16; a.dW = grad_w; a.S = ray_sum; a.N = N; a.M = M; a.T = 0;
+    a.gs_scale = density_scale;
+    const uint32_t nwg = (N + 3) / 4;
+    LNH_LAUNCH((k_color_backward_wi<false, true>), dim3(nwg < 256 ? nwg : 256), dim3(256), 0, (hipStream_t)stream, a);
+    return lnh_check_launch("lnh_ragged_color_backward");
 }
 
 }  // extern "C"

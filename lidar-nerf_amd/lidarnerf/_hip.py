@@ -83,6 +83,8 @@ _SIGS = {
     "lnh_zero_regions": [P, P, U32],
     "lnh_lidar_color_backward": [P, P, P, P, P, P, P, U32, U32, P, P, P],
     "lnh_lidar_color_backward_image": [P, P, P, P, P, P, P, U32, U32, P, P, P],
+    "lnh_ragged_color_forward": [P, P, P, P, U32, U32, P],
+    "lnh_ragged_color_backward": [P, P, F32, P, P, P, P, U32, U32, P, P, P],
     "lnh_ragged_points": [P, F32, U32, P],
     "lnh_ragged_pack_weights": [P, U32, P, U32, P, U32, U32, P, U32, P, U32, P, P],
     "lnh_ragged_color_input": [P, P, U32, U32, P],
@@ -95,7 +97,7 @@ for _n in ("lnh_mlp_forward", "lnh_mlp_backward", "lnh_mlp_backward_data", "lnh_
            "lnh_lidar_dir_term", "lnh_lidar_pack_weights", "lnh_lidar_step_prologue", "lnh_lidar_color_forward", "lnh_lidar_color_backward",
            "lnh_lidar_color_composite_forward", "lnh_lidar_color_backward_image", "lnh_lidar_dir_term_freq",
            "lnh_ragged_pack_weights", "lnh_ragged_color_input", "lnh_ragged_color_input_rays", "lnh_ragged_color_output",
-           "lnh_ragged_color_output_backward", "lnh_ragged_grad_rows"):
+           "lnh_ragged_color_output_backward", "lnh_ragged_grad_rows", "lnh_ragged_color_forward", "lnh_ragged_color_backward"):
     _SIGS[_n + "_bf16"] = _SIGS[_n]  # bf16-operand build of the MLP kernels (include/lidarnerf_hip.h, last section)
 EXPORTS = sorted(list(_SIGS) + ["lnh_version", "lnh_last_error", "lnh_arch", "lnh_build_variant",
                                  "lnh_grid_backward_workspace_size", "lnh_grid_backward_workspace_size_min",

@@ -553,11 +553,17 @@ class FusedLidarRagged(Function):
         kd, deg = spec.n_dir, int(spec.dir_freq_degree)  # 75, 12
         mats = [m.detach() if m.dtype == torch.float32 and m.stride(-1) == 1 else m.detach().float().contiguous()
                 for m in (ws0, ws1, wc0, wc1, wc2)]
+        # the dense chain's packing: wcol16 = [(0 | wc0[:, kd:kd+15]) | wc1 | wc2 padded to 16 rows] — the direction columns of
+        # the first matrix act once per RAY (cdir), a sample's colour input is its own 16-wide sigma-net row
         wsig16 = torch.empty(64 * 32 + 16 * 64, dtype=mdt, device=dev)
-        wcol16 = torch.empty(64 * 96 + 64 * 64 + 16 * 64, dtype=mdt, device=dev)
-        _hip.call("lnh_ragged_pack_weights" + sfx, mats[0].data_ptr(), mats[0].stride(0), mats[1].data_ptr(),
-                  mats[1].stride(0), mats[2].data_ptr(), mats[2].stride(0), kd + 15, mats[3].data_ptr(), mats[3].stride(0),
+        wcol16 = torch.empty(64 * 16 + 64 * 64 + 16 * 64, dtype=mdt, device=dev)
+        _hip.call("lnh_lidar_pack_weights" + sfx, mats[0].data_ptr(), mats[0].stride(0), mats[1].data_ptr(),
+                  mats[1].stride(0), mats[2].data_ptr(), mats[2].stride(0), kd, mats[3].data_ptr(), mats[3].stride(0),
                   mats[4].data_ptr(), mats[4].stride(0), wsig16.data_ptr(), wcol16.data_ptr())
+        enc_d16 = torch.empty((N, kd), dtype=torch.float32, device=dev)
+        cdir = torch.empty((N, 64), dtype=torch.float32, device=dev)
+        _hip.call("lnh_lidar_dir_term_freq" + sfx, rays_d.data_ptr(), deg, mats[2].data_ptr(), mats[2].stride(0), N,
+                  enc_d16.data_ptr(), cdir.data_ptr())
         x01 = torch.empty((M, 3), dtype=torch.float32, device=dev)
         _hip.call("lnh_ragged_points", xyzs.data_ptr(), bound, M, x01.data_ptr())
         feat = torch.empty((L, M, 2), dtype=torch.half, device=dev)
@@ -567,15 +573,11 @@ class FusedLidarRagged(Function):
         sigma = torch.empty(M, dtype=torch.float32, device=dev)
         _hip.call("lnh_density_mlp_forward" + sfx, feat.data_ptr(), wsig16.data_ptr(), M, M, M, 0, 0, h16.data_ptr(),
                   sigma.data_ptr())
-        # colour head: [freq(d) | geo_feat | 0] -> MFMA MLP 96 -> 64 -> 64 -> 16 -> sigmoid of the first two outputs
-        cin = torch.empty((M, 96), dtype=mdt, device=dev)
-        # (ray by ray: the direction terms once per ray; rows no ray owns are zeroed — they enter the weight-gradient GEMM)
-        _hip.call("lnh_ragged_color_input_rays" + sfx, dirs.data_ptr(), h16.data_ptr(), rays.data_ptr(), deltas.data_ptr(),
-                  N, M, deg, cin.data_ptr())
-        y = torch.empty((M, 16), dtype=mdt, device=dev)
-        _hip.call("lnh_mlp_forward" + sfx, cin.data_ptr(), wcol16.data_ptr(), M, 96, 16, 64, 1, 0, 6, None, y.data_ptr())
-        rgb = torch.empty((M, 2), dtype=torch.float32, device=dev)
-        _hip.call("lnh_ragged_color_output" + sfx, y.data_ptr(), M, rgb.data_ptr())
+        # colour head, one wave per ray of the marcher's table (round 5; before: a [M, 96] input assembled per sample, the
+        # generic 96 -> 64 -> 64 -> 16 MLP kernel and a sigmoid pass)
+        rgb = torch.zeros((M, 2), dtype=torch.float32, device=dev)  # (rows no ray owns stay 0)
+        _hip.call("lnh_ragged_color_forward" + sfx, h16.data_ptr(), rays.data_ptr(), cdir.data_ptr(), wcol16.data_ptr(), N, M,
+                  rgb.data_ptr())
         sig_s = sigma * ds if ds != 1.0 else sigma
         ws = torch.empty(N, dtype=torch.float32, device=dev)
         depth = torch.empty(N, dtype=torch.float32, device=dev)
@@ -583,10 +585,13 @@ class FusedLidarRagged(Function):
         _hip.call("lnh_lidar_composite_rays_train_forward", sig_s.data_ptr(), rgb.data_ptr(), deltas.data_ptr(),
                   xyzs.data_ptr(), rays_o.data_ptr(), rays_d.data_ptr(), rays.data_ptr(), M, N, 2, float(T_thresh),
                   ws.data_ptr(), depth.data_ptr(), image.data_ptr())
-        ctx.save_for_backward(x01, feat, h16, sig_s, cin, rgb, deltas, xyzs, rays_o, rays_d, rays, ws, depth, image, wsig16,
-                              wcol16)
+        ctx.save_for_backward(x01, feat, h16, sig_s, cdir, enc_d16, rgb, deltas, xyzs, rays_o, rays_d, rays, ws, depth, image,
+                              wsig16, wcol16)
         ctx.meta = (model, enc, spec.table_param, mdt, float(T_thresh), kd, ds,
                     (embeddings.dtype, ws0.dtype, ws1.dtype, wc0.dtype, wc1.dtype, wc2.dtype))
+        small = (ws0, ws1, wc0, wc1, wc2)
+        ctx.small_params = small if all(isinstance(w, torch.nn.Parameter) and w.dtype == torch.float32 and
+                                        w.is_contiguous() for w in small) else None
         ctx.set_materialize_grads(False)
         return ws, depth, image
 
@@ -614,36 +619,41 @@ class FusedLidarRagged(Function):
                 g_table = g_table16.to(dts[0])
             zw = [torch.zeros(sh, dtype=dt, device=dev) for sh, dt in zip(ctx.shapes, dts[1:])]
             return (None, None, None, None, None, None, g_table, zw[0], zw[1], zw[2], zw[3], zw[4], None, None, None, None)
-        (x01, feat, h16, sig_s, cin, rgb, deltas, xyzs, rays_o, rays_d, rays, ws, depth, image, wsig16,
+        (x01, feat, h16, sig_s, cdir, enc_d16, rgb, deltas, xyzs, rays_o, rays_d, rays, ws, depth, image, wsig16,
          wcol16) = ctx.saved_tensors
         sfx = _hip.mlp_suffix(mdt)
         dev = x01.device
         M, N, L = x01.shape[0], rays.shape[0], enc.num_levels
         zN = lambda g, shape: torch.zeros(shape, dtype=torch.float32, device=dev) if g is None else g.contiguous().float()
         g_ws, g_depth, g_image = zN(g_ws, (N,)), zN(g_depth, (N,)), zN(g_image, (N, 2))
-        # every buffer that is accumulated into — both compositing gradients, the small matrices' gradients, the fp16 table
-        # gradient — cleared by ONE launch
+        # every buffer that is accumulated into or only partly written — both compositing gradients, the sigma-net rows'
+        # gradient (rows no ray owns), the per-ray sums, the small matrices' gradients, the fp16 table gradient, the cursors
+        # of the table backward — cleared by ONE launch
         gsf = torch.empty(M * 3, dtype=torch.float32, device=dev)
-        n_col, n_sig = wcol16.numel(), wsig16.numel()
-        zeros = torch.empty(n_col + n_sig, dtype=torch.float32, device=dev)
+        n_col, n_sig, n_c0 = wcol16.numel(), wsig16.numel(), 64 * (kd + 15)
+        zeros = torch.empty(n_col + n_sig + n_c0, dtype=torch.float32, device=dev)
         g_table16 = torch.empty((int(enc._offsets_host[-1]), 2), dtype=torch.half, device=dev)
+        g_h16 = torch.empty((M, 16), dtype=mdt, device=dev)
+        ray_sum = torch.empty((N, 64), dtype=torch.float32, device=dev)
         bwd_ws, bwd_clear = _grid_bwd_workspace(dev, enc, M)
         bwd_flags = _hip.LNH_BWD_TABLE_ZERO | (_hip.LNH_BWD_WS_CLEARED if bwd_clear else 0)
-        _hip.zero_regions((gsf, zeros, g_table16, bwd_ws[:bwd_clear] if bwd_clear else None))
+        _hip.zero_regions((gsf, zeros, g_table16, g_h16, ray_sum, bwd_ws[:bwd_clear] if bwd_clear else None))
         gs, gf = gsf[:M], gsf[M:].view(M, 2)
         _hip.call("lnh_lidar_composite_rays_train_backward", g_ws.data_ptr(), g_depth.data_ptr(), g_image.data_ptr(),
                   sig_s.data_ptr(), rgb.data_ptr(), deltas.data_ptr(), xyzs.data_ptr(), rays_o.data_ptr(),
                   rays_d.data_ptr(), rays.data_ptr(), ws.data_ptr(), depth.data_ptr(), image.data_ptr(), M, N, 2,
                   T_thresh, gs.data_ptr(), gf.data_ptr())
-        gy = torch.empty((M, 16), dtype=mdt, device=dev)
-        _hip.call("lnh_ragged_color_output_backward" + sfx, gf.data_ptr(), rgb.data_ptr(), M, gy.data_ptr())
-        gx = torch.empty((M, 96), dtype=mdt, device=dev)
-        g_wcol, g_wsig = zeros[:n_col], zeros[n_col:]
-        _hip.call("lnh_mlp_backward" + sfx, gy.data_ptr(), cin.data_ptr(), wcol16.data_ptr(), M, 96, 16, 64, 1, 0, 6,
-                  gx.data_ptr(), g_wcol.data_ptr())
-        g_h16 = torch.empty((M, 16), dtype=mdt, device=dev)
-        _hip.call("lnh_ragged_grad_rows" + sfx, gs.data_ptr(), ds, h16.data_ptr(), gx.data_ptr(), (kd - 3) // 6, M,
-                  g_h16.data_ptr())
+        g_wcol, g_wsig = zeros[:n_col], zeros[n_col:n_col + n_sig]
+        # colour head backward ray by ray: sigmoid, the three layers, all weight gradients, the sigma-net rows' gradient
+        # (col 0 = the density gradient through trunc_exp) and the per-ray sum for the direction columns — one launch
+        _hip.call("lnh_ragged_color_backward" + sfx, gf.data_ptr(), gs.data_ptr(), ds, h16.data_ptr(), rays.data_ptr(),
+                  cdir.data_ptr(), wcol16.data_ptr(), N, M, g_h16.data_ptr(), g_wcol.data_ptr(), ray_sum.data_ptr())
+        g_w0g = g_wcol[:64 * 16].view(64, 16)
+        g_wc0 = zeros[n_col + n_sig:].view(64, kd + 15)
+        _hip.call("lnh_lidar_dir_term_backward", ray_sum.data_ptr(), enc_d16.data_ptr(), N, kd, g_w0g.data_ptr(),
+                  g_wc0.data_ptr(), kd + 15)
+        g_wc1 = g_wcol[64 * 16:64 * 16 + 64 * 64].view(64, 64)
+        g_wc2 = g_wcol[64 * 16 + 64 * 64:].view(16, 64)[:2]
         g_feat = torch.empty((L, M, 2), dtype=torch.half, device=dev)
         _hip.call("lnh_density_mlp_backward" + sfx, g_h16.data_ptr(), feat.data_ptr(), wsig16.data_ptr(), M, M, M, 0,
                   g_feat.data_ptr(), g_wsig.data_ptr())
@@ -660,12 +670,15 @@ class FusedLidarRagged(Function):
             g_table = g_table16.to(dts[0])
             if world > 1:
                 g_table.div_(world)
-        g_wc0 = g_wcol[:64 * 96].view(64, 96)[:, :kd + 15]
-        g_wc1 = g_wcol[64 * 96:64 * 96 + 64 * 64].view(64, 64)
-        g_wc2 = g_wcol[64 * 96 + 64 * 64:].view(16, 64)[:2]
-        return (None, None, None, None, None, None, g_table, g_wsig[:64 * 32].view(64, 32).to(dts[1]),
-                g_wsig[64 * 32:].view(16, 64).to(dts[2]), g_wc0.to(dts[3]), g_wc1.to(dts[4]), g_wc2.to(dts[5]),
-                None, None, None, None)
+        g_small = (g_wsig[:64 * 32].view(64, 32), g_wsig[64 * 32:].view(16, 64), g_wc0, g_wc1, g_wc2)
+        if ctx.small_params is not None and getattr(table_param, "_lnh_direct_small_grads", False):
+            for p_, g_ in zip(ctx.small_params, g_small):  # (see FusedLidarRender.backward)
+                p_.grad = g_
+            table_param._lnh_small_arena = zeros
+            g_small = (None,) * 5
+        else:
+            g_small = tuple(g_.to(dt_) for g_, dt_ in zip(g_small, dts[1:]))
+        return (None, None, None, None, None, None, g_table) + g_small + (None, None, None, None)
 
 
 def ragged_supported(model):
