@@ -77,17 +77,27 @@ __device__ __forceinline__ half8_t pack_pair_act_bwd(const f32x4 &lo, const f32x
 }
 
 // ---------------------------------------------------------------------------------------------------- forward
-template <int HT, int NT, int ACT>
-__global__ void __launch_bounds__(256)
+// LDSW (round 5, hidden 256): a hidden -> hidden matrix is 128 KB — the whole LDS budget of one workgroup per CU — and 128
+// fragments per 16-point tile.  Loaded where they are used (L1 / L2), those fragment loads bounded the kernel (1086 us at
+// 1 M points against 879 us for the library GEMM chain, profiles/r04_ffmlp_wide.txt); here the 8 waves of a 512-thread
+// workgroup stage the matrix of the layer in LDS in FRAGMENT order ([tile t][k-step s][lane]: one conflict-free
+// ds_read_b128 per fragment) once per layer and workgroup iteration (256 points), between two barriers.  The iteration
+// count is the same for every wave of the grid (points beyond the batch are masked), so the barriers are uniform.
+template <int HT, int NT, int ACT, bool LDSW = false>
+__global__ void __launch_bounds__(LDSW ? 512 : 256)
 k_mlp_forward_wide(WideFwdArgs a) {
     constexpr int HS = HT >= 2 ? HT / 2 : 1;
     constexpr uint32_t H = HT * 16;
-    const uint32_t lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
-    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+    extern __shared__ __attribute__((aligned(16))) char smem_wide[];
+    half8_t *wfrag = reinterpret_cast<half8_t *>(smem_wide);  // LDSW: [HT * HS][64]
+    const uint32_t lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const uint32_t wave = blockIdx.x * nw + wid;
+    const uint32_t nwaves = gridDim.x * nw;
     const uint32_t in_ks = (a.in_dim + 31) / 32;
     const half_t *W0 = a.W, *Wh = W0 + (size_t)H * a.in_dim, *Wo = Wh + (size_t)a.nhm * H * H;
-    for (uint64_t base = (uint64_t)wave * NT * 16; base < a.B; base += (uint64_t)nwaves * NT * 16) {
+    const uint64_t stride = (uint64_t)nwaves * NT * 16;
+    const uint64_t base_end = LDSW ? (a.B + stride - 1) / stride * stride : a.B;  // LDSW: every wave walks the same number of tiles
+    for (uint64_t base = (uint64_t)wave * NT * 16; base < base_end; base += stride) {
         half8_t bx[NT][kMaxInKs];
 #pragma unroll
         for (int n = 0; n < NT; n++) {
@@ -135,13 +145,19 @@ k_mlp_forward_wide(WideFwdArgs a) {
         // ---- hidden -> hidden
         for (uint32_t m = 0; m < a.nhm; m++) {
             const half_t *Wm = Wh + (size_t)m * H * H;
+            if constexpr (LDSW) {
+                __syncthreads();  // (every wave is done with the fragments of the previous layer / iteration)
+                for (uint32_t f = wid; f < (uint32_t)(HT * HS); f += nw)
+                    wfrag[f * 64 + lane] = load_a_nu(Wm, H, 16 * (f / HS) + c, f % HS, g);
+                __syncthreads();
+            }
 #pragma unroll
             for (int t = 0; t < HT; t++) {
 #pragma unroll
                 for (int n = 0; n < NT; n++) acc[t][n] = zero_f4();
 #pragma unroll
                 for (int s = 0; s < HS; s++) {
-                    const half8_t w = load_a_nu(Wm, H, 16 * t + c, s, g);
+                    const half8_t w = LDSW ? wfrag[(t * HS + s) * 64 + lane] : load_a_nu(Wm, H, 16 * t + c, s, g);
 #pragma unroll
                     for (int n = 0; n < NT; n++) acc[t][n] = MFMA16(w, bh[n][s], acc[t][n]);
                 }
@@ -260,6 +276,17 @@ k_mlp_backward_data_wide(WideBwdArgs a) {
 
 template <int HT, int NT>
 int launch_wide_fwd(const WideFwdArgs &a, hipStream_t s) {
+    if constexpr (HT == 16) {  // hidden 256: hidden matrices staged in LDS (128 KiB), one 512-thread workgroup per CU
+        if (a.nhm > 0) {
+            const size_t lds = (size_t)HT * (HT / 2) * 64 * sizeof(half8_t);
+            const uint32_t tiles = div_up(a.B, NT * 16 * 8), cus = (uint32_t)lnh_cu_count();
+            const uint32_t grid = tiles < cus ? tiles : cus;
+            auto k = a.act == LNH_ACT_RELU ? k_mlp_forward_wide<HT, NT, (int)LNH_ACT_RELU, true> : k_mlp_forward_wide<HT, NT, -1, true>;
+            (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            LNH_LAUNCH(k, dim3(grid), dim3(512), lds, s, a);
+            return lnh_check_launch("lnh_mlp_forward (wide, LDS-staged)");
+        }
+    }
     const uint32_t tiles = div_up(a.B, NT * 16 * 4), grid = tiles < 4096 ? tiles : 4096;
     if (a.act == LNH_ACT_RELU)
         LNH_LAUNCH((k_mlp_forward_wide<HT, NT, (int)LNH_ACT_RELU>), dim3(grid), dim3(256), 0, s, a);
