@@ -524,9 +524,10 @@ class FusedLidarRagged(Function):
     of the bucketed scatter-reduce in fp16 and feeds the fused table optimizer (LidarTrainer) like the dense chain's.
 
     Differences to the dense chain that are properties of the path, not of this implementation: every marched sample lies in
-    an occupied cell, so the colour head runs on ALL of them (no weight mask) through the generic MFMA MLP kernel on an
-    assembled [M, 96] input — [freq(d) (75) | geo_feat (15) | 0 (6)] — rather than the per-ray direction-term kernels
-    (which need the dense [N, T] layout)."""
+    an occupied cell, so the colour head runs on ALL of them (no weight mask); a ray owns `rays[i, 2]` consecutive samples
+    from `rays[i, 1]` on instead of a row of T, so the colour kernels walk the marcher's ray table (one wave per ray group,
+    lnh_ragged_color_forward / _backward: the direction term once per ray, K = 16 per sample — round 5; rounds 3-4 assembled
+    a [M, 96] input per sample for the generic MLP kernel)."""
 
     @staticmethod
     @_no_autocast
