@@ -286,38 +286,52 @@ def run_nerfmvl(args):
     n_pre = 320  # let the occupancy grid settle before anything is timed: 20 grid updates — the first 16 are full 128^3 sweeps
                  # (renderer.py update_extra_state: ~100 ms each), the steady state updates a quarter of the cells
     n_prof = min(args.steps, 5)
-    batches = [batch(s) for s in range(n_pre + args.warmup + args.steps + n_prof)]
+    n_regions = 3  # three timed regions of K steps each, `value` = the median one (see the note in the line printed below)
+    batches = [batch(s) for s in range(n_pre + args.warmup + n_regions * args.steps + n_prof)]
     for s in range(n_pre + args.warmup):
         trainer.step(*batches[s])
     torch.cuda.synchronize()
     use_graph = use_graph and trainer.graph  # (False if a capture did not go through: launch by launch from there on)
     grid_calls = ["lnh_grid_encode_forward", "lnh_grid_encode_backward_ws", "lnh_grid_encode_backward"]
-    if not use_graph:  # (a replayed graph makes no library calls to put events around: the eager pass below times them)
-        _hip.enable_timers(grid_calls)
-    t0 = time.perf_counter()
-    counts = []
-    covered = 0  # marches the ring reads below cover (the first block may reach a few steps back into the warm-up)
-    host_step, host_update = [], []  # host time per step: plain steps / steps that begin with a grid update (which reads the
-    for s in range(args.steps):      # sample counts back, i.e. WAITS for the device to drain its queue)
-        upd = trainer.global_step % trainer.update_extra_interval == 0
-        if upd and model.local_step:
-            # the ring of the last 16 marches, before the grid update resets it: ONE tiny kernel per 16 steps
-            counts.append(model.step_counter[:model.local_step, 0].sum())
-            covered += model.local_step
-        t1 = time.perf_counter()
-        loss = trainer.step(*batches[n_pre + args.warmup + s])
-        (host_update if upd else host_step).append((time.perf_counter() - t1) * 1e3)
-    counts.append(model.step_counter[:model.local_step, 0].sum())
-    covered += model.local_step
-    host_ms = (time.perf_counter() - t0) * 1e3 / args.steps
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    timers = _hip.disable_timers() if not use_graph else {}
-    graphs_captured = len(trainer._graphs)
-    n_rays = sum(b[0].shape[1] for b in batches[n_pre + args.warmup:n_pre + args.warmup + args.steps])
-    samples = float(torch.stack(counts).float().sum()) / (covered * (n_rays / args.steps))  # marched samples per ray
+
+    def region(r):
+        """K steps bracketed by synchronisation; host time per step split into plain steps / steps that begin with a grid
+        update (which reads the sample counts back, i.e. WAITS for the device to drain its queue)."""
+        first = n_pre + args.warmup + r * args.steps
+        if not use_graph:  # (a replayed graph makes no library calls to put events around: the eager pass below times them)
+            _hip.enable_timers(grid_calls)
+        graphs0 = len(trainer._graphs)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        counts, covered, host_step, host_update = [], 0, [], []
+        # (covered: the marches the ring reads below cover — the first block may reach a few steps back before the region)
+        for s in range(args.steps):
+            upd = trainer.global_step % trainer.update_extra_interval == 0
+            if upd and model.local_step:
+                # the ring of the last 16 marches, before the grid update resets it: ONE tiny kernel per 16 steps
+                counts.append(model.step_counter[:model.local_step, 0].sum())
+                covered += model.local_step
+            t1 = time.perf_counter()
+            loss = trainer.step(*batches[first + s])
+            (host_update if upd else host_step).append((time.perf_counter() - t1) * 1e3)
+        counts.append(model.step_counter[:model.local_step, 0].sum())
+        covered += model.local_step
+        host_ms = (time.perf_counter() - t0) * 1e3 / args.steps
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        n_rays = sum(b[0].shape[1] for b in batches[first:first + args.steps])
+        samples = float(torch.stack(counts).float().sum()) / (covered * (n_rays / args.steps))  # marched samples per ray
+        return {"elapsed": elapsed, "host_ms": host_ms, "host_step": host_step, "host_update": host_update, "loss": loss,
+                "n_rays": n_rays, "samples": samples, "captures": len(trainer._graphs) - graphs0,
+                "timers": _hip.disable_timers() if not use_graph else {}}
+
+    regions = [region(r) for r in range(n_regions)]
+    mid = sorted(regions, key=lambda g: g["elapsed"])[n_regions // 2]
+    elapsed, host_ms, host_step, host_update, loss = (mid[k] for k in ("elapsed", "host_ms", "host_step", "host_update", "loss"))
+    n_rays, samples, timers = mid["n_rays"], mid["samples"], mid["timers"]
     samples_total = samples * n_rays
     occ = float((model.density_grid > min(model.mean_density, model.density_thresh)).float().mean())
+    graphs_captured = len(trainer._graphs)
 
     def event_table(tm):
         out = {}
@@ -331,7 +345,7 @@ def run_nerfmvl(args):
     _hip.enable_timers(None)
     trainer.graph = False  # launch by launch (same kernels, same device-side learning rate)
     for s in range(n_prof):
-        trainer.step(*batches[n_pre + args.warmup + args.steps + s])
+        trainer.step(*batches[n_pre + args.warmup + n_regions * args.steps + s])
     torch.cuda.synchronize()
     trainer.graph = use_graph
     eager_tab = event_table(_hip.disable_timers())
@@ -367,6 +381,14 @@ def run_nerfmvl(args):
                    "launch": (f"hipGraph replay of the whole step (march .. optimizers; {graphs_captured} graph(s) captured, "
                               "one per sample capacity; steps at a new capacity run launch by launch once, then capture)")
                    if use_graph else "launch by launch from Python"},
+        "ms_per_step_repeats": [round(1e3 * g["elapsed"] / args.steps, 3) for g in regions],
+        "ms_per_step_first_region": round(1e3 * regions[0]["elapsed"] / args.steps, 3),
+        "captures_in_region": [g["captures"] for g in regions],
+        "repeats_note": "three timed regions of K steps each, one after the other; `value`, `ms_per_step`, the sample and host "
+                        "figures are those of the MEDIAN region.  The occupancy grid keeps changing while it trains, and a "
+                        "step whose sample capacity reaches a rung of the ladder it has not seen is captured anew (a few "
+                        "milliseconds, once per rung for the whole run — captures_in_region says which regions held one): a "
+                        "region of 128 steps that holds a capture is not the steady state the metric names.",
         "samples_per_s": round(samples_total / elapsed, 1), "host_enqueue_ms_per_step": round(host_ms, 3),
         "host_ms": {"per_plain_step_median": round(float(np.median(host_step)), 4) if host_step else None,
                     "per_update_step_mean": round(float(np.mean(host_update)), 3) if host_update else None,
@@ -778,7 +800,7 @@ def main():
                    "table": "fresh init, random per-ray ground truth" if args.table == "init" else
                             f"trained-like: {args.pretrain_steps} untimed steps on the analytic scene (sphere + ground plane)",
                    "patch": args.patch, "dp_windows_forced": bool(args.dp_windows),
-                   "optimizer": "Adam + dynamic loss scaling, in the timed region (hash table: fused lnh_adam_table_step; MLPs: torch fused Adam)", "final_loss": round(loss_val, 5)},
+                   "optimizer": "Adam + dynamic loss scaling + lr schedule, in the timed region (lnh_train_check + lnh_train_step: the hash table and the MLP tensors in two launches)", "final_loss": round(loss_val, 5)},
         "ms_per_step_repeats": spread,  # three timed regions of K steps each; `value` / `ms_per_step` = their median when K < 100
         "ms_per_step_first_region": round(1e3 * elapsed_first / args.steps, 3),
         "roofline": hbm_roofline(dom),

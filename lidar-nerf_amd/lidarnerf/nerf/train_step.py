@@ -203,6 +203,7 @@ class LidarTrainer:
                                (f" and, data parallel, the 'nccl' (RCCL) backend — this process group runs "
                                 f"'{parallel.backend()}', whose collectives cannot be captured" if self.dp else ""))
         self._graphs, self._graph_warm, self._graph_pool, self.graph_error = {}, set(), None, None
+        self._capture_stream = None
         # With the fused optimizer (self.table is not None) this torch optimizer never steps: it holds the parameter groups
         # the scheduler and the checkpoint layout are written against (lr stays a host number; the kernels form the same
         # schedule on the device from their own step counter).
@@ -331,7 +332,7 @@ class LidarTrainer:
         update_extra_state) rounded UP to the next of a geometric ladder of capacities (ratio 2^(1/4), multiples of 1024):
         while the occupancy grid is still settling the mean swings by tens of percent from one grid update to the next
         (measured on the NeRF-MVL-shaped bench: 107 K .. 393 K over 300 steps), and every distinct capacity is one capture
-        (~10 ms) — a ladder has ~8 rungs over that range, each captured once and kept.  On average 9 % of the buffer is
+        (a few ms) — a ladder has ~8 rungs over that range, each captured once and kept.  On average 9 % of the buffer is
         padding (zero samples the chain runs over).  0 while there is no mean yet (the first 16 steps march into N x 1024
         buffers and read the count back)."""
         mc = int(self.model.mean_count)
@@ -380,12 +381,22 @@ class LidarTrainer:
             if self.occupancy:
                 model._static_march = (ent["counter"], cap - 128)  # (march_rays_train adds its 128-alignment on top)
             try:
+                # capture_begin / capture_end by hand: torch.cuda.graph's context manager empties the allocator's cache
+                # first (every cached block back to the driver: the workspaces of this step and of the evaluation pass
+                # are re-allocated afterwards), which made a capture cost 70-80 ms — 140 steps of the occupancy-grid
+                # workload, whose sample capacity moves to a new rung (a new capture) whenever the grid has changed enough
                 torch.cuda.synchronize()
-                # (data parallel: RCCL's watchdog thread polls its events while this thread captures — a capture that
-                #  polices every thread of the process would trip over it)
-                with torch.cuda.graph(ent["graph"], pool=self._graph_pool,
-                                      capture_error_mode="thread_local" if self.dp else "global"):
-                    ent["loss"] = self._step_fused_table(ent["rays_o"], ent["rays_d"], ent["gt"], patch).detach()
+                if self._capture_stream is None:
+                    self._capture_stream = torch.cuda.Stream()
+                with torch.cuda.stream(self._capture_stream):
+                    # (data parallel: RCCL's watchdog thread polls its events while this thread captures — a capture that
+                    #  polices every thread of the process would trip over it)
+                    ent["graph"].capture_begin(self._graph_pool,
+                                               capture_error_mode="thread_local" if self.dp else "global")
+                    try:
+                        ent["loss"] = self._step_fused_table(ent["rays_o"], ent["rays_d"], ent["gt"], patch).detach()
+                    finally:
+                        ent["graph"].capture_end()
                 # the gradient and the scale it carries live in THIS graph's buffers: table_grad() must see the ones of
                 # the graph that was replayed last, not of the one that was captured last
                 ent["g16"] = tp._lnh_grad16
@@ -590,8 +601,14 @@ class LidarTrainer:
     def _drop_graphs(self):
         """Forget every captured step: the next step runs launch by launch (taking every lazy initialisation and version
         check with it), the one after is captured afresh."""
+        had = bool(self._graphs)
         self._graphs.clear()
         self._graph_warm.clear()
+        # the graphs' memory pool goes with them: a pool none of whose graphs is alive any more cannot take a new capture
+        # (the allocator asserts on it); the next capture opens a new one, and the blocks of the old one go back to the driver
+        self._graph_pool = None
+        if had and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+            torch.cuda.empty_cache()
 
     def _after_optimizer_load(self):
         """Graph mode: every captured step is dropped after a load (the next step runs launch by launch and takes the

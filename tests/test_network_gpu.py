@@ -585,7 +585,7 @@ def test_captured_dense_step_trains_like_the_eager_step():
 
 
 def test_failed_capture_falls_back_to_launch_by_launch(monkeypatch):
-    """A capture that does not go through (here: torch.cuda.graph made to raise) must not cost the run: the trainer keeps the
+    """A capture that does not go through (here: CUDAGraph.capture_begin made to raise) must not cost the run: the trainer keeps the
     reason, switches graph mode off and takes that very step — and every later one — launch by launch."""
     from lidarnerf.nerf.train_step import LidarTrainer
     net, _ = _pair(seed=19, table_scale=0.3)
@@ -596,16 +596,13 @@ def test_failed_capture_falls_back_to_launch_by_launch(monkeypatch):
     b = (o.cuda()[None], d.cuda()[None], gt)
     l0 = float(tr.step(*b))                                   # launch by launch (first step at this shape)
 
-    class _Boom:
-        def __init__(self, *a, **k):
-            pass
-
-        def __enter__(self):
+    class _Boom:  # (the trainer opens its captures with CUDAGraph.capture_begin / capture_end)
+        def capture_begin(self, *a, **k):
             raise RuntimeError("capture refused (test)")
 
-        def __exit__(self, *a):
-            return False
-    monkeypatch.setattr(torch.cuda, "graph", _Boom)
+        def capture_end(self):
+            pass
+    monkeypatch.setattr(torch.cuda, "CUDAGraph", _Boom)
     l1 = float(tr.step(*b))                                   # would have been the capture
     assert tr.graph is False and "capture refused" in tr.graph_error and not tr._graphs
     l2 = float(tr.step(*b))
