@@ -208,6 +208,16 @@ def _relaunch_distributed(n):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def _flush_c_stdout():
+    """Flush the C runtime's stdout buffer (libraries of this process that printf — RCCL's banner — would otherwise empty
+    it at exit, after the JSON line)."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+
+
 def lib_sha16():
     """First 16 hex digits of the SHA-256 of the loaded liblidarnerf_hip.so: ties a PMC file to the library it profiled."""
     import hashlib
@@ -384,6 +394,7 @@ def run_nerfmvl(args):
         "ms_per_step_repeats": [round(1e3 * g["elapsed"] / args.steps, 3) for g in regions],
         "ms_per_step_first_region": round(1e3 * regions[0]["elapsed"] / args.steps, 3),
         "captures_in_region": [g["captures"] for g in regions],
+        "capture_host_ms": list(getattr(trainer, "capture_ms", [])),
         "repeats_note": "three timed regions of K steps each, one after the other; `value`, `ms_per_step`, the sample and host "
                         "figures are those of the MEDIAN region.  The occupancy grid keeps changing while it trains, and a "
                         "step whose sample capacity reaches a rung of the ladder it has not seen is captured anew (a few "
@@ -500,6 +511,22 @@ def main():
 
     for s in range(args.warmup):
         trainer.step(*batches[s % len(batches)], **step_kw)
+    if world > 1:
+        # First contact of this step with N ranks (the collectives, and in graph mode their replay from a hipGraph, have met
+        # one-rank groups only on the boxes this was developed on): wait for the warm-up with a deadline and leave with a
+        # message instead of sitting in a collective that never completes.
+        ev = torch.cuda.Event()
+        ev.record()
+        t_dead = time.perf_counter() + 180.0
+        while not ev.query():
+            if time.perf_counter() > t_dead:
+                sys.stderr.write(json.dumps({"error": "the data-parallel warm-up steps did not complete within 180 s",
+                                             "rank": rank, "world": world, "graph": bool(trainer.graph),
+                                             "graph_error": trainer.graph_error,
+                                             "hint": "python bench.py --gpus N --no-graph runs the step launch by launch"}) + "\n")
+                sys.stderr.flush()
+                os._exit(19)
+            time.sleep(0.005)
     sync()
     # HIP events around the encoder entry points only (the roofline candidates): every timed call costs two event
     # records on the stream, and timing all ~25 calls of a step inflates the step by ~4 % (--kernel-timers for all)
@@ -845,7 +872,8 @@ def main():
         model.train()
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(full=not args.cpu_baseline_quick)
-    print(json.dumps(result))
+    _flush_c_stdout()  # (RCCL prints its version banner through C stdio: it must not land BEHIND the line)
+    print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

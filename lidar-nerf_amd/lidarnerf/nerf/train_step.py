@@ -203,7 +203,7 @@ class LidarTrainer:
                                (f" and, data parallel, the 'nccl' (RCCL) backend — this process group runs "
                                 f"'{parallel.backend()}', whose collectives cannot be captured" if self.dp else ""))
         self._graphs, self._graph_warm, self._graph_pool, self.graph_error = {}, set(), None, None
-        self._capture_stream = None
+        self._capture_stream, self.capture_ms = None, []
         # With the fused optimizer (self.table is not None) this torch optimizer never steps: it holds the parameter groups
         # the scheduler and the checkpoint layout are written against (lr stays a host number; the kernels form the same
         # schedule on the device from their own step counter).
@@ -386,6 +386,8 @@ class LidarTrainer:
                 # are re-allocated afterwards), which made a capture cost 70-80 ms — 140 steps of the occupancy-grid
                 # workload, whose sample capacity moves to a new rung (a new capture) whenever the grid has changed enough
                 torch.cuda.synchronize()
+                import time
+                t_cap = time.perf_counter()
                 if self._capture_stream is None:
                     self._capture_stream = torch.cuda.Stream()
                 with torch.cuda.stream(self._capture_stream):
@@ -400,6 +402,7 @@ class LidarTrainer:
                 # the gradient and the scale it carries live in THIS graph's buffers: table_grad() must see the ones of
                 # the graph that was replayed last, not of the one that was captured last
                 ent["g16"] = tp._lnh_grad16
+                self.capture_ms.append(round((time.perf_counter() - t_cap) * 1e3, 2))  # (host time of this capture)
             except Exception as e:  # noqa: BLE001 — a capture that does not go through must not cost the run
                 # (nothing of a captured step has executed: the state is what it was.)  Launch by launch from here on; the
                 # reason stays readable (bench.py reports it).
@@ -408,10 +411,15 @@ class LidarTrainer:
                 return self._step_fused_table(rays_o, rays_d, images_lidar, patch).detach()
             finally:
                 model._static_march = None
+            try:
+                ent["graph"].replay()
+            except Exception as e:  # noqa: BLE001 — a graph the runtime captured and then refuses to launch (same rule)
+                self.graph, self.graph_error = False, f"replay: {type(e).__name__}: {e}"
+                return self._step_fused_table(rays_o, rays_d, images_lidar, patch).detach()
             self._graphs[key] = ent
         else:
             torch._foreach_copy_([ent["rays_o"], ent["rays_d"], ent["gt"]], [rays_o, rays_d, images_lidar])  # one launch
-        ent["graph"].replay()
+            ent["graph"].replay()
         tp._lnh_grad16 = ent["g16"]
         if self.occupancy:
             model.step_counter[model.local_step % 16].copy_(ent["counter"])
