@@ -389,7 +389,7 @@ def run_nerfmvl(args):
                    "render_path": "fused ragged chain (nerf/fused.py FusedLidarRagged) + fused table optimizer"
                    if trainer.table is not None else "modular density()/color() path",
                    "launch": (f"hipGraph replay of the whole step (march .. optimizers; {graphs_captured} graph(s) captured, "
-                              "one per sample capacity; steps at a new capacity run launch by launch once, then capture)")
+                              "one per sample capacity of the ladder; a step at a capacity not seen before is captured then and there)")
                    if use_graph else "launch by launch from Python"},
         "ms_per_step_repeats": [round(1e3 * g["elapsed"] / args.steps, 3) for g in regions],
         "ms_per_step_first_region": round(1e3 * regions[0]["elapsed"] / args.steps, 3),

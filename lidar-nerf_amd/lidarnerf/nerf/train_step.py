@@ -2,6 +2,8 @@
 of train_one_epoch (1206-1226): zero_grad -> autocast(render + loss) -> scaled backward -> [DP all-reduce] ->
 scaler.step(optimizer) -> scaler.update() -> lr_scheduler.step().  Only the LiDAR branch exists in the reference
 path (opt.enable_lidar is forced True, main_lidarnerf.py:229)."""
+import os
+
 import torch
 
 from .. import parallel
@@ -94,6 +96,10 @@ def patch_gradient_loss(pred_depth, gt_depth, gt_raydrop, px, py, scale, alpha_g
 def _hip_consts():
     from .. import _hip
     return _hip
+
+
+# rungs per octave of the captured step's sample-capacity ladder (LidarTrainer._graph_capacity)
+_LADDER_RUNGS_PER_OCTAVE = int(os.environ.get("LNH_GRAPH_LADDER", "8"))
 
 
 class LidarTrainer:
@@ -329,18 +335,21 @@ class LidarTrainer:
     # ---- the captured step (graph=True)
     def _graph_capacity(self):
         """Sample capacity of the marcher for a captured step: the running mean of the recent marches (renderer.py
-        update_extra_state) rounded UP to the next of a geometric ladder of capacities (ratio 2^(1/4), multiples of 1024):
-        while the occupancy grid is still settling the mean swings by tens of percent from one grid update to the next
-        (measured on the NeRF-MVL-shaped bench: 107 K .. 393 K over 300 steps), and every distinct capacity is one capture
-        (a few ms) — a ladder has ~8 rungs over that range, each captured once and kept.  On average 9 % of the buffer is
-        padding (zero samples the chain runs over).  0 while there is no mean yet (the first 16 steps march into N x 1024
+        update_extra_state) rounded UP to the next of a geometric ladder of capacities (ratio 2^(1/8), multiples of 1024;
+        LNH_GRAPH_LADDER = rungs per octave): while the occupancy grid is still settling the mean swings by tens of percent
+        from one grid update to the next (measured on the NeRF-MVL-shaped bench: 107 K .. 393 K over 300 steps), and every
+        distinct capacity is one capture (0.7 .. 0.9 ms since the trainer captures without emptying the allocator's cache) —
+        the ladder has ~15 rungs over that range, each captured once and kept.  On average 4 % of the buffer is padding (zero
+        samples the chain runs over; 9 % with the 2^(1/4) ladder of round 4, when a capture cost 70 ms: 0.500 against
+        0.516 ms per step at 66 .. 69 samples per ray).  0 while there is no mean yet (the first 16 steps march into N x 1024
         buffers and read the count back)."""
         mc = int(self.model.mean_count)
         if mc <= 0:
             return 0
         import math
-        rung = math.ceil(4 * math.log2(max(mc, 1024) / 1024.0) - 1e-9)
-        return int(math.ceil(1024 * 2 ** (rung / 4) / 1024.0)) * 1024
+        per = _LADDER_RUNGS_PER_OCTAVE
+        rung = math.ceil(per * math.log2(max(mc, 1024) / 1024.0) - 1e-9)
+        return int(math.ceil(1024 * 2 ** (rung / per) / 1024.0)) * 1024
 
     def _step_graphed(self, rays_o, rays_d, images_lidar, patch):
         model = self.model

@@ -288,7 +288,7 @@ def test_captured_step_trains_like_the_eager_step():
         le.append(float(eager.step(*batch).detach()))
         lg.append(float(graph.step(*batch).detach()))
     assert len(graph._graphs) >= 1                        # captured (the first 16 steps ran launch by launch)
-    assert len(graph._graphs) <= 4, list(graph._graphs)   # ... and the capacity ladder keeps the number of graphs small
+    assert len(graph._graphs) <= 8, list(graph._graphs)   # ... and the capacity ladder keeps the number of graphs small
     caps = sorted(k[-1] for k in graph._graphs)
     assert all(c % 1024 == 0 for c in caps) and caps[-1] >= nets[1].mean_count
     assert all(np.isfinite(lg))

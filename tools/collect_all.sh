@@ -28,11 +28,11 @@ b dpwindows --dp-windows --no-cpu-baseline --no-eval
 rm -rf /tmp/prof_mvl
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_mvl -o r -- python bench.py --workload nerfmvl --steps 128 --warmup 16 > /dev/null 2>&1
 find /tmp/prof_mvl -name "*kernel_stats.csv" -exec cp {} $out/${tag}_nerfmvl_kernel_stats.csv \;
-python - $out/${tag}_nerfmvl_kernel_stats.csv $((320+16+128+5)) > $out/${tag}_nerfmvl_kernel_summary.txt <<'PY'
+python - $out/${tag}_nerfmvl_kernel_stats.csv $((320+16+3*128+5)) > $out/${tag}_nerfmvl_kernel_summary.txt <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1]))); n = float(sys.argv[2])
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
-print(f"rocprofv3 --kernel-trace --stats -- python bench.py --workload nerfmvl --steps 128 --warmup 16   ({int(n)} steps: 320 settling + 16 warm-up + 128 timed + 5 launch-by-launch; the first 16 grid updates are full 128^3 sweeps)")
+print(f"rocprofv3 --kernel-trace --stats -- python bench.py --workload nerfmvl --steps 128 --warmup 16   ({int(n)} steps: 320 settling + 16 warm-up + 3 x 128 timed + 5 launch-by-launch; the first 16 grid updates are full 128^3 sweeps)")
 print(f"total kernel time per training step (all of the above averaged): {tot/n/1e6:.3f} ms")
 for r in rows[:45]:
     print(f"{float(r['TotalDurationNs'])/n/1e3:8.1f} us/step {int(r['Calls'])/n:6.2f} calls/step  avg {float(r['AverageNs'])/1e3:8.1f} us  {r['Name'][:110]}")
