@@ -231,6 +231,14 @@ LNH_API int lnh_mlp_backward_data(const void *grad, const void *forward_buffer, 
 /* Replaces near_far_from_aabb    lidarnerf/raymarching/src/raymarching.h:6-12 (raymarching.cu:104-177). */
 LNH_API int lnh_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb, uint32_t N,
                                    float min_near, float *nears, float *fars, lnh_stream_t stream);
+/* What NeRFRenderer.run_cuda does in front of the marcher, in ONE launch (no pybind counterpart: the reference's
+ * renderer does it with torch ops — renderer.py:129-138 for the LiDAR range; this build's run_cuda cuts it at the box):
+ *   nears[n] = near;  fars[n] = torch.minimum(near * far_factor, far of lnh_near_far_from_aabb(rays_o, rays_d, aabb, near))
+ * (bit for bit, NaN exits included), and up to 4 device regions cleared (the marcher's zero-initialised sample buffers —
+ * raymarching.py:235-245 —, its counter, the colour buffer): host arrays of pointers and byte counts, 4-byte granular. */
+LNH_API int lnh_lidar_march_prologue(const float *rays_o, const float *rays_d, const float *aabb, uint32_t N, float near,
+                                     float far_factor, float *nears, float *fars, void *const *zero_ptrs,
+                                     const uint64_t *zero_bytes, uint32_t zero_count, lnh_stream_t stream);
 /* Replaces sph_from_ray          raymarching.h:13-17 (raymarching.cu:182-231). */
 LNH_API int lnh_sph_from_ray(const float *rays_o, const float *rays_d, float radius, uint32_t N, float *coords,
                              lnh_stream_t stream);

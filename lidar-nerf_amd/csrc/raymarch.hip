@@ -107,29 +107,82 @@ __device__ __forceinline__ Probe probe(const MarchRay &r, float t, const uint8_t
     return p;
 }
 
+// slab test of one ray against the box (raymarching.cu:104-177); FMAX / FMAX for a miss
+__device__ __forceinline__ void near_far_ray(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                             const float *__restrict__ aabb, uint32_t n, float min_near, float &near_out,
+                                             float &far_out) {
+    const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+    const float rdx = 1 / rays_d[n * 3], rdy = 1 / rays_d[n * 3 + 1], rdz = 1 / rays_d[n * 3 + 2];
+    const float FMAX = 3.402823466e+38f;
+    near_out = far_out = FMAX;
+    float near = (aabb[0] - ox) * rdx, far = (aabb[3] - ox) * rdx;
+    if (near > far) { float t = near; near = far; far = t; }
+    float ny = (aabb[1] - oy) * rdy, fy = (aabb[4] - oy) * rdy;
+    if (ny > fy) { float t = ny; ny = fy; fy = t; }
+    if (near > fy || ny > far) return;
+    if (ny > near) near = ny;
+    if (fy < far) far = fy;
+    float nz = (aabb[2] - oz) * rdz, fz = (aabb[5] - oz) * rdz;
+    if (nz > fz) { float t = nz; nz = fz; fz = t; }
+    if (near > fz || nz > far) return;
+    if (nz > near) near = nz;
+    if (fz < far) far = fz;
+    if (near < min_near) near = min_near;
+    near_out = near;
+    far_out = far;
+}
+
 __global__ void __launch_bounds__(128)
 k_near_far(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ aabb,
            uint32_t N, float min_near, float *__restrict__ nears, float *__restrict__ fars) {
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
-    const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
-    const float rdx = 1 / rays_d[n * 3], rdy = 1 / rays_d[n * 3 + 1], rdz = 1 / rays_d[n * 3 + 2];
-    const float FMAX = 3.402823466e+38f;
-    float near = (aabb[0] - ox) * rdx, far = (aabb[3] - ox) * rdx;
-    if (near > far) { float t = near; near = far; far = t; }
-    float ny = (aabb[1] - oy) * rdy, fy = (aabb[4] - oy) * rdy;
-    if (ny > fy) { float t = ny; ny = fy; fy = t; }
-    if (near > fy || ny > far) { nears[n] = fars[n] = FMAX; return; }
-    if (ny > near) near = ny;
-    if (fy < far) far = fy;
-    float nz = (aabb[2] - oz) * rdz, fz = (aabb[5] - oz) * rdz;
-    if (nz > fz) { float t = nz; nz = fz; fz = t; }
-    if (near > fz || nz > far) { nears[n] = fars[n] = FMAX; return; }
-    if (nz > near) near = nz;
-    if (fz < far) far = fz;
-    if (near < min_near) near = min_near;
+    float near, far;
+    near_far_ray(rays_o, rays_d, aabb, n, min_near, near, far);
     nears[n] = near;
     fars[n] = far;
+}
+
+// What NeRFRenderer.run_cuda does in front of the marcher, in one launch (the occupancy-grid step is launch-bound: every
+// tiny kernel costs ~5 us of device time inside a replayed graph): the LiDAR range of every ray — near = the constant
+// `near`, far = min(near * far_factor, exit of the box) (renderer.py:129-138 with the box cut of nerf/renderer.py run_cuda) —
+// and the clearing of up to four regions (the marcher's sample buffers, its counter, the colour buffer).
+struct PrologueZero {
+    uint32_t *p[4];
+    uint64_t words[4];
+    uint32_t first_block[5];
+    uint32_t count;
+};
+__global__ void __launch_bounds__(256)
+k_march_prologue(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ aabb,
+                 uint32_t N, float near_c, float far_factor, float *__restrict__ nears, float *__restrict__ fars,
+                 uint32_t ray_blocks, PrologueZero z) {
+    if (blockIdx.x < ray_blocks) {
+        const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+        if (n >= N) return;
+        float nb, fb;
+        near_far_ray(rays_o, rays_d, aabb, n, near_c, nb, fb);
+        const float cap = near_c * far_factor;
+        // torch.minimum(cap, far_box): a NaN exit (a ray along a face of the box) stays NaN
+        nears[n] = near_c;
+        fars[n] = fb != fb ? fb : (fb < cap ? fb : cap);
+        return;
+    }
+    const uint32_t bz = blockIdx.x - ray_blocks;
+    uint32_t r = 0;
+    while (r + 1 < z.count && bz >= z.first_block[r + 1]) r++;
+    const uint64_t b = bz - z.first_block[r], nb = z.first_block[r + 1] - z.first_block[r];
+    uint32_t *p = z.p[r];
+    const uint64_t n = z.words[r];
+    const uint64_t head = (uint64_t)((16 - ((uintptr_t)p & 15)) & 15) / 4;
+    const uint64_t h = head < n ? head : n, n4 = (n - h) / 4;
+    uint4 *q = reinterpret_cast<uint4 *>(p + h);
+    for (uint64_t i = b * 256 + threadIdx.x; i < n4; i += nb * 256) q[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (b == 0) {
+        if (threadIdx.x < h) p[threadIdx.x] = 0u;
+        const uint64_t done = h + n4 * 4;
+        if (threadIdx.x < n - done) p[done + threadIdx.x] = 0u;
+    }
 }
 
 __global__ void __launch_bounds__(128)
@@ -659,6 +712,34 @@ int lnh_near_far_from_aabb(const float *rays_o, const float *rays_d, const float
     LNH_LAUNCH(k_near_far, dim3(div_up(N, 128)), dim3(128), 0, (hipStream_t)stream, rays_o, rays_d, aabb, N,
                        min_near, nears, fars);
     return lnh_check_launch("lnh_near_far_from_aabb");
+}
+
+int lnh_lidar_march_prologue(const float *rays_o, const float *rays_d, const float *aabb, uint32_t N, float near,
+                             float far_factor, float *nears, float *fars, void *const *zero_ptrs,
+                             const uint64_t *zero_bytes, uint32_t zero_count, lnh_stream_t stream) {
+    LNH_REQUIRE(zero_count <= 4, LNH_ERR_INVALID_ARG, "lidar_march_prologue: at most 4 regions to clear");
+    LNH_REQUIRE(N == 0 || (rays_o && rays_d && aabb && nears && fars), LNH_ERR_INVALID_ARG,
+                "lidar_march_prologue: null pointer");
+    LNH_REQUIRE(zero_count == 0 || (zero_ptrs && zero_bytes), LNH_ERR_INVALID_ARG, "lidar_march_prologue: null region list");
+    PrologueZero z{};
+    uint32_t blocks = 0;
+    for (uint32_t i = 0; i < zero_count; i++) {
+        if (!zero_bytes[i]) continue;
+        LNH_REQUIRE(zero_ptrs[i] && ((uintptr_t)zero_ptrs[i] & 3) == 0 && (zero_bytes[i] & 3) == 0, LNH_ERR_INVALID_ARG,
+                    "lidar_march_prologue: regions are 4-byte granular");
+        const uint64_t words = zero_bytes[i] / 4, want = (words / 4 + 255) / 256 + 1;
+        z.p[z.count] = (uint32_t *)zero_ptrs[i];
+        z.words[z.count] = words;
+        z.first_block[z.count] = blocks;
+        blocks += (uint32_t)(want < 1024 ? want : 1024);
+        z.count++;
+    }
+    z.first_block[z.count] = blocks;
+    const uint32_t ray_blocks = div_up(N, 256);
+    if (ray_blocks + blocks == 0) return LNH_OK;
+    LNH_LAUNCH(k_march_prologue, dim3(ray_blocks + blocks), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, aabb, N,
+               near, far_factor, nears, fars, ray_blocks, z);
+    return lnh_check_launch("lnh_lidar_march_prologue");
 }
 
 int lnh_sph_from_ray(const float *rays_o, const float *rays_d, float radius, uint32_t N, float *coords,

@@ -81,6 +81,7 @@ _SIGS = {
     "lnh_train_step": [P, P, P, P, P, P, C.c_uint64, P, P, P, U32, P, P, C.c_double, C.c_double, C.c_double, C.c_double,
                        C.c_double, U32],
     "lnh_zero_regions": [P, P, U32],
+    "lnh_lidar_march_prologue": [P, P, P, U32, F32, F32, P, P, P, P, U32],
     "lnh_lidar_color_backward": [P, P, P, P, P, P, P, U32, U32, P, P, P],
     "lnh_lidar_color_backward_image": [P, P, P, P, P, P, P, U32, U32, P, P, P],
     "lnh_ragged_color_forward": [P, P, P, P, U32, U32, P],

@@ -576,7 +576,11 @@ class FusedLidarRagged(Function):
                   sigma.data_ptr())
         # colour head, one wave per ray of the marcher's table (round 5; before: a [M, 96] input assembled per sample, the
         # generic 96 -> 64 -> 64 -> 16 MLP kernel and a sigmoid pass)
-        rgb = torch.zeros((M, 2), dtype=torch.float32, device=dev)  # (rows no ray owns stay 0)
+        # (rows no ray owns stay 0.)  run_cuda hands over rows its prologue launch has already cleared
+        rgb = getattr(model, "_lnh_rgb_rows", None)
+        model._lnh_rgb_rows = None
+        if rgb is None or rgb.shape != (M, 2) or rgb.device != dev or rgb.dtype != torch.float32:
+            rgb = torch.zeros((M, 2), dtype=torch.float32, device=dev)
         _hip.call("lnh_ragged_color_forward" + sfx, h16.data_ptr(), rays.data_ptr(), cdir.data_ptr(), wcol16.data_ptr(), N, M,
                   rgb.data_ptr())
         sig_s = sigma * ds if ds != 1.0 else sigma

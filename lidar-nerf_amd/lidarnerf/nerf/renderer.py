@@ -259,43 +259,43 @@ class NeRFRenderer(nn.Module):
         rays_o = rays_o.contiguous().view(-1, 3).float()
         rays_d = rays_d.contiguous().view(-1, 3).float()
         N = rays_o.shape[0]
-        # (a constant per ray count: kept.  While a step is being captured the tensor is made for the occasion and NOT
-        #  kept — it would come from the graph's private pool with its fill recorded as a graph node only, and a capture
-        #  that fails would leave later eager steps reading uninitialised memory; the cache is bounded: evaluation with
-        #  varying batch sizes must not grow it for ever.  A captured step holds its own reference to the tensor it used.)
-        if rays_o.is_cuda and torch.cuda.is_current_stream_capturing():
-            nears = torch.full((N,), float(self.min_near_lidar), dtype=torch.float32, device=rays_o.device)
-        else:
-            cache = self.__dict__.setdefault("_nears_cache", {})
-            key = (N, rays_o.device, float(self.min_near_lidar))
-            nears = cache.get(key)
-            if nears is None:
-                if len(cache) >= 8:
-                    cache.pop(next(iter(cache)))
-                nears = cache[key] = torch.full((N,), float(self.min_near_lidar), dtype=torch.float32,
-                                                device=rays_o.device)
-        # 1 m .. 81 m, cut at the ray's exit from the box: the marcher clamps sample POSITIONS to the box, and the compositing
-        # kernel recovers a sample's depth from its position ((xyz - o) . d) — a sample marched past the box would enter
-        # the depth sum with a shortened z (the dense path keeps the true z next to the clamped position, renderer.py:164-167)
-        aabb = self.aabb_train if self.training else self.aabb_infer
-        _, far_box = raymarching.near_far_from_aabb(rays_o, rays_d, aabb, float(self.min_near_lidar))
-        fars = torch.minimum(nears * 81.0, far_box)
+        _hip.require_cuda(rays_o, rays_d)
+        dev = rays_o.device
         static = getattr(self, "_static_march", None)
         if self.training and static is not None:
             # LidarTrainer's captured step (train_step.py, graph=True): a fixed counter buffer and a fixed sample capacity —
             # this Python runs at capture only; the trainer copies the counter into the ring and advances local_step per replay
             counter, mean_count = static
-            counter.zero_()
         elif self.training:
             counter = self.step_counter[self.local_step % 16]
-            counter.zero_()
             self.local_step += 1
             mean_count = self.mean_count
         else:
             counter, mean_count, force_all_rays = None, -1, True
+        # ONE launch in front of the marcher (lnh_lidar_march_prologue): the LiDAR range of every ray — 1 m .. 81 m, cut at the
+        # ray's exit from the box: the marcher clamps sample POSITIONS to the box, and the compositing kernel recovers a
+        # sample's depth from its position ((xyz - o) . d) — a sample marched past the box would enter the depth sum with a
+        # shortened z (the dense path keeps the true z next to the clamped position, renderer.py:164-167) — and the clearing
+        # of the marcher's zero-initialised sample buffers, of its counter and of the colour buffer the fused chain fills
+        # (rows no ray owns stay 0).  Before: a fill, a multiply, lnh_near_far_from_aabb, a minimum and two more fills — five
+        # launches of ~5 us each in a step of 0.5 ms.
+        aabb = (self.aabb_train if self.training else self.aabb_infer).contiguous().float()
+        M = raymarching.march_capacity(N, max_steps, mean_count, 128, force_all_rays)
+        nears = torch.empty(N, dtype=torch.float32, device=dev)
+        fars = torch.empty(N, dtype=torch.float32, device=dev)
+        buf = torch.empty(M * 10, dtype=torch.float32, device=dev)  # xyzs 3 | dirs 3 | deltas 2 | lidar colour 2
+        regions = [buf] + ([counter] if counter is not None else [])
+        regions = [t for t in regions if t.numel()]
+        zp = (_hip.C.c_void_p * max(len(regions), 1))(*[t.data_ptr() for t in regions])
+        zb = (_hip.C.c_uint64 * max(len(regions), 1))(*[t.numel() * t.element_size() for t in regions])
+        _hip.call("lnh_lidar_march_prologue", rays_o.data_ptr(), rays_d.data_ptr(), aabb.data_ptr(), N,
+                  float(self.min_near_lidar), 81.0, nears.data_ptr(), fars.data_ptr(), _hip.C.cast(zp, _hip.C.c_void_p),
+                  _hip.C.cast(zb, _hip.C.c_void_p), len(regions))
         xyzs, dirs, deltas, rays = raymarching.march_rays_train(
             rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size, nears, fars, counter,
-            mean_count, perturb, 128, force_all_rays, dt_gamma, max_steps)
+            mean_count, perturb, 128, force_all_rays, dt_gamma, max_steps, sample_buffer=buf)
+        # the cleared colour rows of the samples that were kept (evaluation trims the buffers to the marched count)
+        self._lnh_rgb_rows = buf[M * 8:M * 8 + 2 * xyzs.shape[0]].view(-1, 2)
         from . import fused
         use_fused = (getattr(self, "fused_lidar", False) and xyzs.is_cuda and torch.is_autocast_enabled()
                      and fused.ragged_supported(self))

@@ -59,24 +59,39 @@ def packbits(grid, thresh, bitfield=None):
     return bitfield
 
 
-def march_rays_train(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter=None, mean_count=-1,
-                     perturb=False, align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024):
-    """Returns xyzs [M,3], dirs [M,3], deltas [M,2], rays [N,3] (id, offset, count).  Same argument list and the same
-    output-trimming rules as the reference wrapper (raymarching.py:171-282)."""
-    rays_o = rays_o.contiguous().float().view(-1, 3)
-    rays_d = rays_d.contiguous().float().view(-1, 3)
-    density_bitfield = density_bitfield.contiguous()
-    _hip.require_cuda(rays_o, rays_d, density_bitfield, nears, fars)
-    N = rays_o.shape[0]
+def march_capacity(N, max_steps=1024, mean_count=-1, align=-1, force_all_rays=False):
+    """Rows of the marcher's sample buffers (raymarching.py:235-245 of the reference): N * max_steps, or the running mean
+    of the recent marches rounded up to `align`."""
     M = N * max_steps
     if not force_all_rays and mean_count > 0:
         if align > 0:
             mean_count += align - mean_count % align
         M = mean_count
+    return int(M)
+
+
+def march_rays_train(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter=None, mean_count=-1,
+                     perturb=False, align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024, sample_buffer=None):
+    """Returns xyzs [M,3], dirs [M,3], deltas [M,2], rays [N,3] (id, offset, count).  Same argument list and the same
+    output-trimming rules as the reference wrapper (raymarching.py:171-282).  `sample_buffer` (this build's renderer): a
+    float32 buffer of >= 8 * march_capacity(...) elements that the caller has ALREADY cleared (lnh_lidar_march_prologue
+    clears it together with the counter in its one launch) — the three sample arrays become views of it."""
+    rays_o = rays_o.contiguous().float().view(-1, 3)
+    rays_d = rays_d.contiguous().float().view(-1, 3)
+    density_bitfield = density_bitfield.contiguous()
+    _hip.require_cuda(rays_o, rays_d, density_bitfield, nears, fars)
+    N = rays_o.shape[0]
+    M = march_capacity(N, max_steps, mean_count, align, force_all_rays)
     dev = rays_o.device
-    # (one zero fill for the three sample buffers: the step is launch-bound, every tiny kernel costs ~5 us of GPU time)
-    buf = torch.zeros(M * 8, dtype=torch.float32, device=dev)
-    xyzs, dirs, deltas = buf[:M * 3].view(M, 3), buf[M * 3:M * 6].view(M, 3), buf[M * 6:].view(M, 2)
+    if sample_buffer is not None:
+        if not (sample_buffer.is_cuda and sample_buffer.dtype == torch.float32 and sample_buffer.is_contiguous()
+                and sample_buffer.numel() >= M * 8):
+            raise RuntimeError("march_rays_train: sample_buffer must be a contiguous float32 GPU buffer of >= 8 * M elements")
+        buf = sample_buffer
+    else:
+        # (one zero fill for the three sample buffers: the step is launch-bound, every tiny kernel costs ~5 us of GPU time)
+        buf = torch.zeros(M * 8, dtype=torch.float32, device=dev)
+    xyzs, dirs, deltas = buf[:M * 3].view(M, 3), buf[M * 3:M * 6].view(M, 3), buf[M * 6:M * 8].view(M, 2)
     rays = torch.empty((N, 3), dtype=torch.int32, device=dev)
     if step_counter is None:
         step_counter = torch.zeros(2, dtype=torch.int32, device=dev)

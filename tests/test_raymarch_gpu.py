@@ -272,3 +272,50 @@ def test_sph_from_ray():
         assert np.abs(got[:, 0] - want[:, 0]).max() <= 2e-6 and dphi.max() <= 2e-6
         via_module = raymarching.sph_from_ray(dev(o), dev(d), radius)
         assert torch.equal(via_module, out)
+
+
+def test_march_prologue_equals_the_separate_launches():
+    """lnh_lidar_march_prologue (one launch in front of the marcher) against what it replaced: a fill of the constant near,
+    lnh_near_far_from_aabb + torch.minimum(near * 81, far of the box) — bit for bit, rays that miss the box, rays along an
+    axis (infinite reciprocal direction components) and a NaN exit included — and the clearing of four regions of awkward
+    sizes and alignments, bytes around them untouched."""
+    import ctypes as C
+    from gpu_util import call
+    r = np.random.default_rng(11)
+    N = 5003
+    o = (r.random((N, 3), dtype=np.float32) * 2.4 - 1.2).astype(np.float32)   # some origins outside the box
+    d = r.normal(size=(N, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[:40] = np.array([1.0, 0.0, 0.0], np.float32)          # axis-parallel: two reciprocal components are inf
+    d[40:80] = np.array([0.0, 0.0, -1.0], np.float32)
+    o[40:48] = np.array([1.0, 0.2, 0.3], np.float32)         # ... and on the box's +x face: (aabb[3] - ox) * inf = NaN
+    aabb = torch.tensor([-1, -1, -1, 1, 1, 1], dtype=torch.float32, device="cuda")
+    ro, rd = torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda()
+    near = 0.005
+    want_n = torch.full((N,), near, dtype=torch.float32, device="cuda")
+    nb, fb = torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
+    call("lnh_near_far_from_aabb", ro, rd, aabb, N, near, nb, fb)
+    want_f = torch.minimum(want_n * 81.0, fb)
+    # regions: (offset in floats, length in floats) inside guard-filled buffers
+    bufs = [torch.full((n + 16,), 7.0, device="cuda") for n in (100003, 2, 17, 4096)]
+    offs = (3, 1, 5, 0)
+    lens = (100003 - 3, 2, 9, 4096)
+    views = [b[o_:o_ + n] for b, o_, n in zip(bufs, offs, lens)]
+    zp = (C.c_void_p * 4)(*[v.data_ptr() for v in views])
+    zb = (C.c_uint64 * 4)(*[v.numel() * 4 for v in views])
+    got_n, got_f = torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
+    call("lnh_lidar_march_prologue", ro, rd, aabb, N, near, 81.0, got_n, got_f, C.cast(zp, C.c_void_p),
+         C.cast(zb, C.c_void_p), 4)
+    torch.cuda.synchronize()
+    assert torch.equal(got_n, want_n)
+    a, b = got_f.cpu().numpy(), want_f.cpu().numpy()
+    assert np.isnan(b).any() and (b == np.float32(near) * np.float32(81.0)).any() and (b < 0.4).any()   # every kind occurs
+    np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+    for buf, o_, n in zip(bufs, offs, lens):
+        h = buf.cpu().numpy()
+        assert (h[o_:o_ + n] == 0).all() and (h[:o_] == 7.0).all() and (h[o_ + n:] == 7.0).all()
+    # no rays / no regions: both halves on their own
+    call("lnh_lidar_march_prologue", ro, rd, aabb, 0, near, 81.0, got_n, got_f, C.cast(zp, C.c_void_p), C.cast(zb, C.c_void_p), 1)
+    got_f.fill_(-1.0)
+    call("lnh_lidar_march_prologue", ro, rd, aabb, N, near, 81.0, got_n, got_f, None, None, 0)
+    np.testing.assert_array_equal(got_f.cpu().numpy().view(np.uint32), b.view(np.uint32))
