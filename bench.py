@@ -876,5 +876,22 @@ def main():
     print(json.dumps(result), flush=True)
 
 
+def _shutdown():
+    """Leave the process group in an orderly way (RCCL's teardown at interpreter exit without it warns, and a crash there
+    would turn a finished run into a non-zero exit code)."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            torch.cuda.synchronize()
+            dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        pass
+
+
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    finally:
+        _flush_c_stdout()
+        sys.stdout.flush()
+        _shutdown()

@@ -176,4 +176,8 @@ if parallel.backend() == "nccl":
     for a_, b_ in zip(ls, le):
         assert abs(a_ - b_) <= 2e-3 * abs(b_) + 1e-6, (ls, le)
     print(f"rank {rank}: captured DP step (all-reduce and sharded optimizer) == eager DP step; RCCL-GRAPH-OK")
-print(f"rank {rank}: DP-OK")
+print(f"rank {rank}: DP-OK", flush=True)
+# (an orderly exit: the process group is torn down here, not by the interpreter's finalisers)
+if torch.distributed.is_initialized():
+    torch.cuda.synchronize()
+    torch.distributed.destroy_process_group()

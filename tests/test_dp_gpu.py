@@ -9,13 +9,22 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return str(port)
+
+
 @pytest.mark.parametrize("ranks", [2, 4])
 def test_data_parallel_training_step_matches_single_process(ranks):
     """2 and 4 ranks (4: shard boundaries inside levels, three or more addends per table row in the exchange)."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, LNH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
-           "127.0.0.1", "--master-port", str(29541 + ranks), os.path.join(root, "tests", "dp_worker.py")]
+           "127.0.0.1", "--master-port", _free_port(), os.path.join(root, "tests", "dp_worker.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     out = r.stdout + r.stderr
     assert r.returncode == 0, out[-3000:]

@@ -19,12 +19,22 @@ def _n_gpus():
     return torch.cuda.device_count() if torch.cuda.is_available() else 0
 
 
+def _free_port():
+    """A rendezvous port nobody holds (a fixed one can still sit in TIME_WAIT from the test before)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return str(port)
+
+
 @pytest.mark.skipif(_n_gpus() < 2, reason="needs >= 2 GPUs on one node (RCCL refuses two ranks on one device)")
 def test_rccl_two_ranks_dp_worker():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env.update(LNH_DIST_BACKEND="nccl", LNH_DP_WORKER_ONE_GPU_PER_RANK="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "tests", "dp_worker.py")]
+           "127.0.0.1", "--master-port", _free_port(), os.path.join(ROOT, "tests", "dp_worker.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     out = r.stdout + r.stderr
     assert r.returncode == 0, out[-3000:]
@@ -51,7 +61,7 @@ def test_rccl_single_rank_runs_the_exchange_and_the_captured_dp_step():
     to the step without a process group, and the DP step is captured in a hipGraph WITH its collectives and replayed."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env.update(LNH_DIST_BACKEND="nccl", LNH_DP_SINGLE_RANK="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
-               MASTER_ADDR="127.0.0.1", MASTER_PORT="29549", HSA_ENABLE_IPC_MODE_LEGACY="0")
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py")], env=env, capture_output=True, text=True,
                        timeout=900)
     out = r.stdout + r.stderr
@@ -64,7 +74,7 @@ def test_rccl_bench_single_rank_graph_line():
     """`bench.py --gpus 1` under a one-rank RCCL group: the line says the step (collectives included) was replayed."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env.update(LNH_DIST_BACKEND="nccl", LNH_DP_SINGLE_RANK="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
-               MASTER_ADDR="127.0.0.1", MASTER_PORT="29550", HSA_ENABLE_IPC_MODE_LEGACY="0")
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--no-eval",
            "--no-cpu-baseline", "--no-mfma-states", "--rays", "1024"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
@@ -80,7 +90,7 @@ def test_rccl_refuses_two_ranks_on_one_gpu_loudly():
     if _n_gpus() >= 2:
         pytest.skip("a multi-GPU box runs the real test above")
     env = {k: v for k, v in os.environ.items() if k not in ("LNH_DIST_BACKEND",)}
-    env.update(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29548")
+    env.update(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port())
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
