@@ -132,7 +132,34 @@ COLOR = {"c1wave": ("lidar_color.hip", []),
 CHUNK = {"ch2m": ("grid.hip", [("constexpr uint32_t kChunkPoints = 4u << 20;", "constexpr uint32_t kChunkPoints = 2u << 20;")]),
          "ch1m": ("grid.hip", [("constexpr uint32_t kChunkPoints = 4u << 20;", "constexpr uint32_t kChunkPoints = 1u << 20;")]),
          "full": ("grid.hip", [])}
-SETS = {"chunk": CHUNK, "color": COLOR, "fusion": FUSION, "gather": GATHER, "slices": SLICES, "reduce": REDUCE, "scatter": SCATTER_CUTS, "stagger": STAGGER, "iters": ITERS, "wgsize": WGSIZE}
+# ---- non-temporal hints on the buffers the encoder streams (written once / read once): do they keep the level's table in L2?
+_NT_OUT = ("    store_vec<T, C>(out, res);\n    if constexpr (DYDX) {",
+           "    if constexpr (sizeof(T) * C == 4) { uint32_t raw_o; __builtin_memcpy(&raw_o, &res, 4); "
+           "__builtin_nontemporal_store(raw_o, reinterpret_cast<uint32_t *>(out)); } else store_vec<T, C>(out, res);\n    if constexpr (DYDX) {")
+_NT_IN = ("    float x[D];\n#pragma unroll\n    for (int d = 0; d < D; d++) x[d] = inputs[(size_t)b * D + d];\n    const T *tab = table",
+          "    float x[D];\n#pragma unroll\n    for (int d = 0; d < D; d++) x[d] = __builtin_nontemporal_load(inputs + (size_t)b * D + d);\n    const T *tab = table")
+_NT_SIN = ("    float x0 = px[0], x1 = px[1], x2 = px[2];",
+           "    float x0 = __builtin_nontemporal_load(px), x1 = __builtin_nontemporal_load(px + 1), x2 = __builtin_nontemporal_load(px + 2);")
+_NT_POOL = [("                    *reinterpret_cast<Pair2 *>(pvals + slot * (uint32_t)sizeof(Pair)) = pr;",
+             "                    if constexpr (sizeof(Pair2) == 16) { typedef uint32_t u32x4_nt __attribute__((ext_vector_type(4))); "
+             "__builtin_nontemporal_store(__builtin_bit_cast(u32x4_nt, pr), reinterpret_cast<u32x4_nt *>(pvals + slot * (uint32_t)sizeof(Pair))); } "
+             "else *reinterpret_cast<Pair2 *>(pvals + slot * (uint32_t)sizeof(Pair)) = pr;"),
+            ("                    *reinterpret_cast<uint32_t *>(prows + slot * 2u) = (ks2[i][0] & 0xffffu) | (ks2[i][1] << 16);",
+             "                    __builtin_nontemporal_store((ks2[i][0] & 0xffffu) | (ks2[i][1] << 16), reinterpret_cast<uint32_t *>(prows + slot * 2u));")]
+_RD_NORMAL = [("                for (uint32_t w = 0; w < VQ; w++) v[u][w] = __builtin_nontemporal_load(vals4 + (size_t)q * VQ + w);",
+               "                for (uint32_t w = 0; w < VQ; w++) v[u][w] = vals4[(size_t)q * VQ + w];"),
+              ("                r[u] = __builtin_nontemporal_load(rows4 + q);", "                r[u] = rows4[q];")]
+NTMEM = {"full": ("grid.hip", []),
+         "ntvals": ("grid.hip", _NT_POOL[:1]),
+         "ntrows": ("grid.hip", _NT_POOL[1:]),
+         "rdnorm": ("grid.hip", _RD_NORMAL),
+         "ntout": ("grid.hip", [_NT_OUT]),
+         "ntin": ("grid.hip", [_NT_IN]),
+         "ntfwd": ("grid.hip", [_NT_OUT, _NT_IN]),
+         "ntsin": ("grid.hip", [_NT_SIN]),
+         "ntpool": ("grid.hip", _NT_POOL),
+         "ntall": ("grid.hip", [_NT_OUT, _NT_IN, _NT_SIN] + _NT_POOL)}
+SETS = {"ntmem": NTMEM, "chunk": CHUNK, "color": COLOR, "fusion": FUSION, "gather": GATHER, "slices": SLICES, "reduce": REDUCE, "scatter": SCATTER_CUTS, "stagger": STAGGER, "iters": ITERS, "wgsize": WGSIZE}
 
 
 def build_variant(name, fname, subs):
