@@ -159,7 +159,15 @@ NTMEM = {"full": ("grid.hip", []),
          "ntsin": ("grid.hip", [_NT_SIN]),
          "ntpool": ("grid.hip", _NT_POOL),
          "ntall": ("grid.hip", [_NT_OUT, _NT_IN, _NT_SIN] + _NT_POOL)}
-SETS = {"ntmem": NTMEM, "chunk": CHUNK, "color": COLOR, "fusion": FUSION, "gather": GATHER, "slices": SLICES, "reduce": REDUCE, "scatter": SCATTER_CUTS, "stagger": STAGGER, "iters": ITERS, "wgsize": WGSIZE}
+# ---- workgroup size of the encode forward (256 threads in the product)
+def _fwd_threads(n):
+    return ("grid.hip", [("// ------------------------------------------------------------------------------------------------ forward\ntemplate <typename T, int D, int C, bool DYDX>\n__global__ void __launch_bounds__(256)",
+                          "// ------------------------------------------------------------------------------------------------ forward\ntemplate <typename T, int D, int C, bool DYDX>\n__global__ void __launch_bounds__(%d)" % n),
+                         ("    dim3 grid(div_up(B, 256), /* levels */ L), block(256);", "    dim3 grid(div_up(B, %d), /* levels */ L), block(%d);" % (n, n))])
+
+
+FWDWG = {"full": ("grid.hip", []), "fw64": _fwd_threads(64), "fw128": _fwd_threads(128), "fw512": _fwd_threads(512), "fw1024": _fwd_threads(1024)}
+SETS = {"fwdwg": FWDWG, "ntmem": NTMEM, "chunk": CHUNK, "color": COLOR, "fusion": FUSION, "gather": GATHER, "slices": SLICES, "reduce": REDUCE, "scatter": SCATTER_CUTS, "stagger": STAGGER, "iters": ITERS, "wgsize": WGSIZE}
 
 
 def build_variant(name, fname, subs):
