@@ -988,13 +988,19 @@ k_grid_bwd_scatter_plain(const T *__restrict__ grad, const float *__restrict__ i
     bool ok = in_range & !(__builtin_fmaxf(__builtin_fmaxf(x0, x1), x2) > 1.0f) &
               !(__builtin_fminf(__builtin_fminf(x0, x1), x2) < 0.0f);
     const float g0 = (float)gv.v[0], g1 = (float)gv.v[1];
-    // a sample whose upstream gradient is exactly zero contributes nothing: dropped here, not moved through the pool
-    if constexpr (sizeof(T) == 2) {
-        uint32_t raw;
-        __builtin_memcpy(&raw, &gv, 4);
-        ok = ok & ((raw & 0x7fff7fffu) != 0u);
-    } else {
-        ok = ok & ((g0 != 0.0f) | (g1 != 0.0f));
+    // a sample whose upstream gradient is exactly zero contributes nothing: on the HASHED levels it is dropped here, not
+    // moved through the pool.  On the dense levels it stays a (silent) member of its run: dropped, it would CUT the run of its
+    // neighbours — a field that has trained for a few hundred steps has such samples sprinkled along every ray, the coarse
+    // levels' entry counts went from 0.47 M to 1.7 M (level 0) with them, one bucket of level 0 past its pool share and into
+    // two slices, and the reduce pass from 310 to 680 us (profiles/r05_reduce_drift.txt).  Its zeros add nothing.
+    if constexpr (MODE == 1) {
+        if constexpr (sizeof(T) == 2) {
+            uint32_t raw;
+            __builtin_memcpy(&raw, &gv, 4);
+            ok = ok & ((raw & 0x7fff7fffu) != 0u);
+        } else {
+            ok = ok & ((g0 != 0.0f) | (g1 != 0.0f));
+        }
     }
     // Lanes that are not `ok` never emit and never join a run (masks below); they only must stay FINITE, because the scan
     // multiplies foreign lanes by 0: out-of-range coordinates are replaced by the cube centre.
