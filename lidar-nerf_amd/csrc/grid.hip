@@ -988,19 +988,18 @@ k_grid_bwd_scatter_plain(const T *__restrict__ grad, const float *__restrict__ i
     bool ok = in_range & !(__builtin_fmaxf(__builtin_fmaxf(x0, x1), x2) > 1.0f) &
               !(__builtin_fminf(__builtin_fminf(x0, x1), x2) < 0.0f);
     const float g0 = (float)gv.v[0], g1 = (float)gv.v[1];
-    // a sample whose upstream gradient is exactly zero contributes nothing: on the HASHED levels it is dropped here, not
-    // moved through the pool.  On the dense levels it stays a (silent) member of its run: dropped, it would CUT the run of its
-    // neighbours — a field that has trained for a few hundred steps has such samples sprinkled along every ray, the coarse
+    // A sample whose upstream gradient is exactly zero contributes nothing.  It is not moved through the pool ON ITS OWN (see
+    // emit_m below), but it stays a silent member of a run of same-cell neighbours: dropped outright — as rounds 3-4 did — it
+    // CUT that run.  A field that has trained for a few hundred steps has such samples sprinkled along every ray: the coarse
     // levels' entry counts went from 0.47 M to 1.7 M (level 0) with them, one bucket of level 0 past its pool share and into
-    // two slices, and the reduce pass from 310 to 680 us (profiles/r05_reduce_drift.txt).  Its zeros add nothing.
-    if constexpr (MODE == 1) {
-        if constexpr (sizeof(T) == 2) {
-            uint32_t raw;
-            __builtin_memcpy(&raw, &gv, 4);
-            ok = ok & ((raw & 0x7fff7fffu) != 0u);
-        } else {
-            ok = ok & ((g0 != 0.0f) | (g1 != 0.0f));
-        }
+    // two slices, and the reduce pass from 310 to 680 us (profiles/r05_reduce_drift.txt).  Its zeros add nothing to a sum.
+    bool nonzero;
+    if constexpr (sizeof(T) == 2) {
+        uint32_t raw;
+        __builtin_memcpy(&raw, &gv, 4);
+        nonzero = (raw & 0x7fff7fffu) != 0u;
+    } else {
+        nonzero = (g0 != 0.0f) | (g1 != 0.0f);
     }
     // Lanes that are not `ok` never emit and never join a run (masks below); they only must stay FINITE, because the scan
     // multiplies foreign lanes by 0: out-of-range coordinates are replaced by the cube centre.
@@ -1054,7 +1053,8 @@ k_grid_bwd_scatter_plain(const T *__restrict__ grad, const float *__restrict__ i
     unsigned long long cont = __builtin_amdgcn_ballot_w64(same) & ok_m & (ok_m << 1) & ~kRowStarts;
     constexpr int kMinMerges = 8;  // a wave with fewer mergeable lanes skips the scan (4 / 16 / 24 measured within noise)
     if (__builtin_popcountll(cont) < kMinMerges) cont = 0ull;
-    const unsigned long long emit_m = ok_m & ~(cont >> 1);  // run tails
+    // run tails; a zero-gradient sample that continues nobody's run (a run of one) emits nothing
+    const unsigned long long emit_m = ok_m & ~(cont >> 1) & (__builtin_amdgcn_ballot_w64(nonzero) | cont);
     const bool emit = __builtin_amdgcn_inverse_ballot_w64(emit_m);
     LNH_MARK("F rank");
     // ---- rank inside the workgroup's (bucket) counters
