@@ -55,6 +55,10 @@ def main():
     ap.add_argument("--per-level", action="store_true")
     ap.add_argument("--skip-fwd", action="store_true")
     ap.add_argument("--skip-bwd", action="store_true")
+    ap.add_argument("--zero-sprinkle", type=float, default=0.0,
+                    help="fraction of the samples (drawn independently) whose upstream gradient is exactly zero on every level")
+    ap.add_argument("--zero-tail", type=float, default=0.0,
+                    help="fraction of every ray (its far end: samples behind a surface) whose upstream gradient is exactly zero")
     a = ap.parse_args()
     lib = _hip.lib()
     x = lidar_points(a.rays, a.samples)
@@ -67,6 +71,12 @@ def main():
     tab = ((torch.rand(rows, 2, device="cuda") - 0.5) * 2e-4).half()
     out = torch.empty(Lv, B, 2, dtype=torch.half, device="cuda")
     g = (torch.randn(Lv, B, 2, device="cuda") * 0.01).half()
+    if a.zero_sprinkle > 0 or a.zero_tail > 0:  # what a trained field hands the backward (profiles/r05_reduce_drift.txt)
+        gen = torch.Generator(device="cuda").manual_seed(7)
+        keep = torch.rand(a.rays, a.samples, device="cuda", generator=gen) >= a.zero_sprinkle
+        keep[:, a.samples - int(round(a.zero_tail * a.samples)):] = False
+        g = g * keep.reshape(1, B, 1).half()
+        print(f"zero-gradient samples: {1 - float(keep.float().mean()):.3f}")
     ge = torch.zeros(rows, 2, dtype=torch.half, device="cuda")
     need = lib.lnh_grid_backward_workspace_size(off.data_ptr(), B, 3, 2, Lv, S, 16, 0, 0, 1)
     ws = torch.empty(need, dtype=torch.uint8, device="cuda")
