@@ -177,6 +177,49 @@ def test_backward_bucketed(dt, kind):
     with pytest.raises(RuntimeError, match="workspace too small"):
         call("lnh_grid_encode_backward_ws", dev(g), dev(x), offh, ge, B, 3, CH, L, S, H, 0, 0, 0, code, ws, 1024)
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16])
+@pytest.mark.parametrize("pattern", ["sprinkle30", "sprinkle70", "tail", "both", "all_zero"])
+def test_backward_bucketed_with_zero_gradient_samples(dt, pattern):
+    """Samples whose upstream gradient is exactly zero (everything behind a learned surface; sprinkled ones in a noisy field):
+    within three lanes of a sample that has a gradient they stay silent members of its run, elsewhere they are dropped before
+    the pool (profiles/r05_reduce_drift.txt) — either way the table is the oracle's, bit-reproducibly.  Ray-ordered points, so
+    that runs exist on the coarse and middle levels."""
+    from gpu_util import call, dev, host
+    from lidarnerf import _hip
+    n_rays, T = 48, 256
+    x = _ray_points(n_rays, T, 11)
+    B = x.shape[0]
+    nd = np.float32 if dt == torch.float32 else np.float16
+    r = np.random.default_rng(21)
+    g = (r.standard_normal((L, B, CH)) * 0.1).astype(nd)
+    keep = np.ones((n_rays, T), bool)
+    if pattern in ("sprinkle30", "both"):
+        keep &= r.random((n_rays, T)) >= 0.3
+    if pattern == "sprinkle70":
+        keep &= r.random((n_rays, T)) >= 0.7
+    if pattern in ("tail", "both"):
+        keep[:, T - 100:] = False
+    if pattern == "all_zero":
+        keep[:] = False
+    g *= keep.reshape(1, B, 1).astype(nd)
+    g[3, ::5] = 0  # ... and zeros that differ from level to level (a sample may be silent on one level only)
+    rows = int(OFF[-1])
+    want = c_oracle.grid_backward(g, x, OFF, rows, S, H)
+    code = 0 if dt == torch.float32 else 1
+    offh = torch.from_numpy(OFF)
+    need = _hip.lib().lnh_grid_backward_workspace_size(offh.data_ptr(), B, 3, CH, L, S, H, 0, 0, code)
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    outs = []
+    for _ in range(2):
+        ge = torch.zeros((rows, CH), dtype=dt, device="cuda")
+        call("lnh_grid_encode_backward_ws", dev(g), dev(x), offh, ge, B, 3, CH, L, S, H, 0, 0, 0, code, ws, need)
+        outs.append(ge)
+    assert torch.equal(outs[0], outs[1])
+    _check_table(host(outs[0]).astype(np.float64), want, dt)
+    if pattern == "all_zero":
+        assert float(outs[0].abs().max()) == 0.0
+
+
 def _plan(B, level, code):
     """(buckets of the level, pool slots per bucket, rows per bucket, entries per reduce slice) of the workspace plan."""
     from lidarnerf import _hip
