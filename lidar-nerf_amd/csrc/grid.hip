@@ -675,8 +675,15 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
         (void)locate<D>(x, lv, align != 0, interp, cell);
         const float g0 = ok ? (float)gv.v[0] : 0.0f, g1 = ok ? (float)gv.v[1] : 0.0f;
         // a sample whose upstream gradient is exactly zero (fp16 underflow behind an opaque surface, masked-out
-        // rays) contributes nothing: drop it here instead of moving zero entries through the pool
-        ok = ok && (g0 != 0.0f || g1 != 0.0f);
+        // rays) contributes nothing: it moves no entry of its own through the pool, but within three lanes of a sample
+        // that has a gradient it stays a silent member of the run (k_grid_bwd_scatter_plain has the measurements:
+        // dropped outright, it cut the runs of a trained field's coarse levels)
+        const bool nonzero = ok && (g0 != 0.0f || g1 != 0.0f);
+        {
+            const unsigned long long in_m = __ballot(ok), nz_m = __ballot(nonzero);
+            const unsigned long long nz1_m = nz_m | (nz_m << 1) | (nz_m >> 1);
+            ok = ((in_m & (nz1_m | (nz1_m << 2) | (nz1_m >> 2))) >> lane) & 1ull;
+        }
         // ---- run-merge inside 16-lane rows: consecutive lanes are consecutive samples of a ray, which share their cell
         //      on the coarser levels.  Runs are cut at DPP row starts (pure-VALU row_shr scan, no cross-row traffic), and
         //      a wave with fewer than kMinMerges mergeable lanes skips the scan altogether — on the fine levels almost
@@ -701,7 +708,8 @@ k_grid_bwd_scatter(const T *__restrict__ grad, const float *__restrict__ inputs,
         const unsigned long long below = heads & ((2ull << lane) - 1ull);
         const int run_start = 63 - __builtin_clzll(below);
         const unsigned long long heads_above = (lane == 63) ? 0ull : (heads >> (lane + 1));
-        emit = ok && ((lane == 63) || (heads_above & 1ull));
+        // run tails; a zero-gradient sample that is a run of one emits nothing
+        emit = ok && ((lane == 63) || (heads_above & 1ull)) && (nonzero || !((heads >> lane) & 1ull));
         xterm_xor = cell.term[0][0] ^ cell.term[0][1];
         const f32x2_t gg = {g0, g1};
 #pragma unroll

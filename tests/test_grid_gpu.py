@@ -490,6 +490,11 @@ def test_backward_bucketed_generic_level_classes(dt, interp, gridtype, align):
     B, rows = x.shape[0], int(off[-1])
     nd = np.float32 if dt == torch.float32 else np.float16
     g = (np.random.default_rng(15).standard_normal((L, B, CH)) * 0.1).astype(nd)
+    # zero-gradient samples among the ray-ordered points: sprinkled ones (silent members of their runs) and the far end of
+    # every ray (dropped before the pool)
+    zr = np.random.default_rng(16).random(24 * 256) < 0.4
+    zr.reshape(24, 256)[:, 200:] = True
+    g[:, :24 * 256][:, zr] = 0
     want = c_oracle.grid_backward(g, x, off, rows, S, H, gridtype, align, interp)
     code = 0 if dt == torch.float32 else 1
     offh = torch.from_numpy(off)
