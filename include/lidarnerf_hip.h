@@ -200,14 +200,25 @@ LNH_API int lnh_mlp_forward(const void *inputs, const void *weights, uint32_t B,
                             uint32_t output_dim, uint32_t hidden_dim, uint32_t n_hidden_mats, uint32_t activation,
                             uint32_t output_activation, void *forward_buffer, void *outputs, lnh_stream_t stream);
 /*
- * grad [B,output_dim] f16; grad_weights: f32 flat vector (same ordering as weights), ZERO-INITIALISED by the
- * caller, receives per-workgroup partial sums by atomic add; grad_inputs NULL or [B,input_dim] f16.
+ * Weight gradients of the MLP family are FIXED-ORDER sums: every backward kernel leaves one partial sum per workgroup in
+ * `wgrad_ws` and a second, small launch on the same stream adds the partials up in workgroup-index order and adds the result
+ * to the gradient (csrc/wgrad.h) — the same bits on every run, as with the reference's split-K GEMMs (ffmlp.cu:1107-1142);
+ * rounds 1-5 used fp32 device atomics, whose order changed from run to run.
+ * wgrad_ws: device scratch of lnh_wgrad_workspace_bytes() bytes, 16-byte aligned, contents irrelevant; one workspace serves
+ * all launches of a stream, launches that may overlap in time (several streams) need one each.  Taken by lnh_mlp_backward,
+ * lnh_density_mlp_backward, lnh_lidar_color_backward(_image), lnh_ragged_color_backward, lnh_lidar_dir_term_backward and
+ * their _bf16 builds.
+ */
+LNH_API uint64_t lnh_wgrad_workspace_bytes(void);
+/*
+ * grad [B,output_dim] f16; grad_weights: f32 flat vector (same ordering as weights, 16-byte aligned): the batch's sum is
+ * ADDED to it (clear it first for a plain gradient); grad_inputs NULL or [B,input_dim] f16.
  * The hidden activations are recomputed from `inputs` (no forward_buffer needed).
  */
 LNH_API int lnh_mlp_backward(const void *grad, const void *inputs, const void *weights, uint32_t B,
                              uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t n_hidden_mats,
                              uint32_t activation, uint32_t output_activation, void *grad_inputs, float *grad_weights,
-                             lnh_stream_t stream);
+                             void *wgrad_ws, uint64_t wgrad_ws_bytes, lnh_stream_t stream);
 
 /*
  * Shapes.  hidden_dim 32 / 64 with n_hidden_mats <= 2: register-resident kernels, and lnh_mlp_backward is ONE kernel.
@@ -394,10 +405,11 @@ LNH_API int lnh_grid_encode_forward_mapped(const float *inputs_all, const void *
 LNH_API int lnh_density_mlp_forward(const void *features, const void *weights, uint32_t B, uint32_t T_cur,
                                     uint32_t T_tot, uint32_t slot_off, uint32_t feat_rows, void *h16, float *sigma,
                                     lnh_stream_t stream);
-/* grad_h16 rows addressed like h16 above -> grad_features [16,B,2] fp16, grad_weights fp32 (accumulated). */
+/* grad_h16 rows addressed like h16 above -> grad_features [16,B,2] fp16, grad_weights fp32 += (fixed-order sum, see
+ * lnh_wgrad_workspace_bytes). */
 LNH_API int lnh_density_mlp_backward(const void *grad_h16, const void *features, const void *weights, uint32_t B,
                                      uint32_t T_cur, uint32_t T_tot, uint32_t slot_off, void *grad_features,
-                                     float *grad_weights, lnh_stream_t stream);
+                                     float *grad_weights, void *wgrad_ws, uint64_t wgrad_ws_bytes, lnh_stream_t stream);
 /*
  * lnh_lidar_merge_weights: sigma_m[n,i] = sigma_pt[n, perm[n,i]] and the compositing weights of the merged samples
  * (renderer.py:217-243); z [N,T] merged (sorted) depths, perm from lnh_lidar_resample.
@@ -428,11 +440,12 @@ LNH_API int lnh_lidar_dir_term(const float *dir_features, const float *w0, uint3
 LNH_API int lnh_lidar_dir_term_freq(const float *dirs, uint32_t degree, const float *w0, uint32_t ldw, uint32_t N,
                                     float *features16, float *cdir, lnh_stream_t stream);
 /* grad_w0[o*ldw + k] += sum_n ray_sum[n,o] * features16[n,k], k < K  (ray_sum [N,64] from lnh_lidar_color_backward; the
- * sums are ADDED with device atomics: clear grad_w0 first).  grad_w0g != NULL: the packed [64,16] gradient of the colour
+ * sum over the rays is formed in a fixed order — wgrad_ws, see lnh_wgrad_workspace_bytes — and ADDED: clear grad_w0 first).  grad_w0g != NULL: the packed [64,16] gradient of the colour
  * head's geo-feature columns (what lnh_lidar_color_backward accumulates at the front of its grad_w) is copied to
  * grad_w0[o*ldw + K + c] = grad_w0g[o*16 + 1 + c], c < 15 — the whole gradient of network.py:199's first Linear in one launch. */
 LNH_API int lnh_lidar_dir_term_backward(const float *ray_sum, const float *features16, uint32_t N, uint32_t K,
-                                        const float *grad_w0g, float *grad_w0, uint32_t ldw, lnh_stream_t stream);
+                                        const float *grad_w0g, float *grad_w0, uint32_t ldw, void *wgrad_ws,
+                                        uint64_t wgrad_ws_bytes, lnh_stream_t stream);
 LNH_API int lnh_lidar_pack_weights(const float *ws0, uint32_t ld_s0, const float *ws1, uint32_t ld_s1,
                                    const float *wc0, uint32_t ld_c0, uint32_t n_dir, const float *wc1, uint32_t ld_c1,
                                    const float *wc2, uint32_t ld_c2, void *wsig16, void *wcol16, lnh_stream_t stream);
@@ -471,7 +484,8 @@ LNH_API int lnh_ragged_color_forward(const void *h16, const int32_t *rays, const
                                      uint32_t M, float *rgb, lnh_stream_t stream);
 LNH_API int lnh_ragged_color_backward(const float *grad_rgb, const float *grad_sigma, float density_scale, const void *h16,
                                       const int32_t *rays, const float *cdir, const void *w16, uint32_t N, uint32_t M,
-                                      void *grad_h16, float *grad_w, float *ray_sum, lnh_stream_t stream);
+                                      void *grad_h16, float *grad_w, float *ray_sum, void *wgrad_ws,
+                                      uint64_t wgrad_ws_bytes, lnh_stream_t stream);
 /*
  * Element-wise stages of the occupancy-grid render chain over the marcher's flat sample list [M] (BASELINE config 4; the
  * reference kept torch-ngp's kernels, raymarching.cu:331-772, and dropped this caller — what runs between them are the
@@ -527,20 +541,21 @@ LNH_API int lnh_lidar_color_composite_forward(const float *z, const float *sigma
 /*
  * lnh_lidar_color_backward: grad_rgb [N,T,2], grad_sigma [N,T] (merged order, from lnh_lidar_composite_backward)
  * -> grad_h16 [N*T,16] fp16 in POINT order (col 0 = grad_sigma * exp(clamp(pre,-15,15)), activation.py:17-19;
- * cols 1..15 = colour-head input gradient), grad_w fp32 flat like w16 (accumulated), ray_sum [N,64] f32 = sum over
+ * cols 1..15 = colour-head input gradient), grad_w fp32 flat like w16 (+=, fixed-order sum: wgrad_ws), ray_sum [N,64] f32 = sum over
  * the ray of d(hidden0) (multiply by freq(d) to get the gradient of W0[:, :75]).
  */
 LNH_API int lnh_lidar_color_backward(const float *grad_rgb, const float *grad_sigma, const void *h16,
                                      const int32_t *perm, const float *weights, const float *cdir, const void *w16,
                                      uint32_t N, uint32_t T, void *grad_h16, float *grad_w, float *ray_sum,
-                                     lnh_stream_t stream);
+                                     void *wgrad_ws, uint64_t wgrad_ws_bytes, lnh_stream_t stream);
 /* The same with grad_rgb formed on the fly from grad_image [N,2] = d loss / d image: grad_rgb[n,i,:] = weights[n,i] *
  * grad_image[n,:], which is all lnh_lidar_composite_backward would have written there (call it with grad_rgb = NULL):
  * the [N,T,2] gradient never travels through HBM. */
 LNH_API int lnh_lidar_color_backward_image(const float *grad_image, const float *grad_sigma, const void *h16,
                                            const int32_t *perm, const float *weights, const float *cdir,
                                            const void *w16, uint32_t N, uint32_t T, void *grad_h16, float *grad_w,
-                                           float *ray_sum, lnh_stream_t stream);
+                                           float *ray_sum, void *wgrad_ws, uint64_t wgrad_ws_bytes,
+                                           lnh_stream_t stream);
 
 /* ---- range image <-> point cloud (lidarnerf/convert.py:99-160, 194-237) ---------------------------
  * lnh_lidar_to_pano: points [N,4] f32 (x,y,z,intensity) in the sensor frame -> pano [H,W] f32 (distance of the nearest
@@ -641,7 +656,7 @@ LNH_API int lnh_mlp_forward_bf16(const void *inputs, const void *weights, uint32
 LNH_API int lnh_mlp_backward_bf16(const void *grad, const void *inputs, const void *weights, uint32_t B,
                              uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t n_hidden_mats,
                              uint32_t activation, uint32_t output_activation, void *grad_inputs, float *grad_weights,
-                             lnh_stream_t stream);
+                             void *wgrad_ws, uint64_t wgrad_ws_bytes, lnh_stream_t stream);
 LNH_API int lnh_mlp_backward_data_bf16(const void *grad, const void *forward_buffer, const void *weights_t, uint32_t B,
                                        uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim,
                                        uint32_t n_hidden_mats, uint32_t activation, void *backward_buffer,
@@ -651,7 +666,7 @@ LNH_API int lnh_density_mlp_forward_bf16(const void *features, const void *weigh
                                     lnh_stream_t stream);
 LNH_API int lnh_density_mlp_backward_bf16(const void *grad_h16, const void *features, const void *weights, uint32_t B,
                                      uint32_t T_cur, uint32_t T_tot, uint32_t slot_off, void *grad_features,
-                                     float *grad_weights, lnh_stream_t stream);
+                                     float *grad_weights, void *wgrad_ws, uint64_t wgrad_ws_bytes, lnh_stream_t stream);
 LNH_API int lnh_ragged_pack_weights_bf16(const float *ws0, uint32_t ld_s0, const float *ws1, uint32_t ld_s1, const float *wc0,
                                          uint32_t ld_c0, uint32_t n_in, const float *wc1, uint32_t ld_c1, const float *wc2,
                                          uint32_t ld_c2, void *wsig16, void *wcol16, lnh_stream_t stream);
@@ -682,7 +697,7 @@ LNH_API int lnh_ragged_color_forward_bf16(const void *h16, const int32_t *rays, 
 LNH_API int lnh_ragged_color_backward_bf16(const float *grad_rgb, const float *grad_sigma, float density_scale,
                                            const void *h16, const int32_t *rays, const float *cdir, const void *w16,
                                            uint32_t N, uint32_t M, void *grad_h16, float *grad_w, float *ray_sum,
-                                           lnh_stream_t stream);
+                                           void *wgrad_ws, uint64_t wgrad_ws_bytes, lnh_stream_t stream);
 LNH_API int lnh_lidar_color_forward_bf16(const void *h16, const int32_t *perm, const float *weights, const float *cdir,
                                     const void *w16, uint32_t N, uint32_t T, float *rgb, lnh_stream_t stream);
 LNH_API int lnh_lidar_color_composite_forward_bf16(const float *z, const float *sigma_pt, const int32_t *perm,
@@ -693,11 +708,12 @@ LNH_API int lnh_lidar_color_composite_forward_bf16(const float *z, const float *
 LNH_API int lnh_lidar_color_backward_bf16(const float *grad_rgb, const float *grad_sigma, const void *h16,
                                      const int32_t *perm, const float *weights, const float *cdir, const void *w16,
                                      uint32_t N, uint32_t T, void *grad_h16, float *grad_w, float *ray_sum,
-                                     lnh_stream_t stream);
+                                     void *wgrad_ws, uint64_t wgrad_ws_bytes, lnh_stream_t stream);
 LNH_API int lnh_lidar_color_backward_image_bf16(const float *grad_image, const float *grad_sigma, const void *h16,
                                                 const int32_t *perm, const float *weights, const float *cdir,
                                                 const void *w16, uint32_t N, uint32_t T, void *grad_h16,
-                                                float *grad_w, float *ray_sum, lnh_stream_t stream);
+                                                float *grad_w, float *ray_sum, void *wgrad_ws,
+                                                uint64_t wgrad_ws_bytes, lnh_stream_t stream);
 
 #ifdef __cplusplus
 }

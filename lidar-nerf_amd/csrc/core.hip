@@ -1,5 +1,6 @@
 // core.hip — version / error plumbing of liblidarnerf_hip.so.
 #include "common.h"
+#include "wgrad.h"
 
 static thread_local char g_err[512] = "";
 
@@ -27,4 +28,5 @@ int lnh_version(void) { return 100; }
 const char *lnh_last_error(void) { return g_err; }
 const char *lnh_arch(void) { return "gfx950"; }
 const char *lnh_build_variant(void) { return LNH_VARIANT_TAG; }
+uint64_t lnh_wgrad_workspace_bytes(void) { return wgrad_ws_bytes(); }
 }

@@ -1635,11 +1635,14 @@ k_grid_bwd_reduce(T *__restrict__ grad_table, GridMeta meta, BucketPlan plan, co
         constexpr uint32_t RPT = kBucketRows / 1024;
         Vec<T, 2> cur[RPT];
         // table_zero (workgroup-uniform): the caller has just cleared the gradient and this is its first chunk — the rows
-        // hold zeros, nothing to read (27 MB per step and the round trip at the end of every workgroup)
+        // hold zeros, nothing to read (27 MB per step and the round trip at the end of every workgroup).  Not so on a level
+        // whose spill list ran full: the scatter pass has then added entries straight into the table with device atomics
+        // (its last resort), and those rows must be read like any others.
+        const bool rows_are_zero = table_zero && spill_cursor[level] <= plan.spill_cap;
 #pragma unroll
         for (uint32_t i = 0; i < RPT; i++) {
             const uint32_t row = table_row(threadIdx.x + i * 1024u);
-            if (table_zero) {
+            if (rows_are_zero) {
                 cur[i].v[0] = (T)0.0f;
                 cur[i].v[1] = (T)0.0f;
             } else {

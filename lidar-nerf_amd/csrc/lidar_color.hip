@@ -4,6 +4,7 @@
 // mlp_common.h for the register-resident layer chaining and the fp16 / bf16 element-type builds
 // (lidar_color_bf16.hip compiles this file again with bf16 MFMA operands: entry points lnh_lidar_color_*_bf16).
 #include "mlp_common.h"
+#include "wgrad.h"
 #include <type_traits>
 
 namespace LNH_MLP_NS {
@@ -25,7 +26,8 @@ struct ColorArgs {
     const float *g_image;   // bwd in  [N,2] (used when g_rgb is null)
     const float *g_sigma;   // bwd in  [N,T] merged order
     half_t *g_h16;          // bwd out [N*T,16] point order
-    float *dW;              // bwd out flat fp32 (kWTotal), atomically accumulated
+    float *dW;              // bwd out flat fp32 (kWTotal): the sum over all workgroups is ADDED to it, in a fixed order (wgrad.h)
+    WgradWs ws;             // bwd: scratch of that sum
     float *S;               // bwd out [N,64] fp32: sum over the ray of d(hidden0 pre-activation)
     uint32_t N, T;
     // fused forward tail only (k_color_forward_ray): merge + weights + colour + compositing of a ray in one kernel
@@ -368,7 +370,8 @@ k_color_forward_ragged(ColorArgs a) {
 // what the layer chain leaves in registers; a transpose of a packed fp16 fragment is one MFMA against an identity
 // fragment (the A and B operand layouts are mirror images: row/col = lane & 15, same k enumeration), which is exact.
 // Every wave owns all 24 gradient tiles (dW2 4, dW1 16, dW0g 4) in accumulators; the four waves of a workgroup are
-// combined through LDS once at the end and flushed with one atomic per weight.
+// combined through LDS once at the end (wave order) and the workgroups' sums are added up in index order (wgrad.h): the
+// gradient carries the same bits on every run.  (Rounds 1-5: one fp32 device atomic per weight and workgroup.)
 // Round 5 built the transposes on gfx950's transposing LDS read as well (ds_read_b64_tr_b16: the sigma-net backward in
 // mlp_bwd.h runs on it) — for THIS kernel, one wave per SIMD, both LDS forms lost to the identity MFMAs (283.9 / 291.4
 // against 268.4 us: profiles/r05_color_backward_wgrad.txt) and were removed again.
@@ -760,7 +763,8 @@ k_color_backward_wi(ColorArgs a) {
         for (int i = 0; i < HT; i++) agpr_settle(gW1[t][i]);
     }
 
-    // ---- combine the waves of the workgroup through LDS, then one atomic per weight
+    // ---- combine the waves of the workgroup through LDS (wave order); the workgroups' sums are added in index order by the
+    //      launcher's second launch (k_wgrad_reduce, wgrad.h)
     for (uint32_t w = 0; w < nw; w++) {
         if (wid == w) {
 #pragma unroll
@@ -780,18 +784,9 @@ k_color_backward_wi(ColorArgs a) {
         }
         __syncthreads();
     }
-    for (uint32_t e = threadIdx.x; e < NTILE * 256; e += blockDim.x) {
-        const uint32_t tile = e >> 8, r = (e >> 6) & 3, ln = e & 63, gg = ln >> 4, cc = ln & 15;
-        const float v = red[e];
-        if (tile < HT) {
-            unsafeAtomicAdd(a.dW + kW2 + (size_t)(4 * gg + r) * 64 + 16 * tile + cc, v);
-        } else if (tile < HT + HT * HT) {
-            const uint32_t t = (tile - HT) / HT, i = (tile - HT) % HT;
-            unsafeAtomicAdd(a.dW + kW1 + (size_t)(16 * t + 4 * gg + r) * 64 + 16 * i + cc, v);
-        } else {
-            const uint32_t t = tile - HT - HT * HT;
-            unsafeAtomicAdd(a.dW + kW0g + (size_t)(16 * t + 4 * gg + r) * 16 + cc, v);
-        }
+    {
+        float4 *mine = reinterpret_cast<float4 *>(wgrad_partial(a.ws, NTILE * 256));
+        for (uint32_t e = threadIdx.x; e < NTILE * 64; e += blockDim.x) mine[e] = reinterpret_cast<const float4 *>(red)[e];
     }
 #undef WF
 }
@@ -833,43 +828,55 @@ int LNH_MLP_FN(lnh_lidar_color_composite_forward)(const float *z, const float *s
     return lnh_check_launch("lnh_lidar_color_composite_forward");
 }
 
+// second launch of the colour backward: the workgroups' partials [W2: 4 tiles | W1: 16 tiles | W0g: 4 tiles] added up in
+// index order and added to grad_w (wgrad.h)
+static void color_wgrad_reduce(const ColorArgs &a, uint32_t nwg, hipStream_t s) {
+    const WgradTileMap map{{{a.dW + kW2, 0, 4, 4, 64}, {a.dW + kW1, 4, 4, 4, 64}, {a.dW + kW0g, 20, 1, 1, 16}}};
+    wgrad_reduce_launch(a.ws, nwg, 24 * 256, map, s);
+}
+
 static int color_backward_launch(const float *grad_rgb, const float *grad_image, const float *grad_sigma, const void *h16, const int32_t *perm,
                              const float *weights, const float *cdir, const void *w16, uint32_t N, uint32_t T,
-                             void *grad_h16, float *grad_w, float *ray_sum, lnh_stream_t stream) {
+                             void *grad_h16, float *grad_w, float *ray_sum, void *wgrad_ws, uint64_t wgrad_ws_bytes,
+                             lnh_stream_t stream) {
     LNH_REQUIRE((grad_rgb || grad_image) && grad_sigma && h16 && perm && weights && cdir && w16 && grad_h16 && grad_w && ray_sum,
                 LNH_ERR_INVALID_ARG, "lidar_color_backward: null pointer");
+    LNH_REQUIRE(((uintptr_t)grad_w & 15) == 0, LNH_ERR_INVALID_ARG, "lidar_color_backward: grad_w must be 16-byte aligned");
     if (N == 0 || T == 0) return LNH_OK;
     LNH_REQUIRE((uint64_t)N * T < 0xffffffffull, LNH_ERR_UNSUPPORTED, "lidar_color_backward: N*T must fit 32 bits");
     ColorArgs a{};
     a.h16 = (const half_t *)h16; a.perm = perm; a.weights = weights; a.cdir = cdir; a.W = (const half_t *)w16;
     a.g_rgb = grad_rgb; a.g_image = grad_image; a.g_sigma = grad_sigma; a.g_h16 = (half_t *)grad_h16; a.dW = grad_w; a.S = ray_sum;
     a.N = N; a.T = T;
-    // persistent workgroups: each flushes 6144 weight-gradient partials with device atomics (~20 G/s chip-wide), so
-    // keep the workgroup count near the CU count rather than one per ray
-    const uint32_t nwg = (N + 3) / 4;
+    if (int rc = wgrad_ws_open(wgrad_ws, wgrad_ws_bytes, a.ws, "lidar_color_backward")) return rc;
+    // persistent workgroups (one per CU): each leaves 6144 weight-gradient partials behind
+    const uint32_t nwg = (N + 3) / 4 < 256 ? (N + 3) / 4 : 256;
     if (grad_rgb) {
-        LNH_LAUNCH((k_color_backward_wi<false>), dim3(nwg < 256 ? nwg : 256), dim3(256), 0, (hipStream_t)stream, a);
+        LNH_LAUNCH((k_color_backward_wi<false>), dim3(nwg), dim3(256), 0, (hipStream_t)stream, a);
     } else {
-        LNH_LAUNCH((k_color_backward_wi<true>), dim3(nwg < 256 ? nwg : 256), dim3(256), 0, (hipStream_t)stream, a);
+        LNH_LAUNCH((k_color_backward_wi<true>), dim3(nwg), dim3(256), 0, (hipStream_t)stream, a);
     }
+    color_wgrad_reduce(a, nwg, (hipStream_t)stream);
     return lnh_check_launch("lnh_lidar_color_backward");
 }
 
 int LNH_MLP_FN(lnh_lidar_color_backward)(const float *grad_rgb, const float *grad_sigma, const void *h16, const int32_t *perm,
                              const float *weights, const float *cdir, const void *w16, uint32_t N, uint32_t T,
-                             void *grad_h16, float *grad_w, float *ray_sum, lnh_stream_t stream) {
+                             void *grad_h16, float *grad_w, float *ray_sum, void *wgrad_ws, uint64_t wgrad_ws_bytes,
+                             lnh_stream_t stream) {
     LNH_REQUIRE(grad_rgb, LNH_ERR_INVALID_ARG, "lidar_color_backward: null pointer");
     return color_backward_launch(grad_rgb, nullptr, grad_sigma, h16, perm, weights, cdir, w16, N, T, grad_h16, grad_w, ray_sum,
-                                 stream);
+                                 wgrad_ws, wgrad_ws_bytes, stream);
 }
 
 int LNH_MLP_FN(lnh_lidar_color_backward_image)(const float *grad_image, const float *grad_sigma, const void *h16,
                                                const int32_t *perm, const float *weights, const float *cdir,
                                                const void *w16, uint32_t N, uint32_t T, void *grad_h16, float *grad_w,
-                                               float *ray_sum, lnh_stream_t stream) {
+                                               float *ray_sum, void *wgrad_ws, uint64_t wgrad_ws_bytes,
+                                               lnh_stream_t stream) {
     LNH_REQUIRE(grad_image, LNH_ERR_INVALID_ARG, "lidar_color_backward_image: null pointer");
     return color_backward_launch(nullptr, grad_image, grad_sigma, h16, perm, weights, cdir, w16, N, T, grad_h16, grad_w,
-                                 ray_sum, stream);
+                                 ray_sum, wgrad_ws, wgrad_ws_bytes, stream);
 }
 
 
@@ -886,16 +893,20 @@ int LNH_MLP_FN(lnh_ragged_color_forward)(const void *h16, const int32_t *rays, c
 
 int LNH_MLP_FN(lnh_ragged_color_backward)(const float *grad_rgb, const float *grad_sigma, float density_scale, const void *h16,
                                          const int32_t *rays, const float *cdir, const void *w16, uint32_t N, uint32_t M,
-                                         void *grad_h16, float *grad_w, float *ray_sum, lnh_stream_t stream) {
+                                         void *grad_h16, float *grad_w, float *ray_sum, void *wgrad_ws,
+                                         uint64_t wgrad_ws_bytes, lnh_stream_t stream) {
     LNH_REQUIRE(grad_rgb && grad_sigma && h16 && rays && cdir && w16 && grad_h16 && grad_w && ray_sum, LNH_ERR_INVALID_ARG,
                 "ragged_color_backward: null pointer");
+    LNH_REQUIRE(((uintptr_t)grad_w & 15) == 0, LNH_ERR_INVALID_ARG, "ragged_color_backward: grad_w must be 16-byte aligned");
     if (N == 0 || M == 0) return LNH_OK;
     ColorArgs a{};
     a.h16 = (const half_t *)h16; a.rays = rays; a.cdir = cdir; a.W = (const half_t *)w16; a.g_rgb = grad_rgb;
     a.g_sigma = grad_sigma; a.g_h16 = (half_t *)grad_h16; a.dW = grad_w; a.S = ray_sum; a.N = N; a.M = M; a.T = 0;
     a.gs_scale = density_scale;
-    const uint32_t nwg = (N + 3) / 4;
-    LNH_LAUNCH((k_color_backward_wi<false, true>), dim3(nwg < 256 ? nwg : 256), dim3(256), 0, (hipStream_t)stream, a);
+    if (int rc = wgrad_ws_open(wgrad_ws, wgrad_ws_bytes, a.ws, "ragged_color_backward")) return rc;
+    const uint32_t nwg = (N + 3) / 4 < 256 ? (N + 3) / 4 : 256;
+    LNH_LAUNCH((k_color_backward_wi<false, true>), dim3(nwg), dim3(256), 0, (hipStream_t)stream, a);
+    color_wgrad_reduce(a, nwg, (hipStream_t)stream);
     return lnh_check_launch("lnh_ragged_color_backward");
 }
 

@@ -3,6 +3,7 @@
 // loss).  Each is one launch here; none of them is bandwidth- or compute-relevant, the point is the launch count.
 #include "common.h"
 #include "lidar_steps.h"
+#include "wgrad.h"
 
 namespace {
 
@@ -66,16 +67,17 @@ k_dir_term(const float *__restrict__ enc, const float *__restrict__ W0, uint32_t
 // d cdir / d W0_dir:  gW[o, k] += sum_n S[n, o] * enc16[n, k]  (S = per-ray sum of dH0 from the colour backward).
 // A library GEMM with M = 64, N = K <= 128 and a 4096-long reduction runs as one tile for ~43 us; rounds 1-4 ran two
 // passes (32-ray chunks staged in LDS to [64, 128] partials in scratch, then a sum over the 128 partials: 16 + 8 us).
-// Round 5, one launch: a workgroup owns the 64 outputs of ONE feature over a 1/16th of the rays (grid K x 16), its four
-// waves taking every fourth ray (S rows are 256-byte lines, one lane per output; the feature is a wave-uniform value), eight
-// rays in flight per wave; the four partial sums meet in LDS and 64 device atomics per workgroup add them into the
-// gradient — 16 adds per address instead of the 128 that made the atomic form lose in round 1.  Block (0, 0) also copies
-// the geo-feature columns of the colour head's first matrix, which the colour backward produced in its packed [64, 16]
-// layout (col 0 unused), to columns K .. K+14 of the same gradient.
+// One launch: a workgroup owns the 64 outputs of ONE feature over a 1/16th of the rays (grid K x 16), its four waves taking
+// every fourth ray (S rows are 256-byte lines, one lane per output; the feature is a wave-uniform value), eight rays in
+// flight per wave; the four partial sums meet in LDS (fixed order).  The 16 segments leave their sums in scratch and a second
+// launch adds them up in segment order and adds the result to the gradient (wgrad.h; round 5: 16 fp32 device atomics per
+// address, i.e. an order that changed from run to run).  Block (0, 0) also copies the geo-feature columns
+// of the colour head's first matrix, which the colour backward produced in its packed [64, 16] layout (col 0 unused), to
+// columns K .. K+14 of the same gradient.
 constexpr uint32_t kDirSegments = 16;
 __global__ void __launch_bounds__(256)
 k_dir_term_backward(const float *__restrict__ S, const float *__restrict__ enc16, uint32_t N, uint32_t K,
-                    const float *__restrict__ g_w0g, float *__restrict__ gW, uint32_t ldw) {
+                    const float *__restrict__ g_w0g, float *__restrict__ gW, uint32_t ldw, WgradWs ws) {
     __shared__ float part[4][64];
     const uint32_t o = threadIdx.x & 63, w = threadIdx.x >> 6, k = blockIdx.x;
     const uint32_t per = (N + kDirSegments - 1) / kDirSegments;
@@ -98,14 +100,29 @@ k_dir_term_backward(const float *__restrict__ S, const float *__restrict__ enc16
     for (; r < r1; r += 4) acc[0] = fmaf(S[(size_t)r * 64 + o], enc16[(size_t)r * K + k], acc[0]);
     part[w][o] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     __syncthreads();
-    if (w == 0) unsafeAtomicAdd(gW + (size_t)o * ldw + k, (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]));
     if (g_w0g && blockIdx.x == 0 && blockIdx.y == 0) {
         for (uint32_t i = threadIdx.x; i < 64 * 15; i += 256) {
             const uint32_t oo = i / 15, c = i % 15;
             gW[(size_t)oo * ldw + K + c] = g_w0g[oo * 16 + 1 + c];
         }
     }
+    // partial of segment y: [K][64] floats; the second launch (k_wgrad_reduce, wgrad.h) adds the 16 segments in order
+    if (w == 0) ws.partials[((size_t)blockIdx.y * K + k) * 64 + o] = (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]);
 }
+
+// element e4 of the summed partial = outputs o .. o + 3 of feature k
+struct DirTermEmit {
+    float *gW;
+    uint32_t ldw;
+    __device__ __forceinline__ void operator()(uint32_t e4, const float4 &v) const {
+        const uint32_t k = e4 >> 4, o = (e4 & 15) * 4;
+        float *p = gW + (size_t)o * ldw + k;
+        p[0] += v.x;
+        p[ldw] += v.y;
+        p[2 * (size_t)ldw] += v.z;
+        p[3 * (size_t)ldw] += v.w;
+    }
+};
 
 // ------------------------------------------------------------------------------------------------ weight packing
 // fp32 master weights (possibly strided views) -> the flat fp16 vectors the fused kernels read:
@@ -393,13 +410,17 @@ int lnh_lidar_dir_term_freq_bf16(const float *dirs, uint32_t degree, const float
 }
 
 int lnh_lidar_dir_term_backward(const float *ray_sum, const float *features16, uint32_t N, uint32_t K,
-                                const float *grad_w0g, float *grad_w0, uint32_t ldw, lnh_stream_t stream) {
+                                const float *grad_w0g, float *grad_w0, uint32_t ldw, void *wgrad_ws, uint64_t wgrad_ws_bytes,
+                                lnh_stream_t stream) {
     LNH_REQUIRE(ray_sum && features16 && grad_w0, LNH_ERR_INVALID_ARG, "lidar_dir_term_backward: null pointer");
+    WgradWs ws;
+    if (int rc = wgrad_ws_open(wgrad_ws, wgrad_ws_bytes, ws, "lidar_dir_term_backward")) return rc;
     LNH_REQUIRE(K >= 1 && K <= 128 && ldw >= K + (grad_w0g ? 15u : 0u), LNH_ERR_INVALID_ARG,
                 "lidar_dir_term_backward: need 1 <= K <= 128 and ldw >= K (+ 15 with grad_w0g)");
     if (N == 0 && !grad_w0g) return LNH_OK;
     LNH_LAUNCH(k_dir_term_backward, dim3(K, kDirSegments), dim3(256), 0, (hipStream_t)stream, ray_sum, features16,
-               N, K, grad_w0g, grad_w0, ldw);
+               N, K, grad_w0g, grad_w0, ldw, ws);
+    wgrad_reduce_launch(ws, kDirSegments, K * 64, DirTermEmit{grad_w0, ldw}, (hipStream_t)stream);
     return lnh_check_launch("lnh_lidar_dir_term_backward");
 }
 

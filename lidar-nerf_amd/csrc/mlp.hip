@@ -254,8 +254,10 @@ int LNH_MLP_FN(lnh_mlp_forward)(const void *inputs, const void *weights, uint32_
 
 int LNH_MLP_FN(lnh_mlp_backward)(const void *grad, const void *inputs, const void *weights, uint32_t B, uint32_t input_dim,
                      uint32_t output_dim, uint32_t hidden_dim, uint32_t n_hidden_mats, uint32_t activation,
-                     uint32_t output_activation, void *grad_inputs, float *grad_weights, lnh_stream_t stream) {
+                     uint32_t output_activation, void *grad_inputs, float *grad_weights, void *wgrad_ws,
+                     uint64_t wgrad_ws_bytes, lnh_stream_t stream) {
     LNH_REQUIRE(grad && inputs && weights && grad_weights, LNH_ERR_INVALID_ARG, "mlp backward: null pointer");
+    LNH_REQUIRE(((uintptr_t)grad_weights & 15) == 0, LNH_ERR_INVALID_ARG, "mlp backward: grad_weights must be 16-byte aligned");
     LNH_REQUIRE(activation <= LNH_ACT_NONE && activation != LNH_ACT_SINE, LNH_ERR_UNSUPPORTED,
                 "mlp backward: Sine needs stored pre-activations (unsupported by the reference as well, utils.h:626-630)");
     LNH_REQUIRE(output_activation == LNH_ACT_NONE, LNH_ERR_UNSUPPORTED,
@@ -270,7 +272,9 @@ int LNH_MLP_FN(lnh_mlp_backward)(const void *grad, const void *inputs, const voi
     if (rc) return rc;
     if (B == 0) return LNH_OK;
     MlpBwdArgs a{(const half_t *)grad, inputs, (const half_t *)weights, grad_inputs,
-                 grad_weights, B, input_dim, hidden_dim, activation, output_activation, IoDims{1, 1, 0, 0}};
+                 grad_weights, B, input_dim, hidden_dim, activation, output_activation, IoDims{1, 1, 0, 0}, WgradWs{}};
+    rc = wgrad_ws_open(wgrad_ws, wgrad_ws_bytes, a.ws, "mlp backward");
+    if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     const uint32_t iks = (input_dim + 31) / 32;
     if (hidden_dim == 32) return lnh_mlp_backward_h32(iks, n_hidden_mats, a, s);
@@ -296,15 +300,18 @@ int LNH_MLP_FN(lnh_density_mlp_forward)(const void *features, const void *weight
 
 int LNH_MLP_FN(lnh_density_mlp_backward)(const void *grad_h16, const void *features, const void *weights, uint32_t B,
                              uint32_t T_cur, uint32_t T_tot, uint32_t slot_off, void *grad_features,
-                             float *grad_weights, lnh_stream_t stream) {
+                             float *grad_weights, void *wgrad_ws, uint64_t wgrad_ws_bytes, lnh_stream_t stream) {
     const uint32_t feat_rows = 0;
     LNH_REQUIRE(grad_h16 && features && weights && grad_features && grad_weights, LNH_ERR_INVALID_ARG,
                 "density mlp backward: null pointer");
+    LNH_REQUIRE(((uintptr_t)grad_weights & 15) == 0, LNH_ERR_INVALID_ARG,
+                "density mlp backward: grad_weights must be 16-byte aligned");
     LNH_REQUIRE(T_cur >= 1 && slot_off + T_cur <= T_tot && B % T_cur == 0, LNH_ERR_INVALID_ARG,
                 "density mlp backward: need B %% T_cur == 0 and slot_off + T_cur <= T_tot");
     if (B == 0) return LNH_OK;
     MlpBwdArgs a{(const half_t *)grad_h16, features, (const half_t *)weights, grad_features,
-                 grad_weights, B, 32, 64, LNH_ACT_RELU, LNH_ACT_NONE, IoDims{T_cur, T_tot, slot_off, feat_rows}};
+                 grad_weights, B, 32, 64, LNH_ACT_RELU, LNH_ACT_NONE, IoDims{T_cur, T_tot, slot_off, feat_rows}, WgradWs{}};
+    if (int rc = wgrad_ws_open(wgrad_ws, wgrad_ws_bytes, a.ws, "density mlp backward")) return rc;
     return lnh_density_mlp_backward_launch(a, (hipStream_t)stream);
 }
 

@@ -7,11 +7,13 @@
 //   3. each wave drops its dH_l^T / A_{l-1}^T columns into two workgroup-shared LDS tiles ([channel][point] fp16),
 //   4. after a barrier the 16x16 output tiles of dW_l are dealt round-robin to the waves; each wave contracts ITS
 //      tiles over all PB points with MFMA (k = points) into persistent fp32 accumulators.
-// The accumulators live in registers for the whole kernel and are flushed with one fp32 atomic per element per
-// workgroup.  (The reference computes dW with split-K CUTLASS GEMMs on side streams from saved activations,
-// lidarnerf/ffmlp/src/ffmlp.cu:1107-1263; here nothing but X, dY and W is read from HBM.)
+// The accumulators live in registers for the whole kernel; at its end every workgroup leaves its partial sums in scratch and
+// the partials are added up in workgroup-index order (wgrad.h): bit-reproducible gradients, like the split-K CUTLASS GEMMs
+// on saved activations the reference forms them with (lidarnerf/ffmlp/src/ffmlp.cu:1107-1263; here nothing but X, dY and W is
+// read from HBM).  Rounds 1-5 flushed with one fp32 device atomic per element and workgroup.
 #pragma once
 #include "mlp_common.h"
+#include "wgrad.h"
 
 namespace LNH_MLP_NS {
 
@@ -20,9 +22,10 @@ struct MlpBwdArgs {
     const void *X;     // [B,in_dim] MLP element type (RowMajorIO) / level-major fp16 features (DensityIO): IO::in_t
     const half_t *W;   // flat weights (MLP element type)
     void *dX;          // NULL or the gradient of X, same layout and type as X
-    float *dW;         // flat fp32, atomically accumulated
+    float *dW;         // flat fp32: the sum over the batch is ADDED to it (fixed summation order)
     uint32_t B, in_dim, hidden, act, out_act;
     IoDims io;
+    WgradWs ws;        // scratch of that sum (wgrad.h)
 };
 
 template <int IN_KS, int HT, int NHM, int NT>
@@ -269,26 +272,27 @@ k_mlp_backward(MlpBwdArgs a) {
         }
     }
 
-    // ---- flush (D layout: element (row 4g+r, col c) of each 16x16 tile)
+    // ---- this workgroup's partial sums, tile by tile (256 floats per tile: element r of lane 16 g + c = row 4g + r, col c),
+    //      for the sum over workgroups in index order (k_wgrad_reduce, wgrad.h: the launcher's second launch)
+    constexpr uint32_t NT0 = HT * IT, NTH = NHM * HT * HT, NTILES = NT0 + NTH + HT;
+    static_assert(NTILES * 256 <= kWgradMaxFloats, "weight-gradient workspace: partial larger than the plan");
+    float *mine = wgrad_partial(a.ws, NTILES * 256);
 #pragma unroll
     for (int q = 0; q < Cfg::NQ0; q++) {
-        const uint32_t idx = 4 * q + wid, t = idx / IT, i = idx % IT;
-        if (idx < HT * IT && i < in_tiles) {
+        const uint32_t idx = 4 * q + wid;
+        if (idx < NT0) {
 #pragma unroll
-            for (int r = 0; r < 4; r++)
-                unsafeAtomicAdd(dW0 + (size_t)(16 * t + 4 * g + r) * in_dim + 16 * i + c, gW0[q][r]);
+            for (int r = 0; r < 4; r++) mine[(idx * 4 + r) * 64 + lane] = gW0[q][r];
         }
     }
 #pragma unroll
     for (int m = 0; m < NHM; m++)
 #pragma unroll
         for (int q = 0; q < Cfg::NQH; q++) {
-            const uint32_t idx = 4 * q + wid, t = idx / HT, i = idx % HT;
+            const uint32_t idx = 4 * q + wid;
             if (idx < HT * HT) {
 #pragma unroll
-                for (int r = 0; r < 4; r++)
-                    unsafeAtomicAdd(dWh + (size_t)m * hidden * hidden + (size_t)(16 * t + 4 * g + r) * hidden + 16 * i + c,
-                                    gWh[m][q][r]);
+                for (int r = 0; r < 4; r++) mine[((NT0 + m * HT * HT + idx) * 4 + r) * 64 + lane] = gWh[m][q][r];
             }
         }
 #pragma unroll
@@ -296,7 +300,7 @@ k_mlp_backward(MlpBwdArgs a) {
         const uint32_t i = 4 * q + wid;
         if (i < HT) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) unsafeAtomicAdd(dWo + (size_t)(4 * g + r) * hidden + 16 * i + c, gWo[q][r]);
+            for (int r = 0; r < 4; r++) mine[((NT0 + NTH + i) * 4 + r) * 64 + lane] = gWo[q][r];
         }
     }
 }
@@ -314,7 +318,7 @@ k_mlp_backward(MlpBwdArgs a) {
 // images, so the product comes out point-major) and by multiplying the quantities that are not products with an identity
 // fragment: 22 MFMAs and a second copy of the activation arithmetic per 32 points, now 12 LDS writes and 22 LDS reads.
 // Waves never wait for each other; the partial sums of a workgroup are combined through LDS once at the end of the
-// kernel and flushed with one atomic per weight.
+// kernel (wave order) and the workgroups' sums are added up in index order (wgrad.h).
 template <int IN_KS, int HT>
 struct WiCfg {
     static constexpr int IT = IN_KS * 2, NT = 2;
@@ -473,8 +477,8 @@ k_mlp_backward_wi(MlpBwdArgs a) {
         }
     }
 
-    // ---- combine the waves of the workgroup through LDS, then one atomic per weight.  The whole gradient is only
-    //      ~100 cache lines, so device atomics on it serialise: keep the number of flushing workgroups ~ #CUs.
+    // ---- combine the waves of the workgroup through LDS (wave order); the workgroups' sums are added in index order by the
+    //      launcher's second launch (k_wgrad_reduce, wgrad.h)
     constexpr int NTILE = Cfg::NTILE;
     __syncthreads();  // (the reduction buffer lies over the slabs)
     for (uint32_t w = 0; w < nw; w++) {
@@ -497,17 +501,9 @@ k_mlp_backward_wi(MlpBwdArgs a) {
         }
         __syncthreads();
     }
-    float *dW0 = a.dW;
-    float *dWo = dW0 + (size_t)hidden * in_dim;
-    for (uint32_t e = threadIdx.x; e < NTILE * 256; e += blockDim.x) {
-        const uint32_t tile = e >> 8, r = (e >> 6) & 3, ln = e & 63, gg = ln >> 4, cc = ln & 15;
-        const float v = red[e];
-        if (tile < HT) {
-            unsafeAtomicAdd(dWo + (size_t)(4 * gg + r) * hidden + 16 * tile + cc, v);
-        } else {
-            const uint32_t t = (tile - HT) / IT, i = (tile - HT) % IT;
-            if (i < in_tiles) unsafeAtomicAdd(dW0 + (size_t)(16 * t + 4 * gg + r) * in_dim + 16 * i + cc, v);
-        }
+    {
+        float4 *mine = reinterpret_cast<float4 *>(wgrad_partial(a.ws, NTILE * 256));
+        for (uint32_t e = threadIdx.x; e < NTILE * 64; e += blockDim.x) mine[e] = reinterpret_cast<const float4 *>(red)[e];
     }
 }
 
@@ -519,6 +515,11 @@ int launch_mlp_backward_wi(const MlpBwdArgs &a, hipStream_t s) {
     auto k = a.act == LNH_ACT_RELU ? k_mlp_backward_wi<IN_KS, HT, IO, (int)LNH_ACT_RELU> : k_mlp_backward_wi<IN_KS, HT, IO, -1>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     LNH_LAUNCH(k, dim3(grid), dim3(64 * LNH_WI_WAVES), lds, s, a);
+    // partial = [dWo: HT tiles | dW0: HT x IT tiles]
+    constexpr uint32_t IT = WiCfg<IN_KS, HT>::IT;
+    float *dWo = a.dW + (size_t)a.hidden * a.in_dim;
+    const WgradTileMap map{{{dWo, 0, HT, HT, a.hidden}, {a.dW, HT, IT, a.in_dim / 16, a.in_dim}, {nullptr, 0xffffffffu, 1, 0, 0}}};
+    wgrad_reduce_launch(a.ws, grid, WiCfg<IN_KS, HT>::NTILE * 256, map, s);
     return lnh_check_launch("lnh_mlp_backward");
 }
 
@@ -528,11 +529,17 @@ int launch_mlp_backward(const MlpBwdArgs &a, hipStream_t s) {
     using Cfg = BwdCfg<IN_KS, HT, NHM, NT>;
     const size_t lds = Cfg::lds_bytes();
     const uint32_t steps = div_up(a.B, Cfg::PB);
-    const uint32_t grid = steps < 512 ? steps : 512;  // each workgroup ends with one atomic per weight: keep them few
+    const uint32_t grid = steps < kWgradMaxBlocks ? steps : kWgradMaxBlocks;  // (one partial of every weight gradient each)
     auto k = a.act == LNH_ACT_RELU ? k_mlp_backward<IN_KS, HT, NHM, NT, IO, (int)LNH_ACT_RELU>
                                    : k_mlp_backward<IN_KS, HT, NHM, NT, IO, -1>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     LNH_LAUNCH(k, dim3(grid), dim3(256), lds, s, a);
+    // partial = [dW0: HT x IT tiles | dWh: NHM x HT x HT tiles | dWo: HT tiles]
+    constexpr uint32_t IT = IN_KS * 2, NT0 = HT * IT, NTH = NHM * HT * HT;
+    float *dWh = a.dW + (size_t)a.hidden * a.in_dim, *dWo = dWh + (size_t)NHM * a.hidden * a.hidden;
+    const WgradTileMap map{{{a.dW, 0, IT, a.in_dim / 16, a.in_dim}, {dWh, NTH ? NT0 : 0xffffffffu, HT, HT, a.hidden},
+                            {dWo, NT0 + NTH, HT, HT, a.hidden}}};
+    wgrad_reduce_launch(a.ws, grid, (NT0 + NTH + HT) * 256, map, s);
     return lnh_check_launch("lnh_mlp_backward");
 }
 

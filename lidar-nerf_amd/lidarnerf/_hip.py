@@ -33,7 +33,7 @@ _SIGS = {
     "lnh_sh_encode_forward": [P, P, U32, U32, U32, P],
     "lnh_sh_encode_backward": [P, P, U32, U32, U32, P, P],
     "lnh_mlp_forward": [P, P, U32, U32, U32, U32, U32, U32, U32, P, P],
-    "lnh_mlp_backward": [P, P, P, U32, U32, U32, U32, U32, U32, U32, P, P],
+    "lnh_mlp_backward": [P, P, P, U32, U32, U32, U32, U32, U32, U32, P, P, P, C.c_uint64],
     "lnh_mlp_backward_data": [P, P, P, U32, U32, U32, U32, U32, U32, P, P],
     "lnh_near_far_from_aabb": [P, P, P, U32, F32, P, P],
     "lnh_sph_from_ray": [P, P, F32, U32, P],
@@ -58,14 +58,14 @@ _SIGS = {
     "lnh_lidar_coarse_sample_points": [P, P, P, P, F32, U32, U32, U32, F32, F32, P, P],
     "lnh_grid_encode_forward_mapped": [P, P, P, P, U32, U32, U32, U32, U32, U32, U32, F32, U32, I32],
     "lnh_density_mlp_forward": [P, P, U32, U32, U32, U32, U32, P, P],
-    "lnh_density_mlp_backward": [P, P, P, U32, U32, U32, U32, P, P],
+    "lnh_density_mlp_backward": [P, P, P, U32, U32, U32, U32, P, P, P, C.c_uint64],
     "lnh_lidar_merge_weights": [P, P, P, P, U32, U32, F32, P, P],
     "lnh_lidar_color_forward": [P, P, P, P, P, U32, U32, P],
     "lnh_lidar_color_composite_forward": [P, P, P, P, P, P, P, U32, U32, F32, P, P, P, P, P, P],
     "lnh_lidar_coarse_samples": [P, U32, U32, F32, F32, P],
     "lnh_lidar_dir_term": [P, P, U32, U32, U32, P, P],
     "lnh_lidar_dir_term_freq": [P, U32, P, U32, U32, P, P],
-    "lnh_lidar_dir_term_backward": [P, P, U32, U32, P, P, U32],
+    "lnh_lidar_dir_term_backward": [P, P, U32, U32, P, P, U32, P, C.c_uint64],
     "lnh_lidar_pack_weights": [P, U32, P, U32, P, U32, U32, P, U32, P, U32, P, P],
     "lnh_lidar_to_pano": [P, U32, U32, U32, F32, F32, F32, P, P, P],
     "lnh_pano_to_lidar": [P, P, U32, U32, F32, F32, P, P],
@@ -82,10 +82,10 @@ _SIGS = {
                        C.c_double, U32],
     "lnh_zero_regions": [P, P, U32],
     "lnh_lidar_march_prologue": [P, P, P, U32, F32, F32, P, P, P, P, U32],
-    "lnh_lidar_color_backward": [P, P, P, P, P, P, P, U32, U32, P, P, P],
-    "lnh_lidar_color_backward_image": [P, P, P, P, P, P, P, U32, U32, P, P, P],
+    "lnh_lidar_color_backward": [P, P, P, P, P, P, P, U32, U32, P, P, P, P, C.c_uint64],
+    "lnh_lidar_color_backward_image": [P, P, P, P, P, P, P, U32, U32, P, P, P, P, C.c_uint64],
     "lnh_ragged_color_forward": [P, P, P, P, U32, U32, P],
-    "lnh_ragged_color_backward": [P, P, F32, P, P, P, P, U32, U32, P, P, P],
+    "lnh_ragged_color_backward": [P, P, F32, P, P, P, P, U32, U32, P, P, P, P, C.c_uint64],
     "lnh_ragged_points": [P, F32, U32, P],
     "lnh_ragged_pack_weights": [P, U32, P, U32, P, U32, U32, P, U32, P, U32, P, P],
     "lnh_ragged_color_input": [P, P, U32, U32, P],
@@ -103,7 +103,7 @@ for _n in ("lnh_mlp_forward", "lnh_mlp_backward", "lnh_mlp_backward_data", "lnh_
 EXPORTS = sorted(list(_SIGS) + ["lnh_version", "lnh_last_error", "lnh_arch", "lnh_build_variant",
                                  "lnh_grid_backward_workspace_size", "lnh_grid_backward_workspace_size_min",
                                  "lnh_grid_backward_plan_info", "lnh_grid_backward_workspace_clear_bytes",
-                                 "lnh_grid_backward_set_slice_entries"])
+                                 "lnh_grid_backward_set_slice_entries", "lnh_wgrad_workspace_bytes"])
 
 LNH_F32, LNH_F16 = 0, 1
 LNH_BWD_WS_CLEARED, LNH_BWD_TABLE_ZERO = 1, 2
@@ -138,6 +138,8 @@ def lib():
         L.lnh_grid_backward_plan_info.restype = C.c_int
         L.lnh_grid_backward_set_slice_entries.argtypes = [U32]
         L.lnh_grid_backward_set_slice_entries.restype = None
+        L.lnh_wgrad_workspace_bytes.argtypes = []
+        L.lnh_wgrad_workspace_bytes.restype = C.c_uint64
         L.lnh_last_error.restype = C.c_char_p
         L.lnh_arch.restype = C.c_char_p
         L.lnh_build_variant.restype = C.c_char_p
@@ -219,6 +221,27 @@ def zero_regions(tensors):
     ptrs = (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
     sizes = (C.c_uint64 * len(ts))(*[t.numel() * t.element_size() for t in ts])
     call("lnh_zero_regions", C.cast(ptrs, C.c_void_p), C.cast(sizes, C.c_void_p), len(ts))
+
+
+_WGRAD_WS = {}
+
+
+def wgrad_ws(device):
+    """(pointer, bytes) of the weight-gradient workspace of `device` for the MLP backward entry points (include/
+    lidarnerf_hip.h, lnh_wgrad_workspace_bytes): allocated once per device and kept for the life of the process —
+    a captured step keeps its address.  The backward launches of a process use it one after the other (one training stream
+    per device, as everywhere in this package); a caller that runs backward passes on several streams of one device at the
+    same time must hand each its own workspace."""
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    t = _WGRAD_WS.get(key)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("lidarnerf_hip: the weight-gradient workspace must exist before a step is captured "
+                               "(run one step eagerly first)")
+        t = _WGRAD_WS[key] = torch.empty(int(lib().lnh_wgrad_workspace_bytes()), dtype=torch.uint8,
+                                         device=torch.device("cuda", key))
+    return t.data_ptr(), t.numel()
 
 
 def ptr_array(values):

@@ -43,7 +43,7 @@ def _backward_raw(gy16, x16, w16, in_dim, hidden, nhm, act, need_dx):
     gx = torch.empty((B, in_dim), dtype=x16.dtype, device=x16.device) if need_dx else None
     gw = torch.zeros(w16.numel(), dtype=torch.float32, device=x16.device)
     _hip.call("lnh_mlp_backward" + _hip.mlp_suffix(x16.dtype), gy16.data_ptr(), x16.data_ptr(), w16.data_ptr(), B, in_dim, 16, hidden, nhm, act, 6,
-              _hip.ptr(gx), gw.data_ptr())
+              _hip.ptr(gx), gw.data_ptr(), *_hip.wgrad_ws(x16.device))
     return gx, gw
 
 

@@ -398,9 +398,10 @@ class FusedLidarRender(Function):
             g_image = torch.zeros((N, 2), dtype=torch.float32, device=dev)
 
         g_h16 = torch.empty((N * Ttot, 16), dtype=mdt, device=dev)
+        wws = _hip.wgrad_ws(dev)  # scratch of the fixed-order weight-gradient sums (one per device and stream, kept)
         kd = enc_d16.shape[1]
         n_col, n_sig, n_c0 = wcol16.numel(), wsig16.numel(), 64 * (kd + 15)
-        # every gradient that is ACCUMULATED into (the small matrices' by atomics, the table's by the reduce pass) is cleared
+        # every gradient that is ACCUMULATED into (the small matrices' by the fixed-order sums, the table's by the reduce pass) is cleared
         # by one launch: the arena of all small gradients and — unless the sharded backward brings its own — the fp16 table
         zeros = torch.empty(n_col + n_sig + n_c0, dtype=torch.float32, device=dev)
         sharded = parallel.dp_active() and getattr(ctx.table_param, "_lnh_shard_optimizer", False)
@@ -413,13 +414,13 @@ class FusedLidarRender(Function):
         ray_sum = torch.empty((N, 64), dtype=torch.float32, device=dev)
         _hip.call("lnh_lidar_color_backward_image" + sfx, g_image.data_ptr(), g_sigma.data_ptr(), h16.data_ptr(), perm.data_ptr(),
                   weights.data_ptr(), cdir.data_ptr(), wcol16.data_ptr(), N, Ttot, g_h16.data_ptr(), g_wcol.data_ptr(),
-                  ray_sum.data_ptr())
+                  ray_sum.data_ptr(), *wws)
         g_w0g = g_wcol[:64 * 16].view(64, 16)
         g_wc0 = zeros[n_col + n_sig:].view(64, kd + 15)
         # the whole gradient of the colour head's first matrix in one launch: direction columns = S^T enc(d), geo-feature
         # columns copied out of the packed [64, 16] block the colour backward accumulated
         _hip.call("lnh_lidar_dir_term_backward", ray_sum.data_ptr(), enc_d16.data_ptr(), N, kd, g_w0g.data_ptr(),
-                  g_wc0.data_ptr(), kd + 15)
+                  g_wc0.data_ptr(), kd + 15, *wws)
         g_wc1 = g_wcol[64 * 16:64 * 16 + 64 * 64].view(64, 64)
         g_wc2 = g_wcol[64 * 16 + 64 * 64:].view(16, 64)[:2]
         dts = ctx.param_dtypes
@@ -437,7 +438,7 @@ class FusedLidarRender(Function):
         B_all = N * Ttot
         g_feat = torch.empty((enc.num_levels, B_all, 2), dtype=torch.half, device=dev)
         _hip.call("lnh_density_mlp_backward" + sfx, g_h16.data_ptr(), feat.data_ptr(), wsig16.data_ptr(), B_all, Ttot, Ttot, 0,
-                  g_feat.data_ptr(), g_wsig.data_ptr())
+                  g_feat.data_ptr(), g_wsig.data_ptr(), *wws)
         if sharded:
             # data parallel, sharded table optimizer: reduce-scatter per window; the trainer steps this rank's rows
             ctx.table_param._lnh_grad16_shards = _grid_bwd_sharded(g_feat, x01, enc, B_all, ctx.table_param)
@@ -649,19 +650,20 @@ class FusedLidarRagged(Function):
                   rays_d.data_ptr(), rays.data_ptr(), ws.data_ptr(), depth.data_ptr(), image.data_ptr(), M, N, 2,
                   T_thresh, gs.data_ptr(), gf.data_ptr())
         g_wcol, g_wsig = zeros[:n_col], zeros[n_col:n_col + n_sig]
+        wws = _hip.wgrad_ws(dev)
         # colour head backward ray by ray: sigmoid, the three layers, all weight gradients, the sigma-net rows' gradient
         # (col 0 = the density gradient through trunc_exp) and the per-ray sum for the direction columns — one launch
         _hip.call("lnh_ragged_color_backward" + sfx, gf.data_ptr(), gs.data_ptr(), ds, h16.data_ptr(), rays.data_ptr(),
-                  cdir.data_ptr(), wcol16.data_ptr(), N, M, g_h16.data_ptr(), g_wcol.data_ptr(), ray_sum.data_ptr())
+                  cdir.data_ptr(), wcol16.data_ptr(), N, M, g_h16.data_ptr(), g_wcol.data_ptr(), ray_sum.data_ptr(), *wws)
         g_w0g = g_wcol[:64 * 16].view(64, 16)
         g_wc0 = zeros[n_col + n_sig:].view(64, kd + 15)
         _hip.call("lnh_lidar_dir_term_backward", ray_sum.data_ptr(), enc_d16.data_ptr(), N, kd, g_w0g.data_ptr(),
-                  g_wc0.data_ptr(), kd + 15)
+                  g_wc0.data_ptr(), kd + 15, *wws)
         g_wc1 = g_wcol[64 * 16:64 * 16 + 64 * 64].view(64, 64)
         g_wc2 = g_wcol[64 * 16 + 64 * 64:].view(16, 64)[:2]
         g_feat = torch.empty((L, M, 2), dtype=torch.half, device=dev)
         _hip.call("lnh_density_mlp_backward" + sfx, g_h16.data_ptr(), feat.data_ptr(), wsig16.data_ptr(), M, M, M, 0,
-                  g_feat.data_ptr(), g_wsig.data_ptr())
+                  g_feat.data_ptr(), g_wsig.data_ptr(), *wws)
         world = parallel.world_size()
         if parallel.dp_active():
             for handle in _grid_bwd_overlapped(g_feat, x01, g_table16, enc, M, table_param, bwd_ws, bwd_flags):

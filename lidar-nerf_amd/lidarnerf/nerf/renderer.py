@@ -283,7 +283,14 @@ class NeRFRenderer(nn.Module):
         M = raymarching.march_capacity(N, max_steps, mean_count, 128, force_all_rays)
         nears = torch.empty(N, dtype=torch.float32, device=dev)
         fars = torch.empty(N, dtype=torch.float32, device=dev)
-        buf = torch.empty(M * 10, dtype=torch.float32, device=dev)  # xyzs 3 | dirs 3 | deltas 2 | lidar colour 2
+        # the two colour columns are the fused ragged chain's (it fills the rows rays own, the others stay 0): evaluation and
+        # the modular path march into M * 8 — with force_all_rays M is N * 1024, and a full LiDAR frame's extra quarter was
+        # hundreds of MB of zero fill per render call
+        from . import fused
+        use_fused = (getattr(self, "fused_lidar", False) and rays_o.is_cuda and torch.is_autocast_enabled()
+                     and fused.ragged_supported(self))
+        cols = 10 if use_fused and torch.is_grad_enabled() else 8
+        buf = torch.empty(M * cols, dtype=torch.float32, device=dev)  # xyzs 3 | dirs 3 | deltas 2 (| lidar colour 2)
         regions = [buf] + ([counter] if counter is not None else [])
         regions = [t for t in regions if t.numel()]
         zp = (_hip.C.c_void_p * max(len(regions), 1))(*[t.data_ptr() for t in regions])
@@ -295,10 +302,7 @@ class NeRFRenderer(nn.Module):
             rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size, nears, fars, counter,
             mean_count, perturb, 128, force_all_rays, dt_gamma, max_steps, sample_buffer=buf)
         # the cleared colour rows of the samples that were kept (evaluation trims the buffers to the marched count)
-        self._lnh_rgb_rows = buf[M * 8:M * 8 + 2 * xyzs.shape[0]].view(-1, 2)
-        from . import fused
-        use_fused = (getattr(self, "fused_lidar", False) and xyzs.is_cuda and torch.is_autocast_enabled()
-                     and fused.ragged_supported(self))
+        self._lnh_rgb_rows = buf[M * 8:M * 8 + 2 * xyzs.shape[0]].view(-1, 2) if cols == 10 else None
         if xyzs.shape[0] == 0 and not (use_fused and torch.is_grad_enabled()):
             # no sample on any ray (evaluation, or the modular path): plain zeros.  The fused training chain below runs its
             # node on zero samples instead — zeros connected to the graph, zero gradients, and under data parallel the same

@@ -243,14 +243,11 @@ class LidarTrainer:
                                               self.scale, ag)
         return loss if grad_scale is None else _ScaleGrad.apply(loss, grad_scale)
 
-    def _step_fused_table(self, rays_o, rays_d, images_lidar, patch):
-        """One iteration with the fused optimizer: render + loss + backward, (the gradient exchange,) and the optimizer as two
-        launches — lnh_train_check (finite check of every gradient, 1 / scale, the learning rate of this step) and
-        lnh_train_step (Adam on the table and on the small tensors, GradScaler's skip / scale update, the step counters)."""
-        from .. import _hip
-        from .fused import table16_of
-        H = _hip
-        tp, st = self.table, self.opt_state
+    def _forward_backward(self, rays_o, rays_d, images_lidar, patch):
+        """Render + loss + backward of one batch with the fused optimizer's conventions: the gradients come out multiplied by
+        the CURRENT loss scale — the table's in fp16 (`table._lnh_grad16`), the small tensors' as `.grad` views of one arena.
+        Nothing is stepped (tests/test_patch_step_gpu.py compares exactly this state with the oracle)."""
+        tp = self.table
         for p in self.small:
             p.grad = None
         tp._lnh_grad16 = None
@@ -260,6 +257,17 @@ class LidarTrainer:
         with torch.autocast("cuda", dtype=self.amp_dtype):
             loss = self.loss(rays_o, rays_d, images_lidar, patch, grad_scale=self.loss_scale)
         loss.backward(gradient=self._one)  # (the loss kernel has multiplied its gradients by the loss scale)
+        return loss
+
+    def _step_fused_table(self, rays_o, rays_d, images_lidar, patch):
+        """One iteration with the fused optimizer: render + loss + backward, (the gradient exchange,) and the optimizer as two
+        launches — lnh_train_check (finite check of every gradient, 1 / scale, the learning rate of this step) and
+        lnh_train_step (Adam on the table and on the small tensors, GradScaler's skip / scale update, the step counters)."""
+        from .. import _hip
+        from .fused import table16_of
+        H = _hip
+        tp, st = self.table, self.opt_state
+        loss = self._forward_backward(rays_o, rays_d, images_lidar, patch)
         # --- data parallel: the small gradients.  The fused chain leaves all of them in ONE arena (views): that tensor goes
         # on the wire as it is, summed — the division by the world size is folded into 1 / scale like the table's
         div_small, small_handle = 1.0, None
@@ -329,6 +337,9 @@ class LidarTrainer:
         H = _hip_consts()
         it = float(self.scheduler.last_epoch)
         self.opt_state[H.TS_IT], self.opt_state[H.TS_IT_NEXT] = it, it
+        # the inf / nan stamp is `it + 1` of the step that saw it and relies on `it` only ever growing: after a rewind a stale
+        # stamp would match again when training reaches that iteration (a finite step skipped, the loss scale halved)
+        self.opt_state[H.TS_FOUND], self.opt_state[H.TS_SKIPPED] = 0.0, 0.0
         if steps is not None:
             self.opt_state[H.TS_T], self.opt_state[H.TS_T_NEXT] = float(steps), float(steps)
 

@@ -19,3 +19,8 @@ def host(t):
 
 def call(name, *args):
     _hip.call(name, *[a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args])
+
+
+def wgrad():
+    """(pointer, bytes): the weight-gradient workspace the MLP backward entry points take as their last two arguments."""
+    return _hip.wgrad_ws(DEV)

@@ -133,7 +133,7 @@ def test_mfma_mlp_backward_on_reference_pairs(g7, dt):
         gx = torch.empty((B, in_pad), dtype=dt, device="cuda")
         gw = torch.zeros(w16.numel(), dtype=torch.float32, device="cuda")
         _hip.call("lnh_mlp_backward" + sfx, gy16.data_ptr(), x16.data_ptr(), w16.data_ptr(), B, in_pad, 16, 64, nhm, 0, 6,
-                  gx.data_ptr(), gw.data_ptr())
+                  gx.data_ptr(), gw.data_ptr(), *_hip.wgrad_ws("cuda"))
         torch.cuda.synchronize()
         gw = gw.cpu().numpy()
         model_gx, model_gw = mlp_ref.mlp_backward(x, mats, gout, half=True if f16 else "bf16")

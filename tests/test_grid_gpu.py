@@ -473,6 +473,25 @@ def test_backward_bucketed_spill_list_full_falls_back_to_atomics(dt):
     assert np.isfinite(got).all() and np.all(got[want == 0] == 0)
     rel = np.linalg.norm(got - want) / np.linalg.norm(want)
     assert rel < (1e-4 if dt == torch.float32 else 0.25), rel
+    # The same batch through lnh_grid_encode_backward_ws_ex with the promises of the training step (workspace head cleared,
+    # gradient table zero: the reduce pass would STORE its sums over the rows): the entries the scatter pass added with
+    # atomics must survive — on such a level the reduce pass reads the rows whatever the flag says.  (Rounds 5: they were
+    # overwritten; found by review, never by a test: this combination was not covered.)
+    from lidarnerf import _hip
+    offh, rows = torch.from_numpy(OFF), int(OFF[-1])
+    need = _hip.lib().lnh_grid_backward_workspace_size(offh.data_ptr(), B, 3, CH, L, S, H, 0, 0, code)
+    clear = _hip.lib().lnh_grid_backward_workspace_clear_bytes(offh.data_ptr(), B, 3, CH, L, S, H, 0, 0, 0, code, need)
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    gd, xd = dev(g), dev(x)
+    for flags in (_hip.LNH_BWD_TABLE_ZERO, _hip.LNH_BWD_WS_CLEARED | _hip.LNH_BWD_TABLE_ZERO):
+        ws.random_(0, 255)
+        ge = torch.full((rows, CH), 9.0, dtype=dt, device="cuda")
+        _hip.zero_regions((ge, ws[:clear] if flags & _hip.LNH_BWD_WS_CLEARED else None))
+        call("lnh_grid_encode_backward_ws_ex", gd, xd, offh, ge, B, 3, CH, L, S, H, 0, 0, 0, code, ws, need, 0, L, 0, flags)
+        got_f = host(ge).astype(np.float64)
+        assert np.isfinite(got_f).all() and np.all(got_f[want == 0] == 0)
+        rel_f = np.linalg.norm(got_f - want) / np.linalg.norm(want)
+        assert rel_f < (1e-4 if dt == torch.float32 else 0.25), (flags, rel_f)
     # rows no point of the batch touches stay exactly zero; every other level's hot rows went the same way (level 0 too: its
     # rows are dealt to 38 buckets, the four holding the cell's even corners overflow like the hashed ones)
 

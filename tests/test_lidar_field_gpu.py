@@ -53,7 +53,7 @@ def _sigma_net(seed):
 # (420, 768, ...): 322 560 points > one pass of the persistent grids (forward 262 144, backward 65 536 per pass)
 @pytest.mark.parametrize("N,Tc,Ttot,off", [(13, 64, 80, 16), (5, 768, 832, 0), (7, 16, 16, 0), (420, 768, 832, 64)])
 def test_density_mlp_forward_backward(N, Tc, Ttot, off):
-    from gpu_util import call, dev, host
+    from gpu_util import call, dev, host, wgrad
     B = N * Tc
     r = np.random.default_rng(2)
     feat = r.standard_normal((16, B, 2)).astype(np.float16)  # level-major, as the encoder writes it
@@ -76,7 +76,7 @@ def test_density_mlp_forward_backward(N, Tc, Ttot, off):
     gx_want, dws = mlp_ref.mlp_backward(x_rows, [w0, w1], gy[rows])
     gfeat = torch.empty((16, B, 2), dtype=torch.float16, device="cuda")
     gw = torch.zeros(wflat.size, dtype=torch.float32, device="cuda")
-    call("lnh_density_mlp_backward", dev(gy), dev(feat), dev(wflat), B, Tc, Ttot, off, gfeat, gw)
+    call("lnh_density_mlp_backward", dev(gy), dev(feat), dev(wflat), B, Tc, Ttot, off, gfeat, gw, *wgrad())
     got_gx = host(gfeat).astype(np.float64).transpose(1, 0, 2).reshape(B, 32)
     # fp16 storage of the hidden layer: a pre-activation within an fp16 ulp of 0 flips its ReLU mask, which moves a few
     # elements in ten million beyond the bulk tolerance
@@ -121,7 +121,7 @@ def _color_reference(h16, perm, weights, cdir, W0g, W1, W2, g_rgb=None, g_sigma=
                                          (6, 1100, "random"), (9, 832, "front"), (7, 1100, "front"), (1300, 96, "front"),
                                          (5, 20, "random"), (3, 2200, "front")])
 def test_color_head_forward_backward(N, T, pattern):
-    from gpu_util import call
+    from gpu_util import call, wgrad
     g = torch.Generator().manual_seed(N + T)
     h16 = (torch.randn(N * T, 16, generator=g) * 0.5).half()
     perm = torch.stack([torch.randperm(T, generator=g) for _ in range(N)]).int()
@@ -150,7 +150,7 @@ def test_color_head_forward_backward(N, T, pattern):
     g_w = torch.zeros(w16.numel(), device="cuda")
     S = torch.empty((N, 64), device="cuda")
     call("lnh_lidar_color_backward", g_rgb.cuda(), g_sigma.cuda(), h16.cuda(), perm.cuda(), weights.cuda(), cdir.cuda(),
-         w16.cuda(), N, T, g_h16, g_w, S)
+         w16.cuda(), N, T, g_h16, g_w, S, *wgrad())
     got_gx = g_h16.cpu().double().view(N, T, 16)
     assert torch.isfinite(got_gx).all()  # every point row written exactly once
     scale = want_gx.abs().max().item()
@@ -168,7 +168,7 @@ def test_color_head_forward_backward(N, T, pattern):
 def test_color_backward_from_image_gradient_equals_explicit_rgb_gradient(sfx):
     """lnh_lidar_color_backward_image(grad_image) == lnh_lidar_color_backward(grad_rgb = weights (x) grad_image), bit for bit
     (the product the compositing backward would have written is formed in the kernel); fp16 and bf16 builds."""
-    from gpu_util import call
+    from gpu_util import call, wgrad
     dt16 = torch.bfloat16 if sfx else torch.float16
     N, T = 37, 832
     g = torch.Generator().manual_seed(99)
@@ -186,9 +186,9 @@ def test_color_backward_from_image_gradient_equals_explicit_rgb_gradient(sfx):
         g_w = torch.zeros(w16.numel(), device="cuda")
         S = torch.empty((N, 64), device="cuda")
         if mode == "rgb":
-            call("lnh_lidar_color_backward" + sfx, g_rgb, g_sigma, h16, perm, weights, cdir, w16, N, T, g_h16, g_w, S)
+            call("lnh_lidar_color_backward" + sfx, g_rgb, g_sigma, h16, perm, weights, cdir, w16, N, T, g_h16, g_w, S, *wgrad())
         else:
-            call("lnh_lidar_color_backward_image" + sfx, g_image, g_sigma, h16, perm, weights, cdir, w16, N, T, g_h16, g_w, S)
+            call("lnh_lidar_color_backward_image" + sfx, g_image, g_sigma, h16, perm, weights, cdir, w16, N, T, g_h16, g_w, S, *wgrad())
         outs.append((g_h16, S, g_w))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     # (the weight gradient is flushed with float atomics from several workgroups: same values, order-dependent last bits)
@@ -411,13 +411,14 @@ def test_dir_term_backward():
         S = torch.randn(N, 64, device="cuda")
         E = torch.randn(N, K, device="cuda")
         g = torch.zeros(64, K + 15, device="cuda")
-        _hip.call("lnh_lidar_dir_term_backward", S.data_ptr(), E.data_ptr(), N, K, None, g.data_ptr(), K + 15)
+        _hip.call("lnh_lidar_dir_term_backward", S.data_ptr(), E.data_ptr(), N, K, None, g.data_ptr(), K + 15, *_hip.wgrad_ws("cuda"))
         want = S.double().t() @ E.double()
         torch.testing.assert_close(g[:, :K].double(), want, rtol=1e-4, atol=1e-3)
         assert float(g[:, K:].abs().max()) == 0.0
         # with the packed geo-feature block: its columns 1..15 land behind the K direction columns, in the same launch
         g2 = torch.zeros(64, K + 15, device="cuda")
         w0g = torch.randn(64, 16, device="cuda")
-        _hip.call("lnh_lidar_dir_term_backward", S.data_ptr(), E.data_ptr(), N, K, w0g.data_ptr(), g2.data_ptr(), K + 15)
+        _hip.call("lnh_lidar_dir_term_backward", S.data_ptr(), E.data_ptr(), N, K, w0g.data_ptr(), g2.data_ptr(), K + 15,
+                  *_hip.wgrad_ws("cuda"))
         torch.testing.assert_close(g2[:, :K].double(), want, rtol=1e-4, atol=1e-3)
         assert torch.equal(g2[:, K:], w0g[:, 1:])

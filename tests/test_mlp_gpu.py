@@ -81,7 +81,7 @@ def test_forward_buffer_matches_hidden_activations():
 @pytest.mark.parametrize("in_dim,nhm", [(32, 0), (96, 1), (32, 1), (64, 2), (16, 0)])
 @pytest.mark.parametrize("B", [128, 1000])
 def test_backward(in_dim, nhm, B):
-    from gpu_util import call, dev, host
+    from gpu_util import call, dev, host, wgrad
     r = np.random.default_rng(in_dim * 3 + nhm)
     x = r.standard_normal((B, in_dim)).astype(np.float16)
     n = mlp_ref.ffmlp_num_params(in_dim, 16, 64, nhm + 1)
@@ -92,20 +92,20 @@ def test_backward(in_dim, nhm, B):
     dw_want = np.concatenate([d.ravel() for d in dws])
     gx = torch.zeros((B, in_dim), dtype=torch.float16, device="cuda")
     dw = torch.zeros(n, dtype=torch.float32, device="cuda")
-    call("lnh_mlp_backward", dev(gy), dev(x), dev(w), B, in_dim, 16, 64, nhm, 0, 6, gx, dw)
+    call("lnh_mlp_backward", dev(gy), dev(x), dev(w), B, in_dim, 16, 64, nhm, 0, 6, gx, dw, *wgrad())
     np.testing.assert_allclose(host(gx).astype(np.float64), gx_want, rtol=5e-3, atol=2e-3)
     scale = np.abs(dw_want).max()
     np.testing.assert_allclose(host(dw).astype(np.float64), dw_want, rtol=5e-3, atol=2e-3 * scale)
     # weights-only variant (grad_inputs == NULL)
     dw2 = torch.zeros(n, dtype=torch.float32, device="cuda")
-    call("lnh_mlp_backward", dev(gy), dev(x), dev(w), B, in_dim, 16, 64, nhm, 0, 6, None, dw2)
+    call("lnh_mlp_backward", dev(gy), dev(x), dev(w), B, in_dim, 16, 64, nhm, 0, 6, None, dw2, *wgrad())
     np.testing.assert_allclose(host(dw2), host(dw), rtol=1e-4, atol=1e-4 * scale)
 
 
 @pytest.mark.parametrize("in_dim,nhm", [(32, 0), (16, 1), (96, 2), (128, 1)])
 def test_hidden_32_forward_backward(in_dim, nhm):
     """hidden = 32 (two 16-row tiles per layer) — same kernels, HT = 2."""
-    from gpu_util import call, dev, host
+    from gpu_util import call, dev, host, wgrad
     B, H = 777, 32
     r = np.random.default_rng(in_dim * 5 + nhm)
     x = r.standard_normal((B, in_dim)).astype(np.float16)
@@ -120,7 +120,7 @@ def test_hidden_32_forward_backward(in_dim, nhm):
     dw_want = np.concatenate([d.ravel() for d in dws])
     gx = torch.zeros((B, in_dim), dtype=torch.float16, device="cuda")
     dw = torch.zeros(n, dtype=torch.float32, device="cuda")
-    call("lnh_mlp_backward", dev(gy), dev(x), dev(w), B, in_dim, 16, H, nhm, 0, 6, gx, dw)
+    call("lnh_mlp_backward", dev(gy), dev(x), dev(w), B, in_dim, 16, H, nhm, 0, 6, gx, dw, *wgrad())
     np.testing.assert_allclose(host(gx).astype(np.float64), gx_want, rtol=5e-3, atol=2e-3)
     np.testing.assert_allclose(host(dw).astype(np.float64), dw_want, rtol=5e-3, atol=2e-3 * np.abs(dw_want).max())
 
@@ -136,7 +136,7 @@ def test_bf16_forward_backward(in_dim, nhm, H):
     """lnh_mlp_forward_bf16 / lnh_mlp_backward_bf16 (v_mfma_f32_16x16x32_bf16 operands, BASELINE config 5) vs the
     oracle with bfloat16 storage roundings.  bf16 keeps 8 significant bits: one rounding is <= 2^-9 relative, so the
     bounds are 8x those of the fp16 tests (2^-8 vs 2^-11)."""
-    from gpu_util import call, host
+    from gpu_util import call, host, wgrad
     B = 1000
     r = np.random.default_rng(in_dim * 7 + nhm)
     x = mlp_ref.round_bf16(r.standard_normal((B, in_dim)))
@@ -152,7 +152,7 @@ def test_bf16_forward_backward(in_dim, nhm, H):
     dw_want = np.concatenate([d.ravel() for d in dws])
     gx = torch.zeros((B, in_dim), dtype=torch.bfloat16, device="cuda")
     dw = torch.zeros(n, dtype=torch.float32, device="cuda")
-    call("lnh_mlp_backward_bf16", _bf(gy), _bf(x), _bf(w), B, in_dim, 16, H, nhm, 0, 6, gx, dw)
+    call("lnh_mlp_backward_bf16", _bf(gy), _bf(x), _bf(w), B, in_dim, 16, H, nhm, 0, 6, gx, dw, *wgrad())
     np.testing.assert_allclose(host(gx.float()).astype(np.float64), gx_want, rtol=4e-2, atol=1.6e-2)
     np.testing.assert_allclose(host(dw).astype(np.float64), dw_want, rtol=4e-2, atol=1.6e-2 * np.abs(dw_want).max())
 
@@ -179,7 +179,7 @@ def test_wide_kernels_vs_oracle(hidden, nhm, in_dim, act, sfx):
     (output + every saved hidden activation), lnh_mlp_backward_data (the activation gradients of every layer + the input
     gradient) against the oracle's MLP (16-bit storage of every layer), a batch that is not a multiple of anything, ReLU /
     sigmoid / softplus; lnh_mlp_backward refuses these shapes and names the entry point that serves them."""
-    from gpu_util import call
+    from gpu_util import call, wgrad
     dt = torch.bfloat16 if sfx else torch.float16
     npd = np.float32
     r = np.random.default_rng(hidden + nhm)
@@ -229,7 +229,7 @@ def test_wide_kernels_vs_oracle(hidden, nhm, in_dim, act, sfx):
     gw = torch.zeros(w.numel(), device="cuda")
     if hidden >= 128 or nhm > 2:
         with pytest.raises(RuntimeError, match="lnh_mlp_backward_data"):
-            call("lnh_mlp_backward" + sfx, gy.cuda(), x.cuda(), w, B, in_dim, 16, hidden, nhm, act, 6, gx, gw)
+            call("lnh_mlp_backward" + sfx, gy.cuda(), x.cuda(), w, B, in_dim, 16, hidden, nhm, act, 6, gx, gw, *wgrad())
 
 
 @pytest.mark.parametrize("hidden,layers,in_dim", [(16, 2, 32), (128, 3, 48), (256, 2, 64), (64, 5, 32), (256, 4, 32)])

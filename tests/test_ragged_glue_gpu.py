@@ -144,7 +144,7 @@ def test_ragged_colour_head_per_ray_equals_the_per_sample_chain(sfx):
     lnh_ragged_color_input_rays -> lnh_mlp_forward (96 -> 64 -> 64 -> 16) -> lnh_ragged_color_output, and backward
     lnh_ragged_color_output_backward -> lnh_mlp_backward -> lnh_ragged_grad_rows.  Ray table with an empty ray, a dropped ray
     (samples beyond M), rays in arrival order != ray index, rows nobody owns."""
-    from gpu_util import call
+    from gpu_util import call, wgrad
     dt = _dt(sfx)
     g = torch.Generator().manual_seed(12)
     N, deg = 37, 12
@@ -197,7 +197,7 @@ def test_ragged_colour_head_per_ray_equals_the_per_sample_chain(sfx):
     call("lnh_ragged_color_output_backward" + sfx, gf_c, rgb_a, Mr, gy)
     gx = torch.empty(Mr, 96, dtype=dt, device="cuda")
     gw96 = torch.zeros(wcol96.numel(), device="cuda")
-    call("lnh_mlp_backward" + sfx, gy, cin, wcol96, Mr, 96, 16, 64, 1, 0, 6, gx, gw96)
+    call("lnh_mlp_backward" + sfx, gy, cin, wcol96, Mr, 96, 16, 64, 1, 0, 6, gx, gw96, *wgrad())
     gh_a = torch.empty(Mr, 16, dtype=dt, device="cuda")
     call("lnh_ragged_grad_rows" + sfx, gs_c, 1.7, h16_c, gx, deg, Mr, gh_a)
     # ---- ray by ray (round 5)
@@ -210,9 +210,9 @@ def test_ragged_colour_head_per_ray_equals_the_per_sample_chain(sfx):
     gh_b = torch.zeros(Mr, 16, dtype=dt, device="cuda")
     gw16 = torch.zeros(wcol16.numel(), device="cuda")
     S = torch.zeros(N, 64, device="cuda")
-    call("lnh_ragged_color_backward" + sfx, gf_c, gs_c, 1.7, h16_c, rays_c, cdir, wcol16, N, Mr, gh_b, gw16, S)
+    call("lnh_ragged_color_backward" + sfx, gf_c, gs_c, 1.7, h16_c, rays_c, cdir, wcol16, N, Mr, gh_b, gw16, S, *wgrad())
     g_wc0 = torch.zeros(64, kd + 15, device="cuda")
-    call("lnh_lidar_dir_term_backward", S, enc16, N, kd, gw16[:1024], g_wc0, kd + 15)
+    call("lnh_lidar_dir_term_backward", S, enc16, N, kd, gw16[:1024], g_wc0, kd + 15, *wgrad())
     torch.cuda.synchronize()
     ow = owned.cuda()
     tol = 4e-3 if sfx == "" else 3e-2                                     # (two different summation orders of the first layer)

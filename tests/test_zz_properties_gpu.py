@@ -223,7 +223,7 @@ def test_fused_table_trainer_checkpoint_resume(tmp_path):
 def test_empty_batches_are_no_ops_on_the_fused_step_entry_points():
     """N = 0 rays / B = 0 points: every entry point of the fused render step returns success without touching a byte of
     its outputs (and without launching anything: a zero-sized grid is a launch error on HIP)."""
-    from gpu_util import call
+    from gpu_util import call, wgrad
     from lidarnerf.gridencoder.grid import level_offsets
     canary = 123456.0
     d = torch.full((4096,), canary, device="cuda")              # stands in for every fp32 / fp16 / int32 pointer
@@ -243,10 +243,10 @@ def test_empty_batches_are_no_ops_on_the_fused_step_entry_points():
         ("lnh_lidar_color_composite_forward", d, d, d, d, d, d, d, 0, T + t, 1.0, d, d, d, d, d, d),
         ("lnh_lidar_composite_forward", d, d, d, d, 0, T + t, 2, 1.0, None, d, d, d),
         ("lnh_lidar_composite_backward", d, d, d, d, d, d, d, 0, T + t, 2, 1.0, d, None),
-        ("lnh_lidar_color_backward", d, d, d, d, d, d, d, 0, T + t, d, d, d),
-        ("lnh_lidar_color_backward_image", d, d, d, d, d, d, d, 0, T + t, d, d, d),
-        ("lnh_lidar_dir_term_backward", d, d, 0, 75, None, d, 90),
-        ("lnh_density_mlp_backward", d, d, d, 0, T + t, T + t, 0, d, d),
+        ("lnh_lidar_color_backward", d, d, d, d, d, d, d, 0, T + t, d, d, d, *wgrad()),
+        ("lnh_lidar_color_backward_image", d, d, d, d, d, d, d, 0, T + t, d, d, d, *wgrad()),
+        ("lnh_lidar_dir_term_backward", d, d, 0, 75, None, d, 90, *wgrad()),
+        ("lnh_density_mlp_backward", d, d, d, 0, T + t, T + t, 0, d, d, *wgrad()),
     ]
     for c in calls:
         call(*c)
@@ -257,13 +257,13 @@ def test_empty_batches_are_no_ops_on_the_fused_step_entry_points():
 def test_batches_beyond_32_bit_sample_indices_are_refused():
     """N * T >= 2^32: the per-sample indices of the fused-step kernels are 32 bits wide; the entry points say so instead of
     wrapping around (nothing is launched, the dummy pointers are never dereferenced)."""
-    from gpu_util import call
+    from gpu_util import call, wgrad
     d = torch.zeros(64, device="cuda")
     N, T = 1 << 22, 1 << 10
     for c in (("lnh_lidar_sample_points", d, d, d, d, 1.0, N, T, T, 0, d),
               ("lnh_lidar_color_forward", d, d, d, d, d, N, T, d),
               ("lnh_lidar_color_composite_forward", d, d, d, d, d, d, d, N, T, 1.0, d, d, d, d, d, d),
-              ("lnh_lidar_color_backward", d, d, d, d, d, d, d, N, T, d, d, d),
-              ("lnh_lidar_color_backward_image", d, d, d, d, d, d, d, N, T, d, d, d)):
+              ("lnh_lidar_color_backward", d, d, d, d, d, d, d, N, T, d, d, d, *wgrad()),
+              ("lnh_lidar_color_backward_image", d, d, d, d, d, d, d, N, T, d, d, d, *wgrad())):
         with pytest.raises(RuntimeError, match="32 bits"):
             call(*c)

@@ -62,7 +62,7 @@ def main():
     def bwd():
         _hip.call("lnh_lidar_color_backward", g_rgb.data_ptr(), g_sigma.data_ptr(), h16.data_ptr(), perm.data_ptr(),
                   weights.data_ptr(), cdir.data_ptr(), wcol.data_ptr(), N, T, g_h16.data_ptr(), g_w.data_ptr(),
-                  ray_sum.data_ptr())
+                  ray_sum.data_ptr(), *_hip.wgrad_ws(dev))
 
     for name, fn in (("lnh_lidar_color_forward", fwd), ("lnh_lidar_color_backward", bwd)):
         fn()
@@ -111,7 +111,7 @@ def main():
 
     def dbwd():
         _hip.call("lnh_density_mlp_backward", g_h16.data_ptr(), feat.data_ptr(), wsig.data_ptr(), B_all, T, T, 0,
-                  g_feat.data_ptr(), g_ws.data_ptr())
+                  g_feat.data_ptr(), g_ws.data_ptr(), *_hip.wgrad_ws(dev))
 
     for name, fn, pts in (("lnh_density_mlp_forward", dfwd, B), ("lnh_density_mlp_backward", dbwd, B_all)):
         fn()
