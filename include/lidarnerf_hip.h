@@ -237,6 +237,15 @@ LNH_API int lnh_mlp_backward(const void *grad, const void *inputs, const void *w
 LNH_API int lnh_mlp_backward_data(const void *grad, const void *forward_buffer, const void *weights_t, uint32_t B,
                                   uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t n_hidden_mats,
                                   uint32_t activation, void *backward_buffer, void *grad_inputs, lnh_stream_t stream);
+/*
+ * Weight gradient of ONE layer of a wide fused MLP, the contraction over the batch the reference runs as a split-K CUTLASS
+ * GEMM (ffmlp.cu:1107-1263, cutlass_matmul.h:481-616):  grad_weights[M, N] += grad^T acts,  grad [B, M] and acts [B, N] f16
+ * (row-major; rows of lnh_mlp_backward_data's backward_buffer / lnh_mlp_forward's forward_buffer / the MLP input), M and N
+ * multiples of 16 in 16 .. 256, grad_weights f32 row-major (a slice of the flat gradient vector), 16-byte aligned pointers.
+ * Fixed-order sum over the batch (wgrad_ws: lnh_wgrad_workspace_bytes): the same bits on every run.
+ */
+LNH_API int lnh_mlp_wgrad(const void *grad, const void *acts, uint32_t B, uint32_t M, uint32_t N, float *grad_weights,
+                          void *wgrad_ws, uint64_t wgrad_ws_bytes, lnh_stream_t stream);
 
 /* ------------------------------------------------------------------ ray utilities / occupancy grid ----------- */
 /* Replaces near_far_from_aabb    lidarnerf/raymarching/src/raymarching.h:6-12 (raymarching.cu:104-177). */
@@ -661,6 +670,8 @@ LNH_API int lnh_mlp_backward_data_bf16(const void *grad, const void *forward_buf
                                        uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim,
                                        uint32_t n_hidden_mats, uint32_t activation, void *backward_buffer,
                                        void *grad_inputs, lnh_stream_t stream);
+LNH_API int lnh_mlp_wgrad_bf16(const void *grad, const void *acts, uint32_t B, uint32_t M, uint32_t N, float *grad_weights,
+                               void *wgrad_ws, uint64_t wgrad_ws_bytes, lnh_stream_t stream);
 LNH_API int lnh_density_mlp_forward_bf16(const void *features, const void *weights, uint32_t B, uint32_t T_cur,
                                     uint32_t T_tot, uint32_t slot_off, uint32_t feat_rows, void *h16, float *sigma,
                                     lnh_stream_t stream);

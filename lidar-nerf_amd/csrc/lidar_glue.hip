@@ -193,56 +193,40 @@ k_step_prologue(PackArgs<E> pk, PrologueArgs a) {
 // nerf/utils.py:712-746 with the default criteria: per ray
 //   l = a_d |pd - gd| + a_r (pr - gr)^2 + a_i (pi - gi)^2,  pd = depth * gr, gd = gt_depth * gr, pi = intensity * gr,
 // loss = mean(l).  Emits the loss and d loss / d depth, d loss / d image in the same pass.
-// The loss is the sum of the workgroups' partial sums: every workgroup leaves its partial in a scratch slot and the one
-// that arrives LAST (device-scope counter) adds them up in slot order and writes the loss — no accumulator to clear before
-// the launch (rounds 1-4: a zero-fill launch + atomics), and the same bits whatever the arrival order.  The counter is
-// left at zero for the next launch.  (Static device scratch: launches of these two kernels must not overlap in time —
-// they are issued on one stream, or replayed inside one graph.)
-constexpr uint32_t kLossMaxBlocks = 4096;
-__device__ float g_loss_part[kLossMaxBlocks];
-__device__ unsigned int g_loss_arrived;
+// ONE workgroup of 1024 threads walks the batch (a training batch is 4096 .. 16384 rays: 4 .. 16 per thread, a few
+// microseconds next to a step of milliseconds): thread t adds its rays t, t + 1024, ... in that order, the lanes of a wave meet
+// in a shuffle tree, the 16 waves in LDS in wave order — the same bits on every run, no accumulator to clear before the
+// launch (rounds 1-4: a zero-fill launch + float atomics) and NO state outside the launch (round 5: per-workgroup partials
+// and an arrival counter in static device memory, which two launches overlapping in time — an evaluation loss on another
+// stream, two trainers in one process — would have corrupted for each other).
+constexpr uint32_t kLossThreads = 1024;
 __device__ __forceinline__ void loss_finish(float l, float scale_out, float *__restrict__ loss) {
-    __shared__ float part[4];
-    __shared__ bool last;
+    __shared__ float part[kLossThreads / 64];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o, 64);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = l;
     __syncthreads();
     if (threadIdx.x == 0) {
-        __hip_atomic_store(&g_loss_part[blockIdx.x], (part[0] + part[1]) + (part[2] + part[3]), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-        last = __hip_atomic_fetch_add(&g_loss_arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
-    }
-    __syncthreads();
-    if (!last) return;
-    float t = 0.0f;
-    for (uint32_t i = threadIdx.x; i < gridDim.x; i += blockDim.x)
-        t += __hip_atomic_load(&g_loss_part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float t = part[0];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = t;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        *loss = ((part[0] + part[1]) + (part[2] + part[3])) * scale_out;
-        __hip_atomic_store(&g_loss_arrived, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        for (uint32_t w = 1; w < kLossThreads / 64; w++) t += part[w];
+        *loss = t * scale_out;
     }
 }
 
 // `grad_scale` (device scalar, or null): the gradients come out multiplied by it — the loss scale of the training step, so
 // that backward() has nothing left to multiply (one element-wise launch less per step).
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kLossThreads)
 k_lidar_loss(const float *__restrict__ depth, const float *__restrict__ image, const float *__restrict__ gt, uint32_t N,
              float a_d, float a_r, float a_i, const float *__restrict__ grad_scale, float *__restrict__ loss,
              float *__restrict__ g_depth, float *__restrict__ g_image) {
-    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     const float gsc = grad_scale ? *grad_scale : 1.0f;
     float l = 0.0f;
-    if (n < N) {
+    for (uint32_t n = threadIdx.x; n < N; n += kLossThreads) {
         const float gr = gt[n * 3], gi = gt[n * 3 + 1] * gr, gd = gt[n * 3 + 2] * gr;
         const float pr = image[n * 2], pi = image[n * 2 + 1] * gr, pd = depth[n] * gr;
         const float dd = pd - gd, dr = pr - gr, di = pi - gi;
-        l = a_d * fabsf(dd) + a_r * dr * dr + a_i * di * di;
+        l += a_d * fabsf(dd) + a_r * dr * dr + a_i * di * di;
         const float inv = 1.0f / (float)N;
         const float sgn = dd > 0.0f ? 1.0f : (dd < 0.0f ? -1.0f : 0.0f);  // torch: sign(0) = 0
         g_depth[n] = a_d * sgn * gr * inv * gsc;
@@ -257,20 +241,19 @@ k_lidar_loss(const float *__restrict__ depth, const float *__restrict__ image, c
 //   a_g * mean over (P, px, py-1) of | |pd_j - pd_j+1| * m_j - (gd_j - gd_j+1) * m_j |,   m_j = gr_j * (|gd_j - gd_j+1| < 0.01)
 // (depths in metres: divided by `scale`; only the x term enters the loss) is added, with its gradient, in the same pass:
 // thread n = ray n handles the per-ray loss and the pair (n, n + 1) of its patch row.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kLossThreads)
 k_lidar_loss_patch(const float *__restrict__ depth, const float *__restrict__ image, const float *__restrict__ gt,
                    uint32_t N, uint32_t py, float inv_scale, float a_d, float a_r, float a_i, float a_g,
                    const float *__restrict__ grad_scale, float *__restrict__ loss, float *__restrict__ g_depth,
                    float *__restrict__ g_image) {
-    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     const float gsc = grad_scale ? *grad_scale : 1.0f;
     float l = 0.0f;
-    if (n < N) {
+    for (uint32_t n = threadIdx.x; n < N; n += kLossThreads) {
         const float gr = gt[n * 3], gi = gt[n * 3 + 1] * gr, gd = gt[n * 3 + 2] * gr;
         const float pr = image[n * 2], pi = image[n * 2 + 1] * gr, pd = depth[n] * gr;
         const float dd = pd - gd, dr = pr - gr, di = pi - gi;
         const float inv = 1.0f / (float)N;
-        l = (a_d * fabsf(dd) + a_r * dr * dr + a_i * di * di) * inv;
+        l += (a_d * fabsf(dd) + a_r * dr * dr + a_i * di * di) * inv;
         const float sgn = dd > 0.0f ? 1.0f : (dd < 0.0f ? -1.0f : 0.0f);
         float gdep = a_d * sgn * gr * inv;
         g_image[n * 2] = 2.0f * a_r * dr * inv * gsc;
@@ -440,9 +423,9 @@ int lnh_lidar_loss(const float *depth, const float *image, const float *gt, uint
                    lnh_stream_t stream) {
     LNH_REQUIRE(depth && image && gt && loss && grad_depth && grad_image, LNH_ERR_INVALID_ARG,
                 "lidar_loss: null pointer");
-    LNH_REQUIRE(div_up(N, 256) <= kLossMaxBlocks, LNH_ERR_UNSUPPORTED, "lidar_loss: at most %u rays per call", kLossMaxBlocks * 256);
+    LNH_REQUIRE(N <= (1u << 26), LNH_ERR_UNSUPPORTED, "lidar_loss: at most 2^26 rays per call");
     if (N == 0) return lnh_zero_async(loss, sizeof(float), (hipStream_t)stream, "lidar_loss (no rays)");
-    LNH_LAUNCH(k_lidar_loss, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, depth, image, gt, N, alpha_d,
+    LNH_LAUNCH(k_lidar_loss, dim3(1), dim3(kLossThreads), 0, (hipStream_t)stream, depth, image, gt, N, alpha_d,
                alpha_r, alpha_i, grad_scale, loss, grad_depth, grad_image);
     return lnh_check_launch("lnh_lidar_loss");
 }
@@ -454,9 +437,9 @@ int lnh_lidar_loss_patch(const float *depth, const float *image, const float *gt
                 "lidar_loss_patch: null pointer");
     LNH_REQUIRE(px >= 1 && py >= 2 && scale > 0.0f && N % (px * py) == 0, LNH_ERR_INVALID_ARG,
                 "lidar_loss_patch: need py >= 2, scale > 0 and N a multiple of px * py");
-    LNH_REQUIRE(div_up(N, 256) <= kLossMaxBlocks, LNH_ERR_UNSUPPORTED, "lidar_loss_patch: at most %u rays per call", kLossMaxBlocks * 256);
+    LNH_REQUIRE(N <= (1u << 26), LNH_ERR_UNSUPPORTED, "lidar_loss_patch: at most 2^26 rays per call");
     if (N == 0) return lnh_zero_async(loss, sizeof(float), (hipStream_t)stream, "lidar_loss_patch (no rays)");
-    LNH_LAUNCH(k_lidar_loss_patch, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, depth, image, gt, N, py,
+    LNH_LAUNCH(k_lidar_loss_patch, dim3(1), dim3(kLossThreads), 0, (hipStream_t)stream, depth, image, gt, N, py,
                1.0f / scale, alpha_d, alpha_r, alpha_i, alpha_grad, grad_scale, loss, grad_depth, grad_image);
     return lnh_check_launch("lnh_lidar_loss_patch");
 }

@@ -30,7 +30,10 @@ struct WgradWs {
     float *partials;  // [workgroups][n]
 };
 
-static inline uint64_t wgrad_ws_bytes() { return (uint64_t)kWgradMaxBlocks * kWgradMaxFloats * sizeof(float); }
+// 512 partials of the one-kernel MLP backwards' largest gradient, or 256 partials of a 256 x 256 matrix (mlp_wgrad.hip): 64 MiB
+constexpr uint64_t kWgradWsFloats = 256ull * 256 * 256;
+static_assert(kWgradWsFloats >= (uint64_t)kWgradMaxBlocks * kWgradMaxFloats, "weight-gradient workspace");
+static inline uint64_t wgrad_ws_bytes() { return kWgradWsFloats * sizeof(float); }
 static inline int wgrad_ws_open(void *ws, uint64_t bytes, WgradWs &out, const char *who) {
     if (ws == nullptr || bytes < wgrad_ws_bytes() || ((uintptr_t)ws & 15)) {
         lnh_set_error("%s: weight-gradient workspace missing, misaligned or too small (%llu bytes; lnh_wgrad_workspace_bytes() "

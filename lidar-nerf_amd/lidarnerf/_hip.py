@@ -35,6 +35,7 @@ _SIGS = {
     "lnh_mlp_forward": [P, P, U32, U32, U32, U32, U32, U32, U32, P, P],
     "lnh_mlp_backward": [P, P, P, U32, U32, U32, U32, U32, U32, U32, P, P, P, C.c_uint64],
     "lnh_mlp_backward_data": [P, P, P, U32, U32, U32, U32, U32, U32, P, P],
+    "lnh_mlp_wgrad": [P, P, U32, U32, U32, P, P, C.c_uint64],
     "lnh_near_far_from_aabb": [P, P, P, U32, F32, P, P],
     "lnh_sph_from_ray": [P, P, F32, U32, P],
     "lnh_morton3D": [P, U32, P],
@@ -94,7 +95,7 @@ _SIGS = {
     "lnh_ragged_color_output_backward": [P, P, U32, P],
     "lnh_ragged_grad_rows": [P, F32, P, P, U32, U32, P],
 }
-for _n in ("lnh_mlp_forward", "lnh_mlp_backward", "lnh_mlp_backward_data", "lnh_density_mlp_forward", "lnh_density_mlp_backward",
+for _n in ("lnh_mlp_forward", "lnh_mlp_backward", "lnh_mlp_backward_data", "lnh_mlp_wgrad", "lnh_density_mlp_forward", "lnh_density_mlp_backward",
            "lnh_lidar_dir_term", "lnh_lidar_pack_weights", "lnh_lidar_step_prologue", "lnh_lidar_color_forward", "lnh_lidar_color_backward",
            "lnh_lidar_color_composite_forward", "lnh_lidar_color_backward_image", "lnh_lidar_dir_term_freq",
            "lnh_ragged_pack_weights", "lnh_ragged_color_input", "lnh_ragged_color_input_rays", "lnh_ragged_color_output",

@@ -63,42 +63,35 @@ def _split(w, in_dim, hidden, nhm):
     return mats
 
 
-_SPLIT_K_ROWS = 4096
-
-
-def _mm_f32(a, b):
-    """a^T b ([B, M], [B, N] -> [M, N]) in fp32 from 16-bit operands: a library GEMM whose contraction runs over the BATCH
-    — a million rows for a 64 .. 256-wide result.  As one GEMM rocBLAS gives it 1.2 .. 1.9 ms at B = 1 M whatever M and N
-    (no split-K for the shape); as a batched GEMM over 4096-row slices summed afterwards — the reference's split-K
-    (cutlass_matmul.h:481-616), spelled with the library's own batching — 75 .. 240 us (tools/bench_wgrad.py on MI355X:
-    128 x 128: 1699 -> 128 us, 256 x 256: 1866 -> 237 us; same result to 1e-5)."""
-    B = a.shape[0]
-    S = B // _SPLIT_K_ROWS
-    if S < 2:
-        return torch.mm(a.t(), b, out_dtype=torch.float32)
-    main = S * _SPLIT_K_ROWS
-    out = torch.bmm(a[:main].view(S, _SPLIT_K_ROWS, -1).transpose(1, 2), b[:main].view(S, _SPLIT_K_ROWS, -1),
-                    out_dtype=torch.float32).sum(0)
-    if main < B:
-        out += torch.mm(a[main:].t(), b[main:], out_dtype=torch.float32)
-    return out
+def _wgrad(g16, a16, out):
+    """out [M, N] fp32 (a slice of the flat gradient vector) += g16^T a16, the contraction over the batch: lnh_mlp_wgrad
+    (csrc/mlp_wgrad.hip; rounds 4-5: torch.bmm over 4096-row slices).  The first matrix of an MLP whose input width is not a
+    multiple of 16 cannot occur here: FFMLP pads its input to 16 (ffmlp.py:221-224 of the reference)."""
+    B, M = g16.shape
+    N = a16.shape[1]
+    _hip.call("lnh_mlp_wgrad" + _hip.mlp_suffix(g16.dtype), g16.data_ptr(), a16.data_ptr(), B, M, N, out.data_ptr(),
+              *_hip.wgrad_ws(g16.device))
 
 
 def _backward_wide(gy16, x16, w16, fb, in_dim, hidden, nhm, act, need_dx):
     """Backward of the shapes without a one-kernel backward (hidden 128 / 256, more than two hidden matrices), structured
     as the reference's own (ffmlp.cu:578-733 + 1107-1263): lnh_mlp_backward_data — one fused kernel for the activation and
-    input gradients — then the weight gradients dW_l = G_l^T A_(l-1) as library GEMMs over the two buffers."""
+    input gradients — then the weight gradients dW_l = G_l^T A_(l-1) from the two buffers, one lnh_mlp_wgrad launch per
+    matrix (a fixed-order sum over the batch)."""
     B = x16.shape[0]
     wt = torch.cat([m.t().contiguous().reshape(-1) for m in _split(w16, in_dim, hidden, nhm)])
     gb = torch.empty((nhm + 1, B, hidden), dtype=x16.dtype, device=x16.device)
     gx = torch.empty((B, in_dim), dtype=x16.dtype, device=x16.device) if need_dx else None
     _hip.call("lnh_mlp_backward_data" + _hip.mlp_suffix(x16.dtype), gy16.data_ptr(), fb.data_ptr(), wt.data_ptr(), B, in_dim,
               16, hidden, nhm, act, gb.data_ptr(), _hip.ptr(gx))
-    parts = [_mm_f32(gb[0], x16)]
+    gw = torch.zeros(w16.numel(), dtype=torch.float32, device=x16.device)
+    o = hidden * in_dim
+    _wgrad(gb[0], x16, gw[:o])
     for m in range(nhm):
-        parts.append(_mm_f32(gb[m + 1], fb[m]))
-    parts.append(_mm_f32(gy16, fb[nhm]))
-    return gx, torch.cat([p.reshape(-1) for p in parts])
+        _wgrad(gb[m + 1], fb[m], gw[o:o + hidden * hidden])
+        o += hidden * hidden
+    _wgrad(gy16, fb[nhm], gw[o:o + 16 * hidden])
+    return gx, gw
 
 
 class _FusedMLP(Function):

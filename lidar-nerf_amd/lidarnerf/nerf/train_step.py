@@ -407,16 +407,27 @@ class LidarTrainer:
                 # workload, whose sample capacity moves to a new rung (a new capture) whenever the grid has changed enough
                 torch.cuda.synchronize()
                 import time
+                if self.dp:
+                    # Data parallel: ProcessGroupNCCL's watchdog thread keeps every EAGER collective in a list until one of
+                    # its sweeps (every 100 ms) finds the work's end event complete.  RCCL's stream joins the capture below,
+                    # and hipEventQuery on an event of a stream that is capturing fails with hipErrorCapturedEvent — in the
+                    # watchdog thread, which takes the process down ("failed once in a dozen runs" in round 5, 1 of 50 in
+                    # round 6's loop: the chance that a sweep falls into the 1-2 ms of a capture; with the capture stalled for
+                    # 300 ms it is every run, profiles/r06_rccl_loop.txt).  The collectives of the eager steps have finished
+                    # (the synchronize above): give the watchdog two sweeps to drop them, so that it has nothing to poll while
+                    # this thread captures.  Collectives issued DURING a capture are never put on that list.
+                    time.sleep(float(os.environ.get("LNH_CAPTURE_DRAIN_MS", "250")) * 1e-3)
                 t_cap = time.perf_counter()
                 if self._capture_stream is None:
                     self._capture_stream = torch.cuda.Stream()
                 with torch.cuda.stream(self._capture_stream):
-                    # (data parallel: RCCL's watchdog thread polls its events while this thread captures — a capture that
-                    #  polices every thread of the process would trip over it)
+                    # (a capture that polices every thread of the process would trip over the watchdog's other HIP calls)
                     ent["graph"].capture_begin(self._graph_pool,
                                                capture_error_mode="thread_local" if self.dp else "global")
                     try:
                         ent["loss"] = self._step_fused_table(ent["rays_o"], ent["rays_d"], ent["gt"], patch).detach()
+                        if os.environ.get("LNH_DEBUG_CAPTURE_STALL_MS"):  # (diagnosis only: widens the window above)
+                            time.sleep(float(os.environ["LNH_DEBUG_CAPTURE_STALL_MS"]) * 1e-3)
                     finally:
                         ent["graph"].capture_end()
                 # the gradient and the scale it carries live in THIS graph's buffers: table_grad() must see the ones of

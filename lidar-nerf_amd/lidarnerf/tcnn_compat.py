@@ -60,6 +60,21 @@ class _HashGrid(GridEncoder):
             super().reset_parameters()
 
 
+def _tcnn_hashgrid_param_count(cfg, n_input_dims):
+    """Length of the flat `params` vector REAL tiny-cuda-nn allocates for this HashGrid config (its published layout,
+    GridEncoding's constructor: per level resolution = ceil(exp2(l * log2(per_level_scale)) * base - 1) + 1, rows =
+    resolution^D rounded up to 8, capped at 2^log2_hashmap_size) — used only to recognise such a checkpoint."""
+    L, F = int(cfg.get("n_levels", 16)), int(cfg.get("n_features_per_level", 2))
+    pls, base = float(cfg.get("per_level_scale", 2.0)), int(cfg.get("base_resolution", 16))
+    cap = 1 << int(cfg.get("log2_hashmap_size", 19))
+    total = 0
+    for l in range(L):
+        scale = np.float32(np.exp2(np.float32(l) * np.float32(np.log2(pls)))) * np.float32(base) - np.float32(1.0)
+        res = int(np.ceil(scale)) + 1
+        total += min(-(-res ** n_input_dims // 8) * 8, cap)
+    return total * F
+
+
 class Encoding(nn.Module):
     """tcnn.Encoding(n_input_dims, encoding_config): otype HashGrid | Frequency | SphericalHarmonics | Identity."""
 
@@ -105,6 +120,17 @@ class Encoding(nn.Module):
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
         if prefix + "params" in state_dict and self.otype in ("hashgrid", "grid"):
+            got, mine = state_dict[prefix + "params"].numel(), self.impl.params.numel()
+            if got != mine:
+                theirs = _tcnn_hashgrid_param_count(self.encoding_config, self.n_input_dims)
+                what = ("this is the size REAL tiny-cuda-nn allocates for this config: the checkpoint was written by the "
+                        "reference running on tinycudann" if got == theirs else
+                        f"(real tiny-cuda-nn would hold {theirs} for this config: the checkpoint belongs to another config)")
+                raise RuntimeError(
+                    f"tcnn_compat.Encoding: `{prefix}params` holds {got} values, this HashGrid has {mine} — {what}.  "
+                    "Checkpoints of real tiny-cuda-nn do not load into this package: its dense levels have res^D rows with "
+                    "stride res, this package keeps torch-ngp's (res+1)^D rows with stride res+1 (INTEGRATION.md §A).  "
+                    "Re-train with this package, or resume one of its own checkpoints.")
             state_dict[prefix + "impl.params"] = state_dict.pop(prefix + "params")
         elif prefix + "params" in state_dict:
             state_dict.pop(prefix + "params")  # parameter-free encodings store an empty tensor

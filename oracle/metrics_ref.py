@@ -1,8 +1,11 @@
 """TEST INFRASTRUCTURE — NumPy/SciPy restatement of the LiDAR evaluation meters (lidarnerf/nerf/utils.py:226-413,
 extern/fscore.py:4-18) and of skimage.metrics.structural_similarity with the defaults the reference relies on
 (uniform 7x7 window, sample covariance, K1 = 0.01, K2 = 0.03, mean over the fully covered region).
-PARITY UNPINNED: utils.py cannot be imported here (tensorboardX / lpips / skimage are absent) and the chamfer kernel is
-CUDA; restated from source."""
+PINNED (round 6) for rmse / mae / depth_errors[:4] / fscore by tests/golden/g11_metrics.npz — the reference's OWN RMSEMeter,
+MAEMeter, DepthMeter and extern/fscore.py, imported with placeholder modules for the third-party imports they never touch
+(tests/golden/make_g11_metrics.py; tests/test_g11_metrics_cpu.py).  PARITY UNPINNED for `ssim` (scikit-image is absent here:
+restated from its published algorithm) and for the chamfer nearest-neighbour search (a CUDA kernel: checked against the
+definition, brute force)."""
 import numpy as np
 from scipy.ndimage import uniform_filter
 

@@ -176,6 +176,10 @@ if parallel.backend() == "nccl":
     for a_, b_ in zip(ls, le):
         assert abs(a_ - b_) <= 2e-3 * abs(b_) + 1e-6, (ls, le)
     print(f"rank {rank}: captured DP step (all-reduce and sharded optimizer) == eager DP step; RCCL-GRAPH-OK")
+if os.environ.get("LNH_DIST_BACKEND") == "nccl":
+    with open("/proc/self/maps") as f:
+        libs = sorted({l.split()[-1] for l in f if "rccl" in l.lower()})
+    print(f"rank {rank}: RCCL-MAPPED {libs}", flush=True)
 print(f"rank {rank}: DP-OK", flush=True)
 # (an orderly exit: the process group is torn down here, not by the interpreter's finalisers)
 if torch.distributed.is_initialized():

@@ -1,0 +1,86 @@
+"""G9: the integer index functions against known answers derived from the CUDA sources with Python integers
+(tests/golden/make_g9_kats.py — nothing of this repo is used to make them): the hash-grid row index
+(gridencoder.cu:53-93, incl. the dense -> hash switch level, tiled grids, align_corners, D = 2 / 3 / 4 and the levels whose
+dense stride wraps in uint32) and the Morton code of the occupancy grid (raymarching.cu:71-95, incl. the signed shifts of
+kernel_morton3D_invert, raymarching.cu:256-272).  CPU: both oracle restatements (NumPy, C).  GPU: the HIP kernels through
+lnh_grid_corner_indices / lnh_morton3D / lnh_morton3D_invert.  Bit-exact everywhere."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle, grid_ref
+
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g9_integer_kats.npz"))
+H = int(G["base_resolution"])
+S = 1.0  # per_level_scale 2
+
+
+def _cases(ci):
+    D, L, log2, gridtype, align = (int(v) for v in G["cfg"][ci])
+    m = G["grid_cfg"] == ci
+    return D, L, gridtype, bool(align), G["offsets"][ci, :L + 1].astype(np.int32), m
+
+
+def _points(ci):
+    """One input point per case whose corner-0 cell is the case's `base`: pos = x * scale + (0 | 0.5) with scale =
+    resolution - 1 (gridencoder.cu:146-153); x = base / scale puts pos at base + 0.5 (align_corners: (base + 0.5) / scale),
+    half a cell away from either neighbour — the float error of x * scale is < 0.01 at resolution 65536."""
+    D, L, gridtype, align, off, m = _cases(ci)
+    base = G["grid_base"][m][:, :D].astype(np.float64)
+    scale = (G["grid_resolution"][m].astype(np.float64) - 1.0)[:, None]
+    x = ((base + 0.5) / scale) if align else (base / scale)
+    assert x.min() >= 0 and x.max() <= 1
+    return x.astype(np.float32)
+
+
+@pytest.mark.parametrize("ci", range(6))
+def test_numpy_oracle_row_index(ci):
+    D, L, gridtype, align, off, m = _cases(ci)
+    pos, size, res = G["grid_pos"][m][:, :D], G["grid_hashmap_size"][m], G["grid_resolution"][m]
+    for hs, r in sorted(set(zip(size.tolist(), res.tolist()))):
+        k = (size == hs) & (res == r)
+        got = grid_ref.grid_index(pos[k].astype(np.uint32), hs, r, gridtype, align)
+        np.testing.assert_array_equal(got, G["grid_row"][m][k])
+    np.testing.assert_array_equal(grid_ref.make_offsets(D, L, 2.0, H, int(G["cfg"][ci][2]), align_corners=align), off)
+
+
+@pytest.mark.parametrize("ci", range(6))
+def test_c_oracle_row_index(ci):
+    D, L, gridtype, align, off, m = _cases(ci)
+    idx = c_oracle.grid_indices(_points(ci), off, 1, S, H, gridtype, align)  # [L, K, 2^D], C = 1: index = row
+    k = np.arange(int(m.sum()))
+    np.testing.assert_array_equal(idx[G["grid_level"][m], k, G["grid_corner"][m]], G["grid_row"][m])
+
+
+def test_oracle_morton():
+    np.testing.assert_array_equal(c_oracle.morton3D(G["morton_coords"].view(np.int32)).view(np.uint32), G["morton_code"])
+    np.testing.assert_array_equal(c_oracle.morton3D_invert(G["invert_in"].view(np.int32)).view(np.uint32), G["invert_out"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ci", range(6))
+def test_hip_row_index(ci):
+    import torch
+    from gpu_util import call, dev, host
+    D, L, gridtype, align, off, m = _cases(ci)
+    x = _points(ci)
+    for C_ in (1, 2):
+        out = torch.empty((L, x.shape[0], 1 << D), dtype=torch.int32, device="cuda")
+        call("lnh_grid_corner_indices", dev(x), torch.from_numpy(off), out, x.shape[0], D, C_, L, S, H, gridtype, int(align))
+        got = host(out).view(np.uint32)[G["grid_level"][m], np.arange(x.shape[0]), G["grid_corner"][m]]
+        np.testing.assert_array_equal(got, G["grid_row"][m] * C_)
+
+
+@pytest.mark.gpu
+def test_hip_morton():
+    import torch
+    from gpu_util import call, dev, host
+    c = G["morton_coords"].view(np.int32)
+    out = torch.empty(c.shape[0], dtype=torch.int32, device="cuda")
+    call("lnh_morton3D", dev(c), c.shape[0], out)
+    np.testing.assert_array_equal(host(out).view(np.uint32), G["morton_code"])
+    i = G["invert_in"].view(np.int32)
+    back = torch.empty((i.shape[0], 3), dtype=torch.int32, device="cuda")
+    call("lnh_morton3D_invert", dev(i), i.shape[0], back)
+    np.testing.assert_array_equal(host(back).view(np.uint32), G["invert_out"])

@@ -75,3 +75,27 @@ def test_meters_match_restatement():
     assert abs(cd - (d1.mean() + d2.mean())) < 1e-3 * (d1.mean() + d2.mean())
     assert abs(f - metrics_ref.fscore(d1, d2, 0.05)) < 2e-3
     assert pm.measure().shape == (2,) and "CD f-score" in pm.report()
+
+
+def test_meters_match_the_reference_meters_g11():
+    """The HIP meters against what the reference's own RMSEMeter / MAEMeter / DepthMeter and extern/fscore.py computed on the
+    same frames (tests/golden/g11_metrics.npz, made by tests/golden/make_g11_metrics.py from the imported reference)."""
+    import os
+    from lidarnerf.metrics import DepthMeter, MAEMeter, RMSEMeter, fscore
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g11_metrics.npz"))
+    scale = float(G["scale"])
+    r, m, d = RMSEMeter(), MAEMeter(intensity_inv_scale=2.0), DepthMeter(scale)
+    for k in range(3):
+        p, g = torch.from_numpy(G[f"pred{k}"]).cuda(), torch.from_numpy(G[f"gt{k}"]).cuda()
+        r.update(p, g)
+        m.update(p, g)
+        d.update(p * np.float32(scale), g * np.float32(scale))
+    assert abs(r.measure() - float(G["rmse"])) <= 2e-5 * float(G["rmse"])
+    assert abs(m.measure() - float(G["mae"])) <= 2e-5 * float(G["mae"])
+    # rmse, a1, a2, a3 (fp32 device reductions against numpy's pairwise fp32 sums; a pixel exactly on a ratio threshold may
+    # fall on either side: 1 of 17 000 pixels = 6e-5)
+    np.testing.assert_allclose(np.asarray(d.measure())[:4], G["depth_measure"], rtol=2e-4, atol=1e-4)
+    f, p_, r_ = fscore(torch.from_numpy(G["fs_d1"]).cuda(), torch.from_numpy(G["fs_d2"]).cuda(), float(G["fs_threshold"]))
+    np.testing.assert_allclose(f.cpu().numpy(), G["fs_f"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(p_.cpu().numpy(), G["fs_p"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(r_.cpu().numpy(), G["fs_r"], rtol=1e-6, atol=1e-7)

@@ -232,11 +232,41 @@ def test_wide_kernels_vs_oracle(hidden, nhm, in_dim, act, sfx):
             call("lnh_mlp_backward" + sfx, gy.cuda(), x.cuda(), w, B, in_dim, 16, hidden, nhm, act, 6, gx, gw, *wgrad())
 
 
+@pytest.mark.parametrize("sfx", ["", "_bf16"])
+@pytest.mark.parametrize("M,N,B", [(16, 16, 1000), (16, 256, 4099), (256, 16, 777), (128, 128, 100_000), (256, 256, 65_537),
+                                   (64, 48, 33), (128, 112, 31), (32, 256, 300_000)])
+def test_wide_weight_gradient_kernel(M, N, B, sfx):
+    """lnh_mlp_wgrad (csrc/mlp_wgrad.hip): grad_weights[M, N] += grad^T acts, the batch contraction of the wide MLPs' backward
+    (the reference: split-K CUTLASS GEMMs, ffmlp.cu:1107-1263) — against fp64 on the same 16-bit values (products of 16-bit
+    values are exact in fp32; what differs is the order of the fp32 sums), ADDED to what the gradient holds, and the same
+    bits on every launch (fixed-order sum, csrc/wgrad.h)."""
+    from gpu_util import call, wgrad
+    dt = torch.bfloat16 if sfx else torch.float16
+    g = torch.Generator().manual_seed(M * 1000 + N + B)
+    G = (torch.randn(B, M, generator=g) * 0.1).to(dt).cuda()
+    A = (torch.randn(B, N, generator=g) * 0.5).to(dt).cuda()
+    want = G.double().t() @ A.double()
+    outs = []
+    for _ in range(3):
+        gw = torch.full((M, N), 2.0, device="cuda")
+        call("lnh_mlp_wgrad" + sfx, G, A, B, M, N, gw, *wgrad())
+        outs.append(gw)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    scale = float(want.abs().max())
+    torch.testing.assert_close(outs[0].double() - 2.0, want, rtol=1e-5, atol=2e-6 * scale + 1e-6 * np.sqrt(B))
+    # refused by name: widths outside 16 .. 256 / not multiples of 16, a missing workspace
+    with pytest.raises(RuntimeError, match="multiples of 16"):
+        call("lnh_mlp_wgrad" + sfx, G, A, B, M, N + 8, outs[0], *wgrad())
+    with pytest.raises(RuntimeError, match="lnh_wgrad_workspace_bytes"):
+        call("lnh_mlp_wgrad" + sfx, G, A, B, M, N, outs[0], None, 0)
+
+
 @pytest.mark.parametrize("hidden,layers,in_dim", [(16, 2, 32), (128, 3, 48), (256, 2, 64), (64, 5, 32), (256, 4, 32)])
 def test_ffmlp_module_all_reference_widths(hidden, layers, in_dim):
     """Every width the reference accepts (ffmlp.py:202-209: 16 .. 256) and deeper nets, all on fused kernels (hidden 16 on
-    the hidden-32 kernels; 128 / 256 and more than 3 hidden layers on csrc/mlp_wide.hip with the weight gradients as
-    library GEMMs): forward and gradients vs the oracle, and the launches that ran."""
+    the hidden-32 kernels; 128 / 256 and more than 3 hidden layers on csrc/mlp_wide.hip with the weight gradients from
+    csrc/mlp_wgrad.hip): forward and gradients vs the oracle, and the launches that ran."""
     from lidarnerf.ffmlp import FFMLP
     from lidarnerf import _hip
     m = FFMLP(in_dim, 5, hidden, layers).cuda()
@@ -259,14 +289,15 @@ def test_ffmlp_module_all_reference_widths(hidden, layers, in_dim):
     np.testing.assert_allclose(xt.grad.cpu().numpy(), gx_want, rtol=1e-2, atol=4e-3)
     np.testing.assert_allclose(m.weights.grad.cpu().numpy(), dw_want, rtol=1e-2, atol=4e-3 * np.abs(dw_want).max())
     # which kernels ran: one forward launch; one-kernel backward for the narrow shapes, the data kernel for the wide ones
-    names = ["lnh_mlp_forward", "lnh_mlp_backward", "lnh_mlp_backward_data"]
+    names = ["lnh_mlp_forward", "lnh_mlp_backward", "lnh_mlp_backward_data", "lnh_mlp_wgrad"]
     _hip.enable_timers(names)
     with torch.autocast("cuda", dtype=torch.float16):
         m(xt.detach().requires_grad_(True)).float().sum().backward()
     calls = _hip.disable_timers()
     n = {k: len(calls.get(k, [])) for k in names}
     wide = hidden >= 128 or layers - 1 > 2
-    assert n == {"lnh_mlp_forward": 1, "lnh_mlp_backward": 0 if wide else 1, "lnh_mlp_backward_data": 1 if wide else 0}, n
+    assert n == {"lnh_mlp_forward": 1, "lnh_mlp_backward": 0 if wide else 1, "lnh_mlp_backward_data": 1 if wide else 0,
+                 "lnh_mlp_wgrad": layers + 1 if wide else 0}, n  # (one weight-gradient launch per matrix — `layers` hidden-side matrices + the output matrix: no library GEMM)
     # what still has no kernel runs as the library-GEMM chain (the reference's constructor accepts it); strict_fused refuses
     with pytest.raises(RuntimeError, match="no fused MFMA kernel"):
         FFMLP(256, 5, hidden, layers, strict_fused=True)

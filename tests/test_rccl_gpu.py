@@ -67,7 +67,8 @@ def test_rccl_single_rank_runs_the_exchange_and_the_captured_dp_step():
     out = r.stdout + r.stderr
     assert r.returncode == 0, out[-4000:]
     assert out.count("DP-OK") == 1 and "RCCL-GRAPH-OK" in out, out[-4000:]
-    assert "librccl" in out or "RCCL version" in out or True  # (RCCL prints its banner only with NCCL_DEBUG=VERSION)
+    # ... and the collectives really went through RCCL: the worker reports the librccl it has mapped
+    assert "RCCL-MAPPED" in out and "librccl" in out, out[-4000:]
 
 
 def test_rccl_bench_single_rank_graph_line():
@@ -77,22 +78,15 @@ def test_rccl_bench_single_rank_graph_line():
                MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--no-eval",
            "--no-cpu-baseline", "--no-mfma-states", "--rays", "1024"]
-    # (one re-run allowed: the full suite saw this subprocess fail once in a dozen runs on the pool's boxes — with fixed
-    #  rendezvous ports and without an orderly process-group teardown at the time — and never when run on its own; what the
-    #  first attempt printed is kept in the assertion message)
-    first = ""
-    for attempt in range(2):
-        env["MASTER_PORT"] = _free_port()
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
-        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-        d = json.loads(lines[0]) if lines else {}
-        ok = (r.returncode == 0 and d.get("n_gpus") == 1 and "graph" in d and "error" not in d["graph"]
-              and "collectives" in d["config"]["launch"])
-        if ok:
-            break
-        first = first or f"attempt 1: rc {r.returncode} graph {d.get('graph')}\n{(r.stdout + r.stderr)[-2500:]}\n"
-    assert ok, first + f"attempt 2: rc {r.returncode} graph {d.get('graph')} launch {d.get('config', {}).get('launch')}\n" + \
-        (r.stdout + r.stderr)[-2500:]
+    # No retry: round 5 allowed one re-run here ("failed once in a dozen runs").  Round 6 looped this very command 50 times on
+    # a box (tools/loop_rccl_bench.sh, profiles/r06_rccl_loop.txt) to find out what that was.
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    d = json.loads(lines[0]) if lines else {}
+    ok = (r.returncode == 0 and d.get("n_gpus") == 1 and "graph" in d and "error" not in d["graph"]
+          and "collectives" in d["config"]["launch"])
+    assert ok, f"rc {r.returncode} graph {d.get('graph')} launch {d.get('config', {}).get('launch')}\n" + \
+        (r.stdout + r.stderr)[-4000:]
 
 
 def test_rccl_refuses_two_ranks_on_one_gpu_loudly():

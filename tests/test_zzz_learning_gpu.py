@@ -4,18 +4,16 @@ on a HELD-OUT ray set must fall from ~11 m at initialisation to well below a met
 2x8 patch epochs (structural-gradient term, nerf/utils.py:760-876, 1057-1065; patch rays of dataset/base_dataset.py:50-70).
 A path that computes plausible numbers but wrong gradients does not pass this.
 
-These are the LAST tests of the suite (file name), behind every deterministic parity test: what they assert is a property of a
-few hundred optimizer steps of a recipe (Adam at lr 1e-2, fp16 gradients behind a dynamic loss scale with torch's growth
-interval of 2000 steps) that is chaotic in its late phase.  Measured in round 6 over 230 runs of the patch mode on seven boxes
-(profiles/r06_learning_distribution.md): after 100 steps EVERY run is at 0.59 .. 0.69 m; between steps 120 and 200 the loss
-spikes (the unscaled table gradient grows 10-20x within ten steps), the loss scale halves at every overflow and cannot grow
-back within the test, and one run in four ends at a scale <= 16 with the field damaged (0.5 .. 5 m at step 400; the others
-0.12 .. 0.25 m) — with torch.optim.Adam + GradScaler in place of the fused optimizer as well, with the captured step, with a
-host sync after every step, and on the round-4 tree.  Round 5's gate went red on such a run (3.89 m against a bound of 2.5).
-Since round 6 the training path has no float atomics left (tests/test_determinism_gpu.py): a seed gives ONE trajectory, on
-every box — the figures below are those of seed 0, not samples of a distribution.  The bounds still do not lean on the
-chaotic phase: the patch test asserts the 100-step figure (17x below the start, a margin of 1.5x over every run ever seen)
-and, for the end state, only that training has not gone backwards."""
+These are the LAST tests of the suite (file name), behind every deterministic parity test.  What they train with is the
+reference's recipe (Adam, fp16 gradients behind a dynamic loss scale with torch's growth interval of 2000 steps) at HALF its
+learning rate: 5e-3.  Measured in round 6 (profiles/r06_learning_distribution.md, ~300 runs): at the reference's 1e-2 this
+synthetic scene sits at the edge of stability — every run is at 0.59 .. 0.69 m after 100 steps, then the loss spikes, the
+loss scale halves at every overflow, and a third to a half of the runs (whatever the seed, the optimizer — torch.optim.Adam +
+GradScaler as well — or the tree, round 4's included) wander at 0.5 .. 5 m for hundreds of steps; round 5's gate went red on
+such a run (3.89 m against a bound of 2.5).  At 5e-3 all 22 measured runs (12 seeds 1 x 1, 10 seeds 2 x 8) lie within
+0.15 .. 0.19 m at step 400 with the loss scale untouched at 4096.  Since round 6 the training path has no float atomics left
+(tests/test_determinism_gpu.py): a seed gives ONE trajectory on every box, so the figures asserted below are those of seed 0,
+with a factor two of room to the whole measured band."""
 import os
 import sys
 
@@ -35,7 +33,7 @@ def _train(patch, steps, every):
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
     model = bench.build_model(dev)
-    tr = LidarTrainer(model, lr=1e-2, iters=30000, fp16=True, scale=bench.SCALE,
+    tr = LidarTrainer(model, lr=5e-3, iters=30000, fp16=True, scale=bench.SCALE,
                       render_kwargs=dict(num_steps=768, upsample_steps=64))
     poses = bench.synthetic_frames(60, dev)
     batches = [bench.make_batch(poses, s, 4096, 0, dev, patch, "analytic") for s in range(60)]
@@ -60,24 +58,21 @@ def _train(patch, steps, every):
 
 
 def test_dense_path_learns_the_analytic_scene():
-    errs, losses, tr = _train((1, 1), 600, 100)
+    errs, losses, tr = _train((1, 1), 400, 100)
     assert np.isfinite(losses).all()
-    # measured on MI355X (rounds 3-6, dozens of runs): 11.6 m -> 0.59 .. 0.61 m after 100 steps, 0.06 .. 0.15 m after 600-800
-    # (not monotonic in between: 0.45 .. 1.1 m at step 300)
-    assert errs[0] > 5.0 and errs[100] < 1.0 and errs[600] < 1.0 and errs[600] < errs[0] / 10, errs
-    # the dynamic loss scale settles where the fp16 table gradient just fits (a 6000-step run: 32 .. 128 — the depth term
-    # carries a factor 1000), it must not collapse towards zero
-    assert float(tr.loss_scale) >= 4.0
+    # measured on MI355X, 12 seeds: 11.6 m -> 0.47 .. 0.49 m after 100 steps, 0.15 .. 0.17 m after 400
+    assert errs[0] > 5.0 and errs[100] < 1.0 and errs[400] < 0.4, errs
+    # the dynamic loss scale stays where the fp16 table gradient fits (measured: 256 .. 4096 after 800 steps)
+    assert float(tr.loss_scale) >= 32.0
 
 
 def test_patch_mode_step_learns_too():
     errs, losses, tr = _train((2, 8), 400, 100)
     assert np.isfinite(losses).all()
-    # 256 patches of 16 neighbouring rays per step + the structural-gradient term.  After 100 steps: 0.59 .. 0.69 m in every
-    # one of 230 measured runs; at step 400: 0.12 .. 0.25 m in three runs of four, 0.5 .. 5 m in the others (module docstring)
-    assert errs[0] > 5.0 and errs[100] < 1.0, errs
-    assert min(errs.values()) < errs[0] / 10 and errs[400] < errs[0] / 2, errs
-    assert float(tr.loss_scale) >= 1.0
+    # 256 patches of 16 neighbouring rays per step + the structural-gradient term; 10 seeds: 0.35 .. 0.46 m after 100 steps,
+    # 0.15 .. 0.19 m after 400 (not monotonic in between: the 60 frames cycle, 0.82 .. 0.95 m at step 300)
+    assert errs[0] > 5.0 and errs[100] < 1.0 and errs[400] < 0.4, errs
+    assert float(tr.loss_scale) >= 32.0
 
 
 def test_patch_gradient_term_matches_the_restatement():
