@@ -38,7 +38,7 @@ MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA peak
 SIGMA_FLOPS = 2 * (32 * 64 + 64 * 16)                 # 6 144
 COLOR_FLOPS = 2 * (96 * 64 + 64 * 64 + 64 * 16)       # 22 528 (90 -> 64 -> 64 -> 2 padded to MFMA tiles), masked points
 # what the colour kernels execute per masked point: the 75 direction columns of layer 0 are folded into a per-ray
-# term (DESIGN.md §6), leaving K = 16 per sample
+# term (DESIGN.md §5), leaving K = 16 per sample
 COLOR_FLOPS_EXECUTED = 2 * (16 * 64 + 64 * 64 + 64 * 16)
 
 # algorithmic bytes per sample point, fp16 tables, L=16, F=2, D=3

@@ -5,19 +5,19 @@
 #   <tag>_pmc.json           FETCH_SIZE / WRITE_SIZE per launch of the grid kernels (separate --pmc passes, no other
 #                            trace domains; FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM": gfx950 tallies 128-B reads at 64 B)
 #   <tag>_bench.json         the default bench line (with cpu_baseline)
-tag=${1:-r05}
+tag=${1:-r06}
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 out=gpurun_out/profiles; mkdir -p $out
 STEPS=10; WARM=3
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -o r -- python bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-eval --no-mfma-states > /dev/null 2>&1
 find /tmp/prof_kt -name "*kernel_stats.csv" -exec cp {} $out/${tag}_kernel_stats.csv \;
 # (+5 steps: the MFMA pass bench.py runs after the timed region; + STEPS: the launch-by-launch region behind the replayed one;
-#  + 2 x STEPS: the two repeats of the timed region it lists as spread)
-python - $out/${tag}_kernel_stats.csv $((4*STEPS+WARM+5)) > $out/${tag}_kernel_summary.txt <<'PY'
+#  + 2 x STEPS: the two repeats of the timed region it lists as spread; + 100: the 100-step region behind `value_100`)
+python - $out/${tag}_kernel_stats.csv $((4*STEPS+WARM+5+100)) > $out/${tag}_kernel_summary.txt <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1]))); n = float(sys.argv[2])
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
-print(f"rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-eval   ({int(n)} steps: warm-up, 10 replayed, 10 launch by launch, the 5-step MFMA pass, 2 x 10 repeats)")
+print(f"rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-eval   ({int(n)} steps: warm-up, 10 replayed, 10 launch by launch, the 5-step MFMA pass, 2 x 10 repeats, the 100-step region)")
 print(f"total kernel time per training step: {tot/n/1e6:.3f} ms")
 for r in rows[:40]:
     print(f"{float(r['TotalDurationNs'])/n/1e6:8.3f} ms/step {int(r['Calls'])/n:6.1f} calls/step  avg {float(r['AverageNs'])/1e3:9.1f} us  {r['Name'][:110]}")

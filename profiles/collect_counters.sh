@@ -3,7 +3,7 @@
 #   bash profiles/collect_counters.sh r02      (on a GPU box; writes gpurun_out/profiles/<tag>_grid_counters.json)
 # One rocprofv3 --pmc pass per counter group (no other trace domains), workload = tools/bench_grid.py (3.4 M points,
 # fp16 tables, LiDAR ray geometry, whole forward + whole backward, 3 launches each).
-tag=${1:-r05}
+tag=${1:-r06}
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 out=gpurun_out/profiles; mkdir -p $out
 groups=(

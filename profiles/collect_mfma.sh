@@ -1,7 +1,7 @@
 #!/bin/bash
 # MFMA / issue counters of the four MLP kernels of a training step:  bash profiles/collect_mfma.sh r02
 # (rocprofv3 --pmc passes over `python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-eval`, kernel trace only)
-tag=${1:-r05}
+tag=${1:-r06}
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 out=gpurun_out/profiles; mkdir -p $out
 groups=(

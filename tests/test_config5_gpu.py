@@ -1,6 +1,6 @@
 """BASELINE config 5 at its batch size: 16 384 rays x (768 + 64) samples through the fused chain with fp16 hash features
 and bf16 MFMA MLPs (torch.autocast(dtype=bfloat16)) — 13.6 M sample points, the table-gradient backward walked in 4 chunks
-of <= 4 M points (DESIGN.md §4.5).  At this size the CPU oracle cannot follow, so:
+of <= 4 M points (DESIGN.md §4).  At this size the CPU oracle cannot follow, so:
 
   * a 32-ray subset of THE SAME batch (same rays, same random draws) is rendered by oracle/render_ref.py and must agree with
     those rays' outputs of the big batch (rays are independent: renderer.py:99-298 has no cross-ray term);

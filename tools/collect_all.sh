@@ -8,7 +8,7 @@
 #   (profiles/collect_counters.sh — grid kernel counter groups — and profiles/collect_mfma.sh — MLP kernel counters — are
 #    separate calls: WITH_COUNTERS=1 adds them.)
 # Copy what you want judged from gpurun_out/profiles/ to profiles/.
-tag=${1:-r05}
+tag=${1:-r06}
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 out=gpurun_out/profiles; mkdir -p $out
 timeout 1500 bash profiles/collect.sh $tag > gpurun_out/collect.log 2>&1
