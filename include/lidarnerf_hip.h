@@ -230,7 +230,7 @@ LNH_API int lnh_mlp_backward(const void *grad, const void *inputs, const void *w
  *     hidden*output_dim (Wo^T, rows = hidden units)] — writes backward_buffer [n_hidden_mats+1, B, hidden] f16 =
  *     dL/d(pre-activation) of every hidden layer and grad_inputs (NULL or [B,input_dim]);
  *   the weight gradients are the GEMMs dW0 = backward_buffer[0]^T inputs, dWh_m = backward_buffer[m+1]^T
- *     forward_buffer[m], dWo = grad^T forward_buffer[n_hidden_mats]: left to the caller's BLAS (ffmlp/ffmlp.py: torch.mm).
+ *     forward_buffer[m], dWo = grad^T forward_buffer[n_hidden_mats]: one lnh_mlp_wgrad call each (below).
  *   lnh_mlp_backward returns LNH_ERR_UNSUPPORTED for these shapes and says so.  Works for the narrow shapes too.
  * hidden_dim 16 has no kernel of its own (the module zero-pads it onto 32); input_dim > 128: LNH_ERR_UNSUPPORTED.
  */
