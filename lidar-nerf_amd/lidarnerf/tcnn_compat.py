@@ -16,6 +16,7 @@ out[dim*2K + 2k + p] = sin(2^k * pi * x[dim] + p * pi/2)); FullyFusedMLP uses tc
 [n_neurons, pad16(n_in)], hidden matrices, last matrix [pad16(n_out), n_neurons], all row-major, bias-free).
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -75,6 +76,67 @@ def _tcnn_hashgrid_param_count(cfg, n_input_dims):
     return total * F
 
 
+def _tcnn_levels(cfg, n_input_dims):
+    """Per level of a tiny-cuda-nn HashGrid (its published GridEncoding constructor / grid_index): (resolution, rows, hashed)."""
+    L = int(cfg.get("n_levels", 16))
+    pls, base = float(cfg.get("per_level_scale", 2.0)), int(cfg.get("base_resolution", 16))
+    cap = 1 << int(cfg.get("log2_hashmap_size", 19))
+    out = []
+    for l in range(L):
+        scale = np.float32(np.exp2(np.float32(l) * np.float32(np.log2(pls)))) * np.float32(base) - np.float32(1.0)
+        res = int(np.ceil(scale)) + 1
+        dense_rows = -(-res ** n_input_dims // 8) * 8
+        out.append((res, min(dense_rows, cap), res ** n_input_dims > min(dense_rows, cap)))
+    return out
+
+
+def convert_tcnn_hashgrid_params(params, cfg, n_input_dims=3):
+    """The flat `params` vector of a HashGrid trained by REAL tiny-cuda-nn -> this package's layout (a new fp32 vector).
+
+    PARITY UNPINNED (tiny-cuda-nn is not in the tree; restated from its published source): tiny-cuda-nn indexes vertex
+    (x, y, z) of a DENSE level at x + y res + z res^2 (mod the level's rows: the vertices x = res alias the next row), this
+    package at x + y (res + 1) + z (res + 1)^2 — every vertex 0 .. res gets the value tiny-cuda-nn would have read for it, so the
+    encoder's OUTPUT is the same at load time (the aliased vertices are separate parameters afterwards).  Hashed levels use
+    the same hash and the same row count: copied.  A level that tiny-cuda-nn keeps dense and this package hashes (res^D <=
+    2^log2_hashmap_size < (res + 1)^D) cannot be converted and raises.  Opt-in: `Encoding.load_state_dict` refuses such a
+    checkpoint by name unless LNH_TCNN_CONVERT=1."""
+    from .gridencoder.grid import level_offsets
+    F_ = int(cfg.get("n_features_per_level", 2))
+    D = int(n_input_dims)
+    theirs = _tcnn_levels(cfg, D)
+    mine = level_offsets(D, int(cfg.get("n_levels", 16)), float(cfg.get("per_level_scale", 2.0)),
+                         int(cfg.get("base_resolution", 16)), int(cfg.get("log2_hashmap_size", 19)), False)
+    mine = [int(v) for v in mine]
+    src = torch.as_tensor(params).detach().float().cpu().reshape(-1, F_)
+    if src.shape[0] != sum(r for _, r, _ in theirs):
+        raise RuntimeError(f"convert_tcnn_hashgrid_params: {src.shape[0]} rows, tiny-cuda-nn holds {sum(r for _, r, _ in theirs)} for this config")
+    out = torch.zeros((mine[-1], F_), dtype=torch.float32)
+    o_t = 0
+    for l, (res, rows_t, hashed_t) in enumerate(theirs):
+        rows_m = mine[l + 1] - mine[l]
+        hashed_m = (res + 1) ** D > rows_m
+        lvl = src[o_t:o_t + rows_t]
+        if hashed_t and hashed_m:
+            if rows_t != rows_m:
+                raise RuntimeError(f"convert_tcnn_hashgrid_params: level {l}: hashed with {rows_t} rows there, {rows_m} here")
+            out[mine[l]:mine[l + 1]] = lvl
+        elif not hashed_t and not hashed_m:
+            g = torch.arange(res + 1)
+            idx_t = torch.zeros((res + 1,) * D, dtype=torch.long)
+            idx_m = torch.zeros((res + 1,) * D, dtype=torch.long)
+            for d in range(D):  # dimension 0 is the fastest in both index functions
+                shape = [1] * D
+                shape[D - 1 - d] = res + 1
+                idx_t += g.view(shape) * res ** d
+                idx_m += g.view(shape) * (res + 1) ** d
+            out[mine[l] + idx_m.reshape(-1)] = lvl[idx_t.reshape(-1) % rows_t]
+        else:
+            raise RuntimeError(f"convert_tcnn_hashgrid_params: level {l} (resolution {res}) is dense in tiny-cuda-nn and hashed "
+                               "here: no exact conversion")
+        o_t += rows_t
+    return out.reshape(-1)
+
+
 class Encoding(nn.Module):
     """tcnn.Encoding(n_input_dims, encoding_config): otype HashGrid | Frequency | SphericalHarmonics | Identity."""
 
@@ -123,14 +185,26 @@ class Encoding(nn.Module):
             got, mine = state_dict[prefix + "params"].numel(), self.impl.params.numel()
             if got != mine:
                 theirs = _tcnn_hashgrid_param_count(self.encoding_config, self.n_input_dims)
-                what = ("this is the size REAL tiny-cuda-nn allocates for this config: the checkpoint was written by the "
-                        "reference running on tinycudann" if got == theirs else
-                        f"(real tiny-cuda-nn would hold {theirs} for this config: the checkpoint belongs to another config)")
-                raise RuntimeError(
-                    f"tcnn_compat.Encoding: `{prefix}params` holds {got} values, this HashGrid has {mine} — {what}.  "
-                    "Checkpoints of real tiny-cuda-nn do not load into this package: its dense levels have res^D rows with "
-                    "stride res, this package keeps torch-ngp's (res+1)^D rows with stride res+1 (INTEGRATION.md §A).  "
-                    "Re-train with this package, or resume one of its own checkpoints.")
+                if got == theirs and os.environ.get("LNH_TCNN_CONVERT") == "1":
+                    import warnings
+                    warnings.warn("tcnn_compat.Encoding: converting a tiny-cuda-nn HashGrid checkpoint to this package's level "
+                                  "layout (convert_tcnn_hashgrid_params: same encoder output at load time; parity unpinned)")
+                    state_dict[prefix + "params"] = convert_tcnn_hashgrid_params(
+                        state_dict[prefix + "params"], self.encoding_config, self.n_input_dims).to(self.impl.params.device)
+                elif got == theirs:
+                    raise RuntimeError(
+                        f"tcnn_compat.Encoding: `{prefix}params` holds {got} values, this HashGrid has {mine} — {got} is what REAL "
+                        "tiny-cuda-nn allocates for this config: the checkpoint was written by the reference running on tinycudann.  "
+                        "Such checkpoints do not load into this package: tiny-cuda-nn's dense levels have res^D rows with stride "
+                        "res, this package keeps torch-ngp's (res+1)^D rows with stride res+1 (INTEGRATION.md §A), so the flat "
+                        "vector has another length AND another index function.  Re-train with this package, resume one of its own "
+                        "checkpoints, or set LNH_TCNN_CONVERT=1 to convert the table at load (tcnn_compat."
+                        "convert_tcnn_hashgrid_params: same encoder output at load time, restated from tiny-cuda-nn's published "
+                        "index function — unpinned).")
+                else:
+                    raise RuntimeError(
+                    f"tcnn_compat.Encoding: `{prefix}params` holds {got} values, this HashGrid has {mine} (real tiny-cuda-nn "
+                    f"would hold {theirs} for this config): the checkpoint belongs to another encoding config.")
             state_dict[prefix + "impl.params"] = state_dict.pop(prefix + "params")
         elif prefix + "params" in state_dict:
             state_dict.pop(prefix + "params")  # parameter-free encodings store an empty tensor
