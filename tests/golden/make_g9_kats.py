@@ -5,7 +5,8 @@ CUDA extensions do not compile here):
   * the hash-grid row index, lidarnerf/gridencoder/src/gridencoder.cu:53-93 (`fast_hash`, `get_grid_index`), with the level
     tables of lidarnerf/gridencoder/grid.py:179-192 (`offsets`);
   * the Morton code of the occupancy grid, lidarnerf/raymarching/src/raymarching.cu:71-95 (`__expand_bits`, `__morton3D`,
-    `__morton3D_invert`).
+    `__morton3D_invert`), the cell lookup built on it (51-69, 386-408: mip level from position and step, cell, bit test) on
+    inputs for which every float operation is exact, and `kernel_packbits` (286-306).
 
 Both are pure uint32 arithmetic, so the answers can be derived WITHOUT any of this repo's code: below, the C expressions are
 evaluated with Python's unbounded integers and an explicit `& 0xFFFFFFFF` wherever C's uint32_t would wrap.  Nothing is imported
@@ -95,6 +96,78 @@ def interleave_by_definition(x, y, z):
     return out
 
 
+def occupancy_bit(index):
+    """The occupancy bitfield the lookups are checked on: bit `index` is set iff this is 1 (tests build the same field)."""
+    return ((index * 2654435761) >> 13) & 1
+
+
+def occupancy_kats():
+    """Cell lookup of kernel_march_rays_train (raymarching.cu:386-408) with mip_from_pos / mip_from_dt (51-69): inputs are
+    dyadic rationals, so every float operation of the CUDA code is exact and the answer follows with Fractions:
+        level = max(frexp-exponent of max |x_i|, frexp-exponent of dt * H / 2), clamped to [0, C - 1]
+        mip_bound = min(2^level, bound);  n_i = trunc(clamp((x_i / mip_bound + 1) * H / 2, 0, H - 1))
+        index = level * H^3 + morton3D(n);  occ = bit `index` of the field."""
+    from fractions import Fraction as Fr
+    import math
+    H = 128
+    cases = []  # (C, bound, x, y, z, dt)
+    pts = [Fr(0), Fr(1, 2), Fr(-1, 2), Fr(1), Fr(-1), Fr(63, 64), Fr(-127, 128), Fr(1, 128), Fr(-1, 256), Fr(3, 4), Fr(5, 4), Fr(2),
+           Fr(-2), Fr(255, 128), Fr(3), Fr(-7, 2), Fr(4), Fr(-4), Fr(1, 1024), Fr(-33, 64)]
+    dts = [Fr(1, 4096), Fr(1, 256), Fr(1, 128), Fr(1, 64), Fr(3, 128), Fr(1, 32), Fr(1, 16)]
+    rng = Lcg(99)
+    for C_, bound in ((1, 1), (2, 2), (3, 4)):
+        inside = [p for p in pts if abs(p) <= bound]
+        for i in range(140):
+            x, y, z = (inside[rng.below(len(inside))] for _ in range(3))
+            cases.append((C_, bound, x, y, z, dts[rng.below(len(dts))]))
+        for p in inside:  # every special value once on every axis, with the smallest step
+            cases += [(C_, bound, p, Fr(0), Fr(0), dts[0]), (C_, bound, Fr(0), p, Fr(1, 128), dts[0]), (C_, bound, Fr(1, 256), Fr(0), p, dts[1])]
+    f32 = lambda q: float(np.float32(float(q)))
+    out = {k: [] for k in ("occ_C", "occ_bound", "occ_xyz", "occ_dt", "occ_level", "occ_cell", "occ_index", "occ_bit")}
+    for C_, bound, x, y, z, dt in cases:
+        for q in (x, y, z, dt):
+            assert Fr(f32(q)) == q  # float32 holds the input exactly
+        mx = max(abs(x), abs(y), abs(z))
+        e_pos = math.frexp(float(mx))[1] if mx else 0  # frexpf(0) = (0, 0)
+        e_dt = math.frexp(float(dt * H / 2))[1]
+        level = max(min(C_ - 1, max(0, e_pos)), min(C_ - 1, max(0, e_dt)))
+        mip_bound = min(Fr(2) ** level, Fr(bound))
+        cell = []
+        for v in (x, y, z):
+            t = (v / mip_bound + 1) * H / 2
+            assert Fr(f32(v / mip_bound)) == v / mip_bound and Fr(f32(t)) == t  # the intermediate floats are exact too
+            cell.append(int(min(max(t, 0), H - 1)))  # clamp, then the C cast truncates (all values >= 0)
+        index = level * H ** 3 + morton3D(*cell)
+        out["occ_C"].append(C_); out["occ_bound"].append(bound); out["occ_xyz"].append([f32(x), f32(y), f32(z)])
+        out["occ_dt"].append(f32(dt)); out["occ_level"].append(level); out["occ_cell"].append(cell); out["occ_index"].append(index)
+        out["occ_bit"].append(occupancy_bit(index))
+    assert len(set(out["occ_level"])) == 3 and 0 < sum(out["occ_bit"]) < len(cases)
+    return {"occ_C": np.array(out["occ_C"], np.int32), "occ_bound": np.array(out["occ_bound"], np.float32),
+            "occ_xyz": np.array(out["occ_xyz"], np.float32), "occ_dt": np.array(out["occ_dt"], np.float32),
+            "occ_level": np.array(out["occ_level"], np.int32), "occ_cell": np.array(out["occ_cell"], np.int32),
+            "occ_index": np.array(out["occ_index"], np.uint32), "occ_bit": np.array(out["occ_bit"], np.uint8)}
+
+
+def packbits_kats():
+    """kernel_packbits (raymarching.cu:286-306): bit i of byte n = grid[8 n + i] > thresh (strictly; NaN compares false)."""
+    thresh = 0.5
+    vals = [0.0, 0.5, 0.50000006, 0.49999997, 1.0, -1.0, float("inf"), float("-inf"), float("nan"), 1e-30, 0.75, 0.25, 3.0e38, -0.0, 0.5, 0.6]
+    rng = Lcg(5)
+    grid = [vals[rng.below(len(vals))] for _ in range(8 * 64)]
+    grid[:16] = vals
+    g32 = np.array(grid, dtype=np.float32)
+    t32 = float(np.float32(thresh))
+    by = []
+    for n in range(len(grid) // 8):
+        b = 0
+        for i in range(8):
+            v = float(g32[8 * n + i])
+            if v == v and v > t32:
+                b |= 1 << i
+        by.append(b)
+    return g32, thresh, np.array(by, dtype=np.uint8)
+
+
 class Lcg:  # a generator that is its own specification (numerical recipes' constants)
     def __init__(self, seed):
         self.s = seed & M
@@ -168,6 +241,9 @@ def main():
     inv_out = [[morton3D_invert((as_int32(v) >> s) & M) for s in range(3)] for v in inv_in]
     assert any(morton3D_invert((as_int32(v) >> 2) & M) != morton3D_invert(v >> 2) for v in inv_in)  # the case is in the set
 
+    occ = occupancy_kats()
+    pb_grid, pb_thresh, pb_bytes = packbits_kats()
+
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "g9_integer_kats.npz")
     np.savez_compressed(
         out,
@@ -176,8 +252,10 @@ def main():
         grid_resolution=rows[:, 3].astype(np.uint32), grid_base=rows[:, 4:8].astype(np.uint32), grid_corner=rows[:, 8],
         grid_pos=rows[:, 9:13].astype(np.uint32), grid_row=rows[:, 13].astype(np.uint32), grid_hashed=rows[:, 14],
         morton_coords=np.array(coords, dtype=np.uint32), morton_code=np.array(mort, dtype=np.uint32),
-        invert_in=np.array(inv_in, dtype=np.uint32), invert_out=np.array(inv_out, dtype=np.uint32))
-    print(f"{out}: {len(rows)} grid cases ({int(rows[:, -1].sum())} hashed), {len(coords)} Morton codes, {len(inv_in)} inversions")
+        invert_in=np.array(inv_in, dtype=np.uint32), invert_out=np.array(inv_out, dtype=np.uint32),
+        pack_grid=pb_grid, pack_thresh=np.float32(pb_thresh), pack_bytes=pb_bytes, **occ)
+    print(f"{out}: {len(rows)} grid cases ({int(rows[:, -1].sum())} hashed), {len(coords)} Morton codes, {len(inv_in)} inversions, "
+          f"{len(occ['occ_index'])} occupancy lookups, {len(pb_bytes)} packed bytes")
 
 
 if __name__ == "__main__":

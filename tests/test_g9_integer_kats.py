@@ -1,9 +1,12 @@
 """G9: the integer index functions against known answers derived from the CUDA sources with Python integers
 (tests/golden/make_g9_kats.py — nothing of this repo is used to make them): the hash-grid row index
 (gridencoder.cu:53-93, incl. the dense -> hash switch level, tiled grids, align_corners, D = 2 / 3 / 4 and the levels whose
-dense stride wraps in uint32) and the Morton code of the occupancy grid (raymarching.cu:71-95, incl. the signed shifts of
-kernel_morton3D_invert, raymarching.cu:256-272).  CPU: both oracle restatements (NumPy, C).  GPU: the HIP kernels through
-lnh_grid_corner_indices / lnh_morton3D / lnh_morton3D_invert.  Bit-exact everywhere."""
+dense stride wraps in uint32), the Morton code of the occupancy grid (raymarching.cu:71-95, incl. the signed shifts of
+kernel_morton3D_invert, raymarching.cu:256-272), the occupancy cell lookup built on it (mip level from position and step,
+cell, bit test: raymarching.cu:51-69, 386-408, on dyadic inputs for which every float operation is exact) and
+kernel_packbits (286-306, incl. NaN / inf / values equal to the threshold).  CPU: both oracle restatements (NumPy, C).
+GPU: the HIP kernels through lnh_grid_corner_indices / lnh_morton3D / lnh_morton3D_invert / lnh_occupancy_lookup /
+lnh_packbits.  Bit-exact everywhere."""
 import os
 
 import numpy as np
@@ -84,3 +87,44 @@ def test_hip_morton():
     back = torch.empty((i.shape[0], 3), dtype=torch.int32, device="cuda")
     call("lnh_morton3D_invert", dev(i), i.shape[0], back)
     np.testing.assert_array_equal(host(back).view(np.uint32), G["invert_out"])
+
+
+# ---- occupancy cell lookup (raymarching.cu:51-69, 386-408) and kernel_packbits (286-306)
+def _bitfield(C_, Hh=128):
+    """The field of tests/golden/make_g9_kats.py::occupancy_bit: bit `index` = ((index * 2654435761) >> 13) & 1."""
+    idx = np.arange(C_ * Hh ** 3, dtype=np.uint64)
+    return np.packbits((((idx * np.uint64(2654435761)) >> np.uint64(13)) & np.uint64(1)).astype(np.uint8), bitorder="little")
+
+
+def _occ_groups():
+    for C_, bound in sorted(set(zip(G["occ_C"].tolist(), G["occ_bound"].tolist()))):
+        yield C_, bound, (G["occ_C"] == C_) & (G["occ_bound"] == bound)
+
+
+def test_oracle_occupancy_lookup_and_packbits():
+    for C_, bound, m in _occ_groups():
+        ci, occ = c_oracle.occupancy_lookup(G["occ_xyz"][m], G["occ_dt"][m], _bitfield(C_), bound, C_, 128)
+        np.testing.assert_array_equal(ci, G["occ_index"][m])
+        np.testing.assert_array_equal(occ != 0, G["occ_bit"][m] != 0)
+        a, b = c_oracle.mip_levels(G["occ_xyz"][m], G["occ_dt"][m], C_, 128)
+        np.testing.assert_array_equal(np.maximum(a, b), G["occ_level"][m])
+        # the index decomposes into the level and the Morton code of the cell
+        np.testing.assert_array_equal(ci // 128 ** 3, G["occ_level"][m])
+        np.testing.assert_array_equal(c_oracle.morton3D_invert((ci % 128 ** 3).astype(np.int32)), G["occ_cell"][m])
+    np.testing.assert_array_equal(c_oracle.packbits(G["pack_grid"], float(G["pack_thresh"])), G["pack_bytes"])
+
+
+@pytest.mark.gpu
+def test_hip_occupancy_lookup_and_packbits():
+    import torch
+    from gpu_util import call, dev, host
+    for C_, bound, m in _occ_groups():
+        n = int(m.sum())
+        ci = torch.empty(n, dtype=torch.int32, device="cuda")
+        occ = torch.empty(n, dtype=torch.uint8, device="cuda")
+        call("lnh_occupancy_lookup", dev(G["occ_xyz"][m]), dev(G["occ_dt"][m]), dev(_bitfield(C_)), float(bound), n, C_, 128, ci, occ)
+        np.testing.assert_array_equal(host(ci).view(np.uint32), G["occ_index"][m])
+        np.testing.assert_array_equal(host(occ) != 0, G["occ_bit"][m] != 0)
+    out = torch.empty(G["pack_bytes"].shape[0], dtype=torch.uint8, device="cuda")
+    call("lnh_packbits", dev(G["pack_grid"]), out.numel(), float(G["pack_thresh"]), out)
+    np.testing.assert_array_equal(host(out), G["pack_bytes"])
