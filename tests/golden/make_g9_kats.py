@@ -6,7 +6,10 @@ CUDA extensions do not compile here):
     tables of lidarnerf/gridencoder/grid.py:179-192 (`offsets`);
   * the Morton code of the occupancy grid, lidarnerf/raymarching/src/raymarching.cu:71-95 (`__expand_bits`, `__morton3D`,
     `__morton3D_invert`), the cell lookup built on it (51-69, 386-408: mip level from position and step, cell, bit test) on
-    inputs for which every float operation is exact, and `kernel_packbits` (286-306).
+    inputs for which every float operation is exact, and `kernel_packbits` (286-306);
+  * the interpolation and the scatter-add of the hash grid (gridencoder.cu:95-263, 265-362) on dyadic inputs / tables /
+    gradients for which every float operation is exact in fp32 resp. fp16 — values that hold whatever the compiler
+    contracts into FMAs and in whatever order atomics arrive.
 
 Both are pure uint32 arithmetic, so the answers can be derived WITHOUT any of this repo's code: below, the C expressions are
 evaluated with Python's unbounded integers and an explicit `& 0xFFFFFFFF` wherever C's uint32_t would wrap.  Nothing is imported
@@ -148,6 +151,70 @@ def occupancy_kats():
             "occ_index": np.array(out["occ_index"], np.uint32), "occ_bit": np.array(out["occ_bit"], np.uint8)}
 
 
+def table_value(global_row, ch, f16):
+    """The hash table the value KATs are computed on (tests build the same one): a small dyadic number per (row, channel) —
+    fp32 set: k / 8 with k in -8 .. 7; fp16 set: 8 k."""
+    k = (((global_row * 2654435761 + ch * 40503 + 12345) >> 7) & 15) - 8
+    return k * 8 if f16 else k / 8.0
+
+
+def grid_value_kats():
+    """kernel_grid / kernel_grid_backward (gridencoder.cu:95-263, 265-362) — the INTERPOLATION and the scatter, linear, D = 3,
+    hash grid, per_level_scale 2 (6 levels: 0-2 dense, 3-5 hashed, 2^19 rows) — on inputs for which every float operation of
+    the CUDA code is EXACT, whatever it contracts into FMAs and in whatever order atomics arrive: x = j / 2^m, so pos =
+    x * scale + 0.5 and its fraction are dyadic, weights have <= 3 (m + 1) bits, table values / gradients are small dyadic
+    numbers, and every partial sum fits the accumulator type (fp32 set: m = 5; fp16 set — the reference accumulates in
+    __half — m = 1 with table values and gradients multiples of 8).  Answers with Fractions + the integer row index above."""
+    from fractions import Fraction as Fr
+    D, L, log2 = 3, 6, 19
+    offs = level_offsets(D, L, H, log2, 0)
+    out = {"val_offsets": np.array(offs, dtype=np.int32)}
+    rng = Lcg(77)
+    for tag, m, f16 in (("f32", 5, False), ("f16", 1, True)):
+        B = 48
+        js = [[rng.below((1 << m) + 1) for _ in range(D)] for _ in range(B)]
+        js[0], js[1], js[2] = [0, 0, 0], [1 << m] * 3, [1 << m, 0, 1 << (m - 1)]
+        x = [[Fr(j, 1 << m) for j in row] for row in js]
+        grad = [[[(rng.below(9) - 4) * (8 if f16 else 1) for _ in range(2)] for _ in range(B)] for _ in range(L)]
+        fwd = [[[Fr(0), Fr(0)] for _ in range(B)] for _ in range(L)]
+        gtab, gabs = {}, {}
+        for l in range(L):
+            res = H * 2 ** l
+            scale = res - 1
+            rows_l = offs[l + 1] - offs[l]
+            for b in range(B):
+                pos = [xd * scale + Fr(1, 2) for xd in x[b]]
+                pg = [int(p) for p in pos]  # floor (pos >= 0)
+                fr = [p - g for p, g in zip(pos, pg)]
+                for c in range(1 << D):
+                    w, cell = Fr(1), []
+                    for d in range(D):
+                        up = (c >> d) & 1
+                        w *= fr[d] if up else 1 - fr[d]
+                        cell.append(pg[d] + up)
+                    row = offs[l] + get_grid_index(0, 0, rows_l, res, cell)
+                    for ch in range(2):
+                        fwd[l][b][ch] += w * Fr(table_value(row, ch, f16))
+                        if w:
+                            gtab[(row, ch)] = gtab.get((row, ch), Fr(0)) + w * grad[l][b][ch]
+                            gabs[(row, ch)] = gabs.get((row, ch), Fr(0)) + abs(w * grad[l][b][ch])
+        exact = lambda q, t: Fr(float(t(float(q)))) == q
+        ft = np.float16 if f16 else np.float32
+        assert all(exact(v, ft) for lv in fwd for pt in lv for v in pt) and all(exact(v, ft) for v in gtab.values())
+        # ... and every PARTIAL sum, in any order: forward terms are multiples of 2^-21 (fp32) / integers (fp16) inside a sum of
+        # weights 1; backward contributions are multiples of 2^-18 (fp32) / integers (fp16), so a row whose absolute sum stays
+        # below 2^(24 - 18) (fp32) / 2048 (fp16) never needs more bits than the accumulator has
+        assert max(gabs.values()) < (2048 if f16 else 64)
+        rows_touched = sorted({r for r, _ in gtab})
+        out[f"val_{tag}_x"] = np.array([[float(v) for v in row] for row in x], dtype=np.float32)
+        out[f"val_{tag}_grad"] = np.array(grad, dtype=np.float32)
+        out[f"val_{tag}_fwd"] = np.array([[[float(v) for v in pt] for pt in lv] for lv in fwd], dtype=np.float32)
+        out[f"val_{tag}_grad_rows"] = np.array(rows_touched, dtype=np.int64)
+        out[f"val_{tag}_grad_table"] = np.array([[float(gtab.get((r, ch), 0)) for ch in range(2)] for r in rows_touched],
+                                                dtype=np.float32)
+    return out
+
+
 def packbits_kats():
     """kernel_packbits (raymarching.cu:286-306): bit i of byte n = grid[8 n + i] > thresh (strictly; NaN compares false)."""
     thresh = 0.5
@@ -242,6 +309,7 @@ def main():
     assert any(morton3D_invert((as_int32(v) >> 2) & M) != morton3D_invert(v >> 2) for v in inv_in)  # the case is in the set
 
     occ = occupancy_kats()
+    occ.update(grid_value_kats())
     pb_grid, pb_thresh, pb_bytes = packbits_kats()
 
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "g9_integer_kats.npz")

@@ -6,7 +6,12 @@ kernel_morton3D_invert, raymarching.cu:256-272), the occupancy cell lookup built
 cell, bit test: raymarching.cu:51-69, 386-408, on dyadic inputs for which every float operation is exact) and
 kernel_packbits (286-306, incl. NaN / inf / values equal to the threshold).  CPU: both oracle restatements (NumPy, C).
 GPU: the HIP kernels through lnh_grid_corner_indices / lnh_morton3D / lnh_morton3D_invert / lnh_occupancy_lookup /
-lnh_packbits.  Bit-exact everywhere."""
+lnh_packbits.  Bit-exact everywhere.
+
+And the hash grid's VALUES (interpolation gridencoder.cu:95-263, scatter-add 265-362) on dyadic inputs, tables and gradients
+for which every float operation is exact in the accumulator type — answers computed with Fractions that hold whatever the
+CUDA compiler contracts into FMAs and in whatever order atomics arrive: both oracle restatements, lnh_grid_encode_forward,
+the atomic backward and the bucketed backward, fp32 and fp16 tables, bit-exact."""
 import os
 
 import numpy as np
@@ -128,3 +133,59 @@ def test_hip_occupancy_lookup_and_packbits():
     out = torch.empty(G["pack_bytes"].shape[0], dtype=torch.uint8, device="cuda")
     call("lnh_packbits", dev(G["pack_grid"]), out.numel(), float(G["pack_thresh"]), out)
     np.testing.assert_array_equal(host(out), G["pack_bytes"])
+
+
+# ---- hash-grid VALUES on exact arithmetic (gridencoder.cu:95-263 interpolation, 265-362 scatter-add)
+def _value_table(f16):
+    """tests/golden/make_g9_kats.py::table_value on every row of the 6-level table."""
+    off = G["val_offsets"]
+    row = np.arange(int(off[-1]), dtype=np.uint64)[:, None]
+    ch = np.arange(2, dtype=np.uint64)[None, :]
+    k = (((row * np.uint64(2654435761) + ch * np.uint64(40503) + np.uint64(12345)) >> np.uint64(7)) & np.uint64(15)).astype(np.int64) - 8
+    return (k * 8).astype(np.float16) if f16 else (k / 8.0).astype(np.float32)
+
+
+def _dense(rows, vals, n):
+    out = np.zeros((n, 2), dtype=np.float64)
+    out[rows] = vals
+    return out
+
+
+@pytest.mark.parametrize("tag", ["f32", "f16"])
+def test_oracles_grid_values_on_exact_arithmetic(tag):
+    f16 = tag == "f16"
+    off, x = G["val_offsets"], G[f"val_{tag}_x"]
+    tab = _value_table(f16)
+    for fwd in (c_oracle.grid_forward(x, tab, off, S, H)[0], grid_ref.forward(x, tab, off, S, H)):
+        np.testing.assert_array_equal(fwd.astype(np.float32), G[f"val_{tag}_fwd"])
+    g = G[f"val_{tag}_grad"].astype(np.float16 if f16 else np.float32)
+    want = _dense(G[f"val_{tag}_grad_rows"], G[f"val_{tag}_grad_table"], int(off[-1]))
+    np.testing.assert_array_equal(c_oracle.grid_backward(g, x, off, int(off[-1]), S, H), want)
+    np.testing.assert_array_equal(grid_ref.backward(g, x, off, int(off[-1]), S, H), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["f32", "f16"])
+def test_hip_grid_values_on_exact_arithmetic(tag):
+    import torch
+    from gpu_util import call, dev, host
+    from lidarnerf import _hip
+    f16 = tag == "f16"
+    dt, code = (torch.float16, 1) if f16 else (torch.float32, 0)
+    off, x = G["val_offsets"], G[f"val_{tag}_x"]
+    B, L, rows = x.shape[0], len(off) - 1, int(off[-1])
+    tab, offh = dev(_value_table(f16)), torch.from_numpy(off)
+    out = torch.empty((L, B, 2), dtype=dt, device="cuda")
+    call("lnh_grid_encode_forward", dev(x), tab, offh, out, B, 3, 2, L, S, H, None, 0, 0, 0, code)
+    np.testing.assert_array_equal(host(out).astype(np.float32), G[f"val_{tag}_fwd"])
+    g = dev(G[f"val_{tag}_grad"].astype(np.float16 if f16 else np.float32))
+    want = _dense(G[f"val_{tag}_grad_rows"], G[f"val_{tag}_grad_table"], rows)
+    # the atomic path (the reference's own method) and the bucketed path (the product's)
+    ge = torch.zeros((rows, 2), dtype=dt, device="cuda")
+    call("lnh_grid_encode_backward", g, dev(x), None, offh, ge, B, 3, 2, L, S, H, None, None, 0, 0, 0, code)
+    np.testing.assert_array_equal(host(ge).astype(np.float64), want)
+    need = _hip.lib().lnh_grid_backward_workspace_size(offh.data_ptr(), B, 3, 2, L, S, H, 0, 0, code)
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    ge2 = torch.zeros((rows, 2), dtype=dt, device="cuda")
+    call("lnh_grid_encode_backward_ws", g, dev(x), offh, ge2, B, 3, 2, L, S, H, 0, 0, 0, code, ws, need)
+    np.testing.assert_array_equal(host(ge2).astype(np.float64), want)
