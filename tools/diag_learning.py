@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Distribution of the learning tests' held-out depth error (tests/test_zz_learning_gpu.py) over repeated runs.
+"""Distribution of the learning tests' held-out depth error (tests/test_zzz_learning_gpu.py) over repeated runs.
 
     python tools/diag_learning.py --patch 2x8 --runs 6 --steps 800 --every 100 [--variant fused|nozero|torchopt|graph]
 
